@@ -1,0 +1,584 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference.
+
+Run in the build container only (the reference lives at /root/reference and never
+travels to the GPU box):
+
+    python tests/golden/gen_golden.py
+
+Every fixture is plain data (inputs + the reference's outputs) stored as .npz.
+Inputs come from ``np.random.RandomState(seed)``; the reference's Gaussian draws
+are replaced by explicit epsilon tensors through a temporary patch of
+``torch.normal`` (the reference draws with ``torch.normal(0., 1., size=...)`` in
+zhusuan/distributions/normal.py:104 and ``torch.normal(mean, std)`` at :102;
+both equal ``mean + std * randn`` bit-for-bit on CPU).
+
+Nothing from the reference is copied here: the script only *calls* it.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+import zhusuan  # noqa: E402  (the reference)
+from zhusuan.distributions import Normal, Bernoulli  # noqa: E402
+from zhusuan.framework.bn import BayesianNet  # noqa: E402
+from zhusuan.variational.elbo import ELBO  # noqa: E402
+from zhusuan.variational.importance_weighted_objective import (  # noqa: E402
+    ImportanceWeightedObjective,
+)
+
+assert zhusuan.__file__.startswith(REF), zhusuan.__file__
+torch.set_num_threads(8)
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# epsilon injection
+# --------------------------------------------------------------------------
+class EpsQueue(object):
+    """Replaces torch.normal while the reference runs; records every draw."""
+
+    def __init__(self, eps_list):
+        self.eps = [torch.as_tensor(e) for e in eps_list]
+        self.calls = []
+        self._orig = None
+
+    def _normal(self, mean, std=None, size=None, **kw):
+        e = self.eps.pop(0)
+        if size is not None:  # torch.normal(0., 1., size=shape)
+            assert tuple(size) == tuple(e.shape), (tuple(size), tuple(e.shape))
+            self.calls.append(("std", tuple(size)))
+            return e.clone()
+        # torch.normal(mean_tensor, std_tensor): detached draw
+        shp = torch.broadcast_shapes(mean.shape, std.shape)
+        assert tuple(shp) == tuple(e.shape), (tuple(shp), tuple(e.shape))
+        self.calls.append(("loc", tuple(shp)))
+        return (mean + std * e).detach()
+
+    def __enter__(self):
+        self._orig = torch.normal
+        torch.normal = self._normal
+        return self
+
+    def __exit__(self, *a):
+        torch.normal = self._orig
+        assert not self.eps, "unused epsilon tensors: %d" % len(self.eps)
+
+
+def t(a, requires_grad=False):
+    x = torch.tensor(np.asarray(a, dtype=F32))
+    x.requires_grad_(requires_grad)
+    return x
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    clean = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        clean[k] = np.asarray(v)
+    np.savez_compressed(path, **clean)
+    print("wrote %-28s %7.1f KB  (%d arrays)" % (name + ".npz", os.path.getsize(path) / 1024.0, len(clean)))
+
+
+# --------------------------------------------------------------------------
+# G-N1: Normal sample + log_prob
+# --------------------------------------------------------------------------
+def gen_normal():
+    rng = np.random.RandomState(101)
+    out = {}
+    case = 0
+    for shape in [(8, 4), (3, 5, 8)]:
+        for K in [None, 1, 5]:
+            for reparam in [True, False]:
+                for use_logstd in [False, True]:
+                    for g in [0, 1, 2]:
+                        mu = rng.standard_normal(shape).astype(F32)
+                        ls = (0.3 * rng.standard_normal(shape) - 0.5).astype(F32)
+                        eshape = shape if (K is None or K == 1) else (K,) + shape
+                        eps = rng.standard_normal(eshape).astype(F32)
+                        mu_t, ls_t = t(mu, True), t(ls, True)
+                        if use_logstd:
+                            d = Normal(mean=mu_t, logstd=ls_t, is_reparameterized=reparam, group_ndims=g)
+                        else:
+                            d = Normal(mean=mu_t, std=torch.exp(ls_t), is_reparameterized=reparam, group_ndims=g)
+                        with EpsQueue([eps]):
+                            z = d.sample(K)
+                        lp = d.log_prob(None)  # uses sample_cache (normal.py:110)
+                        w = rng.standard_normal(tuple(lp.shape)).astype(F32)
+                        wz = rng.standard_normal(tuple(z.shape)).astype(F32)
+                        obj = (lp * t(w)).sum() + (z * t(wz)).sum()
+                        gmu, gls = torch.autograd.grad(obj, [mu_t, ls_t], allow_unused=True)
+                        p = "c%03d_" % case
+                        out[p + "mu"], out[p + "ls"], out[p + "eps"] = mu, ls, eps
+                        out[p + "K"] = np.array(-1 if K is None else K)
+                        out[p + "reparam"] = np.array(int(reparam))
+                        out[p + "use_logstd"] = np.array(int(use_logstd))
+                        out[p + "g"] = np.array(g)
+                        out[p + "z"], out[p + "lp"] = z, lp
+                        out[p + "w"], out[p + "wz"] = w, wz
+                        out[p + "gmu"] = gmu if gmu is not None else np.zeros(shape, F32)
+                        out[p + "gls"] = gls if gls is not None else np.zeros(shape, F32)
+                        case += 1
+    out["n_cases"] = np.array(case)
+    save("g_normal_sample", **out)
+
+    # log_prob of a *given* value with leading-axis / scalar broadcast (prior & likelihood uses)
+    out = {}
+    case = 0
+    specs = [
+        # (mean shape, std shape, given shape, group_ndims)
+        ((6, 4), (6, 4), (6, 4), 0),
+        ((6, 4), (6, 4), (3, 6, 4), 0),     # IWAE prior: params broadcast over K (normal.py:112-116)
+        ((6, 4), (6, 4), (3, 6, 4), 1),
+        ((5, 7), (5, 7), (4, 5, 7), 2),     # BNN prior on w with group_ndims=2 (bnn_vi.py:32)
+        ((4, 6), (1,), (6,), 0),            # BNN likelihood: mean [K,B], std [1], y [B] (bnn_vi.py:55)
+        ((1, 3), (2, 1), (2, 3), 0),        # middle broadcast
+        ((2,), (2, 2), (1,), 0),            # test_normal.py:126 style
+    ]
+    for ms, ss, gs, g in specs:
+        mu = rng.standard_normal(ms).astype(F32)
+        sd = np.exp(0.4 * rng.standard_normal(ss)).astype(F32)
+        x = (2.0 * rng.standard_normal(gs)).astype(F32)
+        mu_t, sd_t, x_t = t(mu, True), t(sd, True), t(x, True)
+        d = Normal(mean=mu_t, std=sd_t, group_ndims=g)
+        lp = d.log_prob(x_t)
+        w = rng.standard_normal(tuple(lp.shape)).astype(F32)
+        gmu, gsd, gx = torch.autograd.grad((lp * t(w)).sum(), [mu_t, sd_t, x_t])
+        p = "c%03d_" % case
+        out[p + "mu"], out[p + "sd"], out[p + "x"], out[p + "g"] = mu, sd, x, np.array(g)
+        out[p + "lp"], out[p + "w"] = lp, w
+        out[p + "gmu"], out[p + "gsd"], out[p + "gx"] = gmu, gsd, gx
+        case += 1
+    out["n_cases"] = np.array(case)
+    save("g_normal_logprob", **out)
+
+    # epsilon-sharing quirk: eps has mean's shape (normal.py:91-92,104)
+    mu = rng.standard_normal((1, 3)).astype(F32)
+    sd = np.exp(rng.standard_normal((2, 1))).astype(F32)
+    eps = rng.standard_normal((2, 1, 3)).astype(F32)
+    d = Normal(mean=t(mu), std=t(sd))
+    with EpsQueue([eps]) as q:
+        z = d.sample(2)
+    save("g_normal_epsshape", mu=mu, sd=sd, eps=eps, z=z, lp=d.log_prob(None),
+         draw_shape=np.array(q.calls[0][1]))
+
+
+# --------------------------------------------------------------------------
+# G-B1: Bernoulli log_prob
+# --------------------------------------------------------------------------
+def gen_bernoulli():
+    rng = np.random.RandomState(202)
+    out = {}
+    case = 0
+    edge = np.array([0.0, 1e-9, 1e-8, 1e-4, 0.2, 0.25, 0.5, 0.75, 0.8, 1 - 1e-4, 1 - 1e-7, 1.0], F32)
+    # edge probabilities against x in {0,1} and fractional x
+    for xs in [np.zeros_like(edge), np.ones_like(edge), np.full_like(edge, 0.3)]:
+        d = Bernoulli(probs=t(edge))
+        lp = d.log_prob(t(xs))
+        p = "c%03d_" % case
+        out[p + "probs"], out[p + "x"], out[p + "lp"] = edge, xs, lp
+        out[p + "from_logits"] = np.array(0)
+        out[p + "g"] = np.array(0)
+        case += 1
+    # random, K-broadcast (x [B,X] against p [K,B,X], bernoulli.py:88-92), grads wrt probs
+    for pshape, xshape, g in [((6, 16), (6, 16), 0), ((3, 6, 16), (6, 16), 0), ((3, 6, 16), (6, 16), 1),
+                              ((2, 5, 784), (5, 784), 0)]:
+        pr = rng.uniform(0.001, 0.999, pshape).astype(F32)
+        x = (rng.uniform(size=xshape) < 0.5).astype(F32)
+        pr_t = t(pr, True)
+        d = Bernoulli(probs=pr_t, group_ndims=g)
+        lp = d.log_prob(t(x))
+        w = rng.standard_normal(tuple(lp.shape)).astype(F32)
+        (gp,) = torch.autograd.grad((lp * t(w)).sum(), [pr_t])
+        p = "c%03d_" % case
+        out[p + "probs"], out[p + "x"], out[p + "lp"] = pr, x, lp
+        out[p + "w"], out[p + "gp"] = w, gp
+        out[p + "from_logits"] = np.array(0)
+        out[p + "g"] = np.array(g)
+        case += 1
+    # logits constructor (bernoulli.py:46-50): probs = sigmoid(logits)
+    for lshape, xshape in [((2,), (2,)), ((4, 9), (4, 9)), ((3, 4, 9), (4, 9))]:
+        lg = (3.0 * rng.standard_normal(lshape)).astype(F32)
+        x = (rng.uniform(size=xshape) < 0.5).astype(F32)
+        lg_t = t(lg, True)
+        d = Bernoulli(logits=lg_t)
+        lp = d.log_prob(t(x))
+        w = rng.standard_normal(tuple(lp.shape)).astype(F32)
+        (gl,) = torch.autograd.grad((lp * t(w)).sum(), [lg_t])
+        p = "c%03d_" % case
+        out[p + "logits"], out[p + "x"], out[p + "lp"], out[p + "probs"] = lg, x, lp, d.probs
+        out[p + "w"], out[p + "gl"] = w, gl
+        out[p + "from_logits"] = np.array(1)
+        out[p + "g"] = np.array(0)
+        case += 1
+    out["n_cases"] = np.array(case)
+    # constructor identities (test_bernoulli.py:20-27)
+    b = Bernoulli(probs=[0.4, 0.5])
+    out["ctor_probs"] = b.probs
+    out["ctor_logits"] = b.logits
+    out["ctor_zero_logit_probs"] = Bernoulli(0.).probs
+    save("g_bernoulli", **out)
+
+
+# --------------------------------------------------------------------------
+# G-ST: StochasticTensor.log_prob reductions; G-LME
+# --------------------------------------------------------------------------
+class _Net(BayesianNet):
+    def forward(self, observed):
+        self.observe(observed)
+        return self
+
+
+def gen_stochastic_tensor():
+    rng = np.random.RandomState(303)
+    out = {}
+    case = 0
+    combos = [
+        # (param shape, K, group_ndims, reduce_mean_dims, reduce_sum_dims, multiplier)
+        ((6, 4), None, 0, [0], [1], None),          # VAE latent (vae_mnist.py:79-85)
+        ((6, 4), 5, 0, None, [2], None),            # IWAE latent (iwae.py:114-119)
+        ((5, 7), 4, 2, [0], None, None),            # BNN weights (bnn_vi.py:91-98)
+        ((6, 4), 3, 0, [0, 1], None, 456),          # BNN likelihood-style (bnn_vi.py:55-60)
+        ((6, 4), 3, 1, None, None, None),
+        ((6, 4), 3, 0, None, None, 2.5),
+        ((6, 4), 3, 0, [1], [0], None),
+        ((2, 6, 4), 3, 0, [1], [3, 2], None),
+        ((6, 4), None, 0, None, [-1], None),
+    ]
+    for shape, K, g, rm, rs, mult in combos:
+        mu = rng.standard_normal(shape).astype(F32)
+        sd = np.exp(0.3 * rng.standard_normal(shape)).astype(F32)
+        eshape = shape if K is None else (K,) + shape
+        e1 = rng.standard_normal(eshape).astype(F32)
+        e2 = rng.standard_normal(eshape).astype(F32)
+        net = _Net()
+        net({})
+        kw = {}
+        if rm is not None:
+            kw["reduce_mean_dims"] = rm
+        if rs is not None:
+            kw["reduce_sum_dims"] = rs
+        if mult is not None:
+            kw["multiplier"] = mult
+        with EpsQueue([e1, e2]):
+            first = net.normal("z", mean=t(mu), std=t(sd), group_ndims=g, n_samples=K, **kw)
+            second = net.nodes["z"].tensor
+        lp = net.nodes["z"].log_prob()
+        p = "c%03d_" % case
+        out[p + "mu"], out[p + "sd"], out[p + "e1"], out[p + "e2"] = mu, sd, e1, e2
+        out[p + "K"] = np.array(-1 if K is None else K)
+        out[p + "g"] = np.array(g)
+        out[p + "rm"] = np.array(rm if rm is not None else [], dtype=np.int64)
+        out[p + "rs"] = np.array(rs if rs is not None else [], dtype=np.int64)
+        out[p + "mult"] = np.array(0.0 if mult is None else mult)
+        out[p + "first"], out[p + "second"], out[p + "lp"] = first, second, lp
+        out[p + "lp_shape"] = np.array(tuple(lp.shape), dtype=np.int64)
+        case += 1
+    out["n_cases"] = np.array(case)
+    save("g_stochastic_tensor", **out)
+
+    # log_mean_exp (zhusuan/utils.py:6-21)
+    out = {}
+    x = np.array([[1., 2.], [3., -1000.]], F32)
+    out["a_x"] = x
+    out["a_dim0"] = zhusuan.log_mean_exp(t(x), 0)
+    out["a_dim1_keep"] = zhusuan.log_mean_exp(t(x), 1, keepdims=True)
+    y = (5 * rng.standard_normal((7, 5, 3))).astype(F32)
+    out["b_x"] = y
+    out["b_dim0"] = zhusuan.log_mean_exp(t(y), 0)
+    out["b_dim1"] = zhusuan.log_mean_exp(t(y), 1)
+    out["b_dim2_keep"] = zhusuan.log_mean_exp(t(y), 2, keepdims=True)
+    save("g_log_mean_exp", **out)
+
+
+# --------------------------------------------------------------------------
+# G-IW / G-ELBO: estimators on raw log-joint tensors
+# --------------------------------------------------------------------------
+def _iw(estimator, axis=0):
+    obj = ImportanceWeightedObjective.__new__(ImportanceWeightedObjective)
+    torch.nn.Module.__init__(obj)
+    obj._axis = axis
+    obj.estimator = estimator
+    return obj
+
+
+def gen_iw():
+    rng = np.random.RandomState(404)
+    out = {}
+    case = 0
+    for (K, B) in [(2, 3), (5, 8), (50, 16), (64, 4), (70, 3), (200, 2)]:
+        for spread in [1.0, 5.0, 30.0]:
+            logp = (-550.0 + spread * rng.standard_normal((K, B))).astype(F32)
+            logq = (-50.0 + 0.3 * spread * rng.standard_normal((K, B))).astype(F32)
+            p = "c%03d_" % case
+            out[p + "logp"], out[p + "logq"] = logp, logq
+            for est in ["sgvb", "vimco"]:
+                lp_t, lq_t = t(logp, True), t(logq, True)
+                obj = _iw(est)
+                cost = getattr(obj, est)(lp_t, lq_t, True)
+                gp, gq = torch.autograd.grad(cost, [lp_t, lq_t])
+                out[p + est + "_cost"] = cost
+                out[p + est + "_glogp"], out[p + est + "_glogq"] = gp, gq
+                # float64 evaluation of the same reference code, to size the fp32 error
+                lp_d = torch.tensor(logp.astype(np.float64), requires_grad=True)
+                lq_d = torch.tensor(logq.astype(np.float64), requires_grad=True)
+                cost_d = getattr(obj, est)(lp_d, lq_d, True)
+                gp_d, gq_d = torch.autograd.grad(cost_d, [lp_d, lq_d])
+                out[p + est + "_cost64"] = cost_d
+                out[p + est + "_glogp64"], out[p + est + "_glogq64"] = gp_d, gq_d
+            out[p + "sgvb_cost_noreduce"] = _iw("sgvb").sgvb(t(logp), t(logq), False)
+            out[p + "bound"] = zhusuan.log_mean_exp(t(logp) - t(logq), 0)
+            case += 1
+    out["n_cases"] = np.array(case)
+    # 1-D log_w (test_iw.py:149-174 runs vimco on a 1-D tensor)
+    lp1 = (-3.0 + rng.standard_normal(37)).astype(F32)
+    lq1 = (-1.0 + 0.5 * rng.standard_normal(37)).astype(F32)
+    for est in ["sgvb", "vimco"]:
+        a, b = t(lp1, True), t(lq1, True)
+        c = getattr(_iw(est), est)(a, b, True)
+        ga, gb = torch.autograd.grad(c, [a, b])
+        out["d1_" + est + "_cost"], out["d1_" + est + "_glogp"], out["d1_" + est + "_glogq"] = c, ga, gb
+    out["d1_logp"], out["d1_logq"] = lp1, lq1
+    save("g_iw", **out)
+
+    # config-3 shape, scalars only
+    out = {}
+    for i, spread in enumerate([1.0, 5.0, 30.0]):
+        r2 = np.random.RandomState(4100 + i)
+        logp = (-550.0 + spread * r2.standard_normal((50, 256))).astype(F32)
+        logq = (-50.0 + 0.3 * spread * r2.standard_normal((50, 256))).astype(F32)
+        for est in ["sgvb", "vimco"]:
+            a, b = t(logp, True), t(logq, True)
+            c = getattr(_iw(est), est)(a, b, True)
+            ga, gb = torch.autograd.grad(c, [a, b])
+            out["s%d_%s_cost" % (i, est)] = c
+            out["s%d_%s_glogp_sum" % (i, est)] = ga.sum()
+            out["s%d_%s_glogq_abs_sum" % (i, est)] = gb.abs().sum()
+            out["s%d_%s_glogq_row0" % (i, est)] = gb[:, 0]
+        out["s%d_bound_mean" % i] = zhusuan.log_mean_exp(t(logp) - t(logq), 0).mean()
+        out["s%d_spread" % i] = np.array(spread)
+    save("g_iw_c3", **out)
+
+
+def gen_elbo():
+    rng = np.random.RandomState(505)
+    out = {}
+    e = ELBO.__new__(ELBO)
+    torch.nn.Module.__init__(e)
+    a = (-500 + 3 * rng.standard_normal((4, 6))).astype(F32)
+    b = (-40 + rng.standard_normal((4, 6))).astype(F32)
+    out["logp"], out["logq"] = a, b
+    out["sgvb_mean"] = e.sgvb(t(a), t(b), True)
+    out["sgvb_nomean"] = e.sgvb(t(a), t(b), False)
+    out["sgvb_scalar"] = e.sgvb(t(a[0, 0]), t(b[0, 0]), True)
+    save("g_elbo_sgvb", **out)
+
+
+# --------------------------------------------------------------------------
+# End-to-end callers
+# --------------------------------------------------------------------------
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def fill_params(module, seed):
+    """Deterministic numpy weights: U(-1/sqrt(fan_in), 1/sqrt(fan_in)); shared with the tests."""
+    rng = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            shp = tuple(p.shape)
+            fan_in = shp[-1] if len(shp) > 1 else shp[0]
+            s = 1.0 / np.sqrt(max(fan_in, 1))
+            p.copy_(torch.tensor(rng.uniform(-s, s, size=shp).astype(F32)))
+
+
+def grad_stats(module):
+    names, norms, sums, heads = [], [], [], []
+    for name, p in module.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        names.append(name)
+        norms.append(float(g.double().norm()))
+        sums.append(float(g.double().sum()))
+        heads.append(g.reshape(-1)[:8].detach().numpy().copy())
+    return names, np.array(norms), np.array(sums), heads
+
+
+def _pack_grads(out, prefix, module):
+    names, norms, sums, heads = grad_stats(module)
+    out[prefix + "grad_names"] = np.array(names)
+    out[prefix + "grad_norms"] = norms
+    out[prefix + "grad_sums"] = sums
+    for n, h in zip(names, heads):
+        out[prefix + "ghead_" + n] = h
+
+
+def gen_vae():
+    vae = _load(os.path.join(REF, "examples/variational_autoencoder/vae_mnist.py"), "ref_vae")
+    for tag, B, full in [("small", 8, True), ("c1", 64, False), ("c2", 512, False)]:
+        rng = np.random.RandomState(600 + B)
+        x_dim, z_dim = 784, 40
+        gen = vae.Generator(x_dim, z_dim, B)
+        var = vae.Variational(x_dim, z_dim, B)
+        model = ELBO(gen, var)
+        fill_params(model, 1000 + B)
+        x = (rng.uniform(size=(B, x_dim)) < 0.5).astype(F32)
+        e1 = rng.standard_normal((B, z_dim)).astype(F32)
+        e2 = rng.standard_normal((B, z_dim)).astype(F32)
+        with EpsQueue([e1, e2]) as q:
+            loss = model({"x": t(x)})
+        model.zero_grad()
+        loss.backward()
+        out = {"B": np.array(B), "seed_params": np.array(1000 + B), "seed_data": np.array(600 + B),
+               "loss": loss, "draws": np.array([c[1] for c in q.calls])}
+        out["logpz"] = gen.nodes["z"].log_prob()
+        out["logpx"] = gen.nodes["x"].log_prob()
+        out["logqz"] = var.nodes["z"].log_prob()
+        _pack_grads(out, "", model)
+        if full:
+            out["x"], out["e1"], out["e2"] = x, e1, e2
+            out["z"] = var.nodes["z"].dist.sample_cache
+            out["x_mean"] = gen.cache["x_mean"]
+        save("g_vae_" + tag, **out)
+
+
+def gen_iwae():
+    iw = _load(os.path.join(REF, "examples/variational_autoencoder/iwae.py"), "ref_iwae")
+    for est in ["sgvb", "vimco"]:
+        for tag, B, K, hidden, full in [("small", 8, 5, 32, True), ("c3", 256, 50, 500, False)]:
+            iw.hidden_dim = hidden
+            iw.reparameterization = (est == "sgvb")
+            rng = np.random.RandomState(700 + B + K)
+            x_dim, z_dim = 784, 40
+            gen = iw.Generator(x_dim, z_dim, K)
+            var = iw.Variational(x_dim, z_dim, K)
+            model = ImportanceWeightedObjective(gen, var, axis=0, estimator=est)
+            fill_params(model, 2000 + B + K)
+            x = (rng.uniform(size=(B, x_dim)) < 0.5).astype(F32)
+            e1 = rng.standard_normal((K, B, z_dim)).astype(F32)
+            e2 = rng.standard_normal((K, B, z_dim)).astype(F32)
+            with EpsQueue([e1, e2]) as q:
+                loss = model({"x": t(x)})
+            model.zero_grad()
+            loss.backward()
+            logpxz = gen.nodes["z"].log_prob() + gen.nodes["x"].log_prob()
+            logqz = var.nodes["z"].log_prob()
+            log_w = (logpxz - logqz).detach()
+            out = {"B": np.array(B), "K": np.array(K), "hidden": np.array(hidden),
+                   "seed_params": np.array(2000 + B + K), "seed_data": np.array(700 + B + K),
+                   "loss": loss, "iw_bound": zhusuan.log_mean_exp(log_w, 0).mean(),
+                   "draws": np.array([c[1] for c in q.calls]),
+                   "draw_kinds": np.array([c[0] for c in q.calls])}
+            _pack_grads(out, "", model)
+            if full:
+                out["x"], out["e1"], out["e2"] = x, e1, e2
+                out["z"] = var.nodes["z"].dist.sample_cache
+                out["log_w"] = log_w
+                out["logqz"] = logqz
+                out["logpz"] = gen.nodes["z"].log_prob()
+                out["logpx"] = gen.nodes["x"].log_prob()
+            else:
+                out["log_w_col0"] = log_w[:, 0]
+            save("g_iwae_%s_%s" % (est, tag), **out)
+
+
+def gen_bnn():
+    bnn = _load(os.path.join(REF, "examples/bayesian_neural_nets/bnn_vi.py"), "ref_bnn")
+    for tag, B, K, full in [("small", 16, 4, True), ("c5", 512, 10, False)]:
+        rng = np.random.RandomState(800 + B + K)
+        layer_sizes = [13, 50, 1]
+        net = bnn.Net(layer_sizes, K)
+        var = bnn.Variational(layer_sizes, K)
+        model = ELBO(net, var)
+        # non-trivial variational parameters (the example starts from zeros, bnn_vi.py:74-79)
+        prng = np.random.RandomState(3000 + B + K)
+        with torch.no_grad():
+            for p in var.w_means:
+                p.copy_(torch.tensor((0.1 * prng.standard_normal(tuple(p.shape))).astype(F32)))
+            for p in var.w_logstds:
+                p.copy_(torch.tensor((-1.0 + 0.1 * prng.standard_normal(tuple(p.shape))).astype(F32)))
+            net.y_logstd.fill_(0.3)
+        x = rng.standard_normal((B, 13)).astype(F32)
+        y = rng.standard_normal((B,)).astype(F32)
+        eps = []
+        for _ in range(2):  # draw order w0#1, w1#1, then w0#2, w1#2
+            eps.append(rng.standard_normal((K, 50, 14)).astype(F32))
+            eps.append(rng.standard_normal((K, 1, 51)).astype(F32))
+        with EpsQueue(list(eps)) as q:
+            loss = model({"x": t(x), "y": t(y)})
+        model.zero_grad()
+        loss.backward()
+        out = {"B": np.array(B), "K": np.array(K), "loss": loss, "rmse": net.cache["rmse"],
+               "seed_params": np.array(3000 + B + K), "seed_data": np.array(800 + B + K),
+               "draws_w0": np.array(q.calls[0][1]), "draws_w1": np.array(q.calls[1][1]),
+               "n_draws": np.array(len(q.calls))}
+        for i in range(2):
+            out["g_w_mean_%d" % i] = var.w_means[i].grad
+            out["g_w_logstd_%d" % i] = var.w_logstds[i].grad
+        out["g_y_logstd"] = net.y_logstd.grad
+        out["logp_w0"] = net.nodes["w0"].log_prob()
+        out["logp_w1"] = net.nodes["w1"].log_prob()
+        out["logp_y"] = net.nodes["y"].log_prob()
+        out["logq_w0"] = var.nodes["w0"].log_prob()
+        out["logq_w1"] = var.nodes["w1"].log_prob()
+        if full:
+            out["x"], out["y"] = x, y
+            for i, e in enumerate(eps):
+                out["eps%d" % i] = e
+        save("g_bnn_" + tag, **out)
+
+
+def gen_reference_tests():
+    """Values of the reference's own statistical tests (test/variational/test_elbo.py, test_iw.py)
+    so the build can re-run them against identical expectations."""
+    from scipy import stats
+    out = {}
+    rng = np.random.RandomState(1)
+    n1 = rng.standard_normal(size=(1, 1000)).astype(F32)
+    n3 = rng.standard_normal(10000).astype(F32)
+    # test_iw.py:149-174 (vimco grads vs sgvb grads) for the two parameterisations
+    for tag, xm, xs in [("a", 0., 1.), ("b", 2., 3.)]:
+        mu = torch.tensor(2., requires_grad=True)
+        sigma = torch.tensor(3., requires_grad=True)
+        eps = torch.tensor(n3)
+        qx = eps * sigma + mu
+        norm = Normal(mean=mu, std=sigma)
+        log_qx = norm.log_prob(qx)
+        vq = eps * sigma.detach() + mu.detach()
+        vlog = norm.log_prob(vq)
+        pm, ps = torch.tensor(xm), torch.tensor(xs)
+        lp_s = Normal(mean=pm, std=ps).log_prob(qx)
+        lp_v = Normal(mean=pm, std=ps).log_prob(vq)
+        cs = _iw("sgvb").sgvb(lp_s, log_qx, True)
+        cv = _iw("vimco").vimco(lp_v, vlog, True)
+        gs = torch.autograd.grad(cs, [mu, sigma], retain_graph=True)
+        gv = torch.autograd.grad(cv, [mu, sigma], retain_graph=True)
+        out[tag + "_sgvb_cost"], out[tag + "_vimco_cost"] = cs, cv
+        out[tag + "_sgvb_grads"] = torch.stack(gs)
+        out[tag + "_vimco_grads"] = torch.stack(gv)
+    out["n1_head"] = n1[0, :8]
+    out["n3_head"] = n3[:8]
+    save("g_reference_tests", **out)
+
+
+if __name__ == "__main__":
+    gen_normal()
+    gen_bernoulli()
+    gen_stochastic_tensor()
+    gen_iw()
+    gen_elbo()
+    gen_vae()
+    gen_iwae()
+    gen_bnn()
+    gen_reference_tests()
