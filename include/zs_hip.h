@@ -1,0 +1,178 @@
+/*
+ * zs_hip.h -- C ABI of the MI355X (gfx950) variational-inference hot path.
+ *
+ * The reference (thuwzy/ZhuSuan-PyTorch) is pure Python and has no FFI of its
+ * own; its boundary for this path is the Python class API.
+ * This header is the private C ABI that sits underneath that API: each entry
+ * point replaces the whole-tensor PyTorch op sequence of one reference method
+ * (cited per function, paths relative to the reference root).  INTEGRATION.md
+ * shows the ctypes stub a reference maintainer would add to call it.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data owned by the caller;
+ *     nothing is allocated, freed or synchronised inside a call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every
+ *     call only enqueues kernels on it and returns;
+ *   - return value: 0 on success, a positive hipError_t if a launch failed,
+ *     ZS_EINVAL / ZS_ENOTSUP (negative) for rejected arguments;
+ *   - "periodic broadcast": an operand given with period P is read as
+ *     a[i % P] for flat index i of the full [K, R, D] problem, which covers the
+ *     reference's leading-axis `repeat` of parameters (normal.py:94-95,112-116)
+ *     and scalars (P = 1).  P must divide K*R*D;
+ *   - row results: element (k, r) of a [K, R] result is written at
+ *     out[k * stride_k + r * stride_r] (strides in elements).  The objectives
+ *     use the K-fastest layout stride_k = 1, stride_r = ld >= K so that the
+ *     importance-weight reduction finds the K particles of one datapoint on
+ *     the 64 lanes of one wavefront.
+ */
+#ifndef ZS_HIP_H
+#define ZS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZS_ABI_VERSION 1
+#define ZS_EINVAL (-1)
+#define ZS_ENOTSUP (-2)
+
+#define ZS_IW_SGVB 0
+#define ZS_IW_VIMCO 1
+
+/* ABI version of the loaded library (== ZS_ABI_VERSION). */
+int zs_abi_version(void);
+
+/* Human-readable text for a return code of any function below. */
+const char* zs_error_string(int code);
+
+/* ---------------------------------------------------------------------------
+ * K1  Normal: fused sample + log-prob.
+ * Replaces Normal._sample (zhusuan/distributions/normal.py:89-107), the
+ * log-density of the fresh sample Normal._log_prob (normal.py:109-126), the
+ * group sum of Distribution.log_prob (zhusuan/distributions/base.py:175-176)
+ * and the trailing reduce_sum of StochasticTensor.log_prob
+ * (zhusuan/framework/stochastic_tensor.py:160-181).
+ *
+ *   z[k, m]   = mu[m] + sigma[m] * eps[k, m]              k < K, m < M
+ *   lp[k, r]  = sum_{d < D} ( -0.5*log(2*pi) - log(sigma) - 0.5*exp(-2*log(sigma)) * (z - mu)^2 )
+ *               over m = r*D + d,  r < R = M / D
+ *
+ * eps == NULL: eps is drawn in-kernel from Philox4x32-10 keyed by `seed`, with
+ * counter (group = (k*M + m) / 4, call = offset); the same (seed, offset)
+ * regenerates the same draw in the backward call.
+ * lp == NULL: sample only.
+ * -------------------------------------------------------------------------*/
+int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const float* eps,
+                                 uint64_t seed, uint64_t offset,
+                                 float* z, float* lp,
+                                 int64_t K, int64_t M, int64_t D,
+                                 int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+
+/* Backward of K1 for a reparameterised node (normal.py:104-105):
+ *   gmu[m]    = sum_k gz[k, m]
+ *   gsigma[m] = sum_k gz[k, m] * eps[k, m]  -  (sum_k glp[k, r(m)]) / sigma[m]
+ * gz or glp may be NULL (treated as zero).  eps as in the forward call. */
+int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float* eps,
+                                     uint64_t seed, uint64_t offset,
+                                     const float* gz, const float* glp,
+                                     int64_t glp_stride_k, int64_t glp_stride_r,
+                                     float* gmu, float* gsigma,
+                                     int64_t K, int64_t M, int64_t D, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K2  Normal: log-prob of a given value (prior p(z), likelihood p(y|.)).
+ * Replaces Normal._log_prob on an observed value with parameters repeated
+ * along the sample axis (normal.py:109-126), plus the group / trailing sums
+ * as for K1.  Problem [K, R, D]; x, mu, sigma periodic with Px, Pm, Ps.
+ * -------------------------------------------------------------------------*/
+int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu, int64_t Pm,
+                          const float* sigma, int64_t Ps, float* lp,
+                          int64_t K, int64_t R, int64_t D,
+                          int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+
+/* Backward of K2, element-wise partials of size K*R*D each (any may be NULL):
+ *   gx = -g*prec*(x-mu),  gmu = +g*prec*(x-mu),  gsigma = g*(prec*(x-mu)^2 - 1)/sigma,
+ * with g = glp[k, r] and prec = exp(-2*log(sigma)). */
+int zs_normal_logprob_bwd_f32(const float* x, int64_t Px, const float* mu, int64_t Pm,
+                              const float* sigma, int64_t Ps,
+                              const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
+                              float* gx, float* gmu, float* gsigma,
+                              int64_t K, int64_t R, int64_t D, void* stream);
+
+/* Backward of K2 reduced over the K axis for parameters of period R*D
+ * (mu, sigma of shape [R, D] repeated K times: the IWAE / non-reparameterised
+ * case, normal.py:102,112-116).  x has full size [K, R, D].
+ *   gmu[r, d] = sum_k ...,  gsigma[r, d] = sum_k ...;  gx (full size) optional. */
+int zs_normal_logprob_bwd_ksum_f32(const float* x, const float* mu, const float* sigma,
+                                   const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
+                                   float* gx, float* gmu, float* gsigma,
+                                   int64_t K, int64_t R, int64_t D, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K3  Bernoulli: log-prob row sums.
+ * Replaces Bernoulli._log_prob (zhusuan/distributions/bernoulli.py:84-95) and
+ * the sums as above:
+ *   lp[k, r] = sum_d  x*log(p + 1e-8) + (1 - x)*log((1 - p) + 1e-8)
+ * p has full size [K, R, D]; x is periodic with Px (x [B, X] against
+ * p [K, B, X], bernoulli.py:88-92).
+ * -------------------------------------------------------------------------*/
+int zs_bernoulli_logprob_f32(const float* p, const float* x, int64_t Px, float* lp,
+                             int64_t K, int64_t R, int64_t D,
+                             int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+
+/* gp[k, r, d] = glp[k, r] * ( x/(p + 1e-8) - (1 - x)/((1 - p) + 1e-8) ) */
+int zs_bernoulli_logprob_bwd_f32(const float* p, const float* x, int64_t Px,
+                                 const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
+                                 float* gp, int64_t K, int64_t R, int64_t D, void* stream);
+
+/* Same density evaluated from logits: p = sigmoid(logit) = 1/(1 + exp(-logit))
+ * (bernoulli.py:46-50) followed by the formula above; removes the separate
+ * sigmoid pass and the round trip of p.
+ * probs_out (optional, full size) receives p. */
+int zs_bernoulli_logits_logprob_f32(const float* logits, const float* x, int64_t Px,
+                                    float* lp, float* probs_out,
+                                    int64_t K, int64_t R, int64_t D,
+                                    int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+
+/* glogits = glp * ( x/(p+1e-8) - (1-x)/((1-p)+1e-8) ) * p * (1-p) */
+int zs_bernoulli_logits_logprob_bwd_f32(const float* logits, const float* x, int64_t Px,
+                                        const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
+                                        float* glogits, int64_t K, int64_t R, int64_t D, void* stream);
+
+/* K5  Bernoulli._sample (bernoulli.py:72-82): out[i] = (u_i < p[i % Pp]) ? 1 : 0,
+ * u from Philox4x32-10 (seed, offset).  Generation path only. */
+int zs_bernoulli_sample_f32(const float* p, int64_t Pp, float* out, int64_t N,
+                            uint64_t seed, uint64_t offset, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K4  Importance-weighted reduction over the K particles of each datapoint.
+ * Replaces compute_iw_term, ImportanceWeightedObjective.sgvb / .vimco
+ * (zhusuan/variational/importance_weighted_objective.py:16-25, 123-132,
+ * 152-191) and log_mean_exp (zhusuan/utils.py:6-21).
+ * Inputs are K-fastest: logp[b*ld_p + k], logq[b*ld_q + k]; log_w = logp - logq.
+ *   bound_b[b] = log_mean_exp_k(log_w)                      (the true IW bound)
+ *   sgvb : cost_b[b] = -sum_k wt_k * log_w_k,               wt = softmax_k(log_w)
+ *          coef_p = -wt,  coef_q = +wt
+ *   vimco: cost_b[b] = -sum_k logq_k * signal_k - sum_k wt_k * log_w_k,
+ *          signal_k = log_mean_exp(log_w) - log_mean_exp(log_w with entry k replaced by
+ *                     the mean of the others);  coef_p = -wt,  coef_q = wt - signal
+ * coef_p / coef_q are d cost_b / d logp, d cost_b / d logq, dense [B, K].
+ * Any output pointer may be NULL.  vimco requires K >= 2.
+ * -------------------------------------------------------------------------*/
+int zs_iw_reduce_f32(const float* logp, int64_t ld_p, const float* logq, int64_t ld_q,
+                     int64_t B, int64_t K, int estimator,
+                     float* cost_b, float* bound_b, float* coef_p, float* coef_q, void* stream);
+
+/* out[b] = log_mean_exp_k(x[b*ld + k])  (zhusuan/utils.py:6-21, K-fastest rows) */
+int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float* out, void* stream);
+
+/* Standard normals from the same Philox4x32-10 + Box-Muller stream K1 uses:
+ * out[i], i < N, group = i / 4.  For tests and for callers that need eps itself. */
+int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZS_HIP_H */

@@ -23,3 +23,50 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+# ---------------------------------------------------------------------------------------------
+# Kernel back-ends for product-level tests.
+#   "hip"  : the real thing -- zhusuan package + libzs_hip.so on cuda:0 (marked gpu).
+#   "host" : the SAME package code with the plain-C oracle (oracle/zs_oracle_c.c, identical C ABI,
+#            host pointers) injected through the package's test hook, so the host logic (shapes,
+#            reductions, autograd wiring, ctypes marshalling) is covered on a CPU-only machine.
+# ---------------------------------------------------------------------------------------------
+import subprocess
+
+import torch
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libzs_oracle.so")
+
+
+def build_oracle_lib():
+    src = os.path.join(ROOT, "oracle", "zs_oracle_c.c")
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+_host_klib = None
+
+
+def host_kernel_library():
+    global _host_klib
+    if _host_klib is None:
+        from zhusuan import _hip
+        _host_klib = _hip.KernelLibrary(build_oracle_lib())
+    return _host_klib
+
+
+@pytest.fixture(params=[pytest.param("host"), pytest.param("hip", marks=pytest.mark.gpu)])
+def dev(request):
+    from zhusuan import _hip
+    if request.param == "host":
+        _hip._install_host_library_for_tests(host_kernel_library())
+        try:
+            yield torch.device("cpu")
+        finally:
+            _hip._install_host_library_for_tests(None)
+    else:
+        _hip._install_host_library_for_tests(None)
+        assert torch.cuda.is_available(), "gpu-marked test needs a GPU"
+        yield torch.device("cuda:0")

@@ -1,0 +1,298 @@
+"""Normal / Bernoulli through the product package.
+
+Restates the reference's own unit tests (test/distributions/test_normal.py, test_bernoulli.py and the
+shape tables of test/distributions/utils.py) and checks values + gradients against the golden
+fixtures.  Every test runs on the "host" back-end (C oracle injected, CPU) and -- marked gpu -- on
+the real HIP library.
+"""
+import numpy as np
+import pytest
+import torch
+from scipy import stats
+
+from conftest import load_golden
+import zhusuan as zs
+from zhusuan.distributions import Normal, Bernoulli
+
+
+def T(a, dev, rg=False):
+    x = torch.tensor(np.asarray(a, dtype=np.float32), device=dev)
+    return x.requires_grad_(rg)
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------ Normal: reference test_normal.py
+def test_normal_init_errors(dev):
+    # test_normal.py:29-43
+    with pytest.raises(ValueError, match=r"Either.*should be passed"):
+        Normal(mean=torch.zeros([2, 1]), std=torch.ones([2, 4, 3]), logstd=torch.zeros([2, 2, 3]), device=dev)
+    with pytest.raises(ValueError, match=r"Either.*should be passed"):
+        Normal(mean=torch.zeros([2, 1]), device=dev)
+    with pytest.raises(RuntimeError):
+        Normal(mean=torch.zeros([2, 1]), logstd=torch.zeros([2, 4, 3]), device=dev)
+    with pytest.raises(TypeError, match="must have a dtype in"):
+        Normal(mean=torch.zeros([2], dtype=torch.int32), std=torch.ones([2], dtype=torch.int32), device=dev)
+    with pytest.raises(TypeError, match="must have the same dtype as"):
+        Normal(mean=torch.zeros([2]), std=torch.ones([2], dtype=torch.float64), device=dev)
+    with pytest.raises(ValueError, match="non-negative"):
+        Normal(mean=0., std=1., group_ndims=-1, device=dev)
+    d = Normal(mean=torch.ones([32, 1]), std=torch.ones([32, 1, 3]), device=dev)
+    assert d.dtype == torch.float32
+    assert Normal(mean=0., std=1., device=dev).dtype == torch.float32
+
+
+def test_normal_sample_shapes(dev):
+    # test/distributions/utils.py:286-303
+    for ctor in ("std", "logstd"):
+        for ms, ss, n, target in [([2, 3], [2, 1], 1, [2, 3]), ([1, 3], [2, 1], 2, [2, 2, 3]),
+                                  ([2, 1, 5], [1, 3, 1], 3, [3, 2, 3, 5])]:
+            kw = {ctor: torch.ones(ss) if ctor == "std" else torch.zeros(ss)}
+            d = Normal(mean=torch.zeros(ms), device=dev, **kw)
+            assert list(d.sample(n).shape) == target
+    d = Normal(mean=torch.zeros([4, 5]), std=torch.ones([4, 5]), device=dev)
+    assert list(d.sample().shape) == [4, 5]
+    assert list(d.sample(None).shape) == [4, 5]
+    assert list(d.sample(1).shape) == [4, 5]       # base.py:146-150: n_samples=1 adds no axis
+    assert list(d.sample(7).shape) == [7, 4, 5]
+
+
+def test_normal_batch_shape(dev):
+    # test/distributions/utils.py:322-337
+    for ms, ss, target in [([2, 3], [3], [2, 3]), ([2, 1, 4], [2, 3, 4], [2, 3, 4]), ([2, 3, 5], [3, 1], [2, 3, 5])]:
+        assert list(Normal(mean=torch.zeros(ms), std=torch.ones(ss), device=dev).batch_shape) == target
+    with pytest.raises(RuntimeError):
+        Normal(mean=torch.zeros([2, 3, 5]), std=torch.ones([3, 2]), device=dev)
+
+
+def test_normal_log_prob_shapes(dev):
+    # test/distributions/utils.py:252-269
+    for ms, ss, gs, target in [([2, 3], [2, 1], [1, 3], [2, 3]), ([1, 3], [1, 1], [2, 1, 3], [2, 1, 3]),
+                               ([1, 5], [3, 1], [1, 2, 1, 1], [1, 2, 3, 5])]:
+        d = Normal(mean=torch.zeros(ms), std=torch.ones(ss), device=dev)
+        assert list(d.log_prob(torch.zeros(gs)).shape) == target
+    # docs/tutorials/concepts.rst:75-79
+    d = Normal(mean=torch.zeros([2, 1, 3]), std=1., group_ndims=2, device=dev)
+    assert list(d.log_prob(torch.zeros([5, 1, 1, 3])).shape) == [5, 2]
+
+
+def test_normal_property(dev):
+    # test_normal.py:55-63
+    mean, std = T([1., 2.], dev), T([1., 4.], dev)
+    d = Normal(mean=mean, std=std)
+    assert mean.equal(d.mean) and std.equal(d.std) and torch.log(std).equal(d.logstd)
+    s = d.sample()
+    assert torch.norm(torch.log(d.prob(s)) - d.log_prob(s)) < 1e-6
+
+
+def test_normal_reparameterized_gradients(dev):
+    # test_normal.py:65-84
+    mean = torch.ones([2, 3], device=dev, requires_grad=True)
+    logstd = torch.ones([2, 3], device=dev, requires_grad=True)
+    s = Normal(mean=mean, logstd=logstd).sample()
+    gm, gl = torch.autograd.grad(s.sum(), [mean, logstd], allow_unused=True)
+    assert gm is not None and gl is not None
+    close(gm, np.ones([2, 3]))
+    s = Normal(mean=mean, logstd=logstd, is_reparameterized=False).sample()
+    assert not s.requires_grad                       # detached draw, normal.py:102
+
+
+def test_normal_known_values(dev):
+    # test_normal.py:92-126, scipy logpdf, rtol 1e-3 there; tighter here
+    def check(given, mean, logstd):
+        mean, given, logstd = (np.array(v, np.float32) for v in (mean, given, logstd))
+        target = np.array(stats.norm.logpdf(given, mean, np.exp(logstd)), np.float32)
+        lp1 = Normal(mean=T(mean, dev), logstd=T(logstd, dev)).log_prob(T(given, dev))
+        lp2 = Normal(mean=T(mean, dev), std=T(np.exp(logstd), dev)).log_prob(T(given, dev))
+        close(lp1, target, 2e-5, 2e-6)
+        close(lp2, target, 2e-5, 2e-6)
+    check([0.], [0.], [0.])
+    check([0.99, 0.9, 9., 99.], [1.], [-3., -1., 1., 10.])
+    check([7.], [0., 4.], [[1., 2.], [3., 5.]])
+    lp = Normal(mean=T([1.], dev), logstd=T([-3., -1., 1., 10.], dev)).log_prob(T([0.99, 0.9, 9., 99.], dev))
+    close(lp, [2.06088996, 0.04411618, -6.24966812, -10.91894817], 2e-6, 2e-6)
+    d = Normal(mean=T([[-1., 1.], [0., -2.]], dev), std=1., group_ndims=1, device=dev)
+    close(d.log_prob(torch.zeros([1])), [-2.83787704, -3.83787727], 1e-6, 1e-6)   # concepts.rst:70-73
+
+
+def test_normal_float64_is_rejected_loudly(dev):
+    d = Normal(mean=torch.zeros([2], dtype=torch.float64), std=torch.ones([2], dtype=torch.float64), device=dev)
+    assert d.dtype == torch.float64
+    with pytest.raises(NotImplementedError, match="float32"):
+        d.sample()
+
+
+# ------------------------------------------------------------------ Normal: golden fixtures
+def test_normal_sample_logprob_golden(dev):
+    g = load_golden("g_normal_sample")
+    for c in range(int(g["n_cases"])):
+        p = "c%03d_" % c
+        K = int(g[p + "K"])
+        K = None if K < 0 else K
+        mu, ls = T(g[p + "mu"], dev, True), T(g[p + "ls"], dev, True)
+        kw = dict(is_reparameterized=bool(g[p + "reparam"]), group_ndims=int(g[p + "g"]))
+        if int(g[p + "use_logstd"]):
+            d = Normal(mean=mu, logstd=ls, **kw)
+        else:
+            d = Normal(mean=mu, std=torch.exp(ls), **kw)
+        with zs.inject_epsilon([g[p + "eps"]]):
+            z = d.sample(K)
+        assert tuple(z.shape) == g[p + "z"].shape
+        assert np.array_equal(z.detach().cpu().numpy(), g[p + "z"]), "z must be bit-exact (case %d)" % c
+        lp = d.log_prob(None)
+        close(lp, g[p + "lp"], 1e-5, 2e-5)
+        obj = (lp * T(g[p + "w"], dev)).sum() + (z * T(g[p + "wz"], dev)).sum()
+        gmu, gls = torch.autograd.grad(obj, [mu, ls], allow_unused=True)
+        gmu = gmu if gmu is not None else torch.zeros_like(mu)
+        gls = gls if gls is not None else torch.zeros_like(ls)
+        close(gmu, g[p + "gmu"], 1e-4, 1e-4)
+        close(gls, g[p + "gls"], 1e-4, 2e-4)
+
+
+def test_normal_logprob_given_golden(dev):
+    g = load_golden("g_normal_logprob")
+    for c in range(int(g["n_cases"])):
+        p = "c%03d_" % c
+        mu, sd, x = T(g[p + "mu"], dev, True), T(g[p + "sd"], dev, True), T(g[p + "x"], dev, True)
+        lp = Normal(mean=mu, std=sd, group_ndims=int(g[p + "g"])).log_prob(x)
+        assert tuple(lp.shape) == g[p + "lp"].shape
+        close(lp, g[p + "lp"], 1e-5, 1e-5)
+        gmu, gsd, gx = torch.autograd.grad((lp * T(g[p + "w"], dev)).sum(), [mu, sd, x])
+        close(gmu, g[p + "gmu"], 1e-4, 1e-4)
+        close(gsd, g[p + "gsd"], 1e-4, 1e-4)
+        close(gx, g[p + "gx"], 1e-4, 1e-4)
+
+
+def test_normal_eps_shared_along_std_only_axes(dev):
+    # normal.py:91-92,104: the draw has mean's shape
+    g = load_golden("g_normal_epsshape")
+    d = Normal(mean=T(g["mu"], dev), std=T(g["sd"], dev))
+    with zs.inject_epsilon([g["eps"]]):
+        z = d.sample(2)
+    assert np.array_equal(z.cpu().numpy(), g["z"])
+    close(d.log_prob(None), g["lp"], 1e-5, 1e-6)
+    z2 = d.sample(2)                       # Philox path: rows along the std-only axis share their draw
+    e = (z2 - d.mean) / d.std
+    close(e[:, 0], e[:, 1], 1e-4, 1e-5)
+
+
+def test_normal_philox_statistics_and_reproducibility(dev):
+    from zhusuan import _rng
+    n = 1 << 18
+    mu = torch.full([n // 4, 4], 1.5, device=dev)
+    sd = torch.full([n // 4, 4], 0.5, device=dev)
+    d = Normal(mean=mu, std=sd, group_ndims=1)
+    torch.manual_seed(7)
+    _rng.manual_seed_host(7)
+    z = d.sample(2)
+    lp = d.log_prob(None)
+    e = ((z - 1.5) / 0.5).double().cpu().numpy().ravel()
+    assert abs(e.mean()) < 6e-3 and abs(e.std() - 1) < 6e-3
+    assert stats.kstest(e[:50000], "norm").pvalue > 1e-4
+    assert abs(stats.skew(e)) < 0.02 and abs(stats.kurtosis(e)) < 0.05
+    ref = stats.norm.logpdf(z.double().cpu().numpy(), 1.5, 0.5).sum(-1)
+    close(lp, ref, 1e-5, 1e-4)
+    torch.manual_seed(7)
+    _rng.manual_seed_host(7)
+    z_again = d.sample(2)
+    assert torch.equal(z, z_again)
+    z_next = d.sample(2)
+    assert not torch.equal(z, z_next)
+
+
+# ------------------------------------------------------------------ Bernoulli: reference test_bernoulli.py
+def test_bernoulli_init(dev):
+    # test_bernoulli.py:20-33
+    ber = Bernoulli(0., device=dev)
+    assert ber.dtype == torch.float32
+    assert float(ber.probs) == 0.5
+    ber = Bernoulli(probs=[0.4, 0.5], device=dev)
+    p = ber.probs
+    assert ber.logits.equal(torch.log(p / (torch.ones_like(p) - p)))
+    with pytest.raises(ValueError, match=r"Either.*should be passed"):
+        Bernoulli(logits=1, probs=0.1, device=dev)
+    with pytest.raises(ValueError, match=r"Either.*should be passed"):
+        Bernoulli(device=dev)
+    with pytest.raises(TypeError, match=r"must have a dtype in"):
+        Bernoulli(probs=0, dtype=torch.int64, device=dev)
+    for bad in (torch.int16, torch.float16, torch.uint8, torch.bool):
+        with pytest.raises(TypeError):
+            Bernoulli(torch.tensor([1.]), dtype=bad, device=dev)
+    assert Bernoulli(logits=torch.zeros(2), device=dev).is_reparameterized is False
+
+
+def test_bernoulli_property_and_shapes(dev):
+    logits = torch.rand([2, 2], device=dev)
+    ber = Bernoulli(logits=logits)
+    assert logits.equal(ber.logits)
+    close(ber.probs, torch.sigmoid(logits), 1e-6, 1e-7)
+    s = ber.sample()
+    assert set(np.unique(s.cpu().numpy())) <= {0.0, 1.0}
+    assert torch.norm(torch.log(ber.prob(s)) - ber.log_prob(s)) < 1e-5
+    for shp in ([], [2], [2, 3], [2, 1, 4]):
+        assert list(Bernoulli(torch.ones(shp), device=dev).batch_shape) == shp
+    for shp, n, target in [([2, 3], 1, [2, 3]), ([1, 3], 2, [2, 1, 3]), ([2, 1, 5], 3, [3, 2, 1, 5])]:
+        s = Bernoulli(torch.ones(shp), device=dev).sample(n)
+        assert list(s.shape) == target and s.dtype == torch.float32
+    for ps, gs, target in [([2, 3], [1, 3], [2, 3]), ([1, 3], [2, 2, 3], [2, 2, 3]), ([1, 5], [1, 2, 3, 1], [1, 2, 3, 5])]:
+        assert list(Bernoulli(torch.ones(ps), device=dev).log_prob(torch.ones(gs)).shape) == target
+
+
+def test_bernoulli_known_values(dev):
+    # test_bernoulli.py:56-73
+    for logits, given in [([0.], [0.]), ([2., 1.], [0., 1.])]:
+        logits = np.array(logits, np.float32)
+        prob = 1. / (1. + np.exp(-logits))
+        given = np.array(given, np.float32)
+        target = stats.bernoulli.logpmf(given, prob)
+        close(Bernoulli(logits, device=dev).log_prob(given), target, 1e-5, 1e-6)
+        close(Bernoulli(probs=prob, device=dev).log_prob(given), target, 1e-5, 1e-6)
+    close(Bernoulli(logits=T([2., 1.], dev)).log_prob(T([0., 1.], dev)), [-2.12692761, -0.31326166], 2e-6, 2e-6)
+    # +1e-8 is part of the contract: p in {0, 1}
+    close(Bernoulli(probs=T([0., 1.], dev)).log_prob(T([1., 1.], dev)), [-18.420681, 0.0], 1e-6, 1e-6)
+
+
+def test_bernoulli_golden(dev):
+    g = load_golden("g_bernoulli")
+    for c in range(int(g["n_cases"])):
+        p = "c%03d_" % c
+        gnd = int(g[p + "g"])
+        x = T(g[p + "x"], dev)
+        if int(g[p + "from_logits"]):
+            lg = T(g[p + "logits"], dev, True)
+            d = Bernoulli(logits=lg, group_ndims=gnd)
+            close(d.probs, g[p + "probs"], 1e-6, 1e-7)
+            lp = d.log_prob(x)
+            close(lp, g[p + "lp"], 1e-5, 2e-6)
+            (gl,) = torch.autograd.grad((lp * T(g[p + "w"], dev)).sum(), [lg])
+            close(gl, g[p + "gl"], 1e-4, 1e-5)
+        else:
+            pr = T(g[p + "probs"], dev, True)
+            lp = Bernoulli(probs=pr, group_ndims=gnd).log_prob(x)
+            assert tuple(lp.shape) == g[p + "lp"].shape
+            close(lp, g[p + "lp"], 1e-5, 1e-4 if gnd else 2e-6)
+            if (p + "gp") in g.files:
+                (gp,) = torch.autograd.grad((lp * T(g[p + "w"], dev)).sum(), [pr])
+                close(gp, g[p + "gp"], 1e-4, 1e-4)
+
+
+def test_bernoulli_sample_rate(dev):
+    p = torch.tensor([0.1, 0.5, 0.9], device=dev).repeat(4)
+    s = Bernoulli(probs=p).sample(20000)
+    rate = s.mean(0).cpu().numpy()
+    np.testing.assert_allclose(rate, p.cpu().numpy(), atol=0.012)
+
+
+def test_cpu_tensor_without_gpu_library_fails_loudly():
+    # no hook installed: a CPU tensor must not be silently computed somewhere else
+    from zhusuan import _hip
+    assert _hip._HOST_LIB is None
+    d = Normal(mean=torch.zeros(4), std=torch.ones(4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        d.sample()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Bernoulli(probs=torch.full([4], 0.5)).log_prob(torch.ones(4))

@@ -1,0 +1,283 @@
+// Bernoulli kernels (K3, K5) for gfx950.  K3 is the byte-dominant kernel of the VAE / IWAE
+// objectives: it streams p[K, B, 784] once (16 B per lane, four independent loads in flight per
+// lane), re-reads the observation row x[b, :] from L2, and reduces each row on the wavefront.
+#include "zs_common.h"
+#include "../../include/zs_hip.h"
+
+using namespace zs;
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_fast(float l) {  // torch.sigmoid: 1 / (1 + exp(-l)), bernoulli.py:50
+  return __builtin_amdgcn_rcpf(1.0f + exp_fast(-l));
+}
+
+__device__ __forceinline__ float bern_row_terms(const float4& pv, const float4& xv) {
+  return bern_lp2_term(pv.x, xv.x) + bern_lp2_term(pv.y, xv.y) + bern_lp2_term(pv.z, xv.z) +
+         bern_lp2_term(pv.w, xv.w);
+}
+
+// d/dp of x*log(p+e) + (1-x)*log((1-p)+e)
+__device__ __forceinline__ float bern_dp(float p, float x) {
+  return x * __builtin_amdgcn_rcpf(p + ZS_BERN_EPS) - (1.0f - x) * __builtin_amdgcn_rcpf((1.0f - p) + ZS_BERN_EPS);
+}
+
+// ------------------------------------------------------------------------------------
+// K3 forward.  One wave handles `rpw` rows per pass with G lanes per row; for long rows
+// (D4 > 64, e.g. 784 pixels = 196 float4) G = 64 and the four chunk loads of a lane are issued
+// back to back before any arithmetic.  LOGITS: the streamed operand holds logits and
+// p = sigmoid(logit) is formed in registers (optionally stored to probs_out).
+// ------------------------------------------------------------------------------------
+template <bool LOGITS, bool WRITE_P>
+__global__ __launch_bounds__(256) void k_bern_logprob_rows(
+    const float4* __restrict__ p, const float4* __restrict__ x, int64_t xrows, float* __restrict__ lp,
+    float4* __restrict__ probs_out, int64_t K, int64_t R, int D4, int G, int rpw, int p2,
+    int64_t sk, int64_t sr) {
+  const int lane = threadIdx.x & 63;
+  const int rw = lane / G, lig = lane - rw * G;
+  const bool lane_on = rw < rpw;
+  const int64_t rows = K * R;
+  const int64_t tiles = (rows + rpw - 1) / rpw;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < tiles; t += nwaves) {
+    const int64_t row = t * rpw + rw;
+    const bool on = lane_on && row < rows;
+    float acc = 0.f;
+    if (on) {
+      const float4* __restrict__ prow = p + row * D4;
+      const float4* __restrict__ xrow = x + (xrows == rows ? row : row % xrows) * D4;
+      float4* __restrict__ orow = WRITE_P ? probs_out + row * D4 : nullptr;
+      for (int c0 = lig; c0 < D4; c0 += 4 * G) {
+        float4 pv[4], xv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + u * G;
+          ok[u] = c < D4;
+          if (ok[u]) {
+            pv[u] = prow[c];
+            xv[u] = xrow[c];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (ok[u]) {
+            if (LOGITS) {
+              pv[u].x = sigmoid_fast(pv[u].x);
+              pv[u].y = sigmoid_fast(pv[u].y);
+              pv[u].z = sigmoid_fast(pv[u].z);
+              pv[u].w = sigmoid_fast(pv[u].w);
+              if (WRITE_P) orow[c0 + u * G] = pv[u];
+            }
+            acc += bern_row_terms(pv[u], xv[u]);
+          }
+        }
+      }
+    }
+    acc = group_sum_down(acc, lig, G, p2);
+    if (on && lig == 0) {
+      const int64_t k = row / R, r = row - k * R;
+      lp[k * sk + r * sr] = acc * ZS_LN2;
+    }
+  }
+}
+
+template <bool LOGITS>
+__global__ __launch_bounds__(256) void k_bern_logprob_serial(
+    const float* __restrict__ p, const float* __restrict__ x, int64_t Px, float* __restrict__ lp,
+    float* __restrict__ probs_out, int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+  const int64_t rows = K * R;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
+       row += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int64_t d = 0; d < D; ++d) {
+      const int64_t i = row * D + d;
+      float pv = p[i];
+      if (LOGITS) {
+        pv = sigmoid_fast(pv);
+        if (probs_out) probs_out[i] = pv;
+      }
+      acc += bern_lp2_term(pv, x[i % Px]);
+    }
+    const int64_t k = row / R, r = row - k * R;
+    lp[k * sk + r * sr] = acc * ZS_LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K3 backward: gp = glp[k, r] * (x/(p+e) - (1-x)/((1-p)+e))   [* p*(1-p) for logits]
+// same row mapping as the forward; reads p and x, writes gp, 16 B per lane.
+// ------------------------------------------------------------------------------------
+template <bool LOGITS>
+__global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
+    const float4* __restrict__ p, const float4* __restrict__ x, int64_t xrows,
+    const float* __restrict__ glp, int64_t gsk, int64_t gsr, float4* __restrict__ gp,
+    int64_t K, int64_t R, int D4, int G, int rpw) {
+  const int lane = threadIdx.x & 63;
+  const int rw = lane / G, lig = lane - rw * G;
+  const bool lane_on = rw < rpw;
+  const int64_t rows = K * R;
+  const int64_t tiles = (rows + rpw - 1) / rpw;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < tiles; t += nwaves) {
+    const int64_t row = t * rpw + rw;
+    if (!(lane_on && row < rows)) continue;
+    const int64_t k = row / R, r = row - k * R;
+    const float g = glp[k * gsk + r * gsr];
+    const float4* __restrict__ prow = p + row * D4;
+    const float4* __restrict__ xrow = x + (xrows == rows ? row : row % xrows) * D4;
+    float4* __restrict__ grow = gp + row * D4;
+    for (int c0 = lig; c0 < D4; c0 += 4 * G) {
+      float4 pv[4], xv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * G;
+        ok[u] = c < D4;
+        if (ok[u]) {
+          pv[u] = prow[c];
+          xv[u] = xrow[c];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ok[u]) {
+          float4 o;
+          if (LOGITS) {
+            const float a = sigmoid_fast(pv[u].x), b = sigmoid_fast(pv[u].y), c = sigmoid_fast(pv[u].z),
+                        d = sigmoid_fast(pv[u].w);
+            o.x = g * bern_dp(a, xv[u].x) * a * (1.0f - a);
+            o.y = g * bern_dp(b, xv[u].y) * b * (1.0f - b);
+            o.z = g * bern_dp(c, xv[u].z) * c * (1.0f - c);
+            o.w = g * bern_dp(d, xv[u].w) * d * (1.0f - d);
+          } else {
+            o.x = g * bern_dp(pv[u].x, xv[u].x);
+            o.y = g * bern_dp(pv[u].y, xv[u].y);
+            o.z = g * bern_dp(pv[u].z, xv[u].z);
+            o.w = g * bern_dp(pv[u].w, xv[u].w);
+          }
+          grow[c0 + u * G] = o;
+        }
+      }
+    }
+  }
+}
+
+template <bool LOGITS>
+__global__ __launch_bounds__(256) void k_bern_logprob_bwd_serial(
+    const float* __restrict__ p, const float* __restrict__ x, int64_t Px, const float* __restrict__ glp,
+    int64_t gsk, int64_t gsr, float* __restrict__ gp, int64_t N, int64_t R, int64_t D) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / D;
+    const int64_t k = row / R, r = row - k * R;
+    const float g = glp[k * gsk + r * gsr];
+    float pv = p[i];
+    float scale = 1.0f;
+    if (LOGITS) {
+      pv = sigmoid_fast(pv);
+      scale = pv * (1.0f - pv);
+    }
+    gp[i] = g * bern_dp(pv, x[i % Px]) * scale;
+  }
+}
+
+// K5: Bernoulli._sample -- out = (u < p), u ~ U(0,1) from Philox (bernoulli.py:80)
+__global__ __launch_bounds__(256) void k_bern_sample(const float* __restrict__ p, int64_t Pp,
+                                                     float* __restrict__ out, int64_t N, uint64_t seed,
+                                                     uint64_t call) {
+  const int64_t groups = (N + 3) / 4;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+    const Philox4 r = philox4x32_10((uint64_t)g, call, seed);
+    const float u[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = g * 4 + j;
+      if (i < N) out[i] = u[j] < p[i % Pp] ? 1.0f : 0.0f;
+    }
+  }
+}
+
+template <bool LOGITS>
+int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* probs_out, int64_t K, int64_t R,
+               int64_t D, int64_t sk, int64_t sr, hipStream_t st) {
+  if (!p || !x || !lp || K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
+  const int64_t N = K * R * D;
+  if (N == 0) return 0;
+  if (N % Px) return ZS_EINVAL;
+  const bool vec = (D % 4 == 0) && Px >= D && (Px % D == 0) && aligned16(p) && aligned16(x) &&
+                   (!probs_out || aligned16(probs_out));
+  if (vec) {
+    const int D4 = (int)(D / 4);
+    const int G = D4 >= 64 ? 64 : D4, rpw = 64 / G, p2 = next_pow2(G);
+    const int64_t tiles = (K * R + rpw - 1) / rpw;
+    const unsigned grid = grid_for(tiles, 4);
+    if (probs_out)
+      hipLaunchKernelGGL((k_bern_logprob_rows<LOGITS, true>), dim3(grid), dim3(256), 0, st, (const float4*)p,
+                         (const float4*)x, Px / D, lp, (float4*)probs_out, K, R, D4, G, rpw, p2, sk, sr);
+    else
+      hipLaunchKernelGGL((k_bern_logprob_rows<LOGITS, false>), dim3(grid), dim3(256), 0, st, (const float4*)p,
+                         (const float4*)x, Px / D, lp, (float4*)nullptr, K, R, D4, G, rpw, p2, sk, sr);
+  } else {
+    hipLaunchKernelGGL((k_bern_logprob_serial<LOGITS>), dim3(grid_for(K * R, 256)), dim3(256), 0, st, p, x, Px,
+                       lp, probs_out, K, R, D, sk, sr);
+  }
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+template <bool LOGITS>
+int launch_bwd(const float* p, const float* x, int64_t Px, const float* glp, int64_t gsk, int64_t gsr, float* gp,
+               int64_t K, int64_t R, int64_t D, hipStream_t st) {
+  if (!p || !x || !glp || !gp || K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
+  const int64_t N = K * R * D;
+  if (N == 0) return 0;
+  if (N % Px) return ZS_EINVAL;
+  const bool vec = (D % 4 == 0) && Px >= D && (Px % D == 0) && aligned16(p) && aligned16(x) && aligned16(gp);
+  if (vec) {
+    const int D4 = (int)(D / 4);
+    const int G = D4 >= 64 ? 64 : D4, rpw = 64 / G;
+    const int64_t tiles = (K * R + rpw - 1) / rpw;
+    hipLaunchKernelGGL((k_bern_logprob_bwd_rows<LOGITS>), dim3(grid_for(tiles, 4)), dim3(256), 0, st,
+                       (const float4*)p, (const float4*)x, Px / D, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
+  } else {
+    hipLaunchKernelGGL((k_bern_logprob_bwd_serial<LOGITS>), dim3(grid_for(N, 256)), dim3(256), 0, st, p, x, Px,
+                       glp, gsk, gsr, gp, N, R, D);
+  }
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int zs_bernoulli_logprob_f32(const float* p, const float* x, int64_t Px, float* lp, int64_t K,
+                                        int64_t R, int64_t D, int64_t sk, int64_t sr, void* stream) {
+  return launch_fwd<false>(p, x, Px, lp, nullptr, K, R, D, sk, sr, (hipStream_t)stream);
+}
+
+extern "C" int zs_bernoulli_logprob_bwd_f32(const float* p, const float* x, int64_t Px, const float* glp,
+                                            int64_t gsk, int64_t gsr, float* gp, int64_t K, int64_t R,
+                                            int64_t D, void* stream) {
+  return launch_bwd<false>(p, x, Px, glp, gsk, gsr, gp, K, R, D, (hipStream_t)stream);
+}
+
+extern "C" int zs_bernoulli_logits_logprob_f32(const float* logits, const float* x, int64_t Px, float* lp,
+                                               float* probs_out, int64_t K, int64_t R, int64_t D, int64_t sk,
+                                               int64_t sr, void* stream) {
+  return launch_fwd<true>(logits, x, Px, lp, probs_out, K, R, D, sk, sr, (hipStream_t)stream);
+}
+
+extern "C" int zs_bernoulli_logits_logprob_bwd_f32(const float* logits, const float* x, int64_t Px,
+                                                   const float* glp, int64_t gsk, int64_t gsr, float* glogits,
+                                                   int64_t K, int64_t R, int64_t D, void* stream) {
+  return launch_bwd<true>(logits, x, Px, glp, gsk, gsr, glogits, K, R, D, (hipStream_t)stream);
+}
+
+extern "C" int zs_bernoulli_sample_f32(const float* p, int64_t Pp, float* out, int64_t N, uint64_t seed,
+                                       uint64_t offset, void* stream) {
+  if (!p || !out || N < 0 || Pp < 1) return ZS_EINVAL;
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_bern_sample, dim3(grid_for((N + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, Pp,
+                     out, N, seed, offset);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}

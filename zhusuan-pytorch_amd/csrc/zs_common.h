@@ -1,0 +1,122 @@
+// Device-side helpers shared by the gfx950 kernels of the VI hot path.
+// Wavefront = 64 lanes everywhere (CDNA4); no MFMA on this path (no dense contraction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZS_WAVE 64
+#define ZS_LN2 0.69314718055994530942f
+#define ZS_NEG_HALF_LOG_2PI (-0.91893853320467274178f)  // -0.5*log(2*pi), normal.py:122
+#define ZS_BERN_EPS 1e-8f                                 // bernoulli.py:94
+
+#define ZS_CHECK_LAUNCH()                           \
+  do {                                              \
+    hipError_t e__ = hipGetLastError();             \
+    if (e__ != hipSuccess) return (int)e__;         \
+  } while (0)
+
+namespace zs {
+
+// ---------------------------------------------------------------- math
+// v_log_f32 / v_exp_f32 are base-2 and 1-ulp; natural log/exp are one multiply away.
+__device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float ln_fast(float x) { return log2_fast(x) * ZS_LN2; }
+__device__ __forceinline__ float exp_fast(float x) { return exp2_fast(x * 1.44269504088896340736f); }
+
+// Normal log-density term for one element given log2(sigma) and prec = sigma^-2
+// (normal.py:121-124: c - logstd - 0.5 * precision * (x - mean)^2).
+__device__ __forceinline__ float normal_lp_term(float diff, float logstd, float prec) {
+  return (ZS_NEG_HALF_LOG_2PI - logstd) - 0.5f * prec * (diff * diff);
+}
+
+// Bernoulli term in log2 units (bernoulli.py:94); caller multiplies the row sum by ln 2.
+__device__ __forceinline__ float bern_lp2_term(float p, float x) {
+  float a = log2_fast(p + ZS_BERN_EPS);
+  float b = log2_fast((1.0f - p) + ZS_BERN_EPS);
+  return x * a + (1.0f - x) * b;
+}
+
+// ---------------------------------------------------------------- wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, ZS_WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, ZS_WAVE));
+  return v;
+}
+// Sum over groups of G consecutive lanes (G need not be a power of two, groups start at
+// multiples of G).  The total lands in the first lane of each group; other lanes hold junk.
+__device__ __forceinline__ float group_sum_down(float v, int lane_in_group, int G, int pow2_ge_G) {
+  for (int o = pow2_ge_G >> 1; o > 0; o >>= 1) {
+    float t = __shfl_down(v, o, ZS_WAVE);
+    if (lane_in_group + o < G) v += t;
+  }
+  return v;
+}
+__host__ __device__ __forceinline__ int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct Philox4 {
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) {
+  uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32);
+  uint32_t c2 = (uint32_t)call, c3 = (uint32_t)(call >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  Philox4 o = {c0, c1, c2, c3};
+  return o;
+}
+// 24-bit uniform strictly inside (0, 1)
+__device__ __forceinline__ float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * 5.9604644775390625e-08f; }
+
+// Four standard normals for Philox group `group` (Box-Muller on (x,y) and (z,w)).
+// v_sin_f32 / v_cos_f32 take their argument in revolutions, so sin(2*pi*u) = v_sin(u).
+__device__ __forceinline__ float4 philox_normal4(uint64_t group, uint64_t call, uint64_t seed) {
+  Philox4 r = philox4x32_10(group, call, seed);
+  float u0 = u01(r.x), u1 = u01(r.y), u2 = u01(r.z), u3 = u01(r.w);
+  float ra = __builtin_sqrtf(-2.0f * ZS_LN2 * log2_fast(u0));
+  float rb = __builtin_sqrtf(-2.0f * ZS_LN2 * log2_fast(u2));
+  float4 n;
+  n.x = ra * __builtin_amdgcn_cosf(u1);
+  n.y = ra * __builtin_amdgcn_sinf(u1);
+  n.z = rb * __builtin_amdgcn_cosf(u3);
+  n.w = rb * __builtin_amdgcn_sinf(u3);
+  return n;
+}
+
+__device__ __forceinline__ float f4_get(const float4& v, int i) {
+  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+__host__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// grid size for a grid-stride kernel: enough blocks to fill 256 CUs several times over,
+// capped so that launch overhead stays flat (cdna_hip_programming.md guideline 11).
+__host__ __forceinline__ unsigned grid_for(int64_t work_items, int per_block, unsigned cap = 256u * 16u) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > (int64_t)cap) b = cap;
+  return (unsigned)b;
+}
+
+}  // namespace zs

@@ -1,0 +1,275 @@
+// Importance-weighted reductions (K4) and RNG utilities for gfx950.
+//
+// Layout: log-joint rows are K-fastest ([B, ld], K particles of one datapoint contiguous), so for
+// K <= 64 one wavefront owns one datapoint with lane == particle: max / sum / arg-max are
+// __shfl_xor butterflies and nothing touches LDS.  For K > 64 one 256-thread workgroup owns a
+// datapoint, lanes stride over K and the per-wave partials are combined through LDS.
+//
+// VIMCO (importance_weighted_objective.py:152-191) needs, for every particle j, the
+// log-mean-exp of the row with entry j replaced by the mean of the others.  The reference
+// materialises a [B, K, K] tensor; here it is O(K) per row:
+//   j != argmax : max stays m1, sum = (S - e_j) + exp(sub_j - m1)      (S - e_j >= 1: no cancellation)
+//   j == argmax : max becomes m2 (second largest), sum = S2 + exp(sub_j - m2) with
+//                 S2 = sum_{i != j} exp(l_i - m2) accumulated separately (exact, no subtraction).
+#include "zs_common.h"
+#include "../../include/zs_hip.h"
+
+using namespace zs;
+
+namespace {
+
+struct IwRow {  // row-level scalars, uniform across the lanes that own the row
+  float m1, m2, S, S2, sumL, logS;
+  int jstar;
+  float invK, invKm1;
+};
+
+// per-particle outputs given the row scalars
+__device__ __forceinline__ void iw_particle(const IwRow& r, float l, float lq, int j, int estimator,
+                                            float& wt, float& cost_term, float& cq) {
+  const float e = exp_fast(l - r.m1);
+  wt = e / r.S;
+  cost_term = -wt * l;
+  cq = wt;
+  if (estimator == ZS_IW_VIMCO) {
+    const float sub = (r.sumL - l) * r.invKm1;
+    float signal;
+    if (j != r.jstar) {
+      const float sx = (r.S - e) + exp_fast(sub - r.m1);
+      signal = r.logS - ln_fast(sx);
+    } else {
+      const float sx = r.S2 + exp_fast(sub - r.m2);
+      signal = (r.logS - ln_fast(sx)) + (r.m1 - r.m2);
+    }
+    cost_term -= lq * signal;
+    cq = wt - signal;
+  }
+}
+
+// ---- K <= 64: one wave per datapoint, lane = particle
+__global__ __launch_bounds__(256) void k_iw_reduce_wave(
+    const float* __restrict__ logp, int64_t ld_p, const float* __restrict__ logq, int64_t ld_q,
+    int64_t B, int K, int estimator, float* __restrict__ cost_b, float* __restrict__ bound_b,
+    float* __restrict__ coef_p, float* __restrict__ coef_q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const bool on = lane < K;
+  for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < B; b += nwaves) {
+    float lq = 0.f, l = -INFINITY;
+    if (on) {
+      lq = logq[b * ld_q + lane];
+      l = logp[b * ld_p + lane] - lq;
+    }
+    IwRow r;
+    r.m1 = wave_max(l);
+    const unsigned long long hit = __ballot(on && l == r.m1);
+    r.jstar = hit ? (int)__ffsll((long long)hit) - 1 : 0;
+    r.m2 = wave_max((on && lane != r.jstar) ? l : -INFINITY);
+    const float e = on ? exp_fast(l - r.m1) : 0.f;
+    r.S = wave_sum(e);
+    r.sumL = wave_sum(on ? l : 0.f);
+    r.S2 = 0.f;
+    if (estimator == ZS_IW_VIMCO) r.S2 = wave_sum((on && lane != r.jstar) ? exp_fast(l - r.m2) : 0.f);
+    r.logS = ln_fast(r.S);
+    r.invK = 1.0f / (float)K;
+    r.invKm1 = K > 1 ? 1.0f / (float)(K - 1) : 0.f;
+    float wt = 0.f, ct = 0.f, cq = 0.f;
+    if (on) iw_particle(r, l, lq, lane, estimator, wt, ct, cq);
+    const float cost = wave_sum(ct);
+    if (on) {
+      if (coef_p) coef_p[b * K + lane] = -wt;
+      if (coef_q) coef_q[b * K + lane] = cq;
+    }
+    if (lane == 0) {
+      if (cost_b) cost_b[b] = cost;
+      if (bound_b) bound_b[b] = ln_fast(r.S * r.invK) + r.m1;  // log(mean(exp(x - max))) + max, utils.py:18
+    }
+  }
+}
+
+// ---- any K: one 256-thread workgroup per datapoint, LDS-staged partials
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ int block_min_int(int v, int* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int t = __shfl_xor(v, o, ZS_WAVE);
+    v = t < v ? t : v;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int a = sh[0] < sh[1] ? sh[0] : sh[1], c = sh[2] < sh[3] ? sh[2] : sh[3];
+  return a < c ? a : c;
+}
+
+__global__ __launch_bounds__(256) void k_iw_reduce_block(
+    const float* __restrict__ logp, int64_t ld_p, const float* __restrict__ logq, int64_t ld_q,
+    int64_t B, int64_t K, int estimator, float* __restrict__ cost_b, float* __restrict__ bound_b,
+    float* __restrict__ coef_p, float* __restrict__ coef_q) {
+  __shared__ float shf[4];
+  __shared__ int shi[4];
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* __restrict__ pp = logp + b * ld_p;
+    const float* __restrict__ qq = logq + b * ld_q;
+    // pass 1: max, sum of l
+    float mx = -INFINITY, sl = 0.f;
+    for (int64_t k = threadIdx.x; k < K; k += 256) {
+      const float l = pp[k] - qq[k];
+      mx = fmaxf(mx, l);
+      sl += l;
+    }
+    IwRow r;
+    r.m1 = block_max(mx, shf);
+    r.sumL = block_sum(sl, shf);
+    // pass 2: first arg-max, S
+    int jm = 0x7fffffff;
+    float s = 0.f;
+    for (int64_t k = threadIdx.x; k < K; k += 256) {
+      const float l = pp[k] - qq[k];
+      if (l == r.m1 && (int)k < jm) jm = (int)k;
+      s += exp_fast(l - r.m1);
+    }
+    r.jstar = block_min_int(jm, shi);
+    r.S = block_sum(s, shf);
+    r.m2 = -INFINITY;
+    r.S2 = 0.f;
+    if (estimator == ZS_IW_VIMCO) {
+      float m2 = -INFINITY;
+      for (int64_t k = threadIdx.x; k < K; k += 256)
+        if ((int)k != r.jstar) m2 = fmaxf(m2, pp[k] - qq[k]);
+      r.m2 = block_max(m2, shf);
+      float s2 = 0.f;
+      for (int64_t k = threadIdx.x; k < K; k += 256)
+        if ((int)k != r.jstar) s2 += exp_fast((pp[k] - qq[k]) - r.m2);
+      r.S2 = block_sum(s2, shf);
+    }
+    r.logS = ln_fast(r.S);
+    r.invK = 1.0f / (float)K;
+    r.invKm1 = K > 1 ? 1.0f / (float)(K - 1) : 0.f;
+    float ct = 0.f;
+    for (int64_t k = threadIdx.x; k < K; k += 256) {
+      const float lq = qq[k];
+      const float l = pp[k] - lq;
+      float wt, c1, cq;
+      iw_particle(r, l, lq, (int)k, estimator, wt, c1, cq);
+      ct += c1;
+      if (coef_p) coef_p[b * K + k] = -wt;
+      if (coef_q) coef_q[b * K + k] = cq;
+    }
+    const float cost = block_sum(ct, shf);
+    if (threadIdx.x == 0) {
+      if (cost_b) cost_b[b] = cost;
+      if (bound_b) bound_b[b] = ln_fast(r.S * r.invK) + r.m1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_philox_normal(float* __restrict__ out, int64_t N, uint64_t seed,
+                                                       uint64_t call) {
+  const int64_t groups = (N + 3) / 4;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+    const float4 n = philox_normal4((uint64_t)g, call, seed);
+    const int64_t i = g * 4;
+    if (i + 3 < N && ((((uintptr_t)out) & 15u) == 0)) {
+      reinterpret_cast<float4*>(out)[g] = n;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j < N) out[i + j] = f4_get(n, j);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int zs_iw_reduce_f32(const float* logp, int64_t ld_p, const float* logq, int64_t ld_q, int64_t B,
+                                int64_t K, int estimator, float* cost_b, float* bound_b, float* coef_p,
+                                float* coef_q, void* stream) {
+  if (!logp || !logq || B < 0 || K < 1 || ld_p < K || ld_q < K) return ZS_EINVAL;
+  if (estimator != ZS_IW_SGVB && estimator != ZS_IW_VIMCO) return ZS_EINVAL;
+  if (estimator == ZS_IW_VIMCO && K < 2) return ZS_EINVAL;
+  if (K > 0x7fffffff) return ZS_ENOTSUP;
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (K <= 64)
+    hipLaunchKernelGGL(k_iw_reduce_wave, dim3(grid_for(B, 4)), dim3(256), 0, st, logp, ld_p, logq, ld_q, B,
+                       (int)K, estimator, cost_b, bound_b, coef_p, coef_q);
+  else
+    hipLaunchKernelGGL(k_iw_reduce_block, dim3(grid_for(B, 1)), dim3(256), 0, st, logp, ld_p, logq, ld_q, B, K,
+                       estimator, cost_b, bound_b, coef_p, coef_q);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+// log_mean_exp over K-fastest rows: the IW reduction with logq == 0 and only the bound requested
+namespace {
+__global__ __launch_bounds__(256) void k_lme_block(const float* __restrict__ x, int64_t ld, int64_t B, int64_t K,
+                                                   float* __restrict__ out) {
+  __shared__ float shf[4];
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* __restrict__ xx = x + b * ld;
+    float mx = -INFINITY;
+    for (int64_t k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, xx[k]);
+    const float m = block_max(mx, shf);
+    float s = 0.f;
+    for (int64_t k = threadIdx.x; k < K; k += 256) s += exp_fast(xx[k] - m);
+    const float S = block_sum(s, shf);
+    if (threadIdx.x == 0) out[b] = ln_fast(S / (float)K) + m;
+  }
+}
+__global__ __launch_bounds__(256) void k_lme_wave(const float* __restrict__ x, int64_t ld, int64_t B, int K,
+                                                  float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < B; b += nwaves) {
+    const float l = lane < K ? x[b * ld + lane] : -INFINITY;
+    const float m = wave_max(l);
+    const float S = wave_sum(lane < K ? exp_fast(l - m) : 0.f);
+    if (lane == 0) out[b] = ln_fast(S / (float)K) + m;
+  }
+}
+}  // namespace
+
+extern "C" int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float* out, void* stream) {
+  if (!x || !out || B < 0 || K < 1 || ld < K) return ZS_EINVAL;
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (K <= 64)
+    hipLaunchKernelGGL(k_lme_wave, dim3(grid_for(B, 4)), dim3(256), 0, st, x, ld, B, (int)K, out);
+  else
+    hipLaunchKernelGGL(k_lme_block, dim3(grid_for(B, 1)), dim3(256), 0, st, x, ld, B, K, out);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, void* stream) {
+  if (!out || N < 0) return ZS_EINVAL;
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_philox_normal, dim3(grid_for((N + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     N, seed, offset);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int zs_abi_version(void) { return ZS_ABI_VERSION; }
+
+extern "C" const char* zs_error_string(int code) {
+  if (code == 0) return "success";
+  if (code == ZS_EINVAL) return "zs: invalid argument (null pointer, non-dividing period, or bad size)";
+  if (code == ZS_ENOTSUP) return "zs: unsupported configuration";
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "zs: unknown error";
+}

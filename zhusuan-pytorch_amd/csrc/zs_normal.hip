@@ -1,0 +1,568 @@
+// Normal distribution kernels (K1, K2) for gfx950.  See include/zs_hip.h for the contract and
+// the reference lines each entry point replaces.  HBM-bound streaming kernels: 16-byte
+// per-lane accesses, G = min(D/4, 64) lanes cooperate on one row of D elements, row sums by
+// wavefront shuffles, no LDS except for the cross-wave K-slice reduction of the backward.
+#include "zs_common.h"
+#include "../../include/zs_hip.h"
+
+using namespace zs;
+
+namespace {
+
+struct RowMap {
+  int G;      // lanes per row
+  int rpw;    // rows per wave pass
+  int p2;     // next pow2 >= G
+};
+inline RowMap row_map(int64_t D4) {
+  RowMap m;
+  m.G = D4 >= 64 ? 64 : (int)D4;
+  m.rpw = 64 / m.G;
+  m.p2 = next_pow2(m.G);
+  return m;
+}
+
+// round-to-nearest mul / add that the compiler may not contract into an FMA: the sample
+// z = mean + std * eps must round twice like the reference's separate mul and add
+// (normal.py:105) so that z is bit-identical for identical eps.
+__device__ __forceinline__ float mul_add_2round(float m, float s, float e) {
+  return __fadd_rn(m, __fmul_rn(s, e));
+}
+
+// ------------------------------------------------------------------------------------
+// K1 forward, rows of up to 256 elements (D4 <= 64): a wave owns `rpw` parameter rows and walks
+// a chunk of the K particles, so log(sigma) and sigma^-2 are computed once per (row, lane) and
+// reused for every particle.  z is written 16 B per lane; each particle's row sum goes to
+// lp[k*sk + r*sr] (K-fastest for the objectives).
+// ------------------------------------------------------------------------------------
+template <bool HAS_EPS, bool HAS_LP>
+__global__ __launch_bounds__(256) void k_normal_sample_smallrow(
+    const float4* __restrict__ mu, const float4* __restrict__ sigma, const float4* __restrict__ eps,
+    uint64_t seed, uint64_t call, float4* __restrict__ z, float* __restrict__ lp,
+    int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t kchunk, int64_t sk, int64_t sr) {
+  const int lane = threadIdx.x & 63;
+  const int rw = lane / G, lig = lane - rw * G;
+  const bool lane_on = rw < rpw;
+  const int64_t M4 = R * (int64_t)D4;
+  const int64_t row_tiles = (R + rpw - 1) / rpw;
+  const int64_t k_tiles = (K + kchunk - 1) / kchunk;
+  const int64_t total = row_tiles * k_tiles;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < total; t += nwaves) {
+    const int64_t rt = t % row_tiles, kt = t / row_tiles;
+    const int64_t r = rt * rpw + rw;
+    const bool on = lane_on && r < R;
+    const int64_t m4 = r * D4 + lig;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (on) {
+      m = mu[m4];
+      s = sigma[m4];
+    }
+    float ls[4], pr[4];
+    {
+      const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float l2 = log2_fast(sv[j]);
+        ls[j] = l2 * ZS_LN2;              // logstd = log(std)         normal.py:121
+        pr[j] = exp2_fast(-2.0f * l2);    // precision = exp(-2*logstd) normal.py:123
+      }
+    }
+    const int64_t k0 = kt * kchunk;
+    const int64_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
+    for (int64_t k = k0; k < k1; ++k) {
+      const int64_t g = k * M4 + m4;
+      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (on) {
+        if (HAS_EPS) e = eps[g];
+        else e = philox_normal4((uint64_t)g, call, seed);
+      }
+      float4 zz;
+      zz.x = mul_add_2round(m.x, s.x, e.x);
+      zz.y = mul_add_2round(m.y, s.y, e.y);
+      zz.z = mul_add_2round(m.z, s.z, e.z);
+      zz.w = mul_add_2round(m.w, s.w, e.w);
+      if (on) z[g] = zz;
+      if (HAS_LP) {
+        float acc = normal_lp_term(zz.x - m.x, ls[0], pr[0]);
+        acc += normal_lp_term(zz.y - m.y, ls[1], pr[1]);
+        acc += normal_lp_term(zz.z - m.z, ls[2], pr[2]);
+        acc += normal_lp_term(zz.w - m.w, ls[3], pr[3]);
+        acc = group_sum_down(acc, lig, G, p2);
+        if (on && lig == 0) lp[k * sk + r * sr] = acc;
+      }
+    }
+  }
+}
+
+// K1 forward, long rows (D4 > 64): one wave per (k, r) row, lanes stride over the row.
+template <bool HAS_EPS, bool HAS_LP>
+__global__ __launch_bounds__(256) void k_normal_sample_longrow(
+    const float4* __restrict__ mu, const float4* __restrict__ sigma, const float4* __restrict__ eps,
+    uint64_t seed, uint64_t call, float4* __restrict__ z, float* __restrict__ lp,
+    int64_t K, int64_t R, int D4, int64_t sk, int64_t sr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t M4 = R * (int64_t)D4;
+  const int64_t rows = K * R;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const int64_t k = row / R, r = row - k * R;
+    float acc = 0.f;
+    for (int c = lane; c < D4; c += 64) {
+      const int64_t m4 = r * D4 + c;
+      const int64_t g = k * M4 + m4;
+      const float4 m = mu[m4], s = sigma[m4];
+      float4 e;
+      if (HAS_EPS) e = eps[g];
+      else e = philox_normal4((uint64_t)g, call, seed);
+      float4 zz;
+      zz.x = mul_add_2round(m.x, s.x, e.x);
+      zz.y = mul_add_2round(m.y, s.y, e.y);
+      zz.z = mul_add_2round(m.z, s.z, e.z);
+      zz.w = mul_add_2round(m.w, s.w, e.w);
+      z[g] = zz;
+      if (HAS_LP) {
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+        const float dv[4] = {zz.x - m.x, zz.y - m.y, zz.z - m.z, zz.w - m.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float l2 = log2_fast(sv[j]);
+          acc += normal_lp_term(dv[j], l2 * ZS_LN2, exp2_fast(-2.0f * l2));
+        }
+      }
+    }
+    if (HAS_LP) {
+      acc = wave_sum(acc);
+      if (lane == 0) lp[k * sk + r * sr] = acc;
+    }
+  }
+}
+
+// K1 forward, any D / any alignment: one thread per (k, r) row, serial over the row.
+template <bool HAS_EPS>
+__global__ __launch_bounds__(256) void k_normal_sample_serial(
+    const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ eps,
+    uint64_t seed, uint64_t call, float* __restrict__ z, float* __restrict__ lp,
+    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+  const int64_t rows = K * R, M = R * D;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
+       row += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = row / R, r = row - k * R;
+    float acc = 0.f;
+    float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t have = -1;
+    for (int64_t d = 0; d < D; ++d) {
+      const int64_t m = r * D + d, i = k * M + m;
+      float e;
+      if (HAS_EPS) {
+        e = eps[i];
+      } else {
+        if ((i >> 2) != have) {
+          have = i >> 2;
+          n4 = philox_normal4((uint64_t)have, call, seed);
+        }
+        e = f4_get(n4, (int)(i & 3));
+      }
+      const float mm = mu[m], s = sigma[m];
+      const float zz = mul_add_2round(mm, s, e);
+      z[i] = zz;
+      if (lp) {
+        float l2 = log2_fast(s);
+        acc += normal_lp_term(zz - mm, l2 * ZS_LN2, exp2_fast(-2.0f * l2));
+      }
+    }
+    if (lp) lp[k * sk + r * sr] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K1 backward (reparameterised): thread tile = 64 parameter float4 groups x 4 K-slices,
+// K-slice partials combined through LDS.
+// ------------------------------------------------------------------------------------
+template <bool HAS_EPS>
+__global__ __launch_bounds__(256) void k_normal_sample_bwd(
+    const float4* __restrict__ sigma, const float4* __restrict__ eps, uint64_t seed, uint64_t call,
+    const float4* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
+    float4* __restrict__ gmu, float4* __restrict__ gsigma, int64_t K, int64_t M4, int D4) {
+  __shared__ float4 red_a[4][64];
+  __shared__ float4 red_b[4][64];
+  __shared__ float red_g[4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int64_t m4 = (int64_t)blockIdx.x * 64 + lane;
+  const bool on = m4 < M4;
+  float4 am = make_float4(0.f, 0.f, 0.f, 0.f), as = am;
+  float gl = 0.f;
+  if (on) {
+    const int64_t r = m4 / D4;
+    for (int64_t k = slice; k < K; k += 4) {
+      const int64_t g = k * M4 + m4;
+      if (gz) {
+        const float4 gv = gz[g];
+        float4 e;
+        if (HAS_EPS) e = eps[g];
+        else e = philox_normal4((uint64_t)g, call, seed);
+        am.x += gv.x; am.y += gv.y; am.z += gv.z; am.w += gv.w;
+        as.x += gv.x * e.x; as.y += gv.y * e.y; as.z += gv.z * e.z; as.w += gv.w * e.w;
+      }
+      if (glp) gl += glp[k * gsk + r * gsr];
+    }
+  }
+  red_a[slice][lane] = am;
+  red_b[slice][lane] = as;
+  red_g[slice][lane] = gl;
+  __syncthreads();
+  if (slice == 0 && on) {
+    float4 a = red_a[0][lane], b = red_b[0][lane];
+    float g = red_g[0][lane];
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+      const float4 a2 = red_a[s][lane], b2 = red_b[s][lane];
+      a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+      b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+      g += red_g[s][lane];
+    }
+    const float4 s = sigma[m4];
+    gmu[m4] = a;
+    gsigma[m4] = make_float4(b.x - g / s.x, b.y - g / s.y, b.z - g / s.z, b.w - g / s.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_normal_sample_bwd_serial(
+    const float* __restrict__ sigma, const float* __restrict__ eps, uint64_t seed, uint64_t call,
+    const float* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
+    float* __restrict__ gmu, float* __restrict__ gsigma, int64_t K, int64_t M, int64_t D) {
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = m / D;
+    float a = 0.f, b = 0.f, g = 0.f;
+    for (int64_t k = 0; k < K; ++k) {
+      const int64_t i = k * M + m;
+      if (gz) {
+        float e;
+        if (eps) e = eps[i];
+        else e = f4_get(philox_normal4((uint64_t)(i >> 2), call, seed), (int)(i & 3));
+        a += gz[i];
+        b += gz[i] * e;
+      }
+      if (glp) g += glp[k * gsk + r * gsr];
+    }
+    gmu[m] = a;
+    gsigma[m] = b - g / sigma[m];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K2 forward: log-prob of a given value, periodic operands.
+// Row-period form: operand row index = row % prow (prow = period / D rows), or scalar (prow = 0).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld_row4(const float4* __restrict__ p, int64_t row, int64_t prow, int D4, int c) {
+  if (prow == 0) {
+    const float v = *reinterpret_cast<const float*>(p);
+    return make_float4(v, v, v, v);
+  }
+  return p[(row % prow) * D4 + c];
+}
+
+__global__ __launch_bounds__(256) void k_normal_logprob_rows(
+    const float4* __restrict__ x, int64_t xr, const float4* __restrict__ mu, int64_t mr,
+    const float4* __restrict__ sigma, int64_t sr_, float* __restrict__ lp,
+    int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t sk, int64_t sr) {
+  const int lane = threadIdx.x & 63;
+  const int rw = lane / G, lig = lane - rw * G;
+  const bool lane_on = rw < rpw;
+  const int64_t rows = K * R;
+  const int64_t tiles = (rows + rpw - 1) / rpw;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < tiles; t += nwaves) {
+    const int64_t row = t * rpw + rw;
+    const bool on = lane_on && row < rows;
+    float acc = 0.f;
+    if (on) {
+      for (int c = lig; c < D4; c += G) {
+        const float4 xv = ld_row4(x, row, xr, D4, c);
+        const float4 m = ld_row4(mu, row, mr, D4, c);
+        const float4 s = ld_row4(sigma, row, sr_, D4, c);
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+        const float dv[4] = {xv.x - m.x, xv.y - m.y, xv.z - m.z, xv.w - m.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float l2 = log2_fast(sv[j]);
+          acc += normal_lp_term(dv[j], l2 * ZS_LN2, exp2_fast(-2.0f * l2));
+        }
+      }
+    }
+    acc = group_sum_down(acc, lig, G, p2);
+    if (on && lig == 0) {
+      const int64_t k = row / R, r = row - k * R;
+      lp[k * sk + r * sr] = acc;
+    }
+  }
+}
+
+// any D / alignment / period: one thread per row, element-wise modulo addressing
+__global__ __launch_bounds__(256) void k_normal_logprob_serial(
+    const float* __restrict__ x, int64_t Px, const float* __restrict__ mu, int64_t Pm,
+    const float* __restrict__ sigma, int64_t Ps, float* __restrict__ lp,
+    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+  const int64_t rows = K * R;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
+       row += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int64_t d = 0; d < D; ++d) {
+      const int64_t i = row * D + d;
+      const float s = sigma[i % Ps];
+      const float l2 = log2_fast(s);
+      acc += normal_lp_term(x[i % Px] - mu[i % Pm], l2 * ZS_LN2, exp2_fast(-2.0f * l2));
+    }
+    const int64_t k = row / R, r = row - k * R;
+    lp[k * sk + r * sr] = acc;
+  }
+}
+
+// K2 backward, element-wise partials (any shape; scalar accesses, coalesced over i)
+__global__ __launch_bounds__(256) void k_normal_logprob_bwd_elem(
+    const float* __restrict__ x, int64_t Px, const float* __restrict__ mu, int64_t Pm,
+    const float* __restrict__ sigma, int64_t Ps, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
+    float* __restrict__ gx, float* __restrict__ gmu, float* __restrict__ gsigma,
+    int64_t N, int64_t R, int64_t D) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / D;
+    const int64_t k = row / R, r = row - k * R;
+    const float g = glp[k * gsk + r * gsr];
+    const float s = sigma[i % Ps];
+    const float diff = x[i % Px] - mu[i % Pm];
+    const float prec = exp2_fast(-2.0f * log2_fast(s));
+    const float t = g * prec * diff;
+    if (gx) gx[i] = -t;
+    if (gmu) gmu[i] = t;
+    if (gsigma) gsigma[i] = g * (prec * diff * diff - 1.0f) / s;
+  }
+}
+
+// K2 backward reduced over K for [R, D] parameters (tile = 64 float4 groups x 4 K-slices)
+__global__ __launch_bounds__(256) void k_normal_logprob_bwd_ksum(
+    const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
+    const float* __restrict__ glp, int64_t gsk, int64_t gsr,
+    float4* __restrict__ gx, float4* __restrict__ gmu, float4* __restrict__ gsigma,
+    int64_t K, int64_t M4, int D4) {
+  __shared__ float4 red[2][4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int64_t m4 = (int64_t)blockIdx.x * 64 + lane;
+  const bool on = m4 < M4;
+  float4 am = make_float4(0.f, 0.f, 0.f, 0.f), as = am;
+  if (on) {
+    const int64_t r = m4 / D4;
+    const float4 m = mu[m4], s = sigma[m4];
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+    const float mv[4] = {m.x, m.y, m.z, m.w};
+    float pr[4], inv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pr[j] = exp2_fast(-2.0f * log2_fast(sv[j]));
+      inv[j] = 1.0f / sv[j];
+    }
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t k = slice; k < K; k += 4) {
+      const int64_t i4 = k * M4 + m4;
+      const float g = glp[k * gsk + r * gsr];
+      const float4 xv = x[i4];
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float diff = xs[j] - mv[j];
+        t[j] = g * pr[j] * diff;
+        a[j] += t[j];
+        b[j] += g * (pr[j] * diff * diff - 1.0f) * inv[j];
+      }
+      if (gx) gx[i4] = make_float4(-t[0], -t[1], -t[2], -t[3]);
+    }
+    am = make_float4(a[0], a[1], a[2], a[3]);
+    as = make_float4(b[0], b[1], b[2], b[3]);
+  }
+  red[0][slice][lane] = am;
+  red[1][slice][lane] = as;
+  __syncthreads();
+  if (slice == 0 && on) {
+    float4 a = red[0][0][lane], b = red[1][0][lane];
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+      const float4 a2 = red[0][s][lane], b2 = red[1][s][lane];
+      a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+      b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+    }
+    if (gmu) gmu[m4] = a;
+    if (gsigma) gsigma[m4] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_normal_logprob_bwd_ksum_serial(
+    const float* __restrict__ x, const float* __restrict__ mu, const float* __restrict__ sigma,
+    const float* __restrict__ glp, int64_t gsk, int64_t gsr,
+    float* __restrict__ gx, float* __restrict__ gmu, float* __restrict__ gsigma,
+    int64_t K, int64_t M, int64_t D) {
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = m / D;
+    const float s = sigma[m], mm = mu[m];
+    const float prec = exp2_fast(-2.0f * log2_fast(s));
+    float a = 0.f, b = 0.f;
+    for (int64_t k = 0; k < K; ++k) {
+      const float g = glp[k * gsk + r * gsr];
+      const float diff = x[k * M + m] - mm;
+      const float t = g * prec * diff;
+      a += t;
+      b += g * (prec * diff * diff - 1.0f) / s;
+      if (gx) gx[k * M + m] = -t;
+    }
+    if (gmu) gmu[m] = a;
+    if (gsigma) gsigma[m] = b;
+  }
+}
+
+inline bool period_ok_rows(int64_t P, int64_t D, int64_t N) {
+  return P == 1 || (P >= D && P % D == 0 && N % P == 0);
+}
+
+}  // namespace
+
+// ======================================================================== C ABI
+extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const float* eps,
+                                            uint64_t seed, uint64_t offset, float* z, float* lp,
+                                            int64_t K, int64_t M, int64_t D,
+                                            int64_t sk, int64_t sr, void* stream) {
+  if (!mu || !sigma || !z || K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
+  if (M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t R = M / D;
+  const bool vec = (D % 4 == 0) && aligned16(mu) && aligned16(sigma) && aligned16(z) && (!eps || aligned16(eps));
+  if (vec) {
+    const int D4 = (int)(D / 4);
+    const float4 *m4 = (const float4*)mu, *s4 = (const float4*)sigma, *e4 = (const float4*)eps;
+    if (D4 <= 64) {
+      RowMap rm = row_map(D4);
+      const int64_t row_tiles = (R + rm.rpw - 1) / rm.rpw;
+      // enough waves to fill the chip (256 CUs x 8 waves) before reusing parameters across K
+      int64_t want = 256 * 8;
+      int64_t kt = (want + row_tiles - 1) / row_tiles;
+      if (kt < 1) kt = 1;
+      if (kt > K) kt = K;
+      const int64_t kchunk = (K + kt - 1) / kt;
+      const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
+      const unsigned grid = grid_for(total, 4);
+#define ZS_LAUNCH_SMALL(E, L)                                                                           \
+  hipLaunchKernelGGL((k_normal_sample_smallrow<E, L>), dim3(grid), dim3(256), 0, st, m4, s4, e4, seed, \
+                     offset, (float4*)z, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr)
+      if (eps) { if (lp) ZS_LAUNCH_SMALL(true, true); else ZS_LAUNCH_SMALL(true, false); }
+      else     { if (lp) ZS_LAUNCH_SMALL(false, true); else ZS_LAUNCH_SMALL(false, false); }
+#undef ZS_LAUNCH_SMALL
+    } else {
+      const unsigned grid = grid_for(K * R, 4);
+#define ZS_LAUNCH_LONG(E, L)                                                                           \
+  hipLaunchKernelGGL((k_normal_sample_longrow<E, L>), dim3(grid), dim3(256), 0, st, m4, s4, e4, seed, \
+                     offset, (float4*)z, lp, K, R, D4, sk, sr)
+      if (eps) { if (lp) ZS_LAUNCH_LONG(true, true); else ZS_LAUNCH_LONG(true, false); }
+      else     { if (lp) ZS_LAUNCH_LONG(false, true); else ZS_LAUNCH_LONG(false, false); }
+#undef ZS_LAUNCH_LONG
+    }
+  } else {
+    const unsigned grid = grid_for(K * R, 256);
+    if (eps)
+      hipLaunchKernelGGL((k_normal_sample_serial<true>), dim3(grid), dim3(256), 0, st, mu, sigma, eps, seed,
+                         offset, z, lp, K, R, D, sk, sr);
+    else
+      hipLaunchKernelGGL((k_normal_sample_serial<false>), dim3(grid), dim3(256), 0, st, mu, sigma, eps, seed,
+                         offset, z, lp, K, R, D, sk, sr);
+  }
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float* eps, uint64_t seed,
+                                                uint64_t offset, const float* gz, const float* glp,
+                                                int64_t gsk, int64_t gsr, float* gmu, float* gsigma,
+                                                int64_t K, int64_t M, int64_t D, void* stream) {
+  if (!sigma || !gmu || !gsigma || K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
+  if (M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (D % 4 == 0) && aligned16(sigma) && aligned16(gmu) && aligned16(gsigma) &&
+                   (!eps || aligned16(eps)) && (!gz || aligned16(gz));
+  if (vec) {
+    const int64_t M4 = M / 4;
+    const unsigned grid = (unsigned)((M4 + 63) / 64);
+    if (eps)
+      hipLaunchKernelGGL((k_normal_sample_bwd<true>), dim3(grid), dim3(256), 0, st, (const float4*)sigma,
+                         (const float4*)eps, seed, offset, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
+                         (float4*)gsigma, K, M4, (int)(D / 4));
+    else
+      hipLaunchKernelGGL((k_normal_sample_bwd<false>), dim3(grid), dim3(256), 0, st, (const float4*)sigma,
+                         (const float4*)eps, seed, offset, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
+                         (float4*)gsigma, K, M4, (int)(D / 4));
+  } else {
+    hipLaunchKernelGGL(k_normal_sample_bwd_serial, dim3(grid_for(M, 256)), dim3(256), 0, st, sigma, eps, seed,
+                       offset, gz, glp, gsk, gsr, gmu, gsigma, K, M, D);
+  }
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu, int64_t Pm,
+                                     const float* sigma, int64_t Ps, float* lp,
+                                     int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, void* stream) {
+  if (!x || !mu || !sigma || !lp || K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
+  const int64_t N = K * R * D;
+  if (N == 0) return 0;
+  if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (D % 4 == 0) && period_ok_rows(Px, D, N) && period_ok_rows(Pm, D, N) &&
+                   period_ok_rows(Ps, D, N) && (Px == 1 || aligned16(x)) && (Pm == 1 || aligned16(mu)) &&
+                   (Ps == 1 || aligned16(sigma));
+  if (vec) {
+    const int D4 = (int)(D / 4);
+    RowMap rm = row_map(D4);
+    const int64_t tiles = (K * R + rm.rpw - 1) / rm.rpw;
+    hipLaunchKernelGGL(k_normal_logprob_rows, dim3(grid_for(tiles, 4)), dim3(256), 0, st, (const float4*)x,
+                       Px == 1 ? 0 : Px / D, (const float4*)mu, Pm == 1 ? 0 : Pm / D, (const float4*)sigma,
+                       Ps == 1 ? 0 : Ps / D, lp, K, R, D4, rm.G, rm.rpw, rm.p2, sk, sr);
+  } else {
+    hipLaunchKernelGGL(k_normal_logprob_serial, dim3(grid_for(K * R, 256)), dim3(256), 0, st, x, Px, mu, Pm,
+                       sigma, Ps, lp, K, R, D, sk, sr);
+  }
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int zs_normal_logprob_bwd_f32(const float* x, int64_t Px, const float* mu, int64_t Pm,
+                                         const float* sigma, int64_t Ps, const float* glp, int64_t gsk,
+                                         int64_t gsr, float* gx, float* gmu, float* gsigma,
+                                         int64_t K, int64_t R, int64_t D, void* stream) {
+  if (!x || !mu || !sigma || !glp || K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
+  const int64_t N = K * R * D;
+  if (N == 0) return 0;
+  if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
+  hipLaunchKernelGGL(k_normal_logprob_bwd_elem, dim3(grid_for(N, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     Px, mu, Pm, sigma, Ps, glp, gsk, gsr, gx, gmu, gsigma, N, R, D);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int zs_normal_logprob_bwd_ksum_f32(const float* x, const float* mu, const float* sigma,
+                                              const float* glp, int64_t gsk, int64_t gsr, float* gx,
+                                              float* gmu, float* gsigma, int64_t K, int64_t R, int64_t D,
+                                              void* stream) {
+  if (!x || !mu || !sigma || !glp || K < 1 || R < 0 || D < 1) return ZS_EINVAL;
+  const int64_t M = R * D;
+  if (M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(mu) && aligned16(sigma) && (!gx || aligned16(gx)) &&
+                   (!gmu || aligned16(gmu)) && (!gsigma || aligned16(gsigma));
+  if (vec) {
+    const int64_t M4 = M / 4;
+    hipLaunchKernelGGL(k_normal_logprob_bwd_ksum, dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st,
+                       (const float4*)x, (const float4*)mu, (const float4*)sigma, glp, gsk, gsr, (float4*)gx,
+                       (float4*)gmu, (float4*)gsigma, K, M4, (int)(D / 4));
+  } else {
+    hipLaunchKernelGGL(k_normal_logprob_bwd_ksum_serial, dim3(grid_for(M, 256)), dim3(256), 0, st, x, mu, sigma,
+                       glp, gsk, gsr, gx, gmu, gsigma, K, M, D);
+  }
+  ZS_CHECK_LAUNCH();
+  return 0;
+}

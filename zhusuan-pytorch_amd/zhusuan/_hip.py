@@ -1,0 +1,123 @@
+"""ctypes binding of the gfx950 kernel library (C ABI: include/zs_hip.h).
+
+The library is loaded from ``zhusuan-pytorch_amd/lib/libzs_hip.so`` (built in-tree by
+``__graft_entry__.build()`` / ``csrc/Makefile``).  There is NO CPU fallback: if the library
+is missing, or a tensor handed to a kernel is not resident on a HIP device, the call raises.
+
+PyTorch is plumbing only: tensors provide device memory (``data_ptr()``) and the current HIP
+stream; no torch type crosses the C ABI.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
+ABI_VERSION = 1
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_u64 = ctypes.c_uint64
+_int = ctypes.c_int
+
+# name -> argtypes ; every function returns int (0 = ok) unless noted
+PROTOTYPES = {
+    "zs_normal_sample_logprob_f32": [_p, _p, _p, _u64, _u64, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "zs_normal_sample_logprob_bwd_f32": [_p, _p, _u64, _u64, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p],
+    "zs_normal_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "zs_normal_logprob_bwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
+    "zs_normal_logprob_bwd_ksum_f32": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
+    "zs_bernoulli_logprob_f32": [_p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "zs_bernoulli_logprob_bwd_f32": [_p, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
+    "zs_bernoulli_logits_logprob_f32": [_p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "zs_bernoulli_logits_logprob_bwd_f32": [_p, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
+    "zs_bernoulli_sample_f32": [_p, _i64, _p, _i64, _u64, _u64, _p],
+    "zs_iw_reduce_f32": [_p, _i64, _p, _i64, _i64, _i64, _int, _p, _p, _p, _p, _p],
+    "zs_log_mean_exp_f32": [_p, _i64, _i64, _i64, _p, _p],
+    "zs_philox_normal_f32": [_p, _i64, _u64, _u64, _p],
+}
+
+
+class KernelLibrary(object):
+    """A loaded shared object exporting the zs_* C ABI."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "zhusuan (MI355X build): kernel library not found at %s -- run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C zhusuan-pytorch_amd/csrc`). "
+                "There is no CPU fallback." % path)
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        self.cdll.zs_abi_version.restype = _int
+        self.cdll.zs_abi_version.argtypes = []
+        self.cdll.zs_error_string.restype = ctypes.c_char_p
+        self.cdll.zs_error_string.argtypes = [_int]
+        got = self.cdll.zs_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError("zhusuan: %s has ABI version %d, expected %d" % (path, got, ABI_VERSION))
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if a symbol is missing
+            fn.restype = _int
+            fn.argtypes = argtypes
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            msg = self.cdll.zs_error_string(rc)
+            raise RuntimeError("%s failed with code %d: %s" % (name, rc, msg.decode() if msg else "?"))
+
+
+_LIB = None          # the HIP library (lazy)
+_HOST_LIB = None     # test hook: a host-pointer implementation of the same ABI (tests/ only)
+
+
+def lib():
+    """The HIP kernel library; raises loudly when it has not been built."""
+    global _LIB
+    if _HOST_LIB is not None:
+        return _HOST_LIB
+    if _LIB is None:
+        _LIB = KernelLibrary(LIB_PATH)
+    return _LIB
+
+
+def _install_host_library_for_tests(klib):
+    """TESTS ONLY: route kernel calls on CPU tensors to ``klib`` (the C oracle built from
+    oracle/zs_oracle_c.c) so host logic can be exercised without a GPU.  Never called by the package."""
+    global _HOST_LIB
+    _HOST_LIB = klib
+
+
+def require_device(*tensors):
+    """Every kernel operand must live on a HIP device (torch device type 'cuda' on ROCm)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if _HOST_LIB is not None:
+            if t.device.type != "cpu":
+                raise RuntimeError("zhusuan test hook: host library installed but tensor is on %s" % t.device)
+            continue
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                "zhusuan (MI355X build): tensor on device '%s' -- this build runs the variational-inference "
+                "hot path only as HIP kernels on an AMD GPU and has no CPU path. Move the model and data to "
+                "the GPU (`.to('cuda')`)." % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("zhusuan: operands on different devices: %s vs %s" % (dev, t.device))
+    return dev
+
+
+def stream_for(t):
+    """Raw hipStream_t of torch's current stream on t's device (kernels are enqueued there)."""
+    if t.device.type != "cuda":
+        return None
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,316 @@
+"""autograd wrappers around the C-ABI kernels (include/zs_hip.h).
+
+Each Function enqueues exactly one kernel in forward and one in backward on torch's current HIP
+stream.  Row results use the K-fastest layout when ``kfast`` is set: the buffer is ``[R, K]`` and the
+user-visible tensor is its transposed view ``[K, *rest]``, so shapes equal the reference's while the
+K particles of a datapoint stay contiguous for the importance-weight reduction.
+"""
+import math
+
+import torch
+
+from . import _hip
+
+ZS_IW_SGVB = 0
+ZS_IW_VIMCO = 1
+
+
+def _prod(shape):
+    return int(math.prod(shape)) if len(shape) else 1
+
+
+def _check_f32(*tensors):
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise NotImplementedError(
+                "zhusuan (MI355X build): the HIP kernels compute in float32 (the dtype of the reference's "
+                "examples); got %s" % t.dtype)
+
+
+def _alloc_rows(K, has_k_axis, rest_shape, kfast, like):
+    """Row-result buffer and its user-visible view.  Returns (buffer, view, stride_k, stride_r)."""
+    R = _prod(rest_shape)
+    if has_k_axis and kfast and K > 1 and R > 0:
+        buf = torch.empty((R, K), dtype=like.dtype, device=like.device)
+        view = buf.t().view((K,) + tuple(rest_shape))
+        return buf, view, 1, K
+    buf = torch.empty((K, R), dtype=like.dtype, device=like.device)
+    view = buf.view(((K,) if has_k_axis else ()) + tuple(rest_shape))
+    return buf, view, R, 1
+
+
+def _kr_view(t, K, R):
+    """View `t` (K*R elements, logical order [K, R]) as a 2-D tensor without copying when possible."""
+    try:
+        v = t.view(K, R)
+    except RuntimeError:
+        v = t.contiguous().view(K, R)
+    return v, v.stride(0), v.stride(1)
+
+
+class NormalSampleLogProb(torch.autograd.Function):
+    """K1: z = mu + sigma*eps and the row-summed log-density of z in one pass.
+    Replaces Normal._sample + Normal._log_prob (zhusuan/distributions/normal.py:89-126)."""
+
+    @staticmethod
+    def forward(ctx, mu, sigma, eps, seed, call, K, has_k_axis, n_fold, reparam, kfast):
+        _hip.require_device(mu, sigma, eps)
+        _check_f32(mu, sigma, eps)
+        lib = _hip.lib()
+        shape = tuple(mu.shape)
+        M = mu.numel()
+        rest = shape[:len(shape) - n_fold]
+        D = _prod(shape[len(shape) - n_fold:])
+        R = _prod(rest)
+        z = torch.empty(((K,) if has_k_axis else ()) + shape, dtype=mu.dtype, device=mu.device)
+        if M == 0:
+            lp = torch.zeros(((K,) if has_k_axis else ()) + rest, dtype=mu.dtype, device=mu.device)
+            ctx.meta = None
+            return z, lp
+        buf, lp, sk, sr = _alloc_rows(K, has_k_axis, rest, kfast, mu)
+        lib.call("zs_normal_sample_logprob_f32", _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(eps), seed, call,
+                 _hip.ptr(z), _hip.ptr(buf), K, M, D, sk, sr, _hip.stream_for(mu))
+        ctx.meta = (seed, call, K, M, D, R, reparam)
+        if reparam:
+            ctx.save_for_backward(mu, sigma, eps)
+        else:
+            ctx.save_for_backward(mu, sigma, z)
+            ctx.mark_non_differentiable(z)  # torch.normal(mean, std) is detached, normal.py:102
+        return z, lp
+
+    @staticmethod
+    def backward(ctx, gz, glp):
+        if ctx.meta is None:
+            return (None,) * 10
+        seed, call, K, M, D, R, reparam = ctx.meta
+        lib = _hip.lib()
+        if reparam:
+            mu, sigma, eps = ctx.saved_tensors
+            gmu = torch.empty_like(mu)
+            gsigma = torch.empty_like(sigma)
+            gsk = gsr = 0
+            if gz is not None:
+                gz = gz.contiguous()
+            if glp is not None:
+                glp, gsk, gsr = _kr_view(glp, K, R)
+            lib.call("zs_normal_sample_logprob_bwd_f32", _hip.ptr(sigma), _hip.ptr(eps), seed, call,
+                     _hip.ptr(gz), _hip.ptr(glp), gsk, gsr, _hip.ptr(gmu), _hip.ptr(gsigma), K, M, D,
+                     _hip.stream_for(mu))
+        else:
+            mu, sigma, z = ctx.saved_tensors
+            if glp is None:
+                return (None,) * 10
+            gmu = torch.empty_like(mu)
+            gsigma = torch.empty_like(sigma)
+            glp, gsk, gsr = _kr_view(glp, K, R)
+            lib.call("zs_normal_logprob_bwd_ksum_f32", _hip.ptr(z), _hip.ptr(mu), _hip.ptr(sigma),
+                     _hip.ptr(glp), gsk, gsr, None, _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D,
+                     _hip.stream_for(mu))
+        return gmu, gsigma, None, None, None, None, None, None, None, None
+
+
+class NormalLogProb(torch.autograd.Function):
+    """K2: row-summed Normal log-density of a given value with periodically broadcast operands.
+    Operands arrive contiguous; `periods` = (Px, Pm, Ps) in elements of the full [*full_shape] problem."""
+
+    @staticmethod
+    def forward(ctx, x, mu, sigma, full_shape, n_fold, periods, kfast):
+        _hip.require_device(x, mu, sigma)
+        _check_f32(x, mu, sigma)
+        lib = _hip.lib()
+        full_shape = tuple(full_shape)
+        out_shape = full_shape[:len(full_shape) - n_fold]
+        D = _prod(full_shape[len(full_shape) - n_fold:])
+        has_k = len(out_shape) >= 2
+        K = out_shape[0] if has_k else 1
+        rest = out_shape[1:] if has_k else out_shape
+        R = _prod(rest)
+        buf, lp, sk, sr = _alloc_rows(K, has_k, rest, kfast and n_fold > 0, x)
+        Px, Pm, Ps = periods
+        if K * R * D > 0:
+            lib.call("zs_normal_logprob_f32", _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
+                     _hip.ptr(buf), K, R, D, sk, sr, _hip.stream_for(x))
+        ctx.meta = (K, R, D, periods)
+        ctx.save_for_backward(x, mu, sigma)
+        return lp
+
+    @staticmethod
+    def backward(ctx, glp):
+        K, R, D, (Px, Pm, Ps) = ctx.meta
+        x, mu, sigma = ctx.saved_tensors
+        need_x, need_mu, need_sigma = ctx.needs_input_grad[:3]
+        N = K * R * D
+        lib = _hip.lib()
+        if N == 0 or not (need_x or need_mu or need_sigma):
+            return (None,) * 7
+        glp, gsk, gsr = _kr_view(glp, K, R)
+        st = _hip.stream_for(x)
+        gx = gmu = gsigma = None
+        if K > 1 and Px == N and Pm == Ps == R * D:
+            # parameters [R, D] repeated over the K particles: reduce over K inside the kernel
+            gx = torch.empty_like(x) if need_x else None
+            gmu = torch.empty_like(mu)
+            gsigma = torch.empty_like(sigma)
+            lib.call("zs_normal_logprob_bwd_ksum_f32", _hip.ptr(x), _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(glp),
+                     gsk, gsr, _hip.ptr(gx), _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D, st)
+        else:
+            def full():
+                return torch.empty(N, dtype=x.dtype, device=x.device)
+            fx = full() if need_x else None
+            fm = full() if need_mu else None
+            fs = full() if need_sigma else None
+            lib.call("zs_normal_logprob_bwd_f32", _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
+                     _hip.ptr(glp), gsk, gsr, _hip.ptr(fx), _hip.ptr(fm), _hip.ptr(fs), K, R, D, st)
+
+            def fold(f, P, like):
+                if f is None:
+                    return None
+                if P != N:
+                    f = f.view(N // P, P).sum(0)
+                return f.view(like.shape)
+            gx, gmu, gsigma = fold(fx, Px, x), fold(fm, Pm, mu), fold(fs, Ps, sigma)
+        return (gx if need_x else None, gmu if need_mu else None, gsigma if need_sigma else None,
+                None, None, None, None)
+
+
+class BernoulliLogProb(torch.autograd.Function):
+    """K3: row-summed Bernoulli log-mass (zhusuan/distributions/bernoulli.py:84-95).  `p` has the
+    full problem shape; `x` is periodic (x [B, X] against p [K, B, X]).  With from_logits the streamed
+    operand holds logits and p = sigmoid(logit) is formed in registers (bernoulli.py:50)."""
+
+    @staticmethod
+    def forward(ctx, p, x, n_fold, Px, kfast, from_logits):
+        _hip.require_device(p, x)
+        _check_f32(p, x)
+        lib = _hip.lib()
+        full_shape = tuple(p.shape)
+        out_shape = full_shape[:len(full_shape) - n_fold]
+        D = _prod(full_shape[len(full_shape) - n_fold:])
+        has_k = len(out_shape) >= 2
+        K = out_shape[0] if has_k else 1
+        rest = out_shape[1:] if has_k else out_shape
+        R = _prod(rest)
+        buf, lp, sk, sr = _alloc_rows(K, has_k, rest, kfast and n_fold > 0, p)
+        if K * R * D > 0:
+            if from_logits:
+                lib.call("zs_bernoulli_logits_logprob_f32", _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(buf), None,
+                         K, R, D, sk, sr, _hip.stream_for(p))
+            else:
+                lib.call("zs_bernoulli_logprob_f32", _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(buf), K, R, D, sk, sr,
+                         _hip.stream_for(p))
+        ctx.meta = (K, R, D, Px, from_logits)
+        ctx.save_for_backward(p, x)
+        return lp
+
+    @staticmethod
+    def backward(ctx, glp):
+        K, R, D, Px, from_logits = ctx.meta
+        p, x = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("zhusuan (MI355X build): gradient w.r.t. the Bernoulli observation is not built")
+        if not ctx.needs_input_grad[0] or K * R * D == 0:
+            return (None,) * 6
+        glp, gsk, gsr = _kr_view(glp, K, R)
+        gp = torch.empty_like(p)
+        name = "zs_bernoulli_logits_logprob_bwd_f32" if from_logits else "zs_bernoulli_logprob_bwd_f32"
+        _hip.lib().call(name, _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(glp), gsk, gsr, _hip.ptr(gp), K, R, D,
+                        _hip.stream_for(p))
+        return gp, None, None, None, None, None
+
+
+class IWReduce(torch.autograd.Function):
+    """K4: per-datapoint importance-weighted reduction over K-fastest rows [B, K].
+    Returns (cost_b, bound_b); bound_b = log_mean_exp(log_w) is a detached diagnostic."""
+
+    @staticmethod
+    def forward(ctx, logp, logq, estimator):
+        _hip.require_device(logp, logq)
+        _check_f32(logp, logq)
+        B, K = logp.shape
+        if logp.stride(1) != 1 and K > 1:
+            logp = logp.contiguous()
+        if logq.stride(1) != 1 and K > 1:
+            logq = logq.contiguous()
+        ld_p = logp.stride(0) if B > 1 else K
+        ld_q = logq.stride(0) if B > 1 else K
+        if ld_p < K:
+            logp, ld_p = logp.contiguous(), K
+        if ld_q < K:
+            logq, ld_q = logq.contiguous(), K
+        cost = torch.empty(B, dtype=logp.dtype, device=logp.device)
+        bound = torch.empty_like(cost)
+        coef_p = torch.empty((B, K), dtype=logp.dtype, device=logp.device)
+        coef_q = torch.empty_like(coef_p)
+        _hip.lib().call("zs_iw_reduce_f32", _hip.ptr(logp), ld_p, _hip.ptr(logq), ld_q, B, K, estimator,
+                        _hip.ptr(cost), _hip.ptr(bound), _hip.ptr(coef_p), _hip.ptr(coef_q), _hip.stream_for(logp))
+        ctx.save_for_backward(coef_p, coef_q)
+        ctx.mark_non_differentiable(bound)
+        return cost, bound
+
+    @staticmethod
+    def backward(ctx, g_cost, g_bound):
+        coef_p, coef_q = ctx.saved_tensors
+        g = g_cost.unsqueeze(1)
+        gp = g * coef_p if ctx.needs_input_grad[0] else None
+        gq = g * coef_q if ctx.needs_input_grad[1] else None
+        return gp, gq, None
+
+
+class LogMeanExpRows(torch.autograd.Function):
+    """log_mean_exp over the last (contiguous) axis of a 2-D tensor (zhusuan/utils.py:6-21)."""
+
+    @staticmethod
+    def forward(ctx, x2d):
+        _hip.require_device(x2d)
+        _check_f32(x2d)
+        x2d = x2d.contiguous()
+        B, K = x2d.shape
+        out = torch.empty(B, dtype=x2d.dtype, device=x2d.device)
+        if B * K > 0:
+            _hip.lib().call("zs_log_mean_exp_f32", _hip.ptr(x2d), K, B, K, _hip.ptr(out), _hip.stream_for(x2d))
+        ctx.save_for_backward(x2d, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2d, out = ctx.saved_tensors
+        K = x2d.shape[1]
+        return g.unsqueeze(1) * torch.exp(x2d - out.unsqueeze(1)) / K
+
+
+def philox_normal(shape, device, seed, call):
+    """Standard normals from the kernels' own Philox stream (the eps K1 would draw for the same ids)."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    _hip.require_device(out)
+    if out.numel():
+        _hip.lib().call("zs_philox_normal_f32", _hip.ptr(out), out.numel(), seed, call, _hip.stream_for(out))
+    return out
+
+
+def bernoulli_sample(probs, Pp, shape, seed, call):
+    """K5: Bernoulli._sample (zhusuan/distributions/bernoulli.py:72-82)."""
+    _hip.require_device(probs)
+    _check_f32(probs)
+    out = torch.empty(tuple(shape), dtype=probs.dtype, device=probs.device)
+    if out.numel():
+        _hip.lib().call("zs_bernoulli_sample_f32", _hip.ptr(probs), Pp, _hip.ptr(out), out.numel(), seed, call,
+                        _hip.stream_for(probs))
+    return out
+
+
+def periodic_operand(t, full_shape):
+    """(contiguous tensor, period) describing how `t` broadcasts into `full_shape`.
+
+    Leading-axis broadcast (the reference's ``repeat`` of parameters along the sample axis,
+    normal.py:94-95,112-116) and scalars are expressed as a period and cost no copy; any other
+    broadcast pattern is materialised with ``expand().contiguous()`` (differentiable plumbing)."""
+    full_shape = tuple(full_shape)
+    N = _prod(full_shape)
+    if t.numel() == 1 and N >= 1:
+        return t.reshape(1), 1
+    shp = tuple(t.shape)
+    while shp and shp[0] == 1:
+        shp = shp[1:]
+    if shp == full_shape[len(full_shape) - len(shp):]:
+        return t.contiguous(), t.numel()
+    return t.expand(full_shape).contiguous(), N

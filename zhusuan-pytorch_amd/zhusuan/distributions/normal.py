@@ -1,0 +1,118 @@
+"""Univariate Normal.  API of zhusuan/distributions/normal.py:12-129 of the reference; the sample and its
+log-density come from the fused HIP kernel K1, the density of a given value from K2 (include/zs_hip.h)."""
+import torch
+
+from .base import Distribution
+from .utils import assert_same_log_float_dtype, check_broadcast
+from .. import _ops, _rng
+
+__all__ = ['Normal']
+
+
+class Normal(Distribution):
+    """
+    :param mean: float tensor (or anything ``torch.as_tensor`` accepts); broadcastable against std.
+    :param std / logstd: exactly one of them (ValueError otherwise, normal.py:51-54).
+    :param is_reparameterized: True: z = mean + std * eps carries gradients to (mean, std)
+        (normal.py:104-105); False: the draw is detached like ``torch.normal(mean, std)`` (:102).
+    :param group_ndims: trailing batch axes summed into one event (base.py:175-176).
+    """
+
+    def __init__(self,
+                 mean=0.,
+                 std=None,
+                 logstd=None,
+                 dtype=None,
+                 is_continuous=True,
+                 is_reparameterized=True,
+                 group_ndims=0,
+                 device=torch.device('cpu'),
+                 **kwargs):
+        self._mean = torch.as_tensor(mean, dtype=dtype).to(device)
+        if (logstd is None) == (std is None):
+            raise ValueError(
+                "Either `std` or `logstd` should be passed. It is not allowed "
+                "that both are specified or both are not.")
+        elif std is None:
+            self._std = torch.exp(torch.as_tensor(logstd, dtype=dtype).to(device))
+        else:
+            self._std = torch.as_tensor(std, dtype=dtype).to(device)
+        check_broadcast(self._std, self._mean)
+        dtype = assert_same_log_float_dtype([(self._mean, "Normal.mean"), (self._std, "Normal.std")])
+        super(Normal, self).__init__(dtype=dtype,
+                                     is_continuous=is_continuous,
+                                     is_reparameterized=is_reparameterized,
+                                     group_ndims=group_ndims,
+                                     device=device,
+                                     **kwargs)
+        self._fused = None  # (sample tensor, its row-summed log-density, n_fold)
+
+    @property
+    def mean(self):
+        return self._mean
+
+    @property
+    def std(self):
+        return self._std
+
+    @property
+    def logstd(self):
+        return torch.log(self._std)
+
+    def _batch_shape(self):
+        return torch.broadcast_shapes(self._mean.shape, self._std.shape)
+
+    def _sample(self, n_samples=1, epsilon=None):
+        """normal.py:89-107.  The standard-normal draw has MEAN's shape (``[K] + mean.shape``), so it is
+        shared along axes where only std broadcasts.  `epsilon` (or zhusuan.inject_epsilon) supplies the
+        draw explicitly; otherwise it comes from the in-kernel Philox stream."""
+        K = int(n_samples)
+        has_k = K > 1
+        mean, std = self._mean, self._std
+        bshape = tuple(self._batch_shape())
+        lead = (K,) if has_k else ()
+        eps_shape = lead + tuple(mean.shape)
+        eps = epsilon
+        if eps is None:
+            eps = _rng.pop_injected(eps_shape, mean.device)
+        else:
+            eps = torch.as_tensor(eps, dtype=mean.dtype).to(mean.device)
+            if tuple(eps.shape) != eps_shape:
+                raise RuntimeError("epsilon has shape %s, expected %s" % (tuple(eps.shape), eps_shape))
+        seed = call = 0
+        if tuple(mean.shape) == tuple(std.shape):
+            mu, sigma = mean.contiguous(), std.contiguous()
+            if eps is None:
+                seed, call = _rng.next_call(mean.device)
+            else:
+                eps = eps.contiguous()
+        else:
+            if eps is None:
+                s, c = _rng.next_call(mean.device)
+                eps = _ops.philox_normal(eps_shape, mean.device, s, c)
+            pad = (1,) * (len(bshape) - mean.dim())
+            eps = eps.reshape(lead + pad + tuple(mean.shape)).expand(lead + bshape).contiguous()
+            mu = mean.expand(bshape).contiguous()
+            sigma = std.expand(bshape).contiguous()
+        n_fold = min(max(1, self._group_ndims), len(bshape))
+        z, lp = _ops.NormalSampleLogProb.apply(mu, sigma, eps, seed, call, K if has_k else 1, has_k, n_fold,
+                                               bool(self._is_reparameterized), True)
+        self.sample_cache = z
+        self._fused = (z, lp, n_fold)
+        return z
+
+    def _log_prob_sum(self, given=None, n_fold=0):
+        """normal.py:109-126 (+ trailing sum over `n_fold` axes)."""
+        x = self.sample_cache if given is None else given
+        if x is None:
+            raise RuntimeError("Normal.log_prob(None) needs a cached sample: call sample() first")
+        if self._fused is not None and self._fused[0] is x and self._fused[2] == n_fold:
+            return self._fused[1]
+        x = torch.as_tensor(x, dtype=self._dtype).to(self._mean.device)
+        full = tuple(torch.broadcast_shapes(x.shape, self._batch_shape()))
+        if n_fold > len(full):
+            raise ValueError("cannot sum %d trailing axes of a result of shape %s" % (n_fold, full))
+        px, Px = _ops.periodic_operand(x, full)
+        pm, Pm = _ops.periodic_operand(self._mean, full)
+        ps, Ps = _ops.periodic_operand(self._std, full)
+        return _ops.NormalLogProb.apply(px, pm, ps, full, n_fold, (Px, Pm, Ps), True)

@@ -1,0 +1,107 @@
+"""StochasticTensor: a named node = (BayesianNet, Distribution, n_samples, reduction kwargs).
+Interface of zhusuan/framework/stochastic_tensor.py:5-181 of the reference."""
+import torch
+
+from ..distributions.base import Distribution
+
+__all__ = ['StochasticTensor']
+
+
+def _norm_dims(dims, nd):
+    return [int(d) % nd if nd else 0 for d in dims] if dims else []
+
+
+class StochasticTensor(object):
+    """
+    :param bn: the owning BayesianNet.
+    :param name: unique node name.
+    :param dist: a Distribution instance.
+    :param n_samples: number of particles drawn by ``.tensor`` (None = one sample, no leading axis).
+    :param reduce_mean_dims / reduce_sum_dims / multiplier: post-processing of ``log_prob()``
+        (stochastic_tensor.py:58-60,160-181).
+    """
+
+    def __init__(self, bn, name, dist, observation=None, n_samples=None, **kwargs):
+        self._bn = bn
+        self._name = name
+        self._dist = dist
+        self._dtype = dist.dtype
+        self._n_samples = n_samples
+        self._observation = observation
+        self._reduce_mean_dims = kwargs.get("reduce_mean_dims", None)
+        self._reduce_sum_dims = kwargs.get("reduce_sum_dims", None)
+        self._multiplier = kwargs.get("multiplier", None)
+
+    @property
+    def bn(self):
+        return self._bn
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def dist(self):
+        return self._dist
+
+    def is_observed(self):
+        return self._name in self._bn.observed.keys()
+
+    @property
+    def tensor(self):
+        """Observed value if the node is observed (also primes ``dist.sample_cache``,
+        stochastic_tensor.py:122-124), otherwise a FRESH sample on every access (:126)."""
+        if self._name in self._bn.observed.keys():
+            self._dist.sample_cache = self._bn.observed[self._name]
+            return self._bn.observed[self._name]
+        return self._dist.sample(n_samples=self._n_samples)
+
+    def sample(self, force=False):
+        if self._name in self._bn.observed.keys() and not force:
+            self._dist.sample_cache = self._bn.observed[self._name]
+            return self._bn.observed[self._name]
+        return self._dist.sample(n_samples=self._n_samples)
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+    def get_shape(self):
+        return self.shape
+
+    def log_prob(self, sample=None):
+        """stochastic_tensor.py:160-181: dist.log_prob -> mean over reduce_mean_dims -> sum over
+        reduce_sum_dims -> drop those axes -> * multiplier.
+
+        Trailing axes that are only summed are folded into the log-prob kernel's row sum (together with
+        the distribution's group_ndims axes); the remaining reductions act on the already reduced,
+        small tensor.  Sums and means over distinct axes commute, so the value is the reference's up to
+        fp32 summation order."""
+        dist = self._dist
+        g = dist.group_ndims
+        x = dist.sample_cache if sample is None else sample
+        if x is None:
+            raise RuntimeError("node '%s' has no value yet" % self._name)
+        full = tuple(torch.broadcast_shapes(tuple(torch.as_tensor(x).shape), tuple(dist.batch_shape)))
+        nd = len(full) - g  # ndim of dist.log_prob(x)
+        mean_dims = _norm_dims(self._reduce_mean_dims, nd)
+        sum_dims = _norm_dims(self._reduce_sum_dims, nd)
+        extra = 0
+        while nd - 1 - extra >= 0 and (nd - 1 - extra) in sum_dims and (nd - 1 - extra) not in mean_dims:
+            extra += 1
+        lp = dist._log_prob_sum(sample, g + extra)
+        rest_sum = [d for d in sum_dims if d < nd - extra]
+        if mean_dims:
+            lp = torch.mean(lp, mean_dims, keepdim=True)
+        if rest_sum:
+            lp = torch.sum(lp, rest_sum, keepdim=True)
+        dims = sorted(set(mean_dims) | set(rest_sum), reverse=True)
+        for d in dims:
+            lp = torch.squeeze(lp, d)
+        if self._multiplier:
+            lp = lp * self._multiplier
+        return lp
