@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py -- ELBO-evals/s of the variational-inference hot path on MI355X.
+
+Workload (BASELINE.json configs[2] / per-GPU shape of configs[3]): IWAE on MNIST-shaped synthetic bits,
+VIMCO estimator, batch 256 per GPU, K = 50 particles, latent 40, x 784, hidden 500, fp32.
+One step = objective forward (sampling, log-probs, VIMCO reduction in HIP kernels; MLPs in
+hipBLASLt via PyTorch) + backward + [one all-reduce of the flat gradient bucket] + Adam.
+One ELBO-eval = one log-importance-weight log w[k, b], so a step does B*K evals per GPU.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (dominant kernel:
+the Bernoulli log-prob row sum, HIP events on the launch stream) and `cpu_baseline` (the CPU oracle,
+oracle/zs_oracle.py, timed on this host's cores on the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+BATCH_PER_GPU, PARTICLES, Z_DIM, X_DIM, HIDDEN = 256, 50, 40, 784, 500
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+DOMINANT = "zs_bernoulli_logprob_f32"
+
+
+def cpu_baseline(budget_s=12.0, max_steps=40):
+    """The CPU oracle (torch-CPU restatement of the reference's op sequence, pinned to the reference by
+    tests/test_oracle_golden.py) on the same workload: forward + backward + Adam, all host cores."""
+    from oracle import zs_oracle as O
+    import helpers as H
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = H.iwae_param_spec(hidden=HIDDEN)
+    p = H.make_params(spec, 1)
+    params = [p[n] for n, _ in spec]
+    opt = torch.optim.Adam(params, 1e-3)
+    rng = np.random.RandomState(1234)
+    x = torch.tensor((rng.uniform(size=(BATCH_PER_GPU, X_DIM)) < 0.5).astype(np.float32))
+
+    def step():
+        torch.randn(PARTICLES, BATCH_PER_GPU, Z_DIM)      # the draw the objective discards
+        eps = torch.randn(PARTICLES, BATCH_PER_GPU, Z_DIM)
+        loss, _ = O.iwae_loss(p, x, eps, PARTICLES, "vimco")
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < max_steps and (time.perf_counter() - t0) < budget_s:
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": BATCH_PER_GPU * PARTICLES * n / dt, "unit": "ELBO-evals/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_step": 1e3 * dt / n,
+            "sample": "%d full training steps (fwd+bwd+Adam) of the same IWAE-VIMCO B=%d K=%d workload, torch-CPU "
+                      "fp32 oracle, %.1f s" % (n, BATCH_PER_GPU, PARTICLES, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--fused-logits", action="store_true",
+                    help="decoder hands logits to Bernoulli(logits=...): sigmoid fused into the log-prob kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import zhusuan  # noqa: F401
+    from zhusuan import _hip, dataparallel
+    from examples import iwae
+
+    torch.manual_seed(0)
+    model = iwae.build(n_samples=PARTICLES, estimator="vimco", x_dim=X_DIM, z_dim=Z_DIM, hidden=HIDDEN,
+                       device=dev, fused_logits=args.fused_logits)
+    dataparallel.broadcast_parameters(model)
+    bucket = dataparallel.GradientBucket(model)
+    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True)
+    torch.manual_seed(1000 + rank)                    # per-rank Philox stream
+    rng = np.random.RandomState(1234 + rank)
+    x = torch.tensor((rng.uniform(size=(BATCH_PER_GPU, X_DIM)) < 0.5).astype(np.float32), device=dev)
+    obs = {"x": x}
+
+    def step():
+        bucket.zero()
+        loss = model(obs)
+        loss.backward()
+        g = bucket.all_reduce_mean(loss)
+        opt.step()
+        return g
+
+    for _ in range(args.warmup):
+        step()
+    dominant = "zs_bernoulli_logits_logprob_f32" if args.fused_logits else DOMINANT
+    timer = _hip.KernelTimer([dominant])
+    _hip.set_kernel_timer(timer)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _hip.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(last)
+    assert np.isfinite(final_loss)
+
+    if rank == 0:
+        N = PARTICLES * BATCH_PER_GPU
+        algo_bytes = 4 * N * X_DIM + 4 * BATCH_PER_GPU * X_DIM + 4 * N      # read p once, x once, write N sums
+        k_ms = timer.mean_ms(dominant)
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms else None
+        out = {
+            "metric": "ELBO-evals/sec (batch x K particles), IWAE-MNIST VIMCO K=50",
+            "value": BATCH_PER_GPU * PARTICLES * world * args.steps / elapsed,
+            "unit": "ELBO-evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "IWAE-MNIST VIMCO, batch=%d per GPU (global %d), K=%d, latent=%d, x=%d, hidden=%d, "
+                                   "full training step (fwd+bwd+all-reduce+Adam)" % (
+                                       BATCH_PER_GPU, BATCH_PER_GPU * world, PARTICLES, Z_DIM, X_DIM, HIDDEN),
+                       "global_batch": BATCH_PER_GPU * world, "particles": PARTICLES,
+                       "parallelism": "dp%d (minibatch shards, one flat-bucket all-reduce of %d bytes)" % (world, bucket.nbytes()),
+                       "bernoulli_path": "logits (sigmoid fused)" if args.fused_logits else "probs (reference default)"},
+            "final_loss": final_loss,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": 1e3 * k_ms if k_ms else None,
+                         "launches_timed": timer.count(dominant)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,399 @@
+"""The C ABI itself (include/zs_hip.h).
+
+not gpu : both shared objects load and export every declared symbol; the plain-C oracle is checked
+          against golden fixtures / known answers through raw ABI calls.
+gpu     : libzs_hip.so vs the C oracle, entry point by entry point, on seeded inputs covering the
+          vector and serial kernel paths, ragged / empty / unaligned inputs, K > 64, periodic operands
+          and strided row outputs.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, host_kernel_library, build_oracle_lib
+from zhusuan import _hip
+
+HDR = os.path.join(ROOT, "include", "zs_hip.h")
+
+
+def declared_symbols():
+    src = open(HDR).read()
+    return sorted(set(re.findall(r"\b(zs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_by_both_libraries():
+    names = declared_symbols()
+    assert len(names) == 15 and set(_hip.PROTOTYPES) <= set(names)
+    hip = ctypes.CDLL(_hip.LIB_PATH)           # loads without a GPU; no compute call is made here
+    orc = ctypes.CDLL(build_oracle_lib())
+    for n in names:
+        assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
+        assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
+    k = _hip.KernelLibrary(_hip.LIB_PATH)
+    assert k.cdll.zs_abi_version() == 1
+    assert b"invalid argument" in k.cdll.zs_error_string(-1)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _hip.KernelLibrary(str(tmp_path / "nope.so"))
+
+
+def test_philox_known_answers():
+    # Random123 known-answer vectors for philox4x32-10
+    orc = ctypes.CDLL(build_oracle_lib())
+    f = orc.zs_oracle_philox4x32_10
+    f.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
+    f.restype = None
+    out = (ctypes.c_uint32 * 4)()
+    f(0, 0, 0, out)
+    assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    f(0xffffffffffffffff, 0xffffffffffffffff, 0xffffffffffffffff, out)
+    assert [hex(v) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    f(0x85a308d3243f6a88, 0x0370734413198a2e, 0x299f31d0a4093822, out)
+    assert [hex(v) for v in out] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+# ------------------------------------------------------------------ raw-call helpers
+class Raw(object):
+    def __init__(self, klib, device):
+        self.k, self.dev = klib, torch.device(device)
+
+    def t(self, a):
+        if a is None:
+            return None
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(self.dev)
+
+    def empty(self, *shape):
+        return torch.full(shape, float("nan"), dtype=torch.float32, device=self.dev)
+
+    def call(self, name, *args):
+        conv = []
+        for a in args:
+            conv.append(_hip.ptr(a) if isinstance(a, torch.Tensor) or a is None else a)
+        st = None
+        if self.dev.type == "cuda":
+            st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.k.call(name, *conv, st)
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    # each op returns a dict of numpy outputs
+    def normal_sample(self, mu, sigma, eps, K, D, seed=0, off=0, kfast=False, want_lp=True):
+        M = mu.size
+        R = M // D
+        z = self.empty(K, M)
+        lp = self.empty(R, K) if kfast else self.empty(K, R)
+        sk, sr = (1, K) if kfast else (R, 1)
+        self.call("zs_normal_sample_logprob_f32", self.t(mu), self.t(sigma), self.t(eps), seed, off, z,
+                  lp if want_lp else None, K, M, D, sk, sr)
+        lpn = lp.cpu().numpy()
+        return dict(z=z.cpu().numpy(), lp=lpn.T if kfast else lpn)
+
+    def normal_sample_bwd(self, sigma, eps, gz, glp, K, D, seed=0, off=0):
+        M = sigma.size
+        R = M // D
+        gmu, gs = self.empty(M), self.empty(M)
+        self.call("zs_normal_sample_logprob_bwd_f32", self.t(sigma), self.t(eps), seed, off, self.t(gz), self.t(glp),
+                  R, 1, gmu, gs, K, M, D)
+        return dict(gmu=gmu.cpu().numpy(), gsigma=gs.cpu().numpy())
+
+    def normal_lp(self, x, mu, sigma, K, R, D, kfast=False):
+        lp = self.empty(R, K) if kfast else self.empty(K, R)
+        sk, sr = (1, K) if kfast else (R, 1)
+        self.call("zs_normal_logprob_f32", self.t(x), x.size, self.t(mu), mu.size, self.t(sigma), sigma.size, lp,
+                  K, R, D, sk, sr)
+        lpn = lp.cpu().numpy()
+        return dict(lp=lpn.T if kfast else lpn)
+
+    def normal_lp_bwd(self, x, mu, sigma, glp, K, R, D):
+        N = K * R * D
+        gx, gm, gs = self.empty(N), self.empty(N), self.empty(N)
+        self.call("zs_normal_logprob_bwd_f32", self.t(x), x.size, self.t(mu), mu.size, self.t(sigma), sigma.size,
+                  self.t(glp), R, 1, gx, gm, gs, K, R, D)
+        return dict(gx=gx.cpu().numpy(), gmu=gm.cpu().numpy(), gsigma=gs.cpu().numpy())
+
+    def normal_lp_bwd_ksum(self, x, mu, sigma, glp, K, R, D, want_gx=True):
+        gx = self.empty(K * R * D)
+        gm, gs = self.empty(R * D), self.empty(R * D)
+        self.call("zs_normal_logprob_bwd_ksum_f32", self.t(x), self.t(mu), self.t(sigma), self.t(glp), R, 1,
+                  gx if want_gx else None, gm, gs, K, R, D)
+        out = dict(gmu=gm.cpu().numpy(), gsigma=gs.cpu().numpy())
+        if want_gx:
+            out["gx"] = gx.cpu().numpy()
+        return out
+
+    def bern_lp(self, p, x, K, R, D, logits=False, kfast=False, want_p=False):
+        lp = self.empty(R, K) if kfast else self.empty(K, R)
+        sk, sr = (1, K) if kfast else (R, 1)
+        po = self.empty(K * R * D)
+        if logits:
+            self.call("zs_bernoulli_logits_logprob_f32", self.t(p), self.t(x), x.size, lp, po if want_p else None,
+                      K, R, D, sk, sr)
+        else:
+            self.call("zs_bernoulli_logprob_f32", self.t(p), self.t(x), x.size, lp, K, R, D, sk, sr)
+        lpn = lp.cpu().numpy()
+        out = dict(lp=lpn.T if kfast else lpn)
+        if want_p:
+            out["p"] = po.cpu().numpy()
+        return out
+
+    def bern_lp_bwd(self, p, x, glp, K, R, D, logits=False):
+        gp = self.empty(K * R * D)
+        name = "zs_bernoulli_logits_logprob_bwd_f32" if logits else "zs_bernoulli_logprob_bwd_f32"
+        self.call(name, self.t(p), self.t(x), x.size, self.t(glp), R, 1, gp, K, R, D)
+        return dict(gp=gp.cpu().numpy())
+
+    def iw(self, logp, logq, est):
+        B, K = logp.shape
+        cost, bound = self.empty(B), self.empty(B)
+        cp, cq = self.empty(B, K), self.empty(B, K)
+        self.call("zs_iw_reduce_f32", self.t(logp), K, self.t(logq), K, B, K, est, cost, bound, cp, cq)
+        return dict(cost=cost.cpu().numpy(), bound=bound.cpu().numpy(), cp=cp.cpu().numpy(), cq=cq.cpu().numpy())
+
+    def lme(self, x):
+        B, K = x.shape
+        out = self.empty(B)
+        self.call("zs_log_mean_exp_f32", self.t(x), K, B, K, out)
+        return out.cpu().numpy()
+
+    def philox(self, n, seed, off):
+        out = self.empty(n)
+        self.call("zs_philox_normal_f32", out, n, seed, off)
+        return out.cpu().numpy()
+
+    def bern_sample(self, p, n, seed, off):
+        out = self.empty(n)
+        self.call("zs_bernoulli_sample_f32", self.t(p), p.size, out, n, seed, off)
+        return out.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Raw(host_kernel_library(), "cpu")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return Raw(_hip.KernelLibrary(_hip.LIB_PATH), "cuda:0")
+
+
+# ------------------------------------------------------------------ C oracle vs goldens (CPU)
+def test_c_oracle_normal_golden(orc):
+    g = load_golden("g_normal_sample")
+    for c in range(int(g["n_cases"])):
+        p = "c%03d_" % c
+        if int(g[p + "g"]) == 0:
+            continue
+        K = max(int(g[p + "K"]), 1)
+        mu, sd, eps = g[p + "mu"], torch.exp(torch.tensor(g[p + "ls"])).numpy(), g[p + "eps"]   # torch.exp like the reference
+        D = int(np.prod(mu.shape[mu.ndim - int(g[p + "g"]):]))
+        out = orc.normal_sample(mu.ravel(), sd.ravel(), eps.ravel(), K, D)
+        assert np.array_equal(out["z"].reshape(g[p + "z"].shape), g[p + "z"])
+        np.testing.assert_allclose(out["lp"].reshape(g[p + "lp"].shape), g[p + "lp"], rtol=1e-5, atol=1e-5)
+
+
+def test_c_oracle_bernoulli_golden(orc):
+    g = load_golden("g_bernoulli")
+    for c in range(int(g["n_cases"])):
+        p = "c%03d_" % c
+        if int(g[p + "from_logits"]):
+            par, logits = g[p + "logits"], True
+        else:
+            par, logits = g[p + "probs"], False
+        x = np.broadcast_to(g[p + "x"], np.broadcast_shapes(g[p + "x"].shape, par.shape)) if g[p + "x"].shape != par.shape and g[p + "x"].size == par.size else g[p + "x"]
+        gnd = int(g[p + "g"])
+        D = int(np.prod(par.shape[par.ndim - gnd:])) if gnd else 1
+        rows = par.size // D
+        out = orc.bern_lp(par.ravel(), np.ascontiguousarray(x).ravel(), 1, rows, D, logits=logits)
+        np.testing.assert_allclose(out["lp"].reshape(g[p + "lp"].shape), g[p + "lp"], rtol=1e-5, atol=1e-4 if gnd else 2e-6)
+
+
+def test_c_oracle_iw_golden(orc):
+    g = load_golden("g_iw")
+    for c in range(int(g["n_cases"])):
+        p = "c%03d_" % c
+        lp, lq = g[p + "logp"].T.copy(), g[p + "logq"].T.copy()      # K-fastest rows [B, K]
+        B = lp.shape[0]
+        for est, tag in [(0, "sgvb"), (1, "vimco")]:
+            out = orc.iw(lp, lq, est)
+            c32, c64 = float(g[p + tag + "_cost"]), float(g[p + tag + "_cost64"])
+            assert abs(out["cost"].mean() - c32) <= 3e-6 * abs(c32) + 1.5 * abs(c32 - c64)
+            np.testing.assert_allclose(out["cp"].T / B, g[p + tag + "_glogp"], rtol=2e-5, atol=1e-7)
+            ref_err = np.abs(g[p + tag + "_glogq"] - g[p + tag + "_glogq64"]).max()
+            np.testing.assert_allclose(out["cq"].T / B, g[p + tag + "_glogq"], rtol=2e-5, atol=max(3 * ref_err, 2e-7))
+            np.testing.assert_allclose(out["bound"], g[p + "bound"], rtol=2e-6, atol=1e-5)
+
+
+def test_c_oracle_rejects_bad_arguments(orc):
+    one = np.ones(4, np.float32)
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.normal_sample(one, one, one, 1, 3)                # D does not divide M
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.normal_lp(np.ones(3, np.float32), one, one, 1, 1, 4)   # period does not divide N
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.iw(np.ones((2, 1), np.float32), np.ones((2, 1), np.float32), 1)   # vimco needs K >= 2
+
+
+# ------------------------------------------------------------------ HIP vs C oracle (GPU)
+def _cmp(a, b, rtol=2e-5, atol=2e-5):
+    assert a.keys() == b.keys()
+    for k in a:
+        np.testing.assert_allclose(a[k], b[k], rtol=rtol, atol=atol, err_msg=k)
+
+
+NORMAL_SHAPES = [  # (K, R, D)
+    (1, 1, 1), (1, 7, 1), (3, 5, 4), (5, 6, 40), (50, 16, 40), (2, 3, 700), (4, 1, 51), (3, 9, 7), (2, 130, 8),
+    (1, 1, 256), (2, 2, 260), (64, 3, 12),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,D", NORMAL_SHAPES)
+@pytest.mark.parametrize("kfast", [False, True])
+def test_hip_normal_sample_and_backward(hip, orc, K, R, D, kfast):
+    rng = np.random.RandomState(K * 1000 + R * 10 + D)
+    M = R * D
+    mu = rng.standard_normal(M).astype(np.float32)
+    sd = np.exp(0.5 * rng.standard_normal(M)).astype(np.float32)
+    eps = rng.standard_normal(K * M).astype(np.float32)
+    a, b = hip.normal_sample(mu, sd, eps, K, D, kfast=kfast), orc.normal_sample(mu, sd, eps, K, D, kfast=kfast)
+    assert np.array_equal(a["z"], b["z"]), "z = mu + sigma*eps must be bit-exact"
+    np.testing.assert_allclose(a["lp"], b["lp"], rtol=1e-5, atol=1e-5 * max(1, D))
+    gz = rng.standard_normal(K * M).astype(np.float32)
+    glp = rng.standard_normal(K * R).astype(np.float32)
+    _cmp(hip.normal_sample_bwd(sd, eps, gz, glp, K, D), orc.normal_sample_bwd(sd, eps, gz, glp, K, D), 1e-4, 1e-4)
+    _cmp(hip.normal_sample_bwd(sd, eps, None, glp, K, D), orc.normal_sample_bwd(sd, eps, None, glp, K, D), 1e-4, 1e-4)
+    # Philox path: same (seed, offset) -> same draw in forward and backward, on both implementations
+    a, b = hip.normal_sample(mu, sd, None, K, D, seed=77, off=5), orc.normal_sample(mu, sd, None, K, D, seed=77, off=5)
+    np.testing.assert_allclose(a["z"], b["z"], rtol=0, atol=2e-5 * float(sd.max()) * 6)
+    _cmp(hip.normal_sample_bwd(sd, None, gz, glp, K, D, 77, 5), orc.normal_sample_bwd(sd, None, gz, glp, K, D, 77, 5),
+         2e-4, 2e-4 * np.sqrt(K))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,D", NORMAL_SHAPES)
+def test_hip_normal_logprob_periods(hip, orc, K, R, D):
+    rng = np.random.RandomState(7 + K + R + D)
+    N = K * R * D
+    full = lambda: rng.standard_normal(N).astype(np.float32)
+    glp = rng.standard_normal(K * R).astype(np.float32)
+    combos = [(N, N, N), (N, R * D, R * D), (N, R * D, 1), (R * D, N, 1), (N, 1, 1)]
+    for Px, Pm, Ps in combos:
+        x, mu = full()[:Px].copy(), full()[:Pm].copy()
+        sd = np.exp(0.3 * full()[:Ps]).astype(np.float32)
+        for kfast in (False, True):
+            a, b = hip.normal_lp(x, mu, sd, K, R, D, kfast), orc.normal_lp(x, mu, sd, K, R, D, kfast)
+            np.testing.assert_allclose(a["lp"], b["lp"], rtol=2e-5, atol=2e-5 * max(1, D))
+        _cmp(hip.normal_lp_bwd(x, mu, sd, glp, K, R, D), orc.normal_lp_bwd(x, mu, sd, glp, K, R, D), 1e-4, 1e-4)
+    x, mu, sd = full(), full()[:R * D].copy(), np.exp(0.3 * full()[:R * D]).astype(np.float32)
+    for want_gx in (True, False):
+        _cmp(hip.normal_lp_bwd_ksum(x, mu, sd, glp, K, R, D, want_gx), orc.normal_lp_bwd_ksum(x, mu, sd, glp, K, R, D, want_gx),
+             2e-4, 2e-4)
+
+
+BERN_SHAPES = [(1, 1, 1), (1, 5, 784), (50, 8, 784), (3, 4, 16), (2, 3, 783), (7, 2, 100), (2, 9, 260), (1, 300, 4)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,D", BERN_SHAPES)
+@pytest.mark.parametrize("logits", [False, True])
+def test_hip_bernoulli(hip, orc, K, R, D, logits):
+    rng = np.random.RandomState(11 + K + R + D)
+    N = K * R * D
+    if logits:
+        p = (4 * rng.standard_normal(N)).astype(np.float32)
+    else:
+        p = rng.uniform(0, 1, N).astype(np.float32)
+        p[:: max(N // 7, 1)] = 0.0             # the +1e-8 edge cases
+        p[1:: max(N // 5, 1)] = 1.0
+    glp = rng.standard_normal(K * R).astype(np.float32)
+    for Px in sorted({N, R * D}):
+        x = (rng.uniform(size=Px) < 0.5).astype(np.float32)
+        if Px == N:
+            x[::3] = 0.25                      # fractional observations are legal
+        for kfast in (False, True):
+            a, b = hip.bern_lp(p, x, K, R, D, logits, kfast, want_p=logits), orc.bern_lp(p, x, K, R, D, logits, kfast, want_p=logits)
+            np.testing.assert_allclose(a["lp"], b["lp"], rtol=2e-5, atol=3e-5 * max(1, D / 16))
+            if logits:
+                np.testing.assert_allclose(a["p"], b["p"], rtol=1e-6, atol=1e-7)
+        a, b = hip.bern_lp_bwd(p, x, glp, K, R, D, logits), orc.bern_lp_bwd(p, x, glp, K, R, D, logits)
+        np.testing.assert_allclose(a["gp"], b["gp"], rtol=1e-4, atol=1e-4 if logits else 1e-30 + 1e-4 * np.abs(b["gp"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K", [(1, 1), (3, 2), (8, 5), (256, 50), (5, 64), (4, 65), (3, 200), (2, 1000), (1, 10000)])
+@pytest.mark.parametrize("spread", [1.0, 5.0, 30.0])
+def test_hip_iw_reduce(hip, orc, B, K, spread):
+    rng = np.random.RandomState(B * 7 + K)
+    logp = (-550 + spread * rng.standard_normal((B, K))).astype(np.float32)
+    logq = (-50 + 0.3 * spread * rng.standard_normal((B, K))).astype(np.float32)
+    if K > 2:
+        logp[0, 1] = logp[0, 0] = logp[0].max() + 1.0      # tie at the maximum
+    for est in (0, 1):
+        if est == 1 and K < 2:
+            with pytest.raises(RuntimeError, match="code -1"):
+                hip.iw(logp, logq, est)
+            continue
+        a, b = hip.iw(logp, logq, est), orc.iw(logp, logq, est)
+        # float64 truth of the same quantities
+        l = torch.tensor(logp, dtype=torch.float64) - torch.tensor(logq, dtype=torch.float64)
+        wt = torch.softmax(l, 1)
+        bound = torch.logsumexp(l, 1) - np.log(K)
+        np.testing.assert_allclose(a["bound"], bound.numpy(), rtol=2e-6, atol=2e-5)
+        np.testing.assert_allclose(a["cp"], -wt.numpy(), rtol=1e-4, atol=1e-6)
+        if est == 0:
+            truth_cost = -(wt * l).sum(1).numpy()
+            np.testing.assert_allclose(a["cost"], truth_cost, rtol=1e-5, atol=1e-4)
+            np.testing.assert_allclose(a["cq"], wt.numpy(), rtol=1e-4, atol=1e-6)
+        else:
+            sub = (l.sum(1, keepdim=True) - l) / (K - 1)
+            sig = torch.empty_like(l)
+            for j in range(min(K, 64)):        # exact leave-one-out for the first columns
+                lj = l.clone()
+                lj[:, j] = sub[:, j]
+                sig[:, j] = bound - (torch.logsumexp(lj, 1) - np.log(K))
+            n = min(K, 64)
+            err_orc = np.abs(b["cq"][:, :n] - (wt - sig)[:, :n].numpy()).max()
+            err_hip = np.abs(a["cq"][:, :n] - (wt - sig)[:, :n].numpy()).max()
+            assert err_hip <= max(2 * err_orc, 2e-6), (err_hip, err_orc)   # at least as accurate as the fp32 reference math
+        np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(a["cq"], b["cq"], rtol=1e-3, atol=max(3e-6 * 550, 1e-5))
+    np.testing.assert_allclose(hip.lme(logp), orc.lme(logp), rtol=2e-6, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_rng(hip, orc):
+    for n in (1, 3, 4, 5, 1023, 4096 + 2):
+        a, b = hip.philox(n, 1234, 9), orc.philox(n, 1234, 9)
+        np.testing.assert_allclose(a, b, rtol=0, atol=3e-5)
+        p = np.linspace(0.01, 0.99, 7).astype(np.float32)
+        assert np.array_equal(hip.bern_sample(p, n, 5, 2), orc.bern_sample(p, n, 5, 2))   # same uniforms bit-for-bit
+    big = hip.philox(1 << 20, 1, 0)
+    assert abs(big.mean()) < 4e-3 and abs(big.std() - 1) < 4e-3
+    assert not np.array_equal(hip.philox(64, 1, 0), hip.philox(64, 1, 1))
+    assert not np.array_equal(hip.philox(64, 1, 0), hip.philox(64, 2, 0))
+
+
+@pytest.mark.gpu
+def test_hip_empty_and_unaligned(hip, orc):
+    z = np.zeros(0, np.float32)
+    hip.call("zs_normal_sample_logprob_f32", hip.t(z), hip.t(z), None, 0, 0, hip.empty(0), hip.empty(0), 3, 0, 1, 1, 1)
+    hip.call("zs_bernoulli_logprob_f32", hip.t(z), hip.t(np.ones(1, np.float32)), 1, hip.empty(0), 1, 0, 4, 1, 1)
+    hip.call("zs_iw_reduce_f32", hip.t(np.ones(4, np.float32)), 4, hip.t(np.ones(4, np.float32)), 4, 0, 4, 0, None, None, None, None)
+    with pytest.raises(RuntimeError, match="code -1"):
+        hip.call("zs_normal_sample_logprob_f32", None, None, None, 0, 0, None, None, 1, 4, 4, 1, 1)
+    # operands offset by one float: the vector path must not be taken on misaligned pointers
+    rng = np.random.RandomState(5)
+    K, R, D = 3, 4, 8
+    N = K * R * D
+    pbuf = hip.t(np.concatenate([[0.5], rng.uniform(0.01, 0.99, N)]).astype(np.float32))
+    xbuf = hip.t(np.concatenate([[0.0], (rng.uniform(size=R * D) < 0.5)]).astype(np.float32))
+    lp = hip.empty(K, R)
+    hip.call("zs_bernoulli_logprob_f32", pbuf[1:], xbuf[1:], R * D, lp, K, R, D, R, 1)
+    ref = orc.bern_lp(pbuf[1:].cpu().numpy(), xbuf[1:].cpu().numpy(), K, R, D)["lp"]
+    np.testing.assert_allclose(lp.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
