@@ -172,6 +172,19 @@ int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float*
  * out[i], i < N, group = i / 4.  For tests and for callers that need eps itself. */
 int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Per-kernel timing for the benchmark harness (no reference counterpart).
+ * While enabled, every launch made by the entry points above is issued with a start/stop HIP event
+ * pair bound to the dispatch on its stream (hipExtLaunchKernelGGL), i.e. the kernel's own duration.
+ *   zs_prof_enable(1) clears earlier records and starts recording; zs_prof_enable(0) stops.
+ *   zs_prof_kernel_id("zs_bernoulli_logprob_f32") -> id of that entry point's kernels (or ZS_EINVAL).
+ *   zs_prof_query(id, &total_ms, &min_ms, &max_ms, &count) waits for the recorded launches of that
+ *   entry point and returns their summed / extreme durations.
+ * -------------------------------------------------------------------------*/
+int zs_prof_enable(int on);
+int zs_prof_kernel_id(const char* entry_point);
+int zs_prof_query(int kernel_id, double* total_ms, double* min_ms, double* max_ms, int64_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,7 +88,9 @@ int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const floa
                                  uint64_t offset, float* z, float* lp, int64_t K, int64_t M, int64_t D,
                                  int64_t sk, int64_t sr, void* stream) {
   (void)stream;
-  if (!mu || !sigma || !z || K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
+  if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
+  if (M == 0) return 0;
+  if (!mu || !sigma || !z) return ZS_EINVAL;
   const int64_t R = M / D;
   for (int64_t k = 0; k < K; ++k)
     for (int64_t r = 0; r < R; ++r) {
@@ -110,7 +112,9 @@ int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float* eps, uint6
                                      const float* gz, const float* glp, int64_t gsk, int64_t gsr, float* gmu,
                                      float* gsigma, int64_t K, int64_t M, int64_t D, void* stream) {
   (void)stream;
-  if (!sigma || !gmu || !gsigma || K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
+  if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
+  if (M == 0) return 0;
+  if (!sigma || !gmu || !gsigma) return ZS_EINVAL;
   for (int64_t m = 0; m < M; ++m) {
     const int64_t r = m / D;
     float a = 0.f, b = 0.f, g = 0.f;
@@ -133,9 +137,11 @@ int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu, int64_t P
                           int64_t Ps, float* lp, int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr,
                           void* stream) {
   (void)stream;
-  if (!x || !mu || !sigma || !lp || K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
-  if (N && (N % Px || N % Pm || N % Ps)) return ZS_EINVAL;
+  if (N == 0) return 0;
+  if (!x || !mu || !sigma || !lp) return ZS_EINVAL;
+  if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
   for (int64_t k = 0; k < K; ++k)
     for (int64_t r = 0; r < R; ++r) {
       float acc = 0.f;
@@ -161,9 +167,11 @@ int zs_normal_logprob_bwd_f32(const float* x, int64_t Px, const float* mu, int64
                               int64_t Ps, const float* glp, int64_t gsk, int64_t gsr, float* gx, float* gmu,
                               float* gsigma, int64_t K, int64_t R, int64_t D, void* stream) {
   (void)stream;
-  if (!x || !mu || !sigma || !glp || K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
-  if (N && (N % Px || N % Pm || N % Ps)) return ZS_EINVAL;
+  if (N == 0) return 0;
+  if (!x || !mu || !sigma || !glp) return ZS_EINVAL;
+  if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
   for (int64_t i = 0; i < N; ++i) {
     const int64_t row = i / D, k = row / R, r = row % R;
     float a, b, c;
@@ -179,8 +187,10 @@ int zs_normal_logprob_bwd_ksum_f32(const float* x, const float* mu, const float*
                                    int64_t gsk, int64_t gsr, float* gx, float* gmu, float* gsigma, int64_t K,
                                    int64_t R, int64_t D, void* stream) {
   (void)stream;
-  if (!x || !mu || !sigma || !glp || K < 1 || R < 0 || D < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1) return ZS_EINVAL;
   const int64_t M = R * D;
+  if (M == 0) return 0;
+  if (!x || !mu || !sigma || !glp) return ZS_EINVAL;
   for (int64_t m = 0; m < M; ++m) {
     const int64_t r = m / D;
     float sa = 0.f, sb = 0.f;
@@ -200,9 +210,11 @@ int zs_normal_logprob_bwd_ksum_f32(const float* x, const float* mu, const float*
 /* ------------------------------------------------------------------ K3 / K5 */
 static int bern_fwd(const float* p, int logits, const float* x, int64_t Px, float* lp, float* probs_out,
                     int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
-  if (!p || !x || !lp || K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
-  if (N && N % Px) return ZS_EINVAL;
+  if (N == 0) return 0;
+  if (!p || !x || !lp) return ZS_EINVAL;
+  if (N % Px) return ZS_EINVAL;
   for (int64_t k = 0; k < K; ++k)
     for (int64_t r = 0; r < R; ++r) {
       float acc = 0.f;
@@ -221,9 +233,11 @@ static int bern_fwd(const float* p, int logits, const float* x, int64_t Px, floa
 }
 static int bern_bwd(const float* p, int logits, const float* x, int64_t Px, const float* glp, int64_t gsk,
                     int64_t gsr, float* gp, int64_t K, int64_t R, int64_t D) {
-  if (!p || !x || !glp || !gp || K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
-  if (N && N % Px) return ZS_EINVAL;
+  if (N == 0) return 0;
+  if (!p || !x || !glp || !gp) return ZS_EINVAL;
+  if (N % Px) return ZS_EINVAL;
   for (int64_t i = 0; i < N; ++i) {
     const int64_t row = i / D, k = row / R, r = row % R;
     float pv = p[i], scale = 1.0f;
@@ -261,7 +275,9 @@ int zs_bernoulli_logits_logprob_bwd_f32(const float* logits, const float* x, int
 int zs_bernoulli_sample_f32(const float* p, int64_t Pp, float* out, int64_t N, uint64_t seed, uint64_t offset,
                             void* stream) {
   (void)stream;
-  if (!p || !out || N < 0 || Pp < 1) return ZS_EINVAL;
+  if (N < 0 || Pp < 1) return ZS_EINVAL;
+  if (N == 0) return 0;
+  if (!p || !out) return ZS_EINVAL;
   for (int64_t i = 0; i < N; ++i) {
     uint32_t r[4];
     philox4((uint64_t)(i >> 2), offset, seed, r);
@@ -282,9 +298,11 @@ static float lme_row(const float* v, int64_t n) { /* zhusuan/utils.py:17-18 */
 int zs_iw_reduce_f32(const float* logp, int64_t ld_p, const float* logq, int64_t ld_q, int64_t B, int64_t K,
                      int estimator, float* cost_b, float* bound_b, float* coef_p, float* coef_q, void* stream) {
   (void)stream;
-  if (!logp || !logq || B < 0 || K < 1 || ld_p < K || ld_q < K) return ZS_EINVAL;
+  if (B < 0 || K < 1 || ld_p < K || ld_q < K) return ZS_EINVAL;
   if (estimator != ZS_IW_SGVB && estimator != ZS_IW_VIMCO) return ZS_EINVAL;
   if (estimator == ZS_IW_VIMCO && K < 2) return ZS_EINVAL;
+  if (B == 0) return 0;
+  if (!logp || !logq) return ZS_EINVAL;
   float* l = (float*)malloc(sizeof(float) * (size_t)K * 2);
   if (!l) return ZS_ENOTSUP;
   float* tmp = l + K;
@@ -325,16 +343,28 @@ int zs_iw_reduce_f32(const float* logp, int64_t ld_p, const float* logq, int64_t
 
 int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float* out, void* stream) {
   (void)stream;
-  if (!x || !out || B < 0 || K < 1 || ld < K) return ZS_EINVAL;
+  if (B < 0 || K < 1 || ld < K) return ZS_EINVAL;
+  if (B == 0) return 0;
+  if (!x || !out) return ZS_EINVAL;
   for (int64_t b = 0; b < B; ++b) out[b] = lme_row(x + b * ld, K);
   return 0;
 }
 
 int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, void* stream) {
   (void)stream;
-  if (!out || N < 0) return ZS_EINVAL;
+  if (N < 0) return ZS_EINVAL;
+  if (N == 0) return 0;
+  if (!out) return ZS_EINVAL;
   for (int64_t i = 0; i < N; ++i) out[i] = eps_at(NULL, i, seed, offset);
   return 0;
+}
+
+/* timing hooks exist only in the HIP library */
+int zs_prof_enable(int on) { (void)on; return ZS_ENOTSUP; }
+int zs_prof_kernel_id(const char* entry_point) { (void)entry_point; return ZS_ENOTSUP; }
+int zs_prof_query(int kernel_id, double* total_ms, double* min_ms, double* max_ms, int64_t* count) {
+  (void)kernel_id; (void)total_ms; (void)min_ms; (void)max_ms; (void)count;
+  return ZS_ENOTSUP;
 }
 
 /* raw Philox words, for the known-answer test of the generator itself */

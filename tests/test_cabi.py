@@ -27,7 +27,7 @@ def declared_symbols():
 
 def test_header_symbols_exported_by_both_libraries():
     names = declared_symbols()
-    assert len(names) == 15 and set(_hip.PROTOTYPES) <= set(names)
+    assert len(names) == 18 and set(_hip.PROTOTYPES) <= set(names)
     hip = ctypes.CDLL(_hip.LIB_PATH)           # loads without a GPU; no compute call is made here
     orc = ctypes.CDLL(build_oracle_lib())
     for n in names:
@@ -325,6 +325,34 @@ def test_hip_bernoulli(hip, orc, K, R, D, logits):
         np.testing.assert_allclose(a["gp"], b["gp"], rtol=1e-4, atol=1e-4 if logits else 1e-30 + 1e-4 * np.abs(b["gp"]).max())
 
 
+def _iw_truth_f64(logp, logq, est):
+    """float64 evaluation of importance_weighted_objective.py:16-25,123-132,152-191 on K-fastest rows."""
+    lq = torch.tensor(logq, dtype=torch.float64)
+    l = torch.tensor(logp, dtype=torch.float64) - lq
+    B, K = l.shape
+    wt = torch.softmax(l, 1)
+    bound = torch.logsumexp(l, 1) - np.log(K)
+    out = dict(bound=bound.numpy(), cp=(-wt).numpy())
+    cost = -(wt * l).sum(1)
+    cq = wt.clone()
+    if est == 1:
+        sub = (l.sum(1, keepdim=True) - l) / (K - 1)
+        srt, idx = torch.sort(l, 1, descending=True)
+        m1, m2 = srt[:, :1], srt[:, 1:2]
+        e = torch.exp(l - m1)
+        S = e.sum(1, keepdim=True)
+        cv = torch.log((S - e + torch.exp(sub - m1)) / K) + m1
+        for b in range(B):                      # the arg-max column needs the second maximum
+            j = int(idx[b, 0])
+            others = torch.cat([l[b, :j], l[b, j + 1:]])
+            cv[b, j] = torch.log((torch.exp(others - m2[b]).sum() + torch.exp(sub[b, j] - m2[b])) / K) + m2[b]
+        signal = bound.unsqueeze(1) - cv
+        cost = cost - (lq * signal).sum(1)
+        cq = wt - signal
+    out["cost"], out["cq"] = cost.numpy(), cq.numpy()
+    return out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,K", [(1, 1), (3, 2), (8, 5), (256, 50), (5, 64), (4, 65), (3, 200), (2, 1000), (1, 10000)])
 @pytest.mark.parametrize("spread", [1.0, 5.0, 30.0])
@@ -340,29 +368,20 @@ def test_hip_iw_reduce(hip, orc, B, K, spread):
                 hip.iw(logp, logq, est)
             continue
         a, b = hip.iw(logp, logq, est), orc.iw(logp, logq, est)
-        # float64 truth of the same quantities
-        l = torch.tensor(logp, dtype=torch.float64) - torch.tensor(logq, dtype=torch.float64)
-        wt = torch.softmax(l, 1)
-        bound = torch.logsumexp(l, 1) - np.log(K)
-        np.testing.assert_allclose(a["bound"], bound.numpy(), rtol=2e-6, atol=2e-5)
-        np.testing.assert_allclose(a["cp"], -wt.numpy(), rtol=1e-4, atol=1e-6)
-        if est == 0:
-            truth_cost = -(wt * l).sum(1).numpy()
-            np.testing.assert_allclose(a["cost"], truth_cost, rtol=1e-5, atol=1e-4)
-            np.testing.assert_allclose(a["cq"], wt.numpy(), rtol=1e-4, atol=1e-6)
-        else:
-            sub = (l.sum(1, keepdim=True) - l) / (K - 1)
-            sig = torch.empty_like(l)
-            for j in range(min(K, 64)):        # exact leave-one-out for the first columns
-                lj = l.clone()
-                lj[:, j] = sub[:, j]
-                sig[:, j] = bound - (torch.logsumexp(lj, 1) - np.log(K))
-            n = min(K, 64)
-            err_orc = np.abs(b["cq"][:, :n] - (wt - sig)[:, :n].numpy()).max()
-            err_hip = np.abs(a["cq"][:, :n] - (wt - sig)[:, :n].numpy()).max()
-            assert err_hip <= max(2 * err_orc, 2e-6), (err_hip, err_orc)   # at least as accurate as the fp32 reference math
-        np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-4, atol=1e-3)
-        np.testing.assert_allclose(a["cq"], b["cq"], rtol=1e-3, atol=max(3e-6 * 550, 1e-5))
+        t = _iw_truth_f64(logp, logq, est)
+        np.testing.assert_allclose(a["bound"], t["bound"], rtol=2e-6, atol=2e-5)
+        np.testing.assert_allclose(a["cp"], t["cp"], rtol=1e-4, atol=1e-6)
+        # The fp32 oracle (reference op order) loses accuracy as K grows: the learning signal is a
+        # difference of two ~550-sized log-mean-exps.  The kernel forms it as log(S) - log(S') and must be
+        # at least as close to the float64 truth as the fp32 reference math is.
+        for key, floor in (("cost", 2e-5 * np.abs(t["cost"]).max()), ("cq", 2e-6)):
+            err_hip = np.abs(a[key] - t[key]).max()
+            err_orc = np.abs(b[key] - t[key]).max()
+            assert err_hip <= max(1.5 * err_orc, floor), (key, err_hip, err_orc)
+        # and agree with the fp32 oracle within the oracle's own distance to the truth
+        for key in ("cost", "cq"):
+            slack = 2.5 * np.abs(b[key] - t[key]).max() + 1e-5 * max(1.0, np.abs(t[key]).max())
+            assert np.abs(a[key] - b[key]).max() <= slack, (key, np.abs(a[key] - b[key]).max(), slack)
     np.testing.assert_allclose(hip.lme(logp), orc.lme(logp), rtol=2e-6, atol=2e-5)
 
 

@@ -23,6 +23,16 @@ def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-30)
 
 
+def _check_z(z, ref, dev):
+    """z = mean + std*eps is bit-exact given identical (mean, std); end to end the encoder GEMMs run in
+    hipBLASLt on the GPU (other summation order than the reference's MKL), so there it is close, not equal."""
+    z = z.detach().cpu().numpy()
+    if dev.type == "cpu":
+        assert np.array_equal(z, ref)
+    else:
+        np.testing.assert_allclose(z, ref, rtol=2e-5, atol=2e-5)
+
+
 def _check_grads(g, model, rtol_norm=5e-4):
     names = [str(n) for n in g["grad_names"]]
     named = list(model.named_parameters())
@@ -51,7 +61,7 @@ def test_vae(dev, tag, B):
     loss.backward()
     _check_grads(g, model)
     if tag == "small":
-        assert np.array_equal(var.nodes["z"].dist.sample_cache.detach().cpu().numpy(), g["z"])
+        _check_z(var.nodes["z"].dist.sample_cache, g["z"], dev)
         np.testing.assert_allclose(gen.cache["x_mean"].detach().cpu().numpy(), g["x_mean"], rtol=1e-4, atol=1e-6)
     # generation path (vae_mnist.py:129-136): fresh prior sample, Bernoulli draw
     gen({})
@@ -79,7 +89,7 @@ def test_iwae(dev, est, tag, B, K, hidden, fused_logits):
     assert tuple(lq.shape) == (K, B) and lq.stride() == (1, K)      # K-fastest rows, reference shape
     log_w = (gen.nodes["z"].log_prob() + gen.nodes["x"].log_prob() - lq).detach().cpu().numpy()
     if tag == "small":
-        assert np.array_equal(var.nodes["z"].dist.sample_cache.detach().cpu().numpy(), g["z"])
+        _check_z(var.nodes["z"].dist.sample_cache, g["z"], dev)
         np.testing.assert_allclose(log_w, g["log_w"], rtol=2e-5, atol=2e-4)
         np.testing.assert_allclose(lq.detach().cpu().numpy(), g["logqz"], rtol=2e-5, atol=2e-5)
     else:

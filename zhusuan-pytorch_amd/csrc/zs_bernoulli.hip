@@ -200,9 +200,10 @@ __global__ __launch_bounds__(256) void k_bern_sample(const float* __restrict__ p
 template <bool LOGITS>
 int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* probs_out, int64_t K, int64_t R,
                int64_t D, int64_t sk, int64_t sr, hipStream_t st) {
-  if (!p || !x || !lp || K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
+  if (!p || !x || !lp) return ZS_EINVAL;
   if (N % Px) return ZS_EINVAL;
   const bool vec = (D % 4 == 0) && Px >= D && (Px % D == 0) && aligned16(p) && aligned16(x) &&
                    (!probs_out || aligned16(probs_out));
@@ -212,13 +213,13 @@ int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* pro
     const int64_t tiles = (K * R + rpw - 1) / rpw;
     const unsigned grid = grid_for(tiles, 4);
     if (probs_out)
-      hipLaunchKernelGGL((k_bern_logprob_rows<LOGITS, true>), dim3(grid), dim3(256), 0, st, (const float4*)p,
+      ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB : KID_BERN_LOGPROB, (k_bern_logprob_rows<LOGITS, true>), dim3(grid), dim3(256), st, (const float4*)p,
                          (const float4*)x, Px / D, lp, (float4*)probs_out, K, R, D4, G, rpw, p2, sk, sr);
     else
-      hipLaunchKernelGGL((k_bern_logprob_rows<LOGITS, false>), dim3(grid), dim3(256), 0, st, (const float4*)p,
+      ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB : KID_BERN_LOGPROB, (k_bern_logprob_rows<LOGITS, false>), dim3(grid), dim3(256), st, (const float4*)p,
                          (const float4*)x, Px / D, lp, (float4*)nullptr, K, R, D4, G, rpw, p2, sk, sr);
   } else {
-    hipLaunchKernelGGL((k_bern_logprob_serial<LOGITS>), dim3(grid_for(K * R, 256)), dim3(256), 0, st, p, x, Px,
+    ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB : KID_BERN_LOGPROB, (k_bern_logprob_serial<LOGITS>), dim3(grid_for(K * R, 256)), dim3(256), st, p, x, Px,
                        lp, probs_out, K, R, D, sk, sr);
   }
   ZS_CHECK_LAUNCH();
@@ -228,19 +229,20 @@ int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* pro
 template <bool LOGITS>
 int launch_bwd(const float* p, const float* x, int64_t Px, const float* glp, int64_t gsk, int64_t gsr, float* gp,
                int64_t K, int64_t R, int64_t D, hipStream_t st) {
-  if (!p || !x || !glp || !gp || K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
+  if (!p || !x || !glp || !gp) return ZS_EINVAL;
   if (N % Px) return ZS_EINVAL;
   const bool vec = (D % 4 == 0) && Px >= D && (Px % D == 0) && aligned16(p) && aligned16(x) && aligned16(gp);
   if (vec) {
     const int D4 = (int)(D / 4);
     const int G = D4 >= 64 ? 64 : D4, rpw = 64 / G;
     const int64_t tiles = (K * R + rpw - 1) / rpw;
-    hipLaunchKernelGGL((k_bern_logprob_bwd_rows<LOGITS>), dim3(grid_for(tiles, 4)), dim3(256), 0, st,
+    ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_rows<LOGITS>), dim3(grid_for(tiles, 4)), dim3(256), st,
                        (const float4*)p, (const float4*)x, Px / D, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
   } else {
-    hipLaunchKernelGGL((k_bern_logprob_bwd_serial<LOGITS>), dim3(grid_for(N, 256)), dim3(256), 0, st, p, x, Px,
+    ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_serial<LOGITS>), dim3(grid_for(N, 256)), dim3(256), st, p, x, Px,
                        glp, gsk, gsr, gp, N, R, D);
   }
   ZS_CHECK_LAUNCH();
@@ -274,9 +276,10 @@ extern "C" int zs_bernoulli_logits_logprob_bwd_f32(const float* logits, const fl
 
 extern "C" int zs_bernoulli_sample_f32(const float* p, int64_t Pp, float* out, int64_t N, uint64_t seed,
                                        uint64_t offset, void* stream) {
-  if (!p || !out || N < 0 || Pp < 1) return ZS_EINVAL;
+  if (N < 0 || Pp < 1) return ZS_EINVAL;
   if (N == 0) return 0;
-  hipLaunchKernelGGL(k_bern_sample, dim3(grid_for((N + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, Pp,
+  if (!p || !out) return ZS_EINVAL;
+  ZS_LAUNCH(KID_BERN_SAMPLE, k_bern_sample, dim3(grid_for((N + 3) / 4, 256)), dim3(256), (hipStream_t)stream, p, Pp,
                      out, N, seed, offset);
   ZS_CHECK_LAUNCH();
   return 0;

@@ -2,6 +2,7 @@
 // Wavefront = 64 lanes everywhere (CDNA4); no MFMA on this path (no dense contraction).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #define ZS_WAVE 64
@@ -16,6 +17,27 @@
   } while (0)
 
 namespace zs {
+
+// ---------------------------------------------------------------- launch + optional per-kernel timing
+// One id per C-ABI entry point.  When profiling is enabled (zs_prof_enable) a launch goes through
+// hipExtLaunchKernelGGL with a start/stop event pair bound to the dispatch itself, so the elapsed time
+// is the kernel's own duration on its stream (what rocprofv3 --kernel-trace reports), not the
+// host-side gap between two hipEventRecord calls.
+enum KernelId {
+  KID_NORMAL_SAMPLE = 0, KID_NORMAL_SAMPLE_BWD, KID_NORMAL_LOGPROB, KID_NORMAL_LOGPROB_BWD,
+  KID_NORMAL_LOGPROB_BWD_KSUM, KID_BERN_LOGPROB, KID_BERN_LOGPROB_BWD, KID_BERN_LOGITS_LOGPROB,
+  KID_BERN_LOGITS_LOGPROB_BWD, KID_BERN_SAMPLE, KID_IW_REDUCE, KID_LME, KID_PHILOX, KID_COUNT
+};
+bool prof_begin_launch(int kid, hipEvent_t* start, hipEvent_t* stop);  // defined in zs_iw.hip
+
+#define ZS_LAUNCH(kid, kern, grid, block, st, ...)                                             \
+  do {                                                                                         \
+    hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                 \
+    if (zs::prof_begin_launch(kid, &e0__, &e1__))                                              \
+      hipExtLaunchKernelGGL(kern, grid, block, 0, st, e0__, e1__, 0, __VA_ARGS__);             \
+    else                                                                                       \
+      hipLaunchKernelGGL(kern, grid, block, 0, st, __VA_ARGS__);                               \
+  } while (0)
 
 // ---------------------------------------------------------------- math
 // v_log_f32 / v_exp_f32 are base-2 and 1-ulp; natural log/exp are one multiply away.

@@ -198,17 +198,18 @@ __global__ __launch_bounds__(256) void k_philox_normal(float* __restrict__ out, 
 extern "C" int zs_iw_reduce_f32(const float* logp, int64_t ld_p, const float* logq, int64_t ld_q, int64_t B,
                                 int64_t K, int estimator, float* cost_b, float* bound_b, float* coef_p,
                                 float* coef_q, void* stream) {
-  if (!logp || !logq || B < 0 || K < 1 || ld_p < K || ld_q < K) return ZS_EINVAL;
+  if (B < 0 || K < 1 || ld_p < K || ld_q < K) return ZS_EINVAL;
   if (estimator != ZS_IW_SGVB && estimator != ZS_IW_VIMCO) return ZS_EINVAL;
   if (estimator == ZS_IW_VIMCO && K < 2) return ZS_EINVAL;
   if (K > 0x7fffffff) return ZS_ENOTSUP;
   if (B == 0) return 0;
+  if (!logp || !logq) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (K <= 64)
-    hipLaunchKernelGGL(k_iw_reduce_wave, dim3(grid_for(B, 4)), dim3(256), 0, st, logp, ld_p, logq, ld_q, B,
+    ZS_LAUNCH(KID_IW_REDUCE, k_iw_reduce_wave, dim3(grid_for(B, 4)), dim3(256), st, logp, ld_p, logq, ld_q, B,
                        (int)K, estimator, cost_b, bound_b, coef_p, coef_q);
   else
-    hipLaunchKernelGGL(k_iw_reduce_block, dim3(grid_for(B, 1)), dim3(256), 0, st, logp, ld_p, logq, ld_q, B, K,
+    ZS_LAUNCH(KID_IW_REDUCE, k_iw_reduce_block, dim3(grid_for(B, 1)), dim3(256), st, logp, ld_p, logq, ld_q, B, K,
                        estimator, cost_b, bound_b, coef_p, coef_q);
   ZS_CHECK_LAUNCH();
   return 0;
@@ -244,23 +245,110 @@ __global__ __launch_bounds__(256) void k_lme_wave(const float* __restrict__ x, i
 }  // namespace
 
 extern "C" int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float* out, void* stream) {
-  if (!x || !out || B < 0 || K < 1 || ld < K) return ZS_EINVAL;
+  if (B < 0 || K < 1 || ld < K) return ZS_EINVAL;
   if (B == 0) return 0;
+  if (!x || !out) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (K <= 64)
-    hipLaunchKernelGGL(k_lme_wave, dim3(grid_for(B, 4)), dim3(256), 0, st, x, ld, B, (int)K, out);
+    ZS_LAUNCH(KID_LME, k_lme_wave, dim3(grid_for(B, 4)), dim3(256), st, x, ld, B, (int)K, out);
   else
-    hipLaunchKernelGGL(k_lme_block, dim3(grid_for(B, 1)), dim3(256), 0, st, x, ld, B, K, out);
+    ZS_LAUNCH(KID_LME, k_lme_block, dim3(grid_for(B, 1)), dim3(256), st, x, ld, B, K, out);
   ZS_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, void* stream) {
-  if (!out || N < 0) return ZS_EINVAL;
+  if (N < 0) return ZS_EINVAL;
   if (N == 0) return 0;
-  hipLaunchKernelGGL(k_philox_normal, dim3(grid_for((N + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out,
+  if (!out) return ZS_EINVAL;
+  ZS_LAUNCH(KID_PHILOX, k_philox_normal, dim3(grid_for((N + 3) / 4, 256)), dim3(256), (hipStream_t)stream, out,
                      N, seed, offset);
   ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ per-kernel timing (bench.py)
+#include <mutex>
+#include <string.h>
+#include <vector>
+namespace {
+struct ProfState {
+  bool on = false;
+  std::mutex mu;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[zs::KID_COUNT];
+};
+ProfState& prof_state() {
+  static ProfState s;
+  return s;
+}
+const char* const kKernelNames[zs::KID_COUNT] = {
+    "zs_normal_sample_logprob_f32", "zs_normal_sample_logprob_bwd_f32", "zs_normal_logprob_f32",
+    "zs_normal_logprob_bwd_f32", "zs_normal_logprob_bwd_ksum_f32", "zs_bernoulli_logprob_f32",
+    "zs_bernoulli_logprob_bwd_f32", "zs_bernoulli_logits_logprob_f32", "zs_bernoulli_logits_logprob_bwd_f32",
+    "zs_bernoulli_sample_f32", "zs_iw_reduce_f32", "zs_log_mean_exp_f32", "zs_philox_normal_f32"};
+void prof_clear(ProfState& s) {
+  for (int k = 0; k < zs::KID_COUNT; ++k) {
+    for (auto& p : s.ev[k]) {
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
+    }
+    s.ev[k].clear();
+  }
+}
+}  // namespace
+
+bool zs::prof_begin_launch(int kid, hipEvent_t* start, hipEvent_t* stop) {
+  ProfState& s = prof_state();
+  if (!s.on || kid < 0 || kid >= zs::KID_COUNT) return false;
+  std::lock_guard<std::mutex> g(s.mu);
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess) return false;
+  if (hipEventCreate(&b) != hipSuccess) {
+    (void)hipEventDestroy(a);
+    return false;
+  }
+  s.ev[kid].push_back(std::make_pair(a, b));
+  *start = a;
+  *stop = b;
+  return true;
+}
+
+extern "C" int zs_prof_enable(int on) {
+  ProfState& s = prof_state();
+  std::lock_guard<std::mutex> g(s.mu);
+  if (on) prof_clear(s);
+  s.on = on != 0;
+  return 0;
+}
+
+extern "C" int zs_prof_kernel_id(const char* entry_point) {
+  if (!entry_point) return ZS_EINVAL;
+  for (int k = 0; k < zs::KID_COUNT; ++k)
+    if (strcmp(entry_point, kKernelNames[k]) == 0) return k;
+  return ZS_EINVAL;
+}
+
+extern "C" int zs_prof_query(int kernel_id, double* total_ms, double* min_ms, double* max_ms, int64_t* count) {
+  ProfState& s = prof_state();
+  if (kernel_id < 0 || kernel_id >= zs::KID_COUNT) return ZS_EINVAL;
+  std::lock_guard<std::mutex> g(s.mu);
+  double tot = 0.0, mn = 1e30, mx = 0.0;
+  int64_t n = 0;
+  for (auto& p : s.ev[kernel_id]) {
+    hipError_t e = hipEventSynchronize(p.second);
+    if (e != hipSuccess) return (int)e;
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, p.first, p.second);
+    if (e != hipSuccess) return (int)e;
+    tot += ms;
+    mn = ms < mn ? ms : mn;
+    mx = ms > mx ? ms : mx;
+    ++n;
+  }
+  if (total_ms) *total_ms = tot;
+  if (min_ms) *min_ms = n ? mn : 0.0;
+  if (max_ms) *max_ms = mx;
+  if (count) *count = n;
   return 0;
 }
 

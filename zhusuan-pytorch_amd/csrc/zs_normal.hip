@@ -26,7 +26,9 @@ inline RowMap row_map(int64_t D4) {
 // z = mean + std * eps must round twice like the reference's separate mul and add
 // (normal.py:105) so that z is bit-identical for identical eps.
 __device__ __forceinline__ float mul_add_2round(float m, float s, float e) {
-  return __fadd_rn(m, __fmul_rn(s, e));
+#pragma clang fp contract(off)   // HIP's __fmul_rn/__fadd_rn are plain * and + and would still fuse
+  const float prod = s * e;
+  return m + prod;
 }
 
 // ------------------------------------------------------------------------------------
@@ -429,8 +431,9 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
                                             uint64_t seed, uint64_t offset, float* z, float* lp,
                                             int64_t K, int64_t M, int64_t D,
                                             int64_t sk, int64_t sr, void* stream) {
-  if (!mu || !sigma || !z || K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
+  if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
   if (M == 0) return 0;
+  if (!mu || !sigma || !z) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t R = M / D;
   const bool vec = (D % 4 == 0) && aligned16(mu) && aligned16(sigma) && aligned16(z) && (!eps || aligned16(eps));
@@ -449,7 +452,7 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
       const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
       const unsigned grid = grid_for(total, 4);
 #define ZS_LAUNCH_SMALL(E, L)                                                                           \
-  hipLaunchKernelGGL((k_normal_sample_smallrow<E, L>), dim3(grid), dim3(256), 0, st, m4, s4, e4, seed, \
+  ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_smallrow<E, L>), dim3(grid), dim3(256), st, m4, s4, e4, seed, \
                      offset, (float4*)z, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr)
       if (eps) { if (lp) ZS_LAUNCH_SMALL(true, true); else ZS_LAUNCH_SMALL(true, false); }
       else     { if (lp) ZS_LAUNCH_SMALL(false, true); else ZS_LAUNCH_SMALL(false, false); }
@@ -457,7 +460,7 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
     } else {
       const unsigned grid = grid_for(K * R, 4);
 #define ZS_LAUNCH_LONG(E, L)                                                                           \
-  hipLaunchKernelGGL((k_normal_sample_longrow<E, L>), dim3(grid), dim3(256), 0, st, m4, s4, e4, seed, \
+  ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_longrow<E, L>), dim3(grid), dim3(256), st, m4, s4, e4, seed, \
                      offset, (float4*)z, lp, K, R, D4, sk, sr)
       if (eps) { if (lp) ZS_LAUNCH_LONG(true, true); else ZS_LAUNCH_LONG(true, false); }
       else     { if (lp) ZS_LAUNCH_LONG(false, true); else ZS_LAUNCH_LONG(false, false); }
@@ -466,10 +469,10 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
   } else {
     const unsigned grid = grid_for(K * R, 256);
     if (eps)
-      hipLaunchKernelGGL((k_normal_sample_serial<true>), dim3(grid), dim3(256), 0, st, mu, sigma, eps, seed,
+      ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_serial<true>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
                          offset, z, lp, K, R, D, sk, sr);
     else
-      hipLaunchKernelGGL((k_normal_sample_serial<false>), dim3(grid), dim3(256), 0, st, mu, sigma, eps, seed,
+      ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_serial<false>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
                          offset, z, lp, K, R, D, sk, sr);
   }
   ZS_CHECK_LAUNCH();
@@ -480,8 +483,9 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
                                                 uint64_t offset, const float* gz, const float* glp,
                                                 int64_t gsk, int64_t gsr, float* gmu, float* gsigma,
                                                 int64_t K, int64_t M, int64_t D, void* stream) {
-  if (!sigma || !gmu || !gsigma || K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
+  if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
   if (M == 0) return 0;
+  if (!sigma || !gmu || !gsigma) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (D % 4 == 0) && aligned16(sigma) && aligned16(gmu) && aligned16(gsigma) &&
                    (!eps || aligned16(eps)) && (!gz || aligned16(gz));
@@ -489,15 +493,15 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
     const int64_t M4 = M / 4;
     const unsigned grid = (unsigned)((M4 + 63) / 64);
     if (eps)
-      hipLaunchKernelGGL((k_normal_sample_bwd<true>), dim3(grid), dim3(256), 0, st, (const float4*)sigma,
+      ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<true>), dim3(grid), dim3(256), st, (const float4*)sigma,
                          (const float4*)eps, seed, offset, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
                          (float4*)gsigma, K, M4, (int)(D / 4));
     else
-      hipLaunchKernelGGL((k_normal_sample_bwd<false>), dim3(grid), dim3(256), 0, st, (const float4*)sigma,
+      ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<false>), dim3(grid), dim3(256), st, (const float4*)sigma,
                          (const float4*)eps, seed, offset, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
                          (float4*)gsigma, K, M4, (int)(D / 4));
   } else {
-    hipLaunchKernelGGL(k_normal_sample_bwd_serial, dim3(grid_for(M, 256)), dim3(256), 0, st, sigma, eps, seed,
+    ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, k_normal_sample_bwd_serial, dim3(grid_for(M, 256)), dim3(256), st, sigma, eps, seed,
                        offset, gz, glp, gsk, gsr, gmu, gsigma, K, M, D);
   }
   ZS_CHECK_LAUNCH();
@@ -507,9 +511,10 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
 extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu, int64_t Pm,
                                      const float* sigma, int64_t Ps, float* lp,
                                      int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, void* stream) {
-  if (!x || !mu || !sigma || !lp || K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
+  if (!x || !mu || !sigma || !lp) return ZS_EINVAL;
   if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (D % 4 == 0) && period_ok_rows(Px, D, N) && period_ok_rows(Pm, D, N) &&
@@ -519,11 +524,11 @@ extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu
     const int D4 = (int)(D / 4);
     RowMap rm = row_map(D4);
     const int64_t tiles = (K * R + rm.rpw - 1) / rm.rpw;
-    hipLaunchKernelGGL(k_normal_logprob_rows, dim3(grid_for(tiles, 4)), dim3(256), 0, st, (const float4*)x,
+    ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_rows, dim3(grid_for(tiles, 4)), dim3(256), st, (const float4*)x,
                        Px == 1 ? 0 : Px / D, (const float4*)mu, Pm == 1 ? 0 : Pm / D, (const float4*)sigma,
                        Ps == 1 ? 0 : Ps / D, lp, K, R, D4, rm.G, rm.rpw, rm.p2, sk, sr);
   } else {
-    hipLaunchKernelGGL(k_normal_logprob_serial, dim3(grid_for(K * R, 256)), dim3(256), 0, st, x, Px, mu, Pm,
+    ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_serial, dim3(grid_for(K * R, 256)), dim3(256), st, x, Px, mu, Pm,
                        sigma, Ps, lp, K, R, D, sk, sr);
   }
   ZS_CHECK_LAUNCH();
@@ -534,11 +539,12 @@ extern "C" int zs_normal_logprob_bwd_f32(const float* x, int64_t Px, const float
                                          const float* sigma, int64_t Ps, const float* glp, int64_t gsk,
                                          int64_t gsr, float* gx, float* gmu, float* gsigma,
                                          int64_t K, int64_t R, int64_t D, void* stream) {
-  if (!x || !mu || !sigma || !glp || K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
+  if (!x || !mu || !sigma || !glp) return ZS_EINVAL;
   if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
-  hipLaunchKernelGGL(k_normal_logprob_bwd_elem, dim3(grid_for(N, 256)), dim3(256), 0, (hipStream_t)stream, x,
+  ZS_LAUNCH(KID_NORMAL_LOGPROB_BWD, k_normal_logprob_bwd_elem, dim3(grid_for(N, 256)), dim3(256), (hipStream_t)stream, x,
                      Px, mu, Pm, sigma, Ps, glp, gsk, gsr, gx, gmu, gsigma, N, R, D);
   ZS_CHECK_LAUNCH();
   return 0;
@@ -548,19 +554,20 @@ extern "C" int zs_normal_logprob_bwd_ksum_f32(const float* x, const float* mu, c
                                               const float* glp, int64_t gsk, int64_t gsr, float* gx,
                                               float* gmu, float* gsigma, int64_t K, int64_t R, int64_t D,
                                               void* stream) {
-  if (!x || !mu || !sigma || !glp || K < 1 || R < 0 || D < 1) return ZS_EINVAL;
+  if (K < 1 || R < 0 || D < 1) return ZS_EINVAL;
   const int64_t M = R * D;
   if (M == 0) return 0;
+  if (!x || !mu || !sigma || !glp) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(mu) && aligned16(sigma) && (!gx || aligned16(gx)) &&
                    (!gmu || aligned16(gmu)) && (!gsigma || aligned16(gsigma));
   if (vec) {
     const int64_t M4 = M / 4;
-    hipLaunchKernelGGL(k_normal_logprob_bwd_ksum, dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st,
+    ZS_LAUNCH(KID_NORMAL_LOGPROB_BWD_KSUM, k_normal_logprob_bwd_ksum, dim3((unsigned)((M4 + 63) / 64)), dim3(256), st,
                        (const float4*)x, (const float4*)mu, (const float4*)sigma, glp, gsk, gsr, (float4*)gx,
                        (float4*)gmu, (float4*)gsigma, K, M4, (int)(D / 4));
   } else {
-    hipLaunchKernelGGL(k_normal_logprob_bwd_ksum_serial, dim3(grid_for(M, 256)), dim3(256), 0, st, x, mu, sigma,
+    ZS_LAUNCH(KID_NORMAL_LOGPROB_BWD_KSUM, k_normal_logprob_bwd_ksum_serial, dim3(grid_for(M, 256)), dim3(256), st, x, mu, sigma,
                        glp, gsk, gsr, gx, gmu, gsigma, K, M, D);
   }
   ZS_CHECK_LAUNCH();

@@ -61,6 +61,30 @@ class KernelLibrary(object):
             fn = getattr(self.cdll, name)  # AttributeError if a symbol is missing
             fn.restype = _int
             fn.argtypes = argtypes
+        self.cdll.zs_prof_enable.restype = _int
+        self.cdll.zs_prof_enable.argtypes = [_int]
+        self.cdll.zs_prof_kernel_id.restype = _int
+        self.cdll.zs_prof_kernel_id.argtypes = [ctypes.c_char_p]
+        self.cdll.zs_prof_query.restype = _int
+        self.cdll.zs_prof_query.argtypes = [_int] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.POINTER(_i64)]
+
+    def prof_enable(self, on):
+        """Record the kernels' own start/stop events for every launch (include/zs_hip.h, zs_prof_*)."""
+        rc = self.cdll.zs_prof_enable(1 if on else 0)
+        if rc != 0:
+            raise RuntimeError("zs_prof_enable failed with code %d" % rc)
+
+    def prof_query(self, entry_point):
+        """{'total_ms', 'min_ms', 'max_ms', 'count'} of the launches recorded for `entry_point`."""
+        kid = self.cdll.zs_prof_kernel_id(entry_point.encode())
+        if kid < 0:
+            raise RuntimeError("unknown entry point %s" % entry_point)
+        tot, mn, mx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        n = _i64()
+        rc = self.cdll.zs_prof_query(kid, ctypes.byref(tot), ctypes.byref(mn), ctypes.byref(mx), ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError("zs_prof_query failed with code %d" % rc)
+        return {"total_ms": tot.value, "min_ms": mn.value, "max_ms": mx.value, "count": n.value}
 
     def call(self, name, *args):
         t = _TIMER
@@ -145,6 +169,26 @@ def require_device(*tensors):
         elif t.device != dev:
             raise RuntimeError("zhusuan: operands on different devices: %s vs %s" % (dev, t.device))
     return dev
+
+
+def default_device():
+    """Where parameters given as Python numbers / lists are placed when no device is named:
+    the current HIP device (the host, only while the tests' host library is installed)."""
+    if _HOST_LIB is not None or not torch.cuda.is_available():
+        return torch.device("cpu")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def resolve_device(device, *params):
+    """Device of a distribution: the explicit `device` argument if given (parameters are moved there,
+    as in the reference, normal.py:50); otherwise the device of the first tensor parameter; otherwise
+    default_device().  (The reference's default is the CPU, which this build has no kernels for.)"""
+    if device is not None:
+        return torch.device(device) if not isinstance(device, torch.device) else device
+    for p in params:
+        if isinstance(p, torch.Tensor):
+            return p.device
+    return default_device()
 
 
 def stream_for(t):

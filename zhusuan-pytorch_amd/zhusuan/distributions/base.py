@@ -18,7 +18,7 @@ class Distribution(object):
                  is_reparameterized,
                  use_path_derivative=False,
                  group_ndims=0,
-                 device=torch.device('cpu'),
+                 device=None,
                  **kwargs):
         self._dtype = dtype
         self._is_continuous = is_continuous

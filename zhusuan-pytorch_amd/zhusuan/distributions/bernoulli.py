@@ -4,7 +4,7 @@ import torch
 
 from .base import Distribution
 from .utils import assert_same_log_float_dtype
-from .. import _ops, _rng
+from .. import _hip, _ops, _rng
 
 __all__ = ['Bernoulli']
 
@@ -26,8 +26,9 @@ class Bernoulli(Distribution):
                  dtype=None,
                  is_continuous=False,
                  group_ndims=0,
-                 device=torch.device('cpu'),
+                 device=None,
                  **kwargs):
+        device = _hip.resolve_device(device, logits, probs)
         if (logits is None) == (probs is None):
             raise ValueError(
                 "Either `probs` or `logits` should be passed. It is not allowed "

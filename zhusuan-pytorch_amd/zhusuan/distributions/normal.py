@@ -4,7 +4,7 @@ import torch
 
 from .base import Distribution
 from .utils import assert_same_log_float_dtype, check_broadcast
-from .. import _ops, _rng
+from .. import _hip, _ops, _rng
 
 __all__ = ['Normal']
 
@@ -16,6 +16,9 @@ class Normal(Distribution):
     :param is_reparameterized: True: z = mean + std * eps carries gradients to (mean, std)
         (normal.py:104-105); False: the draw is detached like ``torch.normal(mean, std)`` (:102).
     :param group_ndims: trailing batch axes summed into one event (base.py:175-176).
+    :param device: where the parameters are moved (normal.py:50).  Default: the device of the first
+        tensor parameter, else the current GPU -- the reference defaults to the CPU, for which this
+        build has no kernels.
     """
 
     def __init__(self,
@@ -26,8 +29,9 @@ class Normal(Distribution):
                  is_continuous=True,
                  is_reparameterized=True,
                  group_ndims=0,
-                 device=torch.device('cpu'),
+                 device=None,
                  **kwargs):
+        device = _hip.resolve_device(device, mean, std, logstd)
         self._mean = torch.as_tensor(mean, dtype=dtype).to(device)
         if (logstd is None) == (std is None):
             raise ValueError(
