@@ -24,22 +24,26 @@ struct IwRow {  // row-level scalars, uniform across the lanes that own the row
   float invK, invKm1;
 };
 
-// per-particle outputs given the row scalars
+// per-particle outputs given the row scalars.
+// Learning signal of VIMCO: signal_j = LME(l) - LME(l with l_j -> sub_j) = log(S) - log(S - e_j + t_j),
+// t_j = exp(sub_j - m1).  Formed as -log1p((t_j - e_j)/S) it carries no cancellation between two
+// ~|log w|-sized numbers (the fp32 reference loses ~1e-5 absolute there).  For the arg-max particle,
+// when it dominates the row (S < 2), S - e_j would cancel instead: there the sum over the other
+// particles S2 (taken relative to the second maximum m2) is used directly.
 __device__ __forceinline__ void iw_particle(const IwRow& r, float l, float lq, int j, int estimator,
                                             float& wt, float& cost_term, float& cq) {
-  const float e = exp_fast(l - r.m1);
+  const float e = expf(l - r.m1);
   wt = e / r.S;
   cost_term = -wt * l;
   cq = wt;
   if (estimator == ZS_IW_VIMCO) {
     const float sub = (r.sumL - l) * r.invKm1;
     float signal;
-    if (j != r.jstar) {
-      const float sx = (r.S - e) + exp_fast(sub - r.m1);
-      signal = r.logS - ln_fast(sx);
+    if (j != r.jstar || r.S >= 2.0f) {
+      signal = -log1pf((expf(sub - r.m1) - e) / r.S);
     } else {
-      const float sx = r.S2 + exp_fast(sub - r.m2);
-      signal = (r.logS - ln_fast(sx)) + (r.m1 - r.m2);
+      const float sx = r.S2 + expf(sub - r.m2);
+      signal = (r.logS - logf(sx)) + (r.m1 - r.m2);
     }
     cost_term -= lq * signal;
     cq = wt - signal;
@@ -65,12 +69,12 @@ __global__ __launch_bounds__(256) void k_iw_reduce_wave(
     const unsigned long long hit = __ballot(on && l == r.m1);
     r.jstar = hit ? (int)__ffsll((long long)hit) - 1 : 0;
     r.m2 = wave_max((on && lane != r.jstar) ? l : -INFINITY);
-    const float e = on ? exp_fast(l - r.m1) : 0.f;
+    const float e = on ? expf(l - r.m1) : 0.f;
     r.S = wave_sum(e);
     r.sumL = wave_sum(on ? l : 0.f);
     r.S2 = 0.f;
-    if (estimator == ZS_IW_VIMCO) r.S2 = wave_sum((on && lane != r.jstar) ? exp_fast(l - r.m2) : 0.f);
-    r.logS = ln_fast(r.S);
+    if (estimator == ZS_IW_VIMCO) r.S2 = wave_sum((on && lane != r.jstar) ? expf(l - r.m2) : 0.f);
+    r.logS = logf(r.S);
     r.invK = 1.0f / (float)K;
     r.invKm1 = K > 1 ? 1.0f / (float)(K - 1) : 0.f;
     float wt = 0.f, ct = 0.f, cq = 0.f;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void k_iw_reduce_wave(
     }
     if (lane == 0) {
       if (cost_b) cost_b[b] = cost;
-      if (bound_b) bound_b[b] = ln_fast(r.S * r.invK) + r.m1;  // log(mean(exp(x - max))) + max, utils.py:18
+      if (bound_b) bound_b[b] = logf(r.S * r.invK) + r.m1;  // log(mean(exp(x - max))) + max, utils.py:18
     }
   }
 }
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void k_iw_reduce_block(
     for (int64_t k = threadIdx.x; k < K; k += 256) {
       const float l = pp[k] - qq[k];
       if (l == r.m1 && (int)k < jm) jm = (int)k;
-      s += exp_fast(l - r.m1);
+      s += expf(l - r.m1);
     }
     r.jstar = block_min_int(jm, shi);
     r.S = block_sum(s, shf);
@@ -153,10 +157,10 @@ __global__ __launch_bounds__(256) void k_iw_reduce_block(
       r.m2 = block_max(m2, shf);
       float s2 = 0.f;
       for (int64_t k = threadIdx.x; k < K; k += 256)
-        if ((int)k != r.jstar) s2 += exp_fast((pp[k] - qq[k]) - r.m2);
+        if ((int)k != r.jstar) s2 += expf((pp[k] - qq[k]) - r.m2);
       r.S2 = block_sum(s2, shf);
     }
-    r.logS = ln_fast(r.S);
+    r.logS = logf(r.S);
     r.invK = 1.0f / (float)K;
     r.invKm1 = K > 1 ? 1.0f / (float)(K - 1) : 0.f;
     float ct = 0.f;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void k_iw_reduce_block(
     const float cost = block_sum(ct, shf);
     if (threadIdx.x == 0) {
       if (cost_b) cost_b[b] = cost;
-      if (bound_b) bound_b[b] = ln_fast(r.S * r.invK) + r.m1;
+      if (bound_b) bound_b[b] = logf(r.S * r.invK) + r.m1;
     }
   }
 }
