@@ -119,6 +119,7 @@ def gen_normal():
                         gmu, gls = torch.autograd.grad(obj, [mu_t, ls_t], allow_unused=True)
                         p = "c%03d_" % case
                         out[p + "mu"], out[p + "ls"], out[p + "eps"] = mu, ls, eps
+                        out[p + "sd"] = d.std   # exp(ls) as evaluated HERE (CPU exp differs by an ulp across ISAs)
                         out[p + "K"] = np.array(-1 if K is None else K)
                         out[p + "reparam"] = np.array(int(reparam))
                         out[p + "use_logstd"] = np.array(int(use_logstd))

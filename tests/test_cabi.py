@@ -190,7 +190,7 @@ def test_c_oracle_normal_golden(orc):
         if int(g[p + "g"]) == 0:
             continue
         K = max(int(g[p + "K"]), 1)
-        mu, sd, eps = g[p + "mu"], torch.exp(torch.tensor(g[p + "ls"])).numpy(), g[p + "eps"]   # torch.exp like the reference
+        mu, sd, eps = g[p + "mu"], g[p + "sd"], g[p + "eps"]
         D = int(np.prod(mu.shape[mu.ndim - int(g[p + "g"]):]))
         out = orc.normal_sample(mu.ravel(), sd.ravel(), eps.ravel(), K, D)
         assert np.array_equal(out["z"].reshape(g[p + "z"].shape), g[p + "z"])

@@ -1,0 +1,113 @@
+"""Data-parallel minibatch shards (zhusuan.dataparallel): world_size-2 gloo run on CPU (C oracle
+injected as the kernel library) must reproduce the single-process gradients / objective of the full
+minibatch -- the mean of equal-size shard means is the global mean."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, host_kernel_library
+import helpers as H
+
+B, K, HID = 16, 5, 32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data():
+    rng = np.random.RandomState(77)
+    x = (rng.uniform(size=(B, 784)) < 0.5).astype(np.float32)
+    e1 = rng.standard_normal((K, B, 40)).astype(np.float32)
+    e2 = rng.standard_normal((K, B, 40)).astype(np.float32)
+    return x, e1, e2
+
+
+def _run_shard(rank, world, estimator):
+    """Objective + gradients of this rank's rows, averaged over the ranks through the flat bucket."""
+    import zhusuan as zs
+    from zhusuan import _hip, dataparallel
+    from examples import iwae
+    _hip._install_host_library_for_tests(host_kernel_library())
+    dev = torch.device("cpu")
+    model = iwae.build(n_samples=K, estimator=estimator, hidden=HID, device=dev)
+    if rank == 0:
+        H.load_params_into(model, 4242)          # other ranks start from different weights on purpose
+    else:
+        H.load_params_into(model, 9999)
+    dataparallel.broadcast_parameters(model, src=0)
+    bucket = dataparallel.GradientBucket(model)
+    x, e1, e2 = _data()
+    xs = dataparallel.shard_rows(torch.tensor(x), rank, world)
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    bucket.zero()
+    with zs.inject_epsilon([e1[:, sl], e2[:, sl]]):
+        loss = model({"x": xs})
+    loss.backward()
+    g = bucket.all_reduce_mean(loss)
+    return float(g), bucket.flat[:bucket.n_grad].clone(), [p.detach().clone() for p in model.parameters()]
+
+
+def _worker(rank, world, port, estimator, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        loss, flat, params = _run_shard(rank, world, estimator)
+        torch.save({"loss": loss, "flat": flat, "p0": params[0]}, os.path.join(out_dir, "r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("estimator", ["vimco", "sgvb"])
+def test_two_rank_gloo_matches_single_process(tmp_path, estimator):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, estimator, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(str(tmp_path / "r0.pt"))
+    r1 = torch.load(str(tmp_path / "r1.pt"))
+    assert r0["loss"] == r1["loss"] and torch.equal(r0["flat"], r1["flat"])      # all-reduced: identical everywhere
+    assert torch.equal(r0["p0"], r1["p0"])                                      # broadcast made the replicas equal
+    # single process, full minibatch
+    loss, flat, _ = _run_shard(0, 1, estimator)
+    from zhusuan import _hip
+    _hip._install_host_library_for_tests(None)
+    assert abs(r0["loss"] - loss) <= 2e-6 * abs(loss)
+    np.testing.assert_allclose(r0["flat"].numpy(), flat.numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_bucket_layout_and_sharding():
+    from zhusuan import dataparallel
+    lin = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+    bucket = dataparallel.GradientBucket(lin)
+    n = sum(p.numel() for p in lin.parameters())
+    assert bucket.flat.numel() == n + 1 and bucket.nbytes() == 4 * (n + 1)
+    lin(torch.ones(5, 3)).sum().backward()
+    off = 0
+    for p in lin.parameters():                   # .grad are views into the flat buffer: no packing step
+        assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off
+        assert torch.equal(bucket.flat[off:off + p.numel()].view_as(p), p.grad)
+        off += p.numel()
+    g = bucket.all_reduce_mean(torch.tensor(3.0))     # no process group: identity
+    assert float(g) == 3.0
+    bucket.zero()
+    assert float(bucket.flat.abs().sum()) == 0.0
+    x = torch.arange(12.).view(6, 2)
+    assert torch.equal(dataparallel.shard_rows(x, 1, 3), x[2:4])
+    with pytest.raises(ValueError, match="does not split evenly"):
+        dataparallel.shard_rows(x, 0, 4)

@@ -140,9 +140,9 @@ def test_normal_sample_logprob_golden(dev):
             d = Normal(mean=mu, logstd=ls, **kw)     # std = exp(logstd) evaluated by torch ON THE DEVICE
             exact = dev.type == "cpu"                # (device exp differs from the CPU's in the last ulp)
         else:
-            ls_host = torch.tensor(g[p + "ls"], requires_grad=True)
-            sd = torch.exp(ls_host).to(dev)          # the reference's std, bit for bit
-            ls = ls_host
+            # std = exp(ls) exactly as the reference run had it (stored: a CPU's vectorised exp can differ
+            # in the last ulp from another CPU's), with the chain rule back to ls applied by hand below
+            sd = T(g[p + "sd"], dev, True)
             d = Normal(mean=mu, std=sd, **kw)
         with zs.inject_epsilon([g[p + "eps"]]):
             z = d.sample(K)
@@ -154,7 +154,11 @@ def test_normal_sample_logprob_golden(dev):
         lp = d.log_prob(None)
         close(lp, g[p + "lp"], 1e-5, 2e-5)
         obj = (lp * T(g[p + "w"], dev)).sum() + (z * T(g[p + "wz"], dev)).sum()
-        gmu, gls = torch.autograd.grad(obj, [mu, ls], allow_unused=True)
+        if int(g[p + "use_logstd"]):
+            gmu, gls = torch.autograd.grad(obj, [mu, ls], allow_unused=True)
+        else:
+            gmu, gsd = torch.autograd.grad(obj, [mu, sd], allow_unused=True)
+            gls = None if gsd is None else gsd * sd.detach()          # d sd / d ls = sd
         gmu = gmu if gmu is not None else torch.zeros_like(mu)
         gls = gls if gls is not None else torch.zeros_like(ls)
         close(gmu, g[p + "gmu"], 1e-4, 1e-4)

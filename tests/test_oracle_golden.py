@@ -36,6 +36,10 @@ def test_normal_sample_logprob_cases():
         gnd = int(g[p + "g"])
         mu, ls = T(g[p + "mu"], True), T(g[p + "ls"], True)
         sd = torch.exp(ls)
+        np.testing.assert_allclose(sd.detach().numpy(), g[p + "sd"], rtol=2e-7, atol=0)
+        with torch.no_grad():
+            sd_exact = T(g[p + "sd"])      # forward with the stored std (bit-exact z), gradients through exp(ls)
+        sd = sd + (sd_exact - sd).detach()
         z = O.normal_sample(mu, sd, T(g[p + "eps"]), K, reparam)
         lp = O.normal_log_prob(mu, sd, z, gnd)
         assert tuple(z.shape) == g[p + "z"].shape
