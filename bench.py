@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--fused-logits", action="store_true",
                     help="decoder hands logits to Bernoulli(logits=...): sigmoid fused into the log-prob kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel from Python each step instead of replaying one captured hipGraph")
+    ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "rocblas"],
+                    help="BLAS library PyTorch uses for the MLPs' fp32 GEMMs (outside the hot path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,6 +105,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.blas != "default":
+        torch.backends.cuda.preferred_blas_library("cublaslt" if args.blas == "hipblaslt" else "cublas")
     import zhusuan  # noqa: F401
     from zhusuan import _hip, dataparallel
     from examples import iwae
@@ -110,13 +116,14 @@ def main():
                        device=dev, fused_logits=args.fused_logits)
     dataparallel.broadcast_parameters(model)
     bucket = dataparallel.GradientBucket(model)
-    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True)
-    torch.manual_seed(1000 + rank)                    # per-rank Philox stream
-    rng = np.random.RandomState(1234 + rank)
-    x = torch.tensor((rng.uniform(size=(BATCH_PER_GPU, X_DIM)) < 0.5).astype(np.float32), device=dev)
+    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
+    rng = zhusuan.DeviceRNG(dev, seed=1000 + rank)          # per-rank Philox stream, state in device memory
+    rs = np.random.RandomState(1234 + rank)
+    x = torch.tensor((rs.uniform(size=(BATCH_PER_GPU, X_DIM)) < 0.5).astype(np.float32), device=dev)
     obs = {"x": x}
 
-    def step():
+    def step_body():
+        rng.begin_step()
         bucket.zero()
         loss = model(obs)
         loss.backward()
@@ -124,27 +131,59 @@ def main():
         opt.step()
         return g
 
-    for _ in range(args.warmup):
-        step()
     dominant = "zs_bernoulli_logits_logprob_f32" if args.fused_logits else DOMINANT
     klib = _hip.lib()
-    klib.prof_enable(True)            # start/stop HIP events bound to each kernel dispatch on its stream
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    klib.prof_enable(False)
+    mode = "eager"
+    with zhusuan.device_rng(rng):
+        for _ in range(max(args.warmup, 3)):
+            step_body()
+        torch.cuda.synchronize()
+        step = step_body
+        if not args.no_graph:
+            # the launch-bound inner loop (~130 kernels, most of them a few microseconds) as ONE hipGraph
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    step_body()
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_loss = step_body()
+
+                def step():
+                    graph.replay()
+                    return static_loss
+                for _ in range(3):
+                    step()
+                mode = "hipgraph"
+            except Exception as e:                      # noqa: BLE001  (report, fall back to eager launches)
+                sys.stderr.write("bench: graph capture failed (%r); running eager\n" % (e,))
+                torch.cuda.synchronize()
+                step = step_body
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        final_loss = float(last)
+        # per-kernel durations: the same steps launched eagerly with start/stop HIP events bound to each
+        # kernel dispatch on its stream (events cannot ride inside a graph replay)
+        n_prof = min(args.steps, 50)
+        klib.prof_enable(True)
+        for _ in range(n_prof):
+            step_body()
+        torch.cuda.synchronize()
+        klib.prof_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(last)
     assert np.isfinite(final_loss)
 
     if rank == 0:
@@ -157,7 +196,7 @@ def main():
         for name in _hip.PROTOTYPES:
             q = klib.prof_query(name)
             if q["count"]:
-                per_kernel[name] = {"launches_per_step": q["count"] / args.steps,
+                per_kernel[name] = {"launches_per_step": q["count"] / n_prof,
                                     "avg_us": 1e3 * q["total_ms"] / q["count"], "min_us": 1e3 * q["min_ms"]}
         out = {
             "metric": "ELBO-evals/sec (batch x K particles), IWAE-MNIST VIMCO K=50",
@@ -172,12 +211,15 @@ def main():
                                        BATCH_PER_GPU, BATCH_PER_GPU * world, PARTICLES, Z_DIM, X_DIM, HIDDEN),
                        "global_batch": BATCH_PER_GPU * world, "particles": PARTICLES,
                        "parallelism": "dp%d (minibatch shards, one flat-bucket all-reduce of %d bytes)" % (world, bucket.nbytes()),
-                       "bernoulli_path": "logits (sigmoid fused)" if args.fused_logits else "probs (reference default)"},
+                       "bernoulli_path": "logits (sigmoid fused)" if args.fused_logits else "probs (reference default)",
+                       "mlp_gemm_library": args.blas, "launch_mode": mode},
             "final_loss": final_loss,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": 1e3 * k_ms if k_ms else None,
-                         "min_launch_us": 1e3 * prof["min_ms"], "launches_timed": prof["count"]},
+                         "min_launch_us": 1e3 * prof["min_ms"], "launches_timed": prof["count"],
+                         "timing": "start/stop HIP events bound to each dispatch (hipExtLaunchKernelGGL) on the launch "
+                                   "stream, %d steps of the same workload run right after the timed region" % n_prof},
             "hip_kernels": per_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:

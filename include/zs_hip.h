@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 1
+#define ZS_ABI_VERSION 2
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -62,10 +62,14 @@ const char* zs_error_string(int code);
  * eps == NULL: eps is drawn in-kernel from Philox4x32-10 keyed by `seed`, with
  * counter (group = (k*M + m) / 4, call = offset); the same (seed, offset)
  * regenerates the same draw in the backward call.
+ * rng_state (optional DEVICE pointer to two uint64 {seed, base}): when non-NULL the
+ * kernel itself reads seed = rng_state[0] and uses call = rng_state[1] + offset, so a
+ * launch captured in a hipGraph draws fresh numbers on every replay once the
+ * caller bumps rng_state[1] between replays (`seed` is then ignored).
  * lp == NULL: sample only.
  * -------------------------------------------------------------------------*/
 int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const float* eps,
-                                 uint64_t seed, uint64_t offset,
+                                 uint64_t seed, uint64_t offset, const uint64_t* rng_state,
                                  float* z, float* lp,
                                  int64_t K, int64_t M, int64_t D,
                                  int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
@@ -75,7 +79,7 @@ int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const floa
  *   gsigma[m] = sum_k gz[k, m] * eps[k, m]  -  (sum_k glp[k, r(m)]) / sigma[m]
  * gz or glp may be NULL (treated as zero).  eps as in the forward call. */
 int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float* eps,
-                                     uint64_t seed, uint64_t offset,
+                                     uint64_t seed, uint64_t offset, const uint64_t* rng_state,
                                      const float* gz, const float* glp,
                                      int64_t glp_stride_k, int64_t glp_stride_r,
                                      float* gmu, float* gsigma,
@@ -144,7 +148,7 @@ int zs_bernoulli_logits_logprob_bwd_f32(const float* logits, const float* x, int
 /* K5  Bernoulli._sample (bernoulli.py:72-82): out[i] = (u_i < p[i % Pp]) ? 1 : 0,
  * u from Philox4x32-10 (seed, offset).  Generation path only. */
 int zs_bernoulli_sample_f32(const float* p, int64_t Pp, float* out, int64_t N,
-                            uint64_t seed, uint64_t offset, void* stream);
+                            uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K4  Importance-weighted reduction over the K particles of each datapoint.
@@ -170,7 +174,8 @@ int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float*
 
 /* Standard normals from the same Philox4x32-10 + Box-Muller stream K1 uses:
  * out[i], i < N, group = i / 4.  For tests and for callers that need eps itself. */
-int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, void* stream);
+int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------
  * Per-kernel timing for the benchmark harness (no reference counterpart).

@@ -84,10 +84,13 @@ const char* zs_error_string(int code) {
 }
 
 /* ------------------------------------------------------------------ K1 */
+#define RNG_STATE(rs, seed, offset) do { if (rs) { seed = (rs)[0]; offset += (rs)[1]; } } while (0)
+
 int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const float* eps, uint64_t seed,
-                                 uint64_t offset, float* z, float* lp, int64_t K, int64_t M, int64_t D,
-                                 int64_t sk, int64_t sr, void* stream) {
+                                 uint64_t offset, const uint64_t* rng_state, float* z, float* lp, int64_t K,
+                                 int64_t M, int64_t D, int64_t sk, int64_t sr, void* stream) {
   (void)stream;
+  RNG_STATE(rng_state, seed, offset);
   if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
   if (M == 0) return 0;
   if (!mu || !sigma || !z) return ZS_EINVAL;
@@ -109,9 +112,11 @@ int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const floa
 }
 
 int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float* eps, uint64_t seed, uint64_t offset,
-                                     const float* gz, const float* glp, int64_t gsk, int64_t gsr, float* gmu,
-                                     float* gsigma, int64_t K, int64_t M, int64_t D, void* stream) {
+                                     const uint64_t* rng_state, const float* gz, const float* glp, int64_t gsk,
+                                     int64_t gsr, float* gmu, float* gsigma, int64_t K, int64_t M, int64_t D,
+                                     void* stream) {
   (void)stream;
+  RNG_STATE(rng_state, seed, offset);
   if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
   if (M == 0) return 0;
   if (!sigma || !gmu || !gsigma) return ZS_EINVAL;
@@ -273,8 +278,9 @@ int zs_bernoulli_logits_logprob_bwd_f32(const float* logits, const float* x, int
   return bern_bwd(logits, 1, x, Px, glp, gsk, gsr, glogits, K, R, D);
 }
 int zs_bernoulli_sample_f32(const float* p, int64_t Pp, float* out, int64_t N, uint64_t seed, uint64_t offset,
-                            void* stream) {
+                            const uint64_t* rng_state, void* stream) {
   (void)stream;
+  RNG_STATE(rng_state, seed, offset);
   if (N < 0 || Pp < 1) return ZS_EINVAL;
   if (N == 0) return 0;
   if (!p || !out) return ZS_EINVAL;
@@ -350,8 +356,10 @@ int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float*
   return 0;
 }
 
-int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, void* stream) {
+int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state,
+                         void* stream) {
   (void)stream;
+  RNG_STATE(rng_state, seed, offset);
   if (N < 0) return ZS_EINVAL;
   if (N == 0) return 0;
   if (!out) return ZS_EINVAL;

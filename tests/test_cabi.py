@@ -34,7 +34,7 @@ def test_header_symbols_exported_by_both_libraries():
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == 1
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 2
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 
@@ -83,22 +83,22 @@ class Raw(object):
             torch.cuda.synchronize()
 
     # each op returns a dict of numpy outputs
-    def normal_sample(self, mu, sigma, eps, K, D, seed=0, off=0, kfast=False, want_lp=True):
+    def normal_sample(self, mu, sigma, eps, K, D, seed=0, off=0, kfast=False, want_lp=True, rs=None):
         M = mu.size
         R = M // D
         z = self.empty(K, M)
         lp = self.empty(R, K) if kfast else self.empty(K, R)
         sk, sr = (1, K) if kfast else (R, 1)
-        self.call("zs_normal_sample_logprob_f32", self.t(mu), self.t(sigma), self.t(eps), seed, off, z,
+        self.call("zs_normal_sample_logprob_f32", self.t(mu), self.t(sigma), self.t(eps), seed, off, rs, z,
                   lp if want_lp else None, K, M, D, sk, sr)
         lpn = lp.cpu().numpy()
         return dict(z=z.cpu().numpy(), lp=lpn.T if kfast else lpn)
 
-    def normal_sample_bwd(self, sigma, eps, gz, glp, K, D, seed=0, off=0):
+    def normal_sample_bwd(self, sigma, eps, gz, glp, K, D, seed=0, off=0, rs=None):
         M = sigma.size
         R = M // D
         gmu, gs = self.empty(M), self.empty(M)
-        self.call("zs_normal_sample_logprob_bwd_f32", self.t(sigma), self.t(eps), seed, off, self.t(gz), self.t(glp),
+        self.call("zs_normal_sample_logprob_bwd_f32", self.t(sigma), self.t(eps), seed, off, rs, self.t(gz), self.t(glp),
                   R, 1, gmu, gs, K, M, D)
         return dict(gmu=gmu.cpu().numpy(), gsigma=gs.cpu().numpy())
 
@@ -161,14 +161,14 @@ class Raw(object):
         self.call("zs_log_mean_exp_f32", self.t(x), K, B, K, out)
         return out.cpu().numpy()
 
-    def philox(self, n, seed, off):
+    def philox(self, n, seed, off, rs=None):
         out = self.empty(n)
-        self.call("zs_philox_normal_f32", out, n, seed, off)
+        self.call("zs_philox_normal_f32", out, n, seed, off, rs)
         return out.cpu().numpy()
 
-    def bern_sample(self, p, n, seed, off):
+    def bern_sample(self, p, n, seed, off, rs=None):
         out = self.empty(n)
-        self.call("zs_bernoulli_sample_f32", self.t(p), p.size, out, n, seed, off)
+        self.call("zs_bernoulli_sample_f32", self.t(p), p.size, out, n, seed, off, rs)
         return out.cpu().numpy()
 
 
@@ -385,6 +385,35 @@ def test_hip_iw_reduce(hip, orc, B, K, spread):
     np.testing.assert_allclose(hip.lme(logp), orc.lme(logp), rtol=2e-6, atol=2e-5)
 
 
+def _check_device_rng_state(raw):
+    """rng_state = {seed, base}: the kernel must behave exactly like (seed, base + offset) passed by value."""
+    st = torch.tensor([1234, 9], dtype=torch.int64, device=raw.dev)
+    assert np.array_equal(raw.philox(1000, 0, 3, rs=st), raw.philox(1000, 1234, 12))
+    p = np.linspace(0.05, 0.95, 5).astype(np.float32)
+    assert np.array_equal(raw.bern_sample(p, 777, 0, 1, rs=st), raw.bern_sample(p, 777, 1234, 10))
+    rng = np.random.RandomState(0)
+    mu, sd = rng.standard_normal(80).astype(np.float32), np.exp(rng.standard_normal(80)).astype(np.float32)
+    a = raw.normal_sample(mu, sd, None, 3, 40, seed=0, off=2, rs=st)
+    b = raw.normal_sample(mu, sd, None, 3, 40, seed=1234, off=11)
+    assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["lp"], b["lp"])
+    gz, glp = rng.standard_normal(240).astype(np.float32), rng.standard_normal(6).astype(np.float32)
+    ga = raw.normal_sample_bwd(sd, None, gz, glp, 3, 40, seed=0, off=2, rs=st)
+    gb = raw.normal_sample_bwd(sd, None, gz, glp, 3, 40, seed=1234, off=11)
+    assert np.array_equal(ga["gsigma"], gb["gsigma"])
+    st[1] += 1                                   # what DeviceRNG.begin_step does between graph replays
+    assert not np.array_equal(raw.philox(1000, 0, 3, rs=st), raw.philox(1000, 1234, 12))
+    assert np.array_equal(raw.philox(1000, 0, 3, rs=st), raw.philox(1000, 1234, 13))
+
+
+def test_c_oracle_device_rng_state(orc):
+    _check_device_rng_state(orc)
+
+
+@pytest.mark.gpu
+def test_hip_device_rng_state(hip):
+    _check_device_rng_state(hip)
+
+
 @pytest.mark.gpu
 def test_hip_rng(hip, orc):
     for n in (1, 3, 4, 5, 1023, 4096 + 2):
@@ -401,11 +430,11 @@ def test_hip_rng(hip, orc):
 @pytest.mark.gpu
 def test_hip_empty_and_unaligned(hip, orc):
     z = np.zeros(0, np.float32)
-    hip.call("zs_normal_sample_logprob_f32", hip.t(z), hip.t(z), None, 0, 0, hip.empty(0), hip.empty(0), 3, 0, 1, 1, 1)
+    hip.call("zs_normal_sample_logprob_f32", hip.t(z), hip.t(z), None, 0, 0, None, hip.empty(0), hip.empty(0), 3, 0, 1, 1, 1)
     hip.call("zs_bernoulli_logprob_f32", hip.t(z), hip.t(np.ones(1, np.float32)), 1, hip.empty(0), 1, 0, 4, 1, 1)
     hip.call("zs_iw_reduce_f32", hip.t(np.ones(4, np.float32)), 4, hip.t(np.ones(4, np.float32)), 4, 0, 4, 0, None, None, None, None)
     with pytest.raises(RuntimeError, match="code -1"):
-        hip.call("zs_normal_sample_logprob_f32", None, None, None, 0, 0, None, None, 1, 4, 4, 1, 1)
+        hip.call("zs_normal_sample_logprob_f32", None, None, None, 0, 0, None, None, None, 1, 4, 4, 1, 1)
     # operands offset by one float: the vector path must not be taken on misaligned pointers
     rng = np.random.RandomState(5)
     K, R, D = 3, 4, 8

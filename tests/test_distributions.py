@@ -308,3 +308,72 @@ def test_cpu_tensor_without_gpu_library_fails_loudly():
         d.sample()
     with pytest.raises(RuntimeError, match="no CPU path"):
         Bernoulli(probs=torch.full([4], 0.5)).log_prob(torch.ones(4))
+
+
+# ------------------------------------------------------------------ device-resident RNG state (hipGraph-safe draws)
+def test_device_rng_state_drives_the_draws(dev):
+    mu = torch.zeros([64, 8], device=dev)
+    sd = torch.ones([64, 8], device=dev)
+    rng = zs.DeviceRNG(dev, seed=5)
+    with zs.device_rng(rng):
+        rng.begin_step()
+        a1 = Normal(mean=mu, std=sd).sample(3)
+        a2 = Normal(mean=mu, std=sd).sample(3)          # next delta inside the same step
+        rng.begin_step()
+        b1 = Normal(mean=mu, std=sd).sample(3)
+    assert not torch.equal(a1, a2) and not torch.equal(a1, b1)
+    rng2 = zs.DeviceRNG(dev, seed=5)
+    with zs.device_rng(rng2):
+        rng2.begin_step()
+        c1 = Normal(mean=mu, std=sd).sample(3)
+    assert torch.equal(a1, c1)                           # same (seed, base, delta) -> same draw
+    rng3 = zs.DeviceRNG(dev, seed=6)
+    with zs.device_rng(rng3):
+        rng3.begin_step()
+        d1 = Normal(mean=mu, std=sd, is_reparameterized=True).sample(3)
+    assert not torch.equal(a1, d1)
+    # backward regenerates the same eps from the device state
+    m = torch.zeros([64, 8], device=dev, requires_grad=True)
+    s = torch.full([64, 8], 2.0, device=dev, requires_grad=True)
+    rng4 = zs.DeviceRNG(dev, seed=5)
+    with zs.device_rng(rng4):
+        rng4.begin_step()
+        z = Normal(mean=m, std=s).sample(3)
+        (gs,) = torch.autograd.grad(z.sum(), [s])
+    close(gs, ((z.detach() - 0.0) / 2.0).sum(0), 1e-5, 1e-5)
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_draws_fresh_numbers():
+    from examples import iwae
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = iwae.build(n_samples=5, estimator="vimco", hidden=32, device=dev)
+    x = (torch.rand(16, 784, device=dev) < 0.5).float()
+    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
+    rng = zs.DeviceRNG(dev, seed=3)
+
+    def body():
+        rng.begin_step()
+        opt.zero_grad(set_to_none=False)
+        loss = model({"x": x})
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    with zs.device_rng(rng):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = body()
+        vals = []
+        for _ in range(4):
+            g.replay()
+            vals.append(float(out))
+    assert all(np.isfinite(v) for v in vals)
+    assert len(set(vals)) == 4, vals                      # fresh epsilon on every replay

@@ -67,16 +67,16 @@ def main():
         eps = torch.randn(K * M, device=dev)
         tag = "N=%d (B=%d)" % (N, B)
         timed("K1 normal sample+lp (Philox)", "zs_normal_sample_logprob_f32", 4 * N * D + 4 * N + 8 * M,
-              lambda: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, 2, P(z), P(lp), K, M, D, 1, K, st), tag)
+              lambda: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, 2, None, P(z), P(lp), K, M, D, 1, K, st), tag)
         timed("K1 normal sample+lp (eps given)", "zs_normal_sample_logprob_f32", 8 * N * D + 4 * N + 8 * M,
-              lambda: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), P(eps), 0, 0, P(z), P(lp), K, M, D, 1, K, st), tag)
+              lambda: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), P(eps), 0, 0, None, P(z), P(lp), K, M, D, 1, K, st), tag)
         timed("K2 normal logprob", "zs_normal_logprob_f32", 4 * N * D + 4 * N + 8 * M,
               lambda: lib.call("zs_normal_logprob_f32", P(z), K * M, P(mu), M, P(sg), M, P(lp), K, B, D, 1, K, st), tag)
         gz = torch.randn(K * M, device=dev)
         glp = torch.randn(B * K, device=dev)
         gmu, gsg = torch.empty(M, device=dev), torch.empty(M, device=dev)
         timed("K1 bwd (reparam, Philox)", "zs_normal_sample_logprob_bwd_f32", 4 * N * D + 4 * N + 12 * M,
-              lambda: lib.call("zs_normal_sample_logprob_bwd_f32", P(sg), None, 1, 2, P(gz), P(glp), 1, K, P(gmu), P(gsg), K, M, D, st), tag)
+              lambda: lib.call("zs_normal_sample_logprob_bwd_f32", P(sg), None, 1, 2, None, P(gz), P(glp), 1, K, P(gmu), P(gsg), K, M, D, st), tag)
         timed("K2 bwd ksum (non-reparam)", "zs_normal_logprob_bwd_ksum_f32", 4 * N * D + 4 * N + 16 * M,
               lambda: lib.call("zs_normal_logprob_bwd_ksum_f32", P(z), P(mu), P(sg), P(glp), 1, K, None, P(gmu), P(gsg), K, B, D, st), tag)
         del eps, gz, z

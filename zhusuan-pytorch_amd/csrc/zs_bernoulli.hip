@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_serial(
 // K5: Bernoulli._sample -- out = (u < p), u ~ U(0,1) from Philox (bernoulli.py:80)
 __global__ __launch_bounds__(256) void k_bern_sample(const float* __restrict__ p, int64_t Pp,
                                                      float* __restrict__ out, int64_t N, uint64_t seed,
-                                                     uint64_t call) {
+                                                     uint64_t call, const uint64_t* __restrict__ rs) {
+  if (rs) { seed = rs[0]; call += rs[1]; }
   const int64_t groups = (N + 3) / 4;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
     const Philox4 r = philox4x32_10((uint64_t)g, call, seed);
@@ -414,12 +415,12 @@ extern "C" int zs_bernoulli_logits_logprob_bwd_f32(const float* logits, const fl
 }
 
 extern "C" int zs_bernoulli_sample_f32(const float* p, int64_t Pp, float* out, int64_t N, uint64_t seed,
-                                       uint64_t offset, void* stream) {
+                                       uint64_t offset, const uint64_t* rng_state, void* stream) {
   if (N < 0 || Pp < 1) return ZS_EINVAL;
   if (N == 0) return 0;
   if (!p || !out) return ZS_EINVAL;
   ZS_LAUNCH(KID_BERN_SAMPLE, k_bern_sample, dim3(grid_for((N + 3) / 4, 256)), dim3(256), (hipStream_t)stream, p, Pp,
-                     out, N, seed, offset);
+                     out, N, seed, offset, rng_state);
   ZS_CHECK_LAUNCH();
   return 0;
 }

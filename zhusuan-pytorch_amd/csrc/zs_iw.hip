@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void k_iw_reduce_block(
 }
 
 __global__ __launch_bounds__(256) void k_philox_normal(float* __restrict__ out, int64_t N, uint64_t seed,
-                                                       uint64_t call) {
+                                                       uint64_t call, const uint64_t* __restrict__ rs) {
+  if (rs) { seed = rs[0]; call += rs[1]; }
   const int64_t groups = (N + 3) / 4;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
     const float4 n = philox_normal4((uint64_t)g, call, seed);
@@ -261,12 +262,13 @@ extern "C" int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_
   return 0;
 }
 
-extern "C" int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, void* stream) {
+extern "C" int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset,
+                                    const uint64_t* rng_state, void* stream) {
   if (N < 0) return ZS_EINVAL;
   if (N == 0) return 0;
   if (!out) return ZS_EINVAL;
   ZS_LAUNCH(KID_PHILOX, k_philox_normal, dim3(grid_for((N + 3) / 4, 256)), dim3(256), (hipStream_t)stream, out,
-                     N, seed, offset);
+                     N, seed, offset, rng_state);
   ZS_CHECK_LAUNCH();
   return 0;
 }

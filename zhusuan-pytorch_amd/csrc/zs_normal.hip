@@ -40,8 +40,9 @@ __device__ __forceinline__ float mul_add_2round(float m, float s, float e) {
 template <bool HAS_EPS, bool HAS_LP>
 __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
     const float4* __restrict__ mu, const float4* __restrict__ sigma, const float4* __restrict__ eps,
-    uint64_t seed, uint64_t call, float4* __restrict__ z, float* __restrict__ lp,
+    uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float4* __restrict__ z, float* __restrict__ lp,
     int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t kchunk, int64_t sk, int64_t sr) {
+  if (rs) { seed = rs[0]; call += rs[1]; }
   const int lane = threadIdx.x & 63;
   const int rw = lane / G, lig = lane - rw * G;
   const bool lane_on = rw < rpw;
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
 template <bool HAS_EPS, bool HAS_LP>
 __global__ __launch_bounds__(256) void k_normal_sample_longrow(
     const float4* __restrict__ mu, const float4* __restrict__ sigma, const float4* __restrict__ eps,
-    uint64_t seed, uint64_t call, float4* __restrict__ z, float* __restrict__ lp,
+    uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float4* __restrict__ z, float* __restrict__ lp,
     int64_t K, int64_t R, int D4, int64_t sk, int64_t sr) {
+  if (rs) { seed = rs[0]; call += rs[1]; }
   const int lane = threadIdx.x & 63;
   const int64_t M4 = R * (int64_t)D4;
   const int64_t rows = K * R;
@@ -144,8 +146,9 @@ __global__ __launch_bounds__(256) void k_normal_sample_longrow(
 template <bool HAS_EPS>
 __global__ __launch_bounds__(256) void k_normal_sample_serial(
     const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ eps,
-    uint64_t seed, uint64_t call, float* __restrict__ z, float* __restrict__ lp,
+    uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float* __restrict__ z, float* __restrict__ lp,
     int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+  if (rs) { seed = rs[0]; call += rs[1]; }
   const int64_t rows = K * R, M = R * D;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
        row += (int64_t)gridDim.x * blockDim.x) {
@@ -184,11 +187,12 @@ __global__ __launch_bounds__(256) void k_normal_sample_serial(
 template <bool HAS_EPS>
 __global__ __launch_bounds__(256) void k_normal_sample_bwd(
     const float4* __restrict__ sigma, const float4* __restrict__ eps, uint64_t seed, uint64_t call,
-    const float4* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
+    const uint64_t* __restrict__ rs, const float4* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float4* __restrict__ gmu, float4* __restrict__ gsigma, int64_t K, int64_t M4, int D4) {
   __shared__ float4 red_a[4][64];
   __shared__ float4 red_b[4][64];
   __shared__ float red_g[4][64];
+  if (rs) { seed = rs[0]; call += rs[1]; }
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int64_t m4 = (int64_t)blockIdx.x * 64 + lane;
   const bool on = m4 < M4;
@@ -231,8 +235,9 @@ __global__ __launch_bounds__(256) void k_normal_sample_bwd(
 
 __global__ __launch_bounds__(256) void k_normal_sample_bwd_serial(
     const float* __restrict__ sigma, const float* __restrict__ eps, uint64_t seed, uint64_t call,
-    const float* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
+    const uint64_t* __restrict__ rs, const float* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float* __restrict__ gmu, float* __restrict__ gsigma, int64_t K, int64_t M, int64_t D) {
+  if (rs) { seed = rs[0]; call += rs[1]; }
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = m / D;
     float a = 0.f, b = 0.f, g = 0.f;
@@ -428,7 +433,8 @@ inline bool period_ok_rows(int64_t P, int64_t D, int64_t N) {
 
 // ======================================================================== C ABI
 extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const float* eps,
-                                            uint64_t seed, uint64_t offset, float* z, float* lp,
+                                            uint64_t seed, uint64_t offset, const uint64_t* rng_state,
+                                            float* z, float* lp,
                                             int64_t K, int64_t M, int64_t D,
                                             int64_t sk, int64_t sr, void* stream) {
   if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
@@ -453,7 +459,7 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
       const unsigned grid = grid_for(total, 4);
 #define ZS_LAUNCH_SMALL(E, L)                                                                           \
   ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_smallrow<E, L>), dim3(grid), dim3(256), st, m4, s4, e4, seed, \
-                     offset, (float4*)z, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr)
+                     offset, rng_state, (float4*)z, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr)
       if (eps) { if (lp) ZS_LAUNCH_SMALL(true, true); else ZS_LAUNCH_SMALL(true, false); }
       else     { if (lp) ZS_LAUNCH_SMALL(false, true); else ZS_LAUNCH_SMALL(false, false); }
 #undef ZS_LAUNCH_SMALL
@@ -461,7 +467,7 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
       const unsigned grid = grid_for(K * R, 4);
 #define ZS_LAUNCH_LONG(E, L)                                                                           \
   ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_longrow<E, L>), dim3(grid), dim3(256), st, m4, s4, e4, seed, \
-                     offset, (float4*)z, lp, K, R, D4, sk, sr)
+                     offset, rng_state, (float4*)z, lp, K, R, D4, sk, sr)
       if (eps) { if (lp) ZS_LAUNCH_LONG(true, true); else ZS_LAUNCH_LONG(true, false); }
       else     { if (lp) ZS_LAUNCH_LONG(false, true); else ZS_LAUNCH_LONG(false, false); }
 #undef ZS_LAUNCH_LONG
@@ -470,17 +476,18 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
     const unsigned grid = grid_for(K * R, 256);
     if (eps)
       ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_serial<true>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
-                         offset, z, lp, K, R, D, sk, sr);
+                         offset, rng_state, z, lp, K, R, D, sk, sr);
     else
       ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_serial<false>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
-                         offset, z, lp, K, R, D, sk, sr);
+                         offset, rng_state, z, lp, K, R, D, sk, sr);
   }
   ZS_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float* eps, uint64_t seed,
-                                                uint64_t offset, const float* gz, const float* glp,
+                                                uint64_t offset, const uint64_t* rng_state,
+                                                const float* gz, const float* glp,
                                                 int64_t gsk, int64_t gsr, float* gmu, float* gsigma,
                                                 int64_t K, int64_t M, int64_t D, void* stream) {
   if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
@@ -494,15 +501,15 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
     const unsigned grid = (unsigned)((M4 + 63) / 64);
     if (eps)
       ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<true>), dim3(grid), dim3(256), st, (const float4*)sigma,
-                         (const float4*)eps, seed, offset, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
+                         (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
                          (float4*)gsigma, K, M4, (int)(D / 4));
     else
       ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<false>), dim3(grid), dim3(256), st, (const float4*)sigma,
-                         (const float4*)eps, seed, offset, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
+                         (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
                          (float4*)gsigma, K, M4, (int)(D / 4));
   } else {
     ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, k_normal_sample_bwd_serial, dim3(grid_for(M, 256)), dim3(256), st, sigma, eps, seed,
-                       offset, gz, glp, gsk, gsr, gmu, gsigma, K, M, D);
+                       offset, rng_state, gz, glp, gsk, gsr, gmu, gsigma, K, M, D);
   }
   ZS_CHECK_LAUNCH();
   return 0;

@@ -14,4 +14,4 @@ __version__ = '0.0.1+mi355x'
 from . import distributions
 from . import framework
 from .utils import *
-from ._rng import inject_epsilon
+from ._rng import inject_epsilon, DeviceRNG, device_rng

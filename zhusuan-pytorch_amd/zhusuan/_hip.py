@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -23,8 +23,8 @@ _int = ctypes.c_int
 
 # name -> argtypes ; every function returns int (0 = ok) unless noted
 PROTOTYPES = {
-    "zs_normal_sample_logprob_f32": [_p, _p, _p, _u64, _u64, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
-    "zs_normal_sample_logprob_bwd_f32": [_p, _p, _u64, _u64, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p],
+    "zs_normal_sample_logprob_f32": [_p, _p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "zs_normal_sample_logprob_bwd_f32": [_p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p],
     "zs_normal_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_normal_logprob_bwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
     "zs_normal_logprob_bwd_ksum_f32": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
@@ -32,10 +32,10 @@ PROTOTYPES = {
     "zs_bernoulli_logprob_bwd_f32": [_p, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
     "zs_bernoulli_logits_logprob_f32": [_p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_bernoulli_logits_logprob_bwd_f32": [_p, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
-    "zs_bernoulli_sample_f32": [_p, _i64, _p, _i64, _u64, _u64, _p],
+    "zs_bernoulli_sample_f32": [_p, _i64, _p, _i64, _u64, _u64, _p, _p],
     "zs_iw_reduce_f32": [_p, _i64, _p, _i64, _i64, _i64, _int, _p, _p, _p, _p, _p],
     "zs_log_mean_exp_f32": [_p, _i64, _i64, _i64, _p, _p],
-    "zs_philox_normal_f32": [_p, _i64, _u64, _u64, _p],
+    "zs_philox_normal_f32": [_p, _i64, _u64, _u64, _p, _p],
 }
 
 

@@ -53,7 +53,7 @@ class NormalSampleLogProb(torch.autograd.Function):
     Replaces Normal._sample + Normal._log_prob (zhusuan/distributions/normal.py:89-126)."""
 
     @staticmethod
-    def forward(ctx, mu, sigma, eps, seed, call, K, has_k_axis, n_fold, reparam, kfast):
+    def forward(ctx, mu, sigma, eps, seed, call, rng_state, K, has_k_axis, n_fold, reparam, kfast):
         _hip.require_device(mu, sigma, eps)
         _check_f32(mu, sigma, eps)
         lib = _hip.lib()
@@ -69,8 +69,9 @@ class NormalSampleLogProb(torch.autograd.Function):
             return z, lp
         buf, lp, sk, sr = _alloc_rows(K, has_k_axis, rest, kfast, mu)
         lib.call("zs_normal_sample_logprob_f32", _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(eps), seed, call,
-                 _hip.ptr(z), _hip.ptr(buf), K, M, D, sk, sr, _hip.stream_for(mu))
+                 _hip.ptr(rng_state), _hip.ptr(z), _hip.ptr(buf), K, M, D, sk, sr, _hip.stream_for(mu))
         ctx.meta = (seed, call, K, M, D, R, reparam)
+        ctx.rng_state = rng_state
         if reparam:
             ctx.save_for_backward(mu, sigma, eps)
         else:
@@ -81,7 +82,7 @@ class NormalSampleLogProb(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gz, glp):
         if ctx.meta is None:
-            return (None,) * 10
+            return (None,) * 11
         seed, call, K, M, D, R, reparam = ctx.meta
         lib = _hip.lib()
         if reparam:
@@ -94,19 +95,19 @@ class NormalSampleLogProb(torch.autograd.Function):
             if glp is not None:
                 glp, gsk, gsr = _kr_view(glp, K, R)
             lib.call("zs_normal_sample_logprob_bwd_f32", _hip.ptr(sigma), _hip.ptr(eps), seed, call,
-                     _hip.ptr(gz), _hip.ptr(glp), gsk, gsr, _hip.ptr(gmu), _hip.ptr(gsigma), K, M, D,
+                     _hip.ptr(ctx.rng_state), _hip.ptr(gz), _hip.ptr(glp), gsk, gsr, _hip.ptr(gmu), _hip.ptr(gsigma), K, M, D,
                      _hip.stream_for(mu))
         else:
             mu, sigma, z = ctx.saved_tensors
             if glp is None:
-                return (None,) * 10
+                return (None,) * 11
             gmu = torch.empty_like(mu)
             gsigma = torch.empty_like(sigma)
             glp, gsk, gsr = _kr_view(glp, K, R)
             lib.call("zs_normal_logprob_bwd_ksum_f32", _hip.ptr(z), _hip.ptr(mu), _hip.ptr(sigma),
                      _hip.ptr(glp), gsk, gsr, None, _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D,
                      _hip.stream_for(mu))
-        return gmu, gsigma, None, None, None, None, None, None, None, None
+        return gmu, gsigma, None, None, None, None, None, None, None, None, None
 
 
 class NormalLogProb(torch.autograd.Function):
@@ -278,23 +279,24 @@ class LogMeanExpRows(torch.autograd.Function):
         return g.unsqueeze(1) * torch.exp(x2d - out.unsqueeze(1)) / K
 
 
-def philox_normal(shape, device, seed, call):
+def philox_normal(shape, device, seed, call, rng_state=None):
     """Standard normals from the kernels' own Philox stream (the eps K1 would draw for the same ids)."""
     out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
     _hip.require_device(out)
     if out.numel():
-        _hip.lib().call("zs_philox_normal_f32", _hip.ptr(out), out.numel(), seed, call, _hip.stream_for(out))
+        _hip.lib().call("zs_philox_normal_f32", _hip.ptr(out), out.numel(), seed, call, _hip.ptr(rng_state),
+                        _hip.stream_for(out))
     return out
 
 
-def bernoulli_sample(probs, Pp, shape, seed, call):
+def bernoulli_sample(probs, Pp, shape, seed, call, rng_state=None):
     """K5: Bernoulli._sample (zhusuan/distributions/bernoulli.py:72-82)."""
     _hip.require_device(probs)
     _check_f32(probs)
     out = torch.empty(tuple(shape), dtype=probs.dtype, device=probs.device)
     if out.numel():
         _hip.lib().call("zs_bernoulli_sample_f32", _hip.ptr(probs), Pp, _hip.ptr(out), out.numel(), seed, call,
-                        _hip.stream_for(probs))
+                        _hip.ptr(rng_state), _hip.stream_for(probs))
     return out
 
 

@@ -56,8 +56,62 @@ def manual_seed_host(seed):
     _host_state["call"] = 0
 
 
+class DeviceRNG(object):
+    """Philox (seed, base offset) kept in DEVICE memory, so that sampling kernels captured in a hipGraph
+    draw fresh numbers on every replay: kernels read the state themselves (``rng_state`` argument of the
+    C ABI) and every draw inside a step uses ``base + delta`` with a host-side ``delta`` that repeats
+    identically on each replay.  ``begin_step()`` (one tiny captured add) moves ``base`` forward.
+
+        rng = zhusuan.DeviceRNG(device, seed=0)
+        with zhusuan.device_rng(rng):
+            with torch.cuda.graph(g):
+                rng.begin_step(); loss = model(obs); loss.backward(); opt.step()
+    """
+
+    def __init__(self, device, seed=0, stride=1 << 16):
+        self.device = torch.device(device)
+        self.state = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=self.device)
+        self.stride = int(stride)
+        self._delta = 0
+
+    def begin_step(self):
+        self.state[1:].add_(self.stride)
+        self._delta = 0
+
+    def next_delta(self):
+        d = self._delta
+        self._delta += 1
+        if d >= self.stride:
+            raise RuntimeError("DeviceRNG: more than %d draws in one step" % self.stride)
+        return d
+
+
+_device_rng = None
+
+
+@contextlib.contextmanager
+def device_rng(rng):
+    """Route the draws of the enclosed code through `rng` (a DeviceRNG)."""
+    global _device_rng
+    prev = _device_rng
+    _device_rng = rng
+    try:
+        yield rng
+    finally:
+        _device_rng = prev
+
+
 def next_call(device):
-    """(seed, call id) for one draw on `device`."""
+    """(seed, call id, device state tensor or None) for one draw on `device`."""
+    if _device_rng is not None:
+        if _device_rng.device != device and not (_device_rng.device.type == device.type == "cpu"):
+            raise RuntimeError("DeviceRNG lives on %s, draw requested on %s" % (_device_rng.device, device))
+        return 0, _device_rng.next_delta(), _device_rng.state
+    s, c = _next_call_host_state(device)
+    return s, c, None
+
+
+def _next_call_host_state(device):
     if device.type == "cuda":
         idx = device.index if device.index is not None else torch.cuda.current_device()
         gen = torch.cuda.default_generators[idx]

@@ -74,8 +74,8 @@ class Bernoulli(Distribution):
         K = int(n_samples)
         p = self.probs.contiguous()
         shape = ((K,) if K > 1 else ()) + tuple(p.shape)
-        seed, call = _rng.next_call(p.device)
-        s = _ops.bernoulli_sample(p, max(p.numel(), 1), shape, seed, call)
+        seed, call, rng_state = _rng.next_call(p.device)
+        s = _ops.bernoulli_sample(p, max(p.numel(), 1), shape, seed, call, rng_state)
         self.sample_cache = s
         return s
 

@@ -84,22 +84,23 @@ class Normal(Distribution):
             if tuple(eps.shape) != eps_shape:
                 raise RuntimeError("epsilon has shape %s, expected %s" % (tuple(eps.shape), eps_shape))
         seed = call = 0
+        rng_state = None
         if tuple(mean.shape) == tuple(std.shape):
             mu, sigma = mean.contiguous(), std.contiguous()
             if eps is None:
-                seed, call = _rng.next_call(mean.device)
+                seed, call, rng_state = _rng.next_call(mean.device)
             else:
                 eps = eps.contiguous()
         else:
             if eps is None:
-                s, c = _rng.next_call(mean.device)
-                eps = _ops.philox_normal(eps_shape, mean.device, s, c)
+                s, c, rs = _rng.next_call(mean.device)
+                eps = _ops.philox_normal(eps_shape, mean.device, s, c, rs)
             pad = (1,) * (len(bshape) - mean.dim())
             eps = eps.reshape(lead + pad + tuple(mean.shape)).expand(lead + bshape).contiguous()
             mu = mean.expand(bshape).contiguous()
             sigma = std.expand(bshape).contiguous()
         n_fold = min(max(1, self._group_ndims), len(bshape))
-        z, lp = _ops.NormalSampleLogProb.apply(mu, sigma, eps, seed, call, K if has_k else 1, has_k, n_fold,
+        z, lp = _ops.NormalSampleLogProb.apply(mu, sigma, eps, seed, call, rng_state, K if has_k else 1, has_k, n_fold,
                                                bool(self._is_reparameterized), True)
         self.sample_cache = z
         self._fused = (z, lp, n_fold)
