@@ -135,18 +135,22 @@ def main():
     klib = _hip.lib()
     mode = "eager"
     with zhusuan.device_rng(rng):
-        for _ in range(max(args.warmup, 3)):
-            step_body()
-        torch.cuda.synchronize()
         step = step_body
-        if not args.no_graph:
-            # the launch-bound inner loop (~130 kernels, most of them a few microseconds) as ONE hipGraph
+        if args.no_graph:
+            for _ in range(args.warmup):
+                step_body()
+        else:
+            # The launch-bound inner loop (~130 kernels, most of them a few microseconds) becomes ONE hipGraph.
+            # All eager warm-up runs on the capture side stream: autograd's AccumulateGrad nodes remember
+            # the stream they were first used on, and a default-stream association breaks the capture.
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    step_body()
+                    for _ in range(max(args.warmup, 3)):
+                        step_body()
                 torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     static_loss = step_body()
@@ -176,8 +180,15 @@ def main():
         # kernel dispatch on its stream (events cannot ride inside a graph replay)
         n_prof = min(args.steps, 50)
         klib.prof_enable(True)
-        for _ in range(n_prof):
-            step_body()
+        if mode == "hipgraph":
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(n_prof):
+                    step_body()
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            for _ in range(n_prof):
+                step_body()
         torch.cuda.synchronize()
         klib.prof_enable(False)
     if world > 1:

@@ -56,7 +56,11 @@ def _run_shard(rank, world, estimator):
         loss = model({"x": xs})
     loss.backward()
     g = bucket.all_reduce_mean(loss)
-    return float(g), bucket.flat[:bucket.n_grad].clone(), [p.detach().clone() for p in model.parameters()]
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    if world > 1:
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+        assert torch.equal(flat, bucket.flat[:bucket.n_grad])
+    return float(g), flat, [p.detach().clone() for p in model.parameters()]
 
 
 def _worker(rank, world, port, estimator, out_dir):
@@ -97,16 +101,19 @@ def test_bucket_layout_and_sharding():
     bucket = dataparallel.GradientBucket(lin)
     n = sum(p.numel() for p in lin.parameters())
     assert bucket.flat.numel() == n + 1 and bucket.nbytes() == 4 * (n + 1)
-    lin(torch.ones(5, 3)).sum().backward()
-    off = 0
-    for p in lin.parameters():                   # .grad are views into the flat buffer: no packing step
-        assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off
-        assert torch.equal(bucket.flat[off:off + p.numel()].view_as(p), p.grad)
-        off += p.numel()
-    g = bucket.all_reduce_mean(torch.tensor(3.0))     # no process group: identity
-    assert float(g) == 3.0
     bucket.zero()
-    assert float(bucket.flat.abs().sum()) == 0.0
+    assert all(p.grad is None for p in lin.parameters())
+    lin(torch.ones(5, 3)).sum().backward()
+    ref = [p.grad.clone() for p in lin.parameters()]
+    g = bucket.all_reduce_mean(torch.tensor(3.0))     # no process group: identity, nothing packed
+    assert float(g) == 3.0
+    bucket.pack(torch.tensor(3.0))                    # what a multi-rank step does before the all-reduce
+    off = 0
+    for p, r in zip(lin.parameters(), ref):           # .grad now aliases the flat buffer: no unpack copy
+        assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off
+        assert torch.equal(p.grad, r)
+        off += p.numel()
+    assert float(bucket.flat[n]) == 3.0
     x = torch.arange(12.).view(6, 2)
     assert torch.equal(dataparallel.shard_rows(x, 1, 3), x[2:4])
     with pytest.raises(ValueError, match="does not split evenly"):
