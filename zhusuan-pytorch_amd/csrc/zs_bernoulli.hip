@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256) void k_bern_logprob_serial(
 // K3 backward: gp = glp[k, r] * (x/(p+e) - (1-x)/((1-p)+e))   [* p*(1-p) for logits]
 // same row mapping as the forward; reads p and x, writes gp, 16 B per lane.
 // ------------------------------------------------------------------------------------
-template <bool LOGITS>
+typedef float zs_f4v __attribute__((ext_vector_type(4)));
+
+template <bool LOGITS, bool NT>
 __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
     const float4* __restrict__ p, const float4* __restrict__ x, int64_t xrows,
     const float* __restrict__ glp, int64_t gsk, int64_t gsr, float4* __restrict__ gp,
@@ -269,7 +271,12 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
             o.z = g * bern_dp(pv[u].z, xv[u].z);
             o.w = g * bern_dp(pv[u].w, xv[u].w);
           }
-          grow[c0 + u * G] = o;
+          if (NT) {   // gradient tensors beyond the Infinity Cache: streaming (non-temporal) stores
+            const zs_f4v v = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(v, reinterpret_cast<zs_f4v*>(&grow[c0 + u * G]));
+          } else {
+            grow[c0 + u * G] = o;
+          }
         }
       }
     }
@@ -379,8 +386,12 @@ int launch_bwd(const float* p, const float* x, int64_t Px, const float* glp, int
     const int D4 = (int)(D / 4);
     const int G = D4 >= 64 ? 64 : D4, rpw = 64 / G;
     const int64_t tiles = (K * R + rpw - 1) / rpw;
-    ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_rows<LOGITS>), dim3(grid_for(tiles, 4)), dim3(256), st,
-                       (const float4*)p, (const float4*)x, Px / D, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
+    if ((double)N * 4.0 > 268435456.0)
+      ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_rows<LOGITS, true>), dim3(grid_for(tiles, 4)), dim3(256), st,
+                (const float4*)p, (const float4*)x, Px / D, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
+    else
+      ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_rows<LOGITS, false>), dim3(grid_for(tiles, 4)), dim3(256), st,
+                (const float4*)p, (const float4*)x, Px / D, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
   } else {
     ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_serial<LOGITS>), dim3(grid_for(N, 256)), dim3(256), st, p, x, Px,
                        glp, gsk, gsr, gp, N, R, D);

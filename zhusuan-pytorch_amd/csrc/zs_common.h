@@ -116,8 +116,9 @@ __device__ __forceinline__ float u01(uint32_t v) { return ((float)(v >> 8) + 0.5
 __device__ __forceinline__ float4 philox_normal4(uint64_t group, uint64_t call, uint64_t seed) {
   Philox4 r = philox4x32_10(group, call, seed);
   float u0 = u01(r.x), u1 = u01(r.y), u2 = u01(r.z), u3 = u01(r.w);
-  float ra = __builtin_sqrtf(-2.0f * ZS_LN2 * log2_fast(u0));
-  float rb = __builtin_sqrtf(-2.0f * ZS_LN2 * log2_fast(u2));
+  // raw v_sqrt_f32 (1 ulp): the IEEE fix-up sequence of sqrtf() costs ~20 extra instructions per root
+  float ra = __builtin_amdgcn_sqrtf(-2.0f * ZS_LN2 * log2_fast(u0));
+  float rb = __builtin_amdgcn_sqrtf(-2.0f * ZS_LN2 * log2_fast(u2));
   float4 n;
   n.x = ra * __builtin_amdgcn_cosf(u1);
   n.y = ra * __builtin_amdgcn_sinf(u1);

@@ -32,16 +32,26 @@ __device__ __forceinline__ float mul_add_2round(float m, float s, float e) {
 }
 
 // ------------------------------------------------------------------------------------
-// K1 forward, rows of up to 256 elements (D4 <= 64): a wave owns `rpw` parameter rows and walks
-// a chunk of the K particles, so log(sigma) and sigma^-2 are computed once per (row, lane) and
-// reused for every particle.  z is written 16 B per lane; each particle's row sum goes to
-// lp[k*sk + r*sr] (K-fastest for the objectives).
+// K1 forward, rows of up to 256 elements (D4 <= 64): a wave owns `rpw` parameter rows (G = D4 lanes
+// each) and walks a chunk of the K particles, so log(sigma) and sigma^-2 are computed once per lane and
+// reused for every particle.  z is written 16 B per lane.  Row sums are LDS-staged: every lane parks its
+// 4-element partial in LDS each particle; after KB particles the wave reads the partials back transposed
+// (lane = (row, particle)), adds the G partials of a row and writes log q coalesced along the particle
+// axis of the K-fastest result.  (A per-particle __shfl_down tree over the 10-lane groups costs 26 % of
+// the kernel: tools/k1_variants.hip.)  NT: non-temporal stores of z for tensors that cannot stay in the
+// 256 MB Infinity Cache (streaming-write rate 4.1 -> 5.3 TB/s at 0.7 GB).
 // ------------------------------------------------------------------------------------
-template <bool HAS_EPS, bool HAS_LP>
+#define ZS_K1_KB 16
+#define ZS_K1_LDW 65
+typedef float zs_f4v __attribute__((ext_vector_type(4)));
+
+template <bool HAS_EPS, bool HAS_LP, bool NT>
 __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
     const float4* __restrict__ mu, const float4* __restrict__ sigma, const float4* __restrict__ eps,
     uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float4* __restrict__ z, float* __restrict__ lp,
-    int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t kchunk, int64_t sk, int64_t sr) {
+    int64_t K, int64_t R, int D4, int G, int rpw, int64_t kchunk, int64_t sk, int64_t sr) {
+  __shared__ float stage[4][ZS_K1_KB * ZS_K1_LDW];
+  float* __restrict__ st = stage[threadIdx.x >> 6];
   if (rs) { seed = rs[0]; call += rs[1]; }
   const int lane = threadIdx.x & 63;
   const int rw = lane / G, lig = lane - rw * G;
@@ -53,7 +63,8 @@ __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < total; t += nwaves) {
     const int64_t rt = t % row_tiles, kt = t / row_tiles;
-    const int64_t r = rt * rpw + rw;
+    const int64_t rbase = rt * rpw;
+    const int64_t r = rbase + rw;
     const bool on = lane_on && r < R;
     const int64_t m4 = r * D4 + lig;
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -61,38 +72,59 @@ __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
       m = mu[m4];
       s = sigma[m4];
     }
-    float ls[4], pr[4];
+    // per-lane row constants, computed once and reused for every particle of the chunk:
+    // rowc = sum_j (c - log sigma_j)  (normal.py:121-124),  hp_j = 0.5 * exp(-2 log sigma_j)
+    float rowc = 0.f, hp[4];
     {
       const float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float l2 = log2_fast(sv[j]);
-        ls[j] = l2 * ZS_LN2;              // logstd = log(std)         normal.py:121
-        pr[j] = exp2_fast(-2.0f * l2);    // precision = exp(-2*logstd) normal.py:123
+        const float l2 = log2_fast(sv[j]);
+        rowc += ZS_NEG_HALF_LOG_2PI - l2 * ZS_LN2;
+        hp[j] = 0.5f * exp2_fast(-2.0f * l2);
       }
     }
     const int64_t k0 = kt * kchunk;
     const int64_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
-    for (int64_t k = k0; k < k1; ++k) {
-      const int64_t g = k * M4 + m4;
-      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (on) {
-        if (HAS_EPS) e = eps[g];
-        else e = philox_normal4((uint64_t)g, call, seed);
+    int64_t g = k0 * M4 + m4;                      // running address: no 64-bit multiplies in the loop
+    for (int64_t kb0 = k0; kb0 < k1; kb0 += ZS_K1_KB) {
+      const int kb = (int)((k1 - kb0 < ZS_K1_KB) ? (k1 - kb0) : ZS_K1_KB);
+      for (int kk = 0; kk < kb; ++kk, g += M4) {
+        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) {
+          if (HAS_EPS) e = eps[g];
+          else e = philox_normal4((uint64_t)g, call, seed);
+        }
+        float4 zz;
+        zz.x = mul_add_2round(m.x, s.x, e.x);
+        zz.y = mul_add_2round(m.y, s.y, e.y);
+        zz.z = mul_add_2round(m.z, s.z, e.z);
+        zz.w = mul_add_2round(m.w, s.w, e.w);
+        if (on) {
+          if (NT) {
+            const zs_f4v v = {zz.x, zz.y, zz.z, zz.w};
+            __builtin_nontemporal_store(v, reinterpret_cast<zs_f4v*>(&z[g]));
+          } else {
+            z[g] = zz;
+          }
+        }
+        if (HAS_LP) {
+          const float d0 = zz.x - m.x, d1 = zz.y - m.y, d2 = zz.z - m.z, d3 = zz.w - m.w;
+          st[kk * ZS_K1_LDW + lane] =
+              rowc - (hp[0] * (d0 * d0) + hp[1] * (d1 * d1) + hp[2] * (d2 * d2) + hp[3] * (d3 * d3));
+        }
       }
-      float4 zz;
-      zz.x = mul_add_2round(m.x, s.x, e.x);
-      zz.y = mul_add_2round(m.y, s.y, e.y);
-      zz.z = mul_add_2round(m.z, s.z, e.z);
-      zz.w = mul_add_2round(m.w, s.w, e.w);
-      if (on) z[g] = zz;
       if (HAS_LP) {
-        float acc = normal_lp_term(zz.x - m.x, ls[0], pr[0]);
-        acc += normal_lp_term(zz.y - m.y, ls[1], pr[1]);
-        acc += normal_lp_term(zz.z - m.z, ls[2], pr[2]);
-        acc += normal_lp_term(zz.w - m.w, ls[3], pr[3]);
-        acc = group_sum_down(acc, lig, G, p2);
-        if (on && lig == 0) lp[k * sk + r * sr] = acc;
+        // same-wave LDS hand-off: the DS queue is in order, no barrier needed between the writes above
+        // and these reads
+        const int nout = rpw * kb;
+        for (int o = lane; o < nout; o += 64) {
+          const int q = o / kb, kk = o - q * kb;
+          const float* __restrict__ src = st + kk * ZS_K1_LDW + q * G;
+          float sum = 0.f;
+          for (int j = 0; j < G; ++j) sum += src[j];
+          if (rbase + q < R) lp[(kb0 + kk) * sk + (rbase + q) * sr] = sum;
+        }
       }
     }
   }
@@ -305,6 +337,126 @@ __global__ __launch_bounds__(256) void k_normal_logprob_rows(
   }
 }
 
+// K2 forward, parameters [R, D] repeated over the K particles (IWAE prior / q of a given sample,
+// normal.py:112-116) and D4 <= 64: same tiling as the fused sampling kernel -- a wave owns `rpw` parameter
+// rows, computes log(sigma) and sigma^-2 once per lane and streams the K value rows past them; no
+// per-element index arithmetic.
+__global__ __launch_bounds__(256) void k_normal_logprob_krep(
+    const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
+    float* __restrict__ lp, int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t kchunk,
+    int64_t sk, int64_t sr) {
+  const int lane = threadIdx.x & 63;
+  const int rw = lane / G, lig = lane - rw * G;
+  const bool lane_on = rw < rpw;
+  const int64_t M4 = R * (int64_t)D4;
+  const int64_t row_tiles = (R + rpw - 1) / rpw;
+  const int64_t k_tiles = (K + kchunk - 1) / kchunk;
+  const int64_t total = row_tiles * k_tiles;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < total; t += nwaves) {
+    const int64_t rt = t % row_tiles, kt = t / row_tiles;
+    const int64_t r = rt * rpw + rw;
+    const bool on = lane_on && r < R;
+    const int64_t m4 = r * D4 + lig;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (on) {
+      m = mu[m4];
+      s = sigma[m4];
+    }
+    float rowc = 0.f, hp[4];
+    {
+      const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float l2 = log2_fast(sv[j]);
+        rowc += ZS_NEG_HALF_LOG_2PI - l2 * ZS_LN2;
+        hp[j] = 0.5f * exp2_fast(-2.0f * l2);
+      }
+    }
+    const int64_t k0 = kt * kchunk;
+    const int64_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
+    int64_t g = k0 * M4 + m4;
+    float* __restrict__ lpp = lp + (k0 * sk + r * sr);
+    int64_t k = k0;
+    for (; k + 1 < k1; k += 2, g += 2 * M4, lpp += 2 * sk) {   // two value rows in flight
+      float4 xa = m, xb = m;
+      if (on) {
+        xa = x[g];
+        xb = x[g + M4];
+      }
+      const float a0 = xa.x - m.x, a1 = xa.y - m.y, a2 = xa.z - m.z, a3 = xa.w - m.w;
+      const float b0 = xb.x - m.x, b1 = xb.y - m.y, b2 = xb.z - m.z, b3 = xb.w - m.w;
+      float acca = rowc - (hp[0] * (a0 * a0) + hp[1] * (a1 * a1) + hp[2] * (a2 * a2) + hp[3] * (a3 * a3));
+      float accb = rowc - (hp[0] * (b0 * b0) + hp[1] * (b1 * b1) + hp[2] * (b2 * b2) + hp[3] * (b3 * b3));
+      acca = group_sum_down(acca, lig, G, p2);
+      accb = group_sum_down(accb, lig, G, p2);
+      if (on && lig == 0) {
+        lpp[0] = acca;
+        lpp[sk] = accb;
+      }
+    }
+    for (; k < k1; ++k, g += M4, lpp += sk) {
+      float4 xa = m;
+      if (on) xa = x[g];
+      const float a0 = xa.x - m.x, a1 = xa.y - m.y, a2 = xa.z - m.z, a3 = xa.w - m.w;
+      float acca = rowc - (hp[0] * (a0 * a0) + hp[1] * (a1 * a1) + hp[2] * (a2 * a2) + hp[3] * (a3 * a3));
+      acca = group_sum_down(acca, lig, G, p2);
+      if (on && lig == 0) lpp[0] = acca;
+    }
+  }
+}
+
+// K2 forward, every operand either full-size or a scalar: rows with no index arithmetic at all.
+__global__ __launch_bounds__(256) void k_normal_logprob_full(
+    const float4* __restrict__ x, int x_scalar, const float4* __restrict__ mu, int mu_scalar,
+    const float4* __restrict__ sigma, int sg_scalar, float* __restrict__ lp,
+    int64_t rows, int64_t R, int D4, int G, int rpw, int p2, int64_t sk, int64_t sr) {
+  const int lane = threadIdx.x & 63;
+  const int rw = lane / G, lig = lane - rw * G;
+  const bool lane_on = rw < rpw;
+  const int64_t tiles = (rows + rpw - 1) / rpw;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float xs = 0.f, ms = 0.f, ss = 1.f, ls_s = 0.f, hp_s = 0.5f;
+  if (x_scalar) xs = *reinterpret_cast<const float*>(x);
+  if (mu_scalar) ms = *reinterpret_cast<const float*>(mu);
+  if (sg_scalar) {
+    ss = *reinterpret_cast<const float*>(sigma);
+    const float l2 = log2_fast(ss);
+    ls_s = l2 * ZS_LN2;
+    hp_s = 0.5f * exp2_fast(-2.0f * l2);
+  }
+  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < tiles; t += nwaves) {
+    const int64_t row = t * rpw + rw;
+    const bool on = lane_on && row < rows;
+    float acc = 0.f;
+    if (on) {
+      const int64_t base = row * D4;
+      for (int c = lig; c < D4; c += G) {
+        const float4 xv = x_scalar ? make_float4(xs, xs, xs, xs) : x[base + c];
+        const float4 mv = mu_scalar ? make_float4(ms, ms, ms, ms) : mu[base + c];
+        const float dv[4] = {xv.x - mv.x, xv.y - mv.y, xv.z - mv.z, xv.w - mv.w};
+        if (sg_scalar) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc += (ZS_NEG_HALF_LOG_2PI - ls_s) - hp_s * (dv[j] * dv[j]);
+        } else {
+          const float4 sv4 = sigma[base + c];
+          const float sv[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float l2 = log2_fast(sv[j]);
+            acc += normal_lp_term(dv[j], l2 * ZS_LN2, exp2_fast(-2.0f * l2));
+          }
+        }
+      }
+    }
+    acc = group_sum_down(acc, lig, G, p2);
+    if (on && lig == 0) {
+      const int64_t k = row / R, r = row - k * R;
+      lp[k * sk + r * sr] = acc;
+    }
+  }
+}
+
 // any D / alignment / period: one thread per row, element-wise modulo addressing
 __global__ __launch_bounds__(256) void k_normal_logprob_serial(
     const float* __restrict__ x, int64_t Px, const float* __restrict__ mu, int64_t Pm,
@@ -457,11 +609,17 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
       const int64_t kchunk = (K + kt - 1) / kt;
       const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
       const unsigned grid = grid_for(total, 4);
-#define ZS_LAUNCH_SMALL(E, L)                                                                           \
-  ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_smallrow<E, L>), dim3(grid), dim3(256), st, m4, s4, e4, seed, \
-                     offset, rng_state, (float4*)z, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr)
-      if (eps) { if (lp) ZS_LAUNCH_SMALL(true, true); else ZS_LAUNCH_SMALL(true, false); }
-      else     { if (lp) ZS_LAUNCH_SMALL(false, true); else ZS_LAUNCH_SMALL(false, false); }
+#define ZS_LAUNCH_SMALL(E, L, T)                                                                          \
+  ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_smallrow<E, L, T>), dim3(grid), dim3(256), st, m4, s4, e4, \
+            seed, offset, rng_state, (float4*)z, lp, K, R, D4, rm.G, rm.rpw, kchunk, sk, sr)
+      const bool nt = (double)K * (double)M * 4.0 > 268435456.0;   // z cannot stay in the Infinity Cache
+      if (nt) {
+        if (eps) { if (lp) ZS_LAUNCH_SMALL(true, true, true); else ZS_LAUNCH_SMALL(true, false, true); }
+        else     { if (lp) ZS_LAUNCH_SMALL(false, true, true); else ZS_LAUNCH_SMALL(false, false, true); }
+      } else {
+        if (eps) { if (lp) ZS_LAUNCH_SMALL(true, true, false); else ZS_LAUNCH_SMALL(true, false, false); }
+        else     { if (lp) ZS_LAUNCH_SMALL(false, true, false); else ZS_LAUNCH_SMALL(false, false, false); }
+      }
 #undef ZS_LAUNCH_SMALL
     } else {
       const unsigned grid = grid_for(K * R, 4);
@@ -530,10 +688,27 @@ extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu
   if (vec) {
     const int D4 = (int)(D / 4);
     RowMap rm = row_map(D4);
-    const int64_t tiles = (K * R + rm.rpw - 1) / rm.rpw;
-    ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_rows, dim3(grid_for(tiles, 4)), dim3(256), st, (const float4*)x,
-                       Px == 1 ? 0 : Px / D, (const float4*)mu, Pm == 1 ? 0 : Pm / D, (const float4*)sigma,
-                       Ps == 1 ? 0 : Ps / D, lp, K, R, D4, rm.G, rm.rpw, rm.p2, sk, sr);
+    const int64_t rows = K * R;
+    const int64_t tiles = (rows + rm.rpw - 1) / rm.rpw;
+    const bool simple = (Px == N || Px == 1) && (Pm == N || Pm == 1) && (Ps == N || Ps == 1);
+    if (K > 1 && D4 <= 64 && Px == N && Pm == R * D && Ps == R * D) {
+      const int64_t row_tiles = (R + rm.rpw - 1) / rm.rpw;
+      int64_t kt = (256 * 8 + row_tiles - 1) / row_tiles;   // enough waves to fill the chip first
+      if (kt < 1) kt = 1;
+      if (kt > K) kt = K;
+      const int64_t kchunk = (K + kt - 1) / kt;
+      const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
+      ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_krep, dim3(grid_for(total, 4)), dim3(256), st, (const float4*)x,
+                (const float4*)mu, (const float4*)sigma, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr);
+    } else if (simple) {
+      ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_full, dim3(grid_for(tiles, 4)), dim3(256), st, (const float4*)x,
+                (int)(Px == 1 && N != 1), (const float4*)mu, (int)(Pm == 1 && N != 1), (const float4*)sigma,
+                (int)(Ps == 1 && N != 1), lp, rows, R, D4, rm.G, rm.rpw, rm.p2, sk, sr);
+    } else {
+      ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_rows, dim3(grid_for(tiles, 4)), dim3(256), st, (const float4*)x,
+                Px == 1 ? 0 : Px / D, (const float4*)mu, Pm == 1 ? 0 : Pm / D, (const float4*)sigma,
+                Ps == 1 ? 0 : Ps / D, lp, K, R, D4, rm.G, rm.rpw, rm.p2, sk, sr);
+    }
   } else {
     ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_serial, dim3(grid_for(K * R, 256)), dim3(256), st, x, Px, mu, Pm,
                        sigma, Ps, lp, K, R, D, sk, sr);
