@@ -34,6 +34,22 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 DOMINANT = "zs_bernoulli_logprob_f32"
 
 
+def pmc_traffic(entry):
+    """HBM bytes per launch of `entry` from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of this same bench command, gfx950 FETCH_SIZE x2 correction
+    applied; see profiles/r01_pmc_traffic.json).  Counters cannot be read from inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"].get(entry)
+        return k["hbm_bytes_corrected"] if k else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(budget_s=12.0, max_steps=40):
     """The CPU oracle (torch-CPU restatement of the reference's op sequence, pinned to the reference by
     tests/test_oracle_golden.py) on the same workload: forward + backward + Adam, all host cores."""
@@ -88,6 +104,8 @@ def main():
     ap.add_argument("--fused-logits", action="store_true",
                     help="decoder hands logits to Bernoulli(logits=...): sigmoid fused into the log-prob kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective-path", action="store_true",
+                    help="run the multi-rank code path (bucket pack + all-reduce + split graphs) even with one rank")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python each step instead of replaying one captured hipGraph")
     ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "rocblas"],
@@ -102,7 +120,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or (args.force_collective_path and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=dev)
 
     if args.blas != "default":
@@ -122,12 +140,29 @@ def main():
     x = torch.tensor((rs.uniform(size=(BATCH_PER_GPU, X_DIM)) < 0.5).astype(np.float32), device=dev)
     obs = {"x": x}
 
-    def step_body():
+    multi = world > 1 or args.force_collective_path
+
+    def compute_part():
+        """objective forward + backward (+ packing the flat [grads | loss] bucket when there is a collective)"""
         rng.begin_step()
         bucket.zero()
         loss = model(obs)
         loss.backward()
-        g = bucket.all_reduce_mean(loss)
+        if multi:
+            bucket.pack(loss)
+        return loss.detach()
+
+    def exchange_part(loss):
+        """the ONE collective of a step: all-reduce of the flat bucket over RCCL/xGMI, then 1/world"""
+        if not multi:
+            return loss
+        if dist.is_initialized():
+            dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM)
+        bucket.flat.mul_(1.0 / world)
+        return bucket.flat[bucket.n_grad]
+
+    def step_body():
+        g = exchange_part(compute_part())
         opt.step()
         return g
 
@@ -151,13 +186,30 @@ def main():
                         step_body()
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    static_loss = step_body()
+                if not multi:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        static_loss = step_body()
 
-                def step():
-                    graph.replay()
-                    return static_loss
+                    def step():
+                        graph.replay()
+                        return static_loss
+                else:
+                    # the collective stays OUTSIDE the graphs: graph A = compute + pack, eager RCCL all-reduce
+                    # of the bucket, graph B = optimizer
+                    graph_a = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_a):
+                        static_local = compute_part()
+                    torch.cuda.synchronize()
+                    graph_b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_b, pool=graph_a.pool()):
+                        opt.step()
+
+                    def step():
+                        graph_a.replay()
+                        g = exchange_part(static_local)
+                        graph_b.replay()
+                        return g
                 for _ in range(3):
                     step()
                 mode = "hipgraph"
@@ -223,10 +275,11 @@ def main():
                        "global_batch": BATCH_PER_GPU * world, "particles": PARTICLES,
                        "parallelism": "dp%d (minibatch shards, one flat-bucket all-reduce of %d bytes)" % (world, bucket.nbytes()),
                        "bernoulli_path": "logits (sigmoid fused)" if args.fused_logits else "probs (reference default)",
-                       "mlp_gemm_library": args.blas, "launch_mode": mode},
+                       "mlp_gemm_library": args.blas, "launch_mode": mode if not (multi and mode == "hipgraph") else "hipgraph x2 around an eager all-reduce"},
             "final_loss": final_loss,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": pmc_traffic(dominant) if not args.fused_logits else None,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": 1e3 * k_ms if k_ms else None,
                          "min_launch_us": 1e3 * prof["min_ms"], "launches_timed": prof["count"],
                          "timing": "start/stop HIP events bound to each dispatch (hipExtLaunchKernelGGL) on the launch "
@@ -236,7 +289,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
