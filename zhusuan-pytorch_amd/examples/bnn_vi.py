@@ -7,6 +7,7 @@ batched GEMM (h [K, B, n_in+1] x w^T [K, n_in+1, n_out]) instead of materialisin
 ``w.repeat([1, B, 1, 1])`` copy (bnn_vi.py:39-44); ``materialize=True`` reproduces that op sequence.
 """
 import argparse
+import math
 import time
 
 import torch
@@ -45,7 +46,7 @@ class Net(BayesianNet):
                             n_samples=K, reduce_mean_dims=[0])
             ones = torch.ones([*h.shape[:-1], 1], device=h.device, dtype=h.dtype)
             h = torch.cat((h, ones), -1)
-            scale = torch.sqrt(torch.as_tensor(h.shape[2], dtype=torch.float32, device=h.device))
+            scale = math.sqrt(h.shape[2])      # host scalar: no H2D copy inside a captured step (bnn_vi.py:42)
             if self.materialize:
                 wr = torch.unsqueeze(w, 1).repeat([1, batch_size, 1, 1])
                 h = torch.squeeze(torch.matmul(wr, torch.unsqueeze(h, -1)), -1) / scale
