@@ -183,6 +183,74 @@ __global__ __launch_bounds__(256) void k1lds(const float4* __restrict__ mu, cons
   }
 }
 
+// tuned: compile-time G, KB particles per LDS batch, two particles per loop iteration
+template <int G, int KB, int NT>
+__global__ __launch_bounds__(256) void k1tuned(const float4* __restrict__ mu, const float4* __restrict__ sigma, uint64_t seed, uint64_t call,
+                                               float4* __restrict__ z, float* __restrict__ lp, int64_t K, int64_t R, int64_t kchunk, int64_t sk, int64_t sr) {
+  constexpr int D4 = G, rpw = 64 / G, LDW = 65;
+  __shared__ float stage[4][KB * LDW];
+  float* __restrict__ st = stage[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int rw = lane / G, lig = lane - rw * G;
+  const bool lane_on = rw < rpw;
+  const int64_t M4 = R * (int64_t)D4;
+  const int64_t row_tiles = (R + rpw - 1) / rpw, k_tiles = (K + kchunk - 1) / kchunk, total = row_tiles * k_tiles;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += nwaves) {
+    const int64_t rt = t % row_tiles, kt = t / row_tiles;
+    const int64_t rbase = rt * rpw;
+    const int64_t r = rbase + rw;
+    const bool on = lane_on && r < R;
+    const int64_t m4 = r * D4 + lig;
+    float4 m = make_float4(0, 0, 0, 0), s = make_float4(1, 1, 1, 1);
+    if (on) { m = mu[m4]; s = sigma[m4]; }
+    float rowc = 0.f, hp[4];
+    { const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float l2 = log2_fast(sv[j]); rowc += ZS_NEG_HALF_LOG_2PI - l2 * ZS_LN2; hp[j] = 0.5f * exp2_fast(-2.0f * l2); } }
+    const int64_t k0 = kt * kchunk, k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
+    int64_t g = k0 * M4 + m4;
+    for (int64_t kb0 = k0; kb0 < k1; kb0 += KB) {
+      const int kb = (int)((k1 - kb0 < KB) ? (k1 - kb0) : KB);
+      int kk = 0;
+      for (; kk + 1 < kb; kk += 2, g += 2 * M4) {
+        Philox4 pa = philox_r<10>((uint64_t)g, call, seed), pb = philox_r<10>((uint64_t)(g + M4), call, seed);
+        const float4 ea = bm4(pa.x, pa.y, pa.z, pa.w), eb = bm4(pb.x, pb.y, pb.z, pb.w);
+        float4 za, zb;
+        za.x = m.x + s.x * ea.x; za.y = m.y + s.y * ea.y; za.z = m.z + s.z * ea.z; za.w = m.w + s.w * ea.w;
+        zb.x = m.x + s.x * eb.x; zb.y = m.y + s.y * eb.y; zb.z = m.z + s.z * eb.z; zb.w = m.w + s.w * eb.w;
+        if (on) {
+          if (NT) { typedef float f4v __attribute__((ext_vector_type(4))); f4v va = {za.x, za.y, za.z, za.w}, vb = {zb.x, zb.y, zb.z, zb.w};
+            __builtin_nontemporal_store(va, (f4v*)&z[g]); __builtin_nontemporal_store(vb, (f4v*)&z[g + M4]); }
+          else { z[g] = za; z[g + M4] = zb; }
+        }
+        { const float d0 = za.x - m.x, d1 = za.y - m.y, d2 = za.z - m.z, d3 = za.w - m.w;
+          st[kk * LDW + lane] = rowc - (hp[0] * (d0 * d0) + hp[1] * (d1 * d1) + hp[2] * (d2 * d2) + hp[3] * (d3 * d3)); }
+        { const float d0 = zb.x - m.x, d1 = zb.y - m.y, d2 = zb.z - m.z, d3 = zb.w - m.w;
+          st[(kk + 1) * LDW + lane] = rowc - (hp[0] * (d0 * d0) + hp[1] * (d1 * d1) + hp[2] * (d2 * d2) + hp[3] * (d3 * d3)); }
+      }
+      for (; kk < kb; ++kk, g += M4) {
+        Philox4 pa = philox_r<10>((uint64_t)g, call, seed);
+        const float4 ea = bm4(pa.x, pa.y, pa.z, pa.w);
+        float4 za;
+        za.x = m.x + s.x * ea.x; za.y = m.y + s.y * ea.y; za.z = m.z + s.z * ea.z; za.w = m.w + s.w * ea.w;
+        if (on) z[g] = za;
+        const float d0 = za.x - m.x, d1 = za.y - m.y, d2 = za.z - m.z, d3 = za.w - m.w;
+        st[kk * LDW + lane] = rowc - (hp[0] * (d0 * d0) + hp[1] * (d1 * d1) + hp[2] * (d2 * d2) + hp[3] * (d3 * d3));
+      }
+      const int nout = rpw * kb;
+      for (int o = lane; o < nout; o += 64) {
+        const int q = o / kb, k2 = o - q * kb;
+        const float* __restrict__ src = st + k2 * LDW + q * G;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < G; ++j) sum += src[j];
+        if (rbase + q < R) lp[(kb0 + k2) * sk + (rbase + q) * sr] = sum;
+      }
+    }
+  }
+}
+
 int main() {
   const int K = 50, D = 40, D4 = 10, G = 10, rpw = 6, p2 = 16;
   int64_t Bs[] = {20971, 83886};
@@ -219,6 +287,13 @@ int main() {
       hipExtLaunchKernelGGL((k1lds<MODE, NT>), dim3(grid), dim3(256), 0, 0, a, b, 0, (const float4*)mu, (const float4*)sg, (uint64_t)1, (uint64_t)it, (float4*)z, lp, (int64_t)K, B, D4, G, rpw, p2, kchunk, (int64_t)1, (int64_t)K); \
       CK(hipDeviceSynchronize()); float m_; CK(hipEventElapsedTime(&m_, a, b)); ms.push_back(m_); } std::sort(ms.begin(), ms.end()); \
       printf("  %-34s median %8.2f us  -> %7.1f GB/s (%4.1f%% of 8 TB/s)\n", name, ms[6] * 1e3, bytes / (ms[6] * 1e-3) / 1e9, bytes / (ms[6] * 1e-3) / 1e9 / 80.0); }
+#define RUNT(name, G_, KB_, NT) { std::vector<float> ms; for (int it = 0; it < 12; ++it) { hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); \
+      hipExtLaunchKernelGGL((k1tuned<G_, KB_, NT>), dim3(grid), dim3(256), 0, 0, a, b, 0, (const float4*)mu, (const float4*)sg, (uint64_t)1, (uint64_t)it, (float4*)z, lp, (int64_t)K, B, kchunk, (int64_t)1, (int64_t)K); \
+      CK(hipDeviceSynchronize()); float m_; CK(hipEventElapsedTime(&m_, a, b)); ms.push_back(m_); } std::sort(ms.begin(), ms.end()); \
+      printf("  %-34s median %8.2f us  -> %7.1f GB/s (%4.1f%% of 8 TB/s)\n", name, ms[6] * 1e3, bytes / (ms[6] * 1e-3) / 1e9, bytes / (ms[6] * 1e-3) / 1e9 / 80.0); }
+    RUNT("tuned G=10 KB=16 2/iter", 10, 16, 0);
+    RUNT("tuned G=10 KB=16 2/iter nt", 10, 16, 1);
+    RUNT("tuned G=10 KB=32 2/iter nt", 10, 32, 1);
     RUNL("philox10 + LDS-staged sums", 0, 0);
     RUNL("philox10 + LDS-staged sums, nt", 0, 1);
     RUNL("no rng + LDS-staged sums, nt", 3, 1);

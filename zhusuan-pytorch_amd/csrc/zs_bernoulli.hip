@@ -283,6 +283,68 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
   }
 }
 
+// K3 backward for big problems with a shared observation (same tiling as k_bern_logprob_xreuse): the wave keeps
+// x[b, :] in registers, streams JC particle rows of p past it and writes the gradient rows, non-temporally when
+// the tensor cannot stay in the Infinity Cache.
+template <bool LOGITS, bool NT>
+__global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
+    const float4* __restrict__ p, const float4* __restrict__ x, int64_t xrows, int64_t J, int64_t JC,
+    const float* __restrict__ glp, int64_t gsk, int64_t gsr, float4* __restrict__ gp, int64_t R, int D4) {
+  const int lane = threadIdx.x & 63;
+  const int64_t jchunks = (J + JC - 1) / JC;
+  const int64_t items = xrows * jchunks;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += nwaves) {
+    const int64_t jc = it / xrows, r0 = it - jc * xrows;
+    const float4* __restrict__ xrow = x + r0 * D4;
+    float4 xv[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = lane + 64 * u;
+      ok[u] = c < D4;
+      xv[u] = ok[u] ? xrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int64_t j0 = jc * JC, j1 = (j0 + JC < J) ? j0 + JC : J;
+    for (int64_t j = j0; j < j1; ++j) {
+      const int64_t row = j * xrows + r0;
+      const int64_t k = row / R, r = row - k * R;
+      const float g = glp[k * gsk + r * gsr];
+      const float4* __restrict__ prow = p + row * D4;
+      float4* __restrict__ grow = gp + row * D4;
+      float4 pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) pv[u] = prow[lane + 64 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ok[u]) {
+          float4 o;
+          if (LOGITS) {
+            const float a = sigmoid_fast(pv[u].x), b = sigmoid_fast(pv[u].y), c = sigmoid_fast(pv[u].z),
+                        d = sigmoid_fast(pv[u].w);
+            o.x = g * bern_dp(a, xv[u].x) * a * (1.0f - a);
+            o.y = g * bern_dp(b, xv[u].y) * b * (1.0f - b);
+            o.z = g * bern_dp(c, xv[u].z) * c * (1.0f - c);
+            o.w = g * bern_dp(d, xv[u].w) * d * (1.0f - d);
+          } else {
+            o.x = g * bern_dp(pv[u].x, xv[u].x);
+            o.y = g * bern_dp(pv[u].y, xv[u].y);
+            o.z = g * bern_dp(pv[u].z, xv[u].z);
+            o.w = g * bern_dp(pv[u].w, xv[u].w);
+          }
+          if (NT) {
+            const zs_f4v v = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(v, reinterpret_cast<zs_f4v*>(&grow[lane + 64 * u]));
+          } else {
+            grow[lane + 64 * u] = o;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <bool LOGITS>
 __global__ __launch_bounds__(256) void k_bern_logprob_bwd_serial(
     const float* __restrict__ p, const float* __restrict__ x, int64_t Px, const float* __restrict__ glp,
@@ -386,12 +448,24 @@ int launch_bwd(const float* p, const float* x, int64_t Px, const float* glp, int
     const int D4 = (int)(D / 4);
     const int G = D4 >= 64 ? 64 : D4, rpw = 64 / G;
     const int64_t tiles = (K * R + rpw - 1) / rpw;
-    if ((double)N * 4.0 > 268435456.0)
-      ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_rows<LOGITS, true>), dim3(grid_for(tiles, 4)), dim3(256), st,
-                (const float4*)p, (const float4*)x, Px / D, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
-    else
-      ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_rows<LOGITS, false>), dim3(grid_for(tiles, 4)), dim3(256), st,
-                (const float4*)p, (const float4*)x, Px / D, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
+    const int kid = LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD;
+    const int64_t rows = K * R, xrows = Px / D;
+    const int64_t J = rows / xrows;
+    const bool nt = (double)N * 4.0 > 268435456.0;
+    if (D4 >= 64 && D4 <= 256 && J >= 2 && rows > 32768) {
+      int64_t JC = rows / 4096;
+      if (JC < 1) JC = 1;
+      if (JC > J) JC = J;
+      const unsigned grid = grid_for(xrows * ((J + JC - 1) / JC), 4);
+      if (nt) ZS_LAUNCH(kid, (k_bern_logprob_bwd_xreuse<LOGITS, true>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, glp, gsk, gsr, (float4*)gp, R, D4);
+      else ZS_LAUNCH(kid, (k_bern_logprob_bwd_xreuse<LOGITS, false>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, glp, gsk, gsr, (float4*)gp, R, D4);
+    } else if (nt) {
+      ZS_LAUNCH(kid, (k_bern_logprob_bwd_rows<LOGITS, true>), dim3(grid_for(tiles, 4)), dim3(256), st,
+                (const float4*)p, (const float4*)x, xrows, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
+    } else {
+      ZS_LAUNCH(kid, (k_bern_logprob_bwd_rows<LOGITS, false>), dim3(grid_for(tiles, 4)), dim3(256), st,
+                (const float4*)p, (const float4*)x, xrows, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
+    }
   } else {
     ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_serial<LOGITS>), dim3(grid_for(N, 256)), dim3(256), st, p, x, Px,
                        glp, gsk, gsr, gp, N, R, D);

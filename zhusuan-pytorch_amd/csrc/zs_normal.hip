@@ -41,7 +41,7 @@ __device__ __forceinline__ float mul_add_2round(float m, float s, float e) {
 // the kernel: tools/k1_variants.hip.)  NT: non-temporal stores of z for tensors that cannot stay in the
 // 256 MB Infinity Cache (streaming-write rate 4.1 -> 5.3 TB/s at 0.7 GB).
 // ------------------------------------------------------------------------------------
-#define ZS_K1_KB 16
+#define ZS_K1_KB 32
 #define ZS_K1_LDW 65
 typedef float zs_f4v __attribute__((ext_vector_type(4)));
 
