@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_rows(
     float acc = 0.f;
     if (on) {
       const float4* __restrict__ prow = p + row * D4;
-      const float4* __restrict__ xrow = x + (xrows == rows ? row : row % xrows) * D4;
+      const float4* __restrict__ xrow = x + (xrows == rows ? row : mod_fast(row, xrows)) * D4;
       float4* __restrict__ orow = WRITE_P ? probs_out + row * D4 : nullptr;
       for (int c0 = lig; c0 < D4; c0 += 4 * G) {
         float4 pv[4], xv[4];
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_rows(
     }
     acc = group_sum_down(acc, lig, G, p2);
     if (on && lig == 0) {
-      const int64_t k = row / R, r = row - k * R;
+      int64_t k, r;
+      divmod(row, R, k, r);
       lp[k * sk + r * sr] = acc * ZS_LN2;
     }
   }
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_longrow(
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
     const float4* __restrict__ prow = p + row * D4;
-    const float4* __restrict__ xrow = x + (xrows == rows ? row : row % xrows) * D4;
+    const float4* __restrict__ xrow = x + (xrows == rows ? row : mod_fast(row, xrows)) * D4;
     float acc = 0.f;
     for (int c0 = lane; c0 < D4; c0 += 256) {
       float4 pv[4], xv[4];
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_longrow(
     }
     acc = wave_sum(acc);
     if (lane == 0) {
-      const int64_t k = row / R, r = row - k * R;
+      int64_t k, r;
+      divmod(row, R, k, r);
       lp[k * sk + r * sr] = acc * ZS_LN2;
     }
   }
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_xreuse(
   const int64_t items = xrows * jchunks;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += nwaves) {
-    const int64_t jc = it / xrows, r0 = it - jc * xrows;   // neighbouring waves -> neighbouring rows of p
+    int64_t jc, r0;
+    divmod(it, xrows, jc, r0);   // neighbouring waves -> neighbouring rows of p
     const float4* __restrict__ xrow = x + r0 * D4;
     float4 xv[4];
     bool ok[4];
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_xreuse(
         }
         acc = wave_sum(acc);
         if (live[v] && lane == 0) {
-          const int64_t k = row / R, r = row - k * R;
+          int64_t k, r;
+      divmod(row, R, k, r);
           lp[k * sk + r * sr] = acc * ZS_LN2;
         }
       }
@@ -210,9 +214,10 @@ __global__ __launch_bounds__(256) void k_bern_logprob_serial(
         pv = sigmoid_fast(pv);
         if (probs_out) probs_out[i] = pv;
       }
-      acc += bern_lp2_term(pv, x[i % Px]);
+      acc += bern_lp2_term(pv, x[mod_fast(i, Px)]);
     }
-    const int64_t k = row / R, r = row - k * R;
+    int64_t k, r;
+      divmod(row, R, k, r);
     lp[k * sk + r * sr] = acc * ZS_LN2;
   }
 }
@@ -237,10 +242,11 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
   for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < tiles; t += nwaves) {
     const int64_t row = t * rpw + rw;
     if (!(lane_on && row < rows)) continue;
-    const int64_t k = row / R, r = row - k * R;
+    int64_t k, r;
+      divmod(row, R, k, r);
     const float g = glp[k * gsk + r * gsr];
     const float4* __restrict__ prow = p + row * D4;
-    const float4* __restrict__ xrow = x + (xrows == rows ? row : row % xrows) * D4;
+    const float4* __restrict__ xrow = x + (xrows == rows ? row : mod_fast(row, xrows)) * D4;
     float4* __restrict__ grow = gp + row * D4;
     for (int c0 = lig; c0 < D4; c0 += 4 * G) {
       float4 pv[4], xv[4];
@@ -295,7 +301,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
   const int64_t items = xrows * jchunks;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += nwaves) {
-    const int64_t jc = it / xrows, r0 = it - jc * xrows;
+    int64_t jc, r0;
+    divmod(it, xrows, jc, r0);
     const float4* __restrict__ xrow = x + r0 * D4;
     float4 xv[4];
     bool ok[4];
@@ -308,7 +315,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
     const int64_t j0 = jc * JC, j1 = (j0 + JC < J) ? j0 + JC : J;
     for (int64_t j = j0; j < j1; ++j) {
       const int64_t row = j * xrows + r0;
-      const int64_t k = row / R, r = row - k * R;
+      int64_t k, r;
+      divmod(row, R, k, r);
       const float g = glp[k * gsk + r * gsr];
       const float4* __restrict__ prow = p + row * D4;
       float4* __restrict__ grow = gp + row * D4;
@@ -351,7 +359,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_serial(
     int64_t gsk, int64_t gsr, float* __restrict__ gp, int64_t N, int64_t R, int64_t D) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / D;
-    const int64_t k = row / R, r = row - k * R;
+    int64_t k, r;
+      divmod(row, R, k, r);
     const float g = glp[k * gsk + r * gsr];
     float pv = p[i];
     float scale = 1.0f;
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_serial(
       pv = sigmoid_fast(pv);
       scale = pv * (1.0f - pv);
     }
-    gp[i] = g * bern_dp(pv, x[i % Px]) * scale;
+    gp[i] = g * bern_dp(pv, x[mod_fast(i, Px)]) * scale;
   }
 }
 
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(256) void k_bern_sample(const float* __restrict__ p
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t i = g * 4 + j;
-      if (i < N) out[i] = u[j] < p[i % Pp] ? 1.0f : 0.0f;
+      if (i < N) out[i] = u[j] < p[mod_fast(i, Pp)] ? 1.0f : 0.0f;
     }
   }
 }

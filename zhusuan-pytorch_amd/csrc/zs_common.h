@@ -59,6 +59,26 @@ __device__ __forceinline__ float bern_lp2_term(float p, float x) {
   return x * a + (1.0f - x) * b;
 }
 
+// ---------------------------------------------------------------- index arithmetic
+// 64-bit integer division expands to ~100 VALU instructions on CDNA; row / tile indices almost always fit
+// 31 bits, where the 32-bit expansion is 4-5x shorter.  (At the config sizes a wave handles 1-3 rows, so
+// two 64-bit divisions per row were costing as much as the row's own arithmetic.)
+__device__ __forceinline__ void divmod(int64_t a, int64_t b, int64_t& q, int64_t& r) {
+  if ((((uint64_t)a | (uint64_t)b) >> 31) == 0) {
+    const uint32_t qq = (uint32_t)a / (uint32_t)b;
+    q = (int64_t)qq;
+    r = (int64_t)((uint32_t)a - qq * (uint32_t)b);
+  } else {
+    q = a / b;
+    r = a - q * b;
+  }
+}
+__device__ __forceinline__ int64_t mod_fast(int64_t a, int64_t b) {
+  int64_t q, r;
+  divmod(a, b, q, r);
+  return r;
+}
+
 // ---------------------------------------------------------------- wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

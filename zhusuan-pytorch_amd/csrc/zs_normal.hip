@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
   const int64_t total = row_tiles * k_tiles;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < total; t += nwaves) {
-    const int64_t rt = t % row_tiles, kt = t / row_tiles;
+    int64_t kt, rt;
+    divmod(t, row_tiles, kt, rt);
     const int64_t rbase = rt * rpw;
     const int64_t r = rbase + rw;
     const bool on = lane_on && r < R;
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(256) void k_normal_sample_longrow(
   const int64_t rows = K * R;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += nwaves) {
-    const int64_t k = row / R, r = row - k * R;
+    int64_t k, r;
+    divmod(row, R, k, r);
     float acc = 0.f;
     for (int c = lane; c < D4; c += 64) {
       const int64_t m4 = r * D4 + c;
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(256) void k_normal_sample_serial(
   const int64_t rows = K * R, M = R * D;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
        row += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t k = row / R, r = row - k * R;
+    int64_t k, r;
+    divmod(row, R, k, r);
     float acc = 0.f;
     float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int64_t have = -1;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void k_normal_sample_bwd(
   float4 am = make_float4(0.f, 0.f, 0.f, 0.f), as = am;
   float gl = 0.f;
   if (on) {
-    const int64_t r = m4 / D4;
+    const int64_t r = (int64_t)((uint64_t)m4 >> 31 ? m4 / D4 : (int64_t)((uint32_t)m4 / (uint32_t)D4));
     for (int64_t k = slice; k < K; k += 4) {
       const int64_t g = k * M4 + m4;
       if (gz) {
@@ -298,7 +301,7 @@ __device__ __forceinline__ float4 ld_row4(const float4* __restrict__ p, int64_t 
     const float v = *reinterpret_cast<const float*>(p);
     return make_float4(v, v, v, v);
   }
-  return p[(row % prow) * D4 + c];
+  return p[mod_fast(row, prow) * D4 + c];
 }
 
 __global__ __launch_bounds__(256) void k_normal_logprob_rows(
@@ -331,7 +334,8 @@ __global__ __launch_bounds__(256) void k_normal_logprob_rows(
     }
     acc = group_sum_down(acc, lig, G, p2);
     if (on && lig == 0) {
-      const int64_t k = row / R, r = row - k * R;
+      int64_t k, r;
+    divmod(row, R, k, r);
       lp[k * sk + r * sr] = acc;
     }
   }
@@ -354,7 +358,8 @@ __global__ __launch_bounds__(256) void k_normal_logprob_krep(
   const int64_t total = row_tiles * k_tiles;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < total; t += nwaves) {
-    const int64_t rt = t % row_tiles, kt = t / row_tiles;
+    int64_t kt, rt;
+    divmod(t, row_tiles, kt, rt);
     const int64_t r = rt * rpw + rw;
     const bool on = lane_on && r < R;
     const int64_t m4 = r * D4 + lig;
@@ -451,7 +456,8 @@ __global__ __launch_bounds__(256) void k_normal_logprob_full(
     }
     acc = group_sum_down(acc, lig, G, p2);
     if (on && lig == 0) {
-      const int64_t k = row / R, r = row - k * R;
+      int64_t k, r;
+    divmod(row, R, k, r);
       lp[k * sk + r * sr] = acc;
     }
   }
@@ -468,11 +474,12 @@ __global__ __launch_bounds__(256) void k_normal_logprob_serial(
     float acc = 0.f;
     for (int64_t d = 0; d < D; ++d) {
       const int64_t i = row * D + d;
-      const float s = sigma[i % Ps];
+      const float s = sigma[mod_fast(i, Ps)];
       const float l2 = log2_fast(s);
-      acc += normal_lp_term(x[i % Px] - mu[i % Pm], l2 * ZS_LN2, exp2_fast(-2.0f * l2));
+      acc += normal_lp_term(x[mod_fast(i, Px)] - mu[mod_fast(i, Pm)], l2 * ZS_LN2, exp2_fast(-2.0f * l2));
     }
-    const int64_t k = row / R, r = row - k * R;
+    int64_t k, r;
+    divmod(row, R, k, r);
     lp[k * sk + r * sr] = acc;
   }
 }
@@ -485,10 +492,11 @@ __global__ __launch_bounds__(256) void k_normal_logprob_bwd_elem(
     int64_t N, int64_t R, int64_t D) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / D;
-    const int64_t k = row / R, r = row - k * R;
+    int64_t k, r;
+    divmod(row, R, k, r);
     const float g = glp[k * gsk + r * gsr];
-    const float s = sigma[i % Ps];
-    const float diff = x[i % Px] - mu[i % Pm];
+    const float s = sigma[mod_fast(i, Ps)];
+    const float diff = x[mod_fast(i, Px)] - mu[mod_fast(i, Pm)];
     const float prec = exp2_fast(-2.0f * log2_fast(s));
     const float t = g * prec * diff;
     if (gx) gx[i] = -t;
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_bwd_ksum(
   const bool on = m4 < M4;
   float4 am = make_float4(0.f, 0.f, 0.f, 0.f), as = am;
   if (on) {
-    const int64_t r = m4 / D4;
+    const int64_t r = (int64_t)((uint64_t)m4 >> 31 ? m4 / D4 : (int64_t)((uint32_t)m4 / (uint32_t)D4));
     const float4 m = mu[m4], s = sigma[m4];
     const float sv[4] = {s.x, s.y, s.z, s.w};
     const float mv[4] = {m.x, m.y, m.z, m.w};
