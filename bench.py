@@ -188,7 +188,7 @@ def main():
                 torch.cuda.synchronize()
                 if not multi:
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         static_loss = step_body()
 
                     def step():
@@ -198,11 +198,11 @@ def main():
                     # the collective stays OUTSIDE the graphs: graph A = compute + pack, eager RCCL all-reduce
                     # of the bucket, graph B = optimizer
                     graph_a = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph_a):
+                    with torch.cuda.graph(graph_a, capture_error_mode="thread_local"):
                         static_local = compute_part()
                     torch.cuda.synchronize()
                     graph_b = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph_b, pool=graph_a.pool()):
+                    with torch.cuda.graph(graph_b, pool=graph_a.pool(), capture_error_mode="thread_local"):
                         opt.step()
 
                     def step():

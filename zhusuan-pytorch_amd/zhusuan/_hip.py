@@ -57,10 +57,12 @@ class KernelLibrary(object):
         got = self.cdll.zs_abi_version()
         if got != ABI_VERSION:
             raise RuntimeError("zhusuan: %s has ABI version %d, expected %d" % (path, got, ABI_VERSION))
+        self._fn = {}
         for name, argtypes in PROTOTYPES.items():
             fn = getattr(self.cdll, name)  # AttributeError if a symbol is missing
             fn.restype = _int
             fn.argtypes = argtypes
+            self._fn[name] = fn
         self.cdll.zs_prof_enable.restype = _int
         self.cdll.zs_prof_enable.argtypes = [_int]
         self.cdll.zs_prof_kernel_id.restype = _int
@@ -87,45 +89,10 @@ class KernelLibrary(object):
         return {"total_ms": tot.value, "min_ms": mn.value, "max_ms": mx.value, "count": n.value}
 
     def call(self, name, *args):
-        t = _TIMER
-        if t is not None and name in t.names:
-            start = torch.cuda.Event(enable_timing=True)
-            stop = torch.cuda.Event(enable_timing=True)
-            start.record()
-            rc = getattr(self.cdll, name)(*args)
-            stop.record()
-            t.events[name].append((start, stop))
-        else:
-            rc = getattr(self.cdll, name)(*args)
+        rc = self._fn[name](*args)
         if rc != 0:
             msg = self.cdll.zs_error_string(rc)
             raise RuntimeError("%s failed with code %d: %s" % (name, rc, msg.decode() if msg else "?"))
-
-
-class KernelTimer(object):
-    """Brackets every launch of the named entry points with HIP events recorded on the stream the
-    kernel is enqueued on (torch's current stream), for bench.py's live roofline measurement."""
-
-    def __init__(self, names):
-        self.names = set(names)
-        self.events = {n: [] for n in names}
-
-    def mean_ms(self, name):
-        ev = self.events[name]
-        if not ev:
-            return None
-        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-
-    def count(self, name):
-        return len(self.events[name])
-
-
-_TIMER = None
-
-
-def set_kernel_timer(timer):
-    global _TIMER
-    _TIMER = timer
 
 
 _LIB = None          # the HIP library (lazy)

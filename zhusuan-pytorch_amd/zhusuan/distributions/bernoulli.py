@@ -5,6 +5,7 @@ import torch
 from .base import Distribution
 from .utils import assert_same_log_float_dtype
 from .. import _hip, _ops, _rng
+from .._shapes import broadcast_shapes
 
 __all__ = ['Bernoulli']
 
@@ -86,7 +87,7 @@ class Bernoulli(Distribution):
             raise RuntimeError("Bernoulli.log_prob(None) needs a cached sample: call sample() first")
         par = self._param()
         x = torch.as_tensor(x, dtype=self._dtype).to(par.device)
-        full = tuple(torch.broadcast_shapes(x.shape, par.shape))
+        full = tuple(broadcast_shapes(x.shape, par.shape))
         if n_fold > len(full):
             raise ValueError("cannot sum %d trailing axes of a result of shape %s" % (n_fold, full))
         p_full = par if tuple(par.shape) == full else par.expand(full)

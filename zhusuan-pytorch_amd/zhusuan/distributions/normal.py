@@ -5,6 +5,7 @@ import torch
 from .base import Distribution
 from .utils import assert_same_log_float_dtype, check_broadcast
 from .. import _hip, _ops, _rng
+from .._shapes import broadcast_shapes
 
 __all__ = ['Normal']
 
@@ -64,7 +65,7 @@ class Normal(Distribution):
         return torch.log(self._std)
 
     def _batch_shape(self):
-        return torch.broadcast_shapes(self._mean.shape, self._std.shape)
+        return torch.Size(broadcast_shapes(self._mean.shape, self._std.shape))
 
     def _sample(self, n_samples=1, epsilon=None):
         """normal.py:89-107.  The standard-normal draw has MEAN's shape (``[K] + mean.shape``), so it is
@@ -114,7 +115,7 @@ class Normal(Distribution):
         if self._fused is not None and self._fused[0] is x and self._fused[2] == n_fold:
             return self._fused[1]
         x = torch.as_tensor(x, dtype=self._dtype).to(self._mean.device)
-        full = tuple(torch.broadcast_shapes(x.shape, self._batch_shape()))
+        full = tuple(broadcast_shapes(x.shape, self._batch_shape()))
         if n_fold > len(full):
             raise ValueError("cannot sum %d trailing axes of a result of shape %s" % (n_fold, full))
         px, Px = _ops.periodic_operand(x, full)

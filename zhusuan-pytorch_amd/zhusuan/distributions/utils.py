@@ -1,6 +1,7 @@
 """dtype / broadcast checks of the distribution constructors.
 Mirrors zhusuan/distributions/utils.py:18-71 of the reference (same exception types and messages)."""
 import torch
+from .._shapes import broadcast_shapes
 
 floating_dtypes = (torch.float32, torch.float16, torch.float64)
 log_floating_dtypes = (torch.float32, torch.float64)
@@ -35,4 +36,4 @@ def assert_same_log_float_dtype(tensors_with_name):
 def check_broadcast(mean, std):
     """RuntimeError when the shapes do not broadcast (the reference evaluates ``mean + std`` for this,
     zhusuan/distributions/utils.py:67-71; only the shapes matter so no kernel is launched here)."""
-    torch.broadcast_shapes(tuple(mean.shape), tuple(std.shape))
+    broadcast_shapes(tuple(mean.shape), tuple(std.shape))

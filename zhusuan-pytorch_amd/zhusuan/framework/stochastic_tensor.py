@@ -3,6 +3,7 @@ Interface of zhusuan/framework/stochastic_tensor.py:5-181 of the reference."""
 import torch
 
 from ..distributions.base import Distribution
+from .._shapes import broadcast_shapes
 
 __all__ = ['StochasticTensor']
 
@@ -86,7 +87,7 @@ class StochasticTensor(object):
         x = dist.sample_cache if sample is None else sample
         if x is None:
             raise RuntimeError("node '%s' has no value yet" % self._name)
-        full = tuple(torch.broadcast_shapes(tuple(torch.as_tensor(x).shape), tuple(dist.batch_shape)))
+        full = tuple(broadcast_shapes(tuple(torch.as_tensor(x).shape), tuple(dist.batch_shape)))
         nd = len(full) - g  # ndim of dist.log_prob(x)
         mean_dims = _norm_dims(self._reduce_mean_dims, nd)
         sum_dims = _norm_dims(self._reduce_sum_dims, nd)

@@ -5,6 +5,7 @@ import torch.nn as nn
 
 from ..framework.stochastic_tensor import StochasticTensor
 from .. import _ops
+from .._shapes import broadcast_shapes
 
 __all__ = ['ImportanceWeightedObjective']
 
@@ -67,7 +68,7 @@ class ImportanceWeightedObjective(nn.Module):
         Tensors produced by the log-prob kernels already have this layout, so no copy happens."""
         logpxz = torch.as_tensor(logpxz)
         logqz = torch.as_tensor(logqz, device=logpxz.device)
-        shape = torch.broadcast_shapes(logpxz.shape, logqz.shape)
+        shape = broadcast_shapes(logpxz.shape, logqz.shape)
         if len(shape) == 0:
             raise ValueError(_ERR_VIMCO)
         axis = self._axis % len(shape)
