@@ -273,8 +273,10 @@ def main():
                     rec["GBps"] = algo[name] / (avg_ms * 1e-3) / 1e9
                     rec["frac_of_hbm_peak"] = rec["GBps"] / HBM_PEAK_GBS
                 per_kernel[name] = rec
-        # the dominant hot-path kernel of the measured step = the one with the most time (and bytes) per step
-        dominant = max(per_kernel, key=lambda n: per_kernel[n]["us_per_step"])
+        # the dominant hot-path kernel of the step = the one that moves the most bytes per step (it is also the
+        # one with the most time per step; bytes are used because they do not move when a profiler is attached)
+        dominant = max((n for n in per_kernel if n in algo),
+                       key=lambda n: algo[n] * per_kernel[n]["launches_per_step"])
         prof = klib.prof_query(dominant)
         k_ms = prof["total_ms"] / prof["count"]
         algo_bytes = algo[dominant]
