@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 2
+#define ZS_ABI_VERSION 3
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -176,6 +176,26 @@ int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float*
  * out[i], i < N, group = i / 4.  For tests and for callers that need eps itself. */
 int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state,
                          void* stream);
+
+/* ---------------------------------------------------------------------------
+ * float64 twins.  The reference accepts float64 parameters for Normal / Bernoulli
+ * (zhusuan/distributions/utils.py:5,57-64); every entry point above exists with the suffix _f64,
+ * identical argument meaning, double* instead of float*.  They are plain (untuned) kernels: none of the
+ * benchmark configurations uses float64.  Draws widen the same Philox / Box-Muller fp32 stream.
+ * -------------------------------------------------------------------------*/
+int zs_normal_sample_logprob_f64(const double* mu, const double* sigma, const double* eps, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+int zs_normal_sample_logprob_bwd_f64(const double* sigma, const double* eps, uint64_t seed, uint64_t offset, const uint64_t* rng_state, const double* gz, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gmu, double* gsigma, int64_t K, int64_t M, int64_t D, void* stream);
+int zs_normal_logprob_f64(const double* x, int64_t Px, const double* mu, int64_t Pm, const double* sigma, int64_t Ps, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+int zs_normal_logprob_bwd_f64(const double* x, int64_t Px, const double* mu, int64_t Pm, const double* sigma, int64_t Ps, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gmu, double* gsigma, int64_t K, int64_t R, int64_t D, void* stream);
+int zs_normal_logprob_bwd_ksum_f64(const double* x, const double* mu, const double* sigma, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gmu, double* gsigma, int64_t K, int64_t R, int64_t D, void* stream);
+int zs_bernoulli_logprob_f64(const double* p, const double* x, int64_t Px, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+int zs_bernoulli_logprob_bwd_f64(const double* p, const double* x, int64_t Px, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gp, int64_t K, int64_t R, int64_t D, void* stream);
+int zs_bernoulli_logits_logprob_f64(const double* logits, const double* x, int64_t Px, double* lp, double* probs_out, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+int zs_bernoulli_logits_logprob_bwd_f64(const double* logits, const double* x, int64_t Px, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* glogits, int64_t K, int64_t R, int64_t D, void* stream);
+int zs_bernoulli_sample_f64(const double* p, int64_t Pp, double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
+int zs_iw_reduce_f64(const double* logp, int64_t ld_p, const double* logq, int64_t ld_q, int64_t B, int64_t K, int estimator, double* cost_b, double* bound_b, double* coef_p, double* coef_q, void* stream);
+int zs_log_mean_exp_f64(const double* x, int64_t ld, int64_t B, int64_t K, double* out, void* stream);
+int zs_philox_normal_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Per-kernel timing for the benchmark harness (no reference counterpart).

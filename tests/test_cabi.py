@@ -27,14 +27,14 @@ def declared_symbols():
 
 def test_header_symbols_exported_by_both_libraries():
     names = declared_symbols()
-    assert len(names) == 18 and set(_hip.PROTOTYPES) <= set(names)
+    assert len(names) == 31 and set(_hip.PROTOTYPES) <= set(names)
     hip = ctypes.CDLL(_hip.LIB_PATH)           # loads without a GPU; no compute call is made here
     orc = ctypes.CDLL(build_oracle_lib())
     for n in names:
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 2
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 3
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 
@@ -60,18 +60,20 @@ def test_philox_known_answers():
 
 # ------------------------------------------------------------------ raw-call helpers
 class Raw(object):
-    def __init__(self, klib, device):
-        self.k, self.dev = klib, torch.device(device)
+    def __init__(self, klib, device, dtype=torch.float32):
+        self.k, self.dev, self.dtype = klib, torch.device(device), dtype
+        self.sfx = "_f32" if dtype == torch.float32 else "_f64"
 
     def t(self, a):
         if a is None:
             return None
-        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(self.dev)
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=self.dtype).to(self.dev)
 
     def empty(self, *shape):
-        return torch.full(shape, float("nan"), dtype=torch.float32, device=self.dev)
+        return torch.full(shape, float("nan"), dtype=self.dtype, device=self.dev)
 
     def call(self, name, *args):
+        name = name.replace("_f32", self.sfx)
         conv = []
         for a in args:
             conv.append(_hip.ptr(a) if isinstance(a, torch.Tensor) or a is None else a)
@@ -180,6 +182,16 @@ def orc():
 @pytest.fixture(scope="module")
 def hip():
     return Raw(_hip.KernelLibrary(_hip.LIB_PATH), "cuda:0")
+
+
+@pytest.fixture(scope="module")
+def orc64():
+    return Raw(host_kernel_library(), "cpu", torch.float64)
+
+
+@pytest.fixture(scope="module")
+def hip64():
+    return Raw(_hip.KernelLibrary(_hip.LIB_PATH), "cuda:0", torch.float64)
 
 
 # ------------------------------------------------------------------ C oracle vs goldens (CPU)
@@ -445,3 +457,53 @@ def test_hip_empty_and_unaligned(hip, orc):
     hip.call("zs_bernoulli_logprob_f32", pbuf[1:], xbuf[1:], R * D, lp, K, R, D, R, 1)
     ref = orc.bern_lp(pbuf[1:].cpu().numpy(), xbuf[1:].cpu().numpy(), K, R, D)["lp"]
     np.testing.assert_allclose(lp.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_c_oracle_f64_matches_scipy(orc64):
+    from scipy import stats
+    rng = np.random.RandomState(3)
+    K, R, D = 3, 4, 6
+    mu, sd, eps = rng.standard_normal(R * D), np.exp(0.3 * rng.standard_normal(R * D)), rng.standard_normal(K * R * D)
+    out = orc64.normal_sample(mu, sd, eps, K, D)
+    z = (mu + sd * eps.reshape(K, -1)).reshape(K, R * D)
+    assert out["z"].dtype == np.float64 and np.array_equal(out["z"], z)
+    np.testing.assert_allclose(out["lp"], stats.norm.logpdf(z, mu, sd).reshape(K, R, D).sum(-1), rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_hip_f64_entry_points(hip64, orc64):
+    rng = np.random.RandomState(64)
+    for (K, R, D) in [(1, 1, 1), (3, 5, 4), (5, 6, 40), (2, 3, 51)]:
+        M, N = R * D, K * R * D
+        mu, sd = rng.standard_normal(M), np.exp(0.4 * rng.standard_normal(M))
+        eps, gz, glp = rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(K * R)
+        for kfast in (False, True):
+            a, b = hip64.normal_sample(mu, sd, eps, K, D, kfast=kfast), orc64.normal_sample(mu, sd, eps, K, D, kfast=kfast)
+            assert np.array_equal(a["z"], b["z"])
+            np.testing.assert_allclose(a["lp"], b["lp"], rtol=1e-12, atol=1e-12)
+        _cmp(hip64.normal_sample_bwd(sd, eps, gz, glp, K, D), orc64.normal_sample_bwd(sd, eps, gz, glp, K, D), 1e-11, 1e-11)
+        a, b = hip64.normal_sample(mu, sd, None, K, D, seed=9, off=4), orc64.normal_sample(mu, sd, None, K, D, seed=9, off=4)
+        np.testing.assert_allclose(a["z"], b["z"], rtol=0, atol=3e-4 * float(sd.max()))
+        x = rng.standard_normal(N)
+        for (Px, Pm, Ps) in [(N, N, N), (N, M, M), (N, M, 1), (M, N, 1)]:
+            xx, mm, ss = x[:Px].copy(), rng.standard_normal(Pm), np.exp(0.3 * rng.standard_normal(Ps))
+            _cmp(hip64.normal_lp(xx, mm, ss, K, R, D, True), orc64.normal_lp(xx, mm, ss, K, R, D, True), 1e-12, 1e-12)
+            _cmp(hip64.normal_lp_bwd(xx, mm, ss, glp, K, R, D), orc64.normal_lp_bwd(xx, mm, ss, glp, K, R, D), 1e-11, 1e-11)
+        _cmp(hip64.normal_lp_bwd_ksum(x, mu, sd, glp, K, R, D), orc64.normal_lp_bwd_ksum(x, mu, sd, glp, K, R, D), 1e-11, 1e-11)
+        p = rng.uniform(0, 1, N)
+        xb = (rng.uniform(size=M) < 0.5).astype(np.float64)
+        for logits in (False, True):
+            pp = 4 * rng.standard_normal(N) if logits else p
+            _cmp(hip64.bern_lp(pp, xb, K, R, D, logits, True, want_p=logits), orc64.bern_lp(pp, xb, K, R, D, logits, True, want_p=logits),
+                 1e-12, 1e-12)
+            _cmp(hip64.bern_lp_bwd(pp, xb, glp, K, R, D, logits), orc64.bern_lp_bwd(pp, xb, glp, K, R, D, logits), 1e-10, 1e-10)
+    for (B, K) in [(3, 2), (8, 50), (2, 300)]:
+        logp, logq = -550 + 5 * rng.standard_normal((B, K)), -50 + rng.standard_normal((B, K))
+        for est in (0, 1):
+            a, t = hip64.iw(logp, logq, est), _iw_truth_f64(logp, logq, est)
+            for key in ("cost", "bound", "cp", "cq"):
+                np.testing.assert_allclose(a[key], t[key], rtol=1e-10, atol=1e-10, err_msg=key)
+        np.testing.assert_allclose(hip64.lme(logp), orc64.lme(logp), rtol=1e-13)
+    pr = np.linspace(0.05, 0.95, 5)
+    assert np.array_equal(hip64.bern_sample(pr, 1001, 5, 2), orc64.bern_sample(pr, 1001, 5, 2))
+    np.testing.assert_allclose(hip64.philox(1001, 1, 2), orc64.philox(1001, 1, 2), rtol=0, atol=3e-5)

@@ -119,11 +119,58 @@ def test_normal_known_values(dev):
     close(d.log_prob(torch.zeros([1])), [-2.83787704, -3.83787727], 1e-6, 1e-6)   # concepts.rst:70-73
 
 
-def test_normal_float64_is_rejected_loudly(dev):
-    d = Normal(mean=torch.zeros([2], dtype=torch.float64), std=torch.ones([2], dtype=torch.float64), device=dev)
-    assert d.dtype == torch.float64
-    with pytest.raises(NotImplementedError, match="float32"):
-        d.sample()
+def test_float64_parameters(dev):
+    # test/distributions/utils.py:test_dtype_2parameter / test_float_dtype_1parameter_discrete: float64 in,
+    # float64 samples and log-probs out; values against scipy at double precision
+    for dt in (torch.float32, torch.float64):
+        d = Normal(mean=torch.tensor([0.01], dtype=dt), std=torch.ones([1], dtype=dt), device=dev)
+        assert d.dtype == dt and d.sample(1).dtype == dt and d.sample().dtype == dt
+        assert d.log_prob(torch.tensor([0.01], dtype=dt)).dtype == dt
+        b = Bernoulli(torch.tensor([[2., 3.], [4., 5.]], dtype=dt), dtype=dt, device=dev)
+        assert b.sample(2).dtype == dt and b.log_prob(torch.ones(2, 2, dtype=dt)).dtype == dt
+    rng = np.random.RandomState(9)
+    mu, ls, x = rng.standard_normal((3, 6, 5)), 0.3 * rng.standard_normal((6, 5)), 2 * rng.standard_normal((4, 3, 6, 5))
+    mu_t = torch.tensor(mu, device=dev, requires_grad=True)
+    sd_t = torch.tensor(np.exp(ls), device=dev, requires_grad=True)
+    x_t = torch.tensor(x, device=dev, requires_grad=True)
+    lp = Normal(mean=mu_t, std=sd_t, group_ndims=2).log_prob(x_t)
+    ref = stats.norm.logpdf(x, mu, np.exp(ls)).sum((-1, -2))
+    assert lp.dtype == torch.float64 and lp.shape == (4, 3)
+    np.testing.assert_allclose(lp.detach().cpu().numpy(), ref, rtol=1e-12, atol=1e-12)
+    w = torch.tensor(rng.standard_normal((4, 3)), device=dev)
+    gmu, gsd, gx = torch.autograd.grad((lp * w).sum(), [mu_t, sd_t, x_t])
+    mu_c, sd_c, x_c = (torch.tensor(v, requires_grad=True) for v in (mu, np.exp(ls), x))
+    ref_lp = (-0.5 * np.log(2 * np.pi) - torch.log(sd_c) - 0.5 * ((x_c - mu_c) / sd_c) ** 2).sum((-1, -2))
+    rmu, rsd, rx = torch.autograd.grad((ref_lp * w.cpu()).sum(), [mu_c, sd_c, x_c])
+    for a, b in ((gmu, rmu), (gsd, rsd), (gx, rx)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-10, atol=1e-10)
+    # fused sample + log-prob in double, explicit epsilon: z exact, log q at double accuracy
+    eps = rng.standard_normal((7, 6, 5))
+    dq = Normal(mean=torch.tensor(mu[0], device=dev), std=torch.tensor(np.exp(ls), device=dev), group_ndims=1)
+    with zs.inject_epsilon([eps]):
+        z = dq.sample(7)
+    assert z.dtype == torch.float64
+    assert np.array_equal(z.cpu().numpy(), mu[0] + np.exp(ls) * eps)
+    np.testing.assert_allclose(dq.log_prob(None).cpu().numpy(), stats.norm.logpdf(z.cpu().numpy(), mu[0], np.exp(ls)).sum(-1),
+                               rtol=1e-12, atol=1e-12)
+    zf = Normal(mean=torch.zeros(4000, 4, dtype=torch.float64, device=dev),
+                std=torch.ones(4000, 4, dtype=torch.float64, device=dev)).sample(3)
+    assert zf.dtype == torch.float64 and abs(float(zf.mean())) < 0.03 and abs(float(zf.std()) - 1) < 0.03
+    # Bernoulli and the IW reduction in double
+    p = rng.uniform(0.01, 0.99, (3, 4, 16))
+    xb = (rng.uniform(size=(4, 16)) < 0.5).astype(np.float64)
+    lpb = Bernoulli(probs=torch.tensor(p, device=dev), group_ndims=1).log_prob(torch.tensor(xb, device=dev))
+    refb = (xb * np.log(p + 1e-8) + (1 - xb) * np.log(1 - p + 1e-8)).sum(-1)
+    np.testing.assert_allclose(lpb.cpu().numpy(), refb, rtol=1e-12, atol=1e-12)
+    from zhusuan.variational.importance_weighted_objective import ImportanceWeightedObjective
+    lpq = torch.tensor(-50 + rng.standard_normal((9, 5)), device=dev)
+    lpp = torch.tensor(-550 + 5 * rng.standard_normal((9, 5)), device=dev)
+    obj = ImportanceWeightedObjective(None, None, axis=0, estimator="vimco")
+    cost = obj.vimco(lpp, lpq)
+    assert cost.dtype == torch.float64
+    lw = (lpp - lpq).cpu()
+    np.testing.assert_allclose(obj.last_iw_bound.cpu().numpy(), (torch.logsumexp(lw, 0) - np.log(9)).numpy(), rtol=1e-12)
+    np.testing.assert_allclose(zs.log_mean_exp(lpp, 0).cpu().numpy(), (torch.logsumexp(lpp.cpu(), 0) - np.log(9)).numpy(), rtol=1e-12)
 
 
 # ------------------------------------------------------------------ Normal: golden fixtures

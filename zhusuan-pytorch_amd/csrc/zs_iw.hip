@@ -329,8 +329,14 @@ extern "C" int zs_prof_enable(int on) {
 
 extern "C" int zs_prof_kernel_id(const char* entry_point) {
   if (!entry_point) return ZS_EINVAL;
-  for (int k = 0; k < zs::KID_COUNT; ++k)
-    if (strcmp(entry_point, kKernelNames[k]) == 0) return k;
+  const size_t n = strlen(entry_point);
+  if (n < 5) return ZS_EINVAL;
+  for (int k = 0; k < zs::KID_COUNT; ++k) {   // the _f32 and _f64 forms of an entry point share one id
+    const char* name = kKernelNames[k];
+    if (strlen(name) == n && strncmp(entry_point, name, n - 4) == 0 &&
+        (strcmp(entry_point + n - 4, "_f32") == 0 || strcmp(entry_point + n - 4, "_f64") == 0))
+      return k;
+  }
   return ZS_EINVAL;
 }
 

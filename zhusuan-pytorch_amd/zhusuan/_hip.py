@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -37,6 +37,10 @@ PROTOTYPES = {
     "zs_log_mean_exp_f32": [_p, _i64, _i64, _i64, _p, _p],
     "zs_philox_normal_f32": [_p, _i64, _u64, _u64, _p, _p],
 }
+
+
+# every compute entry point exists as name_f32 and name_f64 with the same argument list
+PROTOTYPES.update({name[:-4] + "_f64": args for name, args in list(PROTOTYPES.items())})
 
 
 class KernelLibrary(object):

@@ -19,12 +19,21 @@ def _prod(shape):
     return int(math.prod(shape)) if len(shape) else 1
 
 
-def _check_f32(*tensors):
+def _sfx(*tensors):
+    """'_f32' / '_f64': which precision of an entry point to call; operands must agree."""
+    dt = None
     for t in tensors:
-        if t is not None and t.dtype != torch.float32:
-            raise NotImplementedError(
-                "zhusuan (MI355X build): the HIP kernels compute in float32 (the dtype of the reference's "
-                "examples); got %s" % t.dtype)
+        if t is None:
+            continue
+        if dt is None:
+            dt = t.dtype
+        elif t.dtype != dt:
+            raise TypeError("zhusuan: kernel operands must share one dtype, got %s and %s" % (dt, t.dtype))
+    if dt == torch.float32:
+        return "_f32"
+    if dt == torch.float64:
+        return "_f64"
+    raise TypeError("zhusuan (MI355X build): kernels exist for float32 and float64, got %s" % dt)
 
 
 def _alloc_rows(K, has_k_axis, rest_shape, kfast, like):
@@ -55,7 +64,7 @@ class NormalSampleLogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu, sigma, eps, seed, call, rng_state, K, has_k_axis, n_fold, reparam, kfast):
         _hip.require_device(mu, sigma, eps)
-        _check_f32(mu, sigma, eps)
+        sfx = _sfx(mu, sigma, eps)
         lib = _hip.lib()
         shape = tuple(mu.shape)
         M = mu.numel()
@@ -68,7 +77,7 @@ class NormalSampleLogProb(torch.autograd.Function):
             ctx.meta = None
             return z, lp
         buf, lp, sk, sr = _alloc_rows(K, has_k_axis, rest, kfast, mu)
-        lib.call("zs_normal_sample_logprob_f32", _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(eps), seed, call,
+        lib.call("zs_normal_sample_logprob" + sfx, _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(eps), seed, call,
                  _hip.ptr(rng_state), _hip.ptr(z), _hip.ptr(buf), K, M, D, sk, sr, _hip.stream_for(mu))
         ctx.meta = (seed, call, K, M, D, R, reparam)
         ctx.rng_state = rng_state
@@ -85,6 +94,7 @@ class NormalSampleLogProb(torch.autograd.Function):
             return (None,) * 11
         seed, call, K, M, D, R, reparam = ctx.meta
         lib = _hip.lib()
+        sfx = _sfx(ctx.saved_tensors[0])
         if reparam:
             mu, sigma, eps = ctx.saved_tensors
             gmu = torch.empty_like(mu)
@@ -94,7 +104,7 @@ class NormalSampleLogProb(torch.autograd.Function):
                 gz = gz.contiguous()
             if glp is not None:
                 glp, gsk, gsr = _kr_view(glp, K, R)
-            lib.call("zs_normal_sample_logprob_bwd_f32", _hip.ptr(sigma), _hip.ptr(eps), seed, call,
+            lib.call("zs_normal_sample_logprob_bwd" + sfx, _hip.ptr(sigma), _hip.ptr(eps), seed, call,
                      _hip.ptr(ctx.rng_state), _hip.ptr(gz), _hip.ptr(glp), gsk, gsr, _hip.ptr(gmu), _hip.ptr(gsigma), K, M, D,
                      _hip.stream_for(mu))
         else:
@@ -104,7 +114,7 @@ class NormalSampleLogProb(torch.autograd.Function):
             gmu = torch.empty_like(mu)
             gsigma = torch.empty_like(sigma)
             glp, gsk, gsr = _kr_view(glp, K, R)
-            lib.call("zs_normal_logprob_bwd_ksum_f32", _hip.ptr(z), _hip.ptr(mu), _hip.ptr(sigma),
+            lib.call("zs_normal_logprob_bwd_ksum" + sfx, _hip.ptr(z), _hip.ptr(mu), _hip.ptr(sigma),
                      _hip.ptr(glp), gsk, gsr, None, _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D,
                      _hip.stream_for(mu))
         return gmu, gsigma, None, None, None, None, None, None, None, None, None
@@ -117,7 +127,7 @@ class NormalLogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mu, sigma, full_shape, n_fold, periods, kfast):
         _hip.require_device(x, mu, sigma)
-        _check_f32(x, mu, sigma)
+        sfx = _sfx(x, mu, sigma)
         lib = _hip.lib()
         full_shape = tuple(full_shape)
         out_shape = full_shape[:len(full_shape) - n_fold]
@@ -129,7 +139,7 @@ class NormalLogProb(torch.autograd.Function):
         buf, lp, sk, sr = _alloc_rows(K, has_k, rest, kfast and n_fold > 0, x)
         Px, Pm, Ps = periods
         if K * R * D > 0:
-            lib.call("zs_normal_logprob_f32", _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
+            lib.call("zs_normal_logprob" + sfx, _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
                      _hip.ptr(buf), K, R, D, sk, sr, _hip.stream_for(x))
         ctx.meta = (K, R, D, periods)
         ctx.save_for_backward(x, mu, sigma)
@@ -139,6 +149,7 @@ class NormalLogProb(torch.autograd.Function):
     def backward(ctx, glp):
         K, R, D, (Px, Pm, Ps) = ctx.meta
         x, mu, sigma = ctx.saved_tensors
+        sfx = _sfx(x)
         need_x, need_mu, need_sigma = ctx.needs_input_grad[:3]
         N = K * R * D
         lib = _hip.lib()
@@ -152,7 +163,7 @@ class NormalLogProb(torch.autograd.Function):
             gx = torch.empty_like(x) if need_x else None
             gmu = torch.empty_like(mu)
             gsigma = torch.empty_like(sigma)
-            lib.call("zs_normal_logprob_bwd_ksum_f32", _hip.ptr(x), _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(glp),
+            lib.call("zs_normal_logprob_bwd_ksum" + sfx, _hip.ptr(x), _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(glp),
                      gsk, gsr, _hip.ptr(gx), _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D, st)
         else:
             def full():
@@ -160,7 +171,7 @@ class NormalLogProb(torch.autograd.Function):
             fx = full() if need_x else None
             fm = full() if need_mu else None
             fs = full() if need_sigma else None
-            lib.call("zs_normal_logprob_bwd_f32", _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
+            lib.call("zs_normal_logprob_bwd" + sfx, _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
                      _hip.ptr(glp), gsk, gsr, _hip.ptr(fx), _hip.ptr(fm), _hip.ptr(fs), K, R, D, st)
 
             def fold(f, P, like):
@@ -182,7 +193,7 @@ class BernoulliLogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, x, n_fold, Px, kfast, from_logits):
         _hip.require_device(p, x)
-        _check_f32(p, x)
+        sfx = _sfx(p, x)
         lib = _hip.lib()
         full_shape = tuple(p.shape)
         out_shape = full_shape[:len(full_shape) - n_fold]
@@ -194,10 +205,10 @@ class BernoulliLogProb(torch.autograd.Function):
         buf, lp, sk, sr = _alloc_rows(K, has_k, rest, kfast and n_fold > 0, p)
         if K * R * D > 0:
             if from_logits:
-                lib.call("zs_bernoulli_logits_logprob_f32", _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(buf), None,
+                lib.call("zs_bernoulli_logits_logprob" + sfx, _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(buf), None,
                          K, R, D, sk, sr, _hip.stream_for(p))
             else:
-                lib.call("zs_bernoulli_logprob_f32", _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(buf), K, R, D, sk, sr,
+                lib.call("zs_bernoulli_logprob" + sfx, _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(buf), K, R, D, sk, sr,
                          _hip.stream_for(p))
         ctx.meta = (K, R, D, Px, from_logits)
         ctx.save_for_backward(p, x)
@@ -213,7 +224,8 @@ class BernoulliLogProb(torch.autograd.Function):
             return (None,) * 6
         glp, gsk, gsr = _kr_view(glp, K, R)
         gp = torch.empty_like(p)
-        name = "zs_bernoulli_logits_logprob_bwd_f32" if from_logits else "zs_bernoulli_logprob_bwd_f32"
+        sfx = _sfx(p)
+        name = ("zs_bernoulli_logits_logprob_bwd" if from_logits else "zs_bernoulli_logprob_bwd") + sfx
         _hip.lib().call(name, _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(glp), gsk, gsr, _hip.ptr(gp), K, R, D,
                         _hip.stream_for(p))
         return gp, None, None, None, None, None
@@ -226,7 +238,7 @@ class IWReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logp, logq, estimator):
         _hip.require_device(logp, logq)
-        _check_f32(logp, logq)
+        sfx = _sfx(logp, logq)
         B, K = logp.shape
         if logp.stride(1) != 1 and K > 1:
             logp = logp.contiguous()
@@ -242,7 +254,7 @@ class IWReduce(torch.autograd.Function):
         bound = torch.empty_like(cost)
         coef_p = torch.empty((B, K), dtype=logp.dtype, device=logp.device)
         coef_q = torch.empty_like(coef_p)
-        _hip.lib().call("zs_iw_reduce_f32", _hip.ptr(logp), ld_p, _hip.ptr(logq), ld_q, B, K, estimator,
+        _hip.lib().call("zs_iw_reduce" + sfx, _hip.ptr(logp), ld_p, _hip.ptr(logq), ld_q, B, K, estimator,
                         _hip.ptr(cost), _hip.ptr(bound), _hip.ptr(coef_p), _hip.ptr(coef_q), _hip.stream_for(logp))
         ctx.save_for_backward(coef_p, coef_q)
         ctx.mark_non_differentiable(bound)
@@ -263,12 +275,12 @@ class LogMeanExpRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d):
         _hip.require_device(x2d)
-        _check_f32(x2d)
+        sfx = _sfx(x2d)
         x2d = x2d.contiguous()
         B, K = x2d.shape
         out = torch.empty(B, dtype=x2d.dtype, device=x2d.device)
         if B * K > 0:
-            _hip.lib().call("zs_log_mean_exp_f32", _hip.ptr(x2d), K, B, K, _hip.ptr(out), _hip.stream_for(x2d))
+            _hip.lib().call("zs_log_mean_exp" + sfx, _hip.ptr(x2d), K, B, K, _hip.ptr(out), _hip.stream_for(x2d))
         ctx.save_for_backward(x2d, out)
         return out
 
@@ -279,12 +291,13 @@ class LogMeanExpRows(torch.autograd.Function):
         return g.unsqueeze(1) * torch.exp(x2d - out.unsqueeze(1)) / K
 
 
-def philox_normal(shape, device, seed, call, rng_state=None):
+def philox_normal(shape, device, seed, call, rng_state=None, dtype=torch.float32):
     """Standard normals from the kernels' own Philox stream (the eps K1 would draw for the same ids)."""
-    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    out = torch.empty(tuple(shape), dtype=dtype, device=device)
     _hip.require_device(out)
+    sfx = _sfx(out)
     if out.numel():
-        _hip.lib().call("zs_philox_normal_f32", _hip.ptr(out), out.numel(), seed, call, _hip.ptr(rng_state),
+        _hip.lib().call("zs_philox_normal" + sfx, _hip.ptr(out), out.numel(), seed, call, _hip.ptr(rng_state),
                         _hip.stream_for(out))
     return out
 
@@ -292,10 +305,10 @@ def philox_normal(shape, device, seed, call, rng_state=None):
 def bernoulli_sample(probs, Pp, shape, seed, call, rng_state=None):
     """K5: Bernoulli._sample (zhusuan/distributions/bernoulli.py:72-82)."""
     _hip.require_device(probs)
-    _check_f32(probs)
+    sfx = _sfx(probs)
     out = torch.empty(tuple(shape), dtype=probs.dtype, device=probs.device)
     if out.numel():
-        _hip.lib().call("zs_bernoulli_sample_f32", _hip.ptr(probs), Pp, _hip.ptr(out), out.numel(), seed, call,
+        _hip.lib().call("zs_bernoulli_sample" + sfx, _hip.ptr(probs), Pp, _hip.ptr(out), out.numel(), seed, call,
                         _hip.ptr(rng_state), _hip.stream_for(probs))
     return out
 

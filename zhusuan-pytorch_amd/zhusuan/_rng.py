@@ -37,13 +37,13 @@ def inject_epsilon(eps_list, strict=True):
         _queue = prev
 
 
-def pop_injected(shape, device):
-    """Next injected epsilon (moved to `device`) or None when no injection is active."""
+def pop_injected(shape, device, dtype=torch.float32):
+    """Next injected epsilon (moved to `device`, cast to `dtype`) or None when no injection is active."""
     if _queue is None:
         return None
     if not _queue:
         raise RuntimeError("inject_epsilon: the model drew more Normal samples than epsilons were supplied")
-    e = torch.as_tensor(_queue.pop(0), dtype=torch.float32)
+    e = torch.as_tensor(_queue.pop(0), dtype=dtype)
     if tuple(e.shape) != tuple(shape):
         raise RuntimeError("inject_epsilon: next epsilon has shape %s, the draw needs %s"
                            % (tuple(e.shape), tuple(shape)))

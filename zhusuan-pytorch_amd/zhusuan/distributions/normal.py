@@ -79,7 +79,7 @@ class Normal(Distribution):
         eps_shape = lead + tuple(mean.shape)
         eps = epsilon
         if eps is None:
-            eps = _rng.pop_injected(eps_shape, mean.device)
+            eps = _rng.pop_injected(eps_shape, mean.device, mean.dtype)
         else:
             eps = torch.as_tensor(eps, dtype=mean.dtype).to(mean.device)
             if tuple(eps.shape) != eps_shape:
@@ -95,7 +95,7 @@ class Normal(Distribution):
         else:
             if eps is None:
                 s, c, rs = _rng.next_call(mean.device)
-                eps = _ops.philox_normal(eps_shape, mean.device, s, c, rs)
+                eps = _ops.philox_normal(eps_shape, mean.device, s, c, rs, mean.dtype)
             pad = (1,) * (len(bshape) - mean.dim())
             eps = eps.reshape(lead + pad + tuple(mean.shape)).expand(lead + bshape).contiguous()
             mu = mean.expand(bshape).contiguous()
