@@ -98,7 +98,8 @@ def test_normal_reparameterized_gradients(dev):
     assert gm is not None and gl is not None
     close(gm, np.ones([2, 3]))
     s = Normal(mean=mean, logstd=logstd, is_reparameterized=False).sample()
-    assert not s.requires_grad                       # detached draw, normal.py:102
+    gm, gl = torch.autograd.grad(s.sum(), [mean, logstd], allow_unused=True)      # test_normal.py:77-84
+    assert float(gm.abs().sum()) == 0.0 and float(gl.abs().sum()) == 0.0        # zero gradient, normal.py:102
 
 
 def test_normal_known_values(dev):

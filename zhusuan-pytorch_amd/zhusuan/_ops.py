@@ -84,8 +84,9 @@ class NormalSampleLogProb(torch.autograd.Function):
         if reparam:
             ctx.save_for_backward(mu, sigma, eps)
         else:
+            # torch.normal(mean, std) (normal.py:102) is a differentiable op whose derivative w.r.t. mean and
+            # std is ZERO: z keeps a grad_fn, but nothing flows through it (backward ignores gz)
             ctx.save_for_backward(mu, sigma, z)
-            ctx.mark_non_differentiable(z)  # torch.normal(mean, std) is detached, normal.py:102
         return z, lp
 
     @staticmethod
@@ -110,7 +111,7 @@ class NormalSampleLogProb(torch.autograd.Function):
         else:
             mu, sigma, z = ctx.saved_tensors
             if glp is None:
-                return (None,) * 11
+                return (torch.zeros_like(mu), torch.zeros_like(sigma)) + (None,) * 9
             gmu = torch.empty_like(mu)
             gsigma = torch.empty_like(sigma)
             glp, gsk, gsr = _kr_view(glp, K, R)
