@@ -6,6 +6,18 @@ import torch.nn as nn
 __all__ = ['ELBO', 'EvidenceLowerBoundObjective']
 
 
+def latent_value(node):
+    """``node.tensor`` as handed to the generator.  A non-reparameterised draw carries a grad_fn whose
+    derivative is identically zero (``torch.normal(mean, std)``, normal.py:102); detaching it here changes no
+    gradient and lets autograd skip the dead branches through the generator (first decoder dgrad, prior
+    log-prob backward)."""
+    t = node.tensor
+    dist = getattr(node, 'dist', None)
+    if dist is not None and not dist.is_reparameterized and isinstance(t, torch.Tensor):
+        return t.detach()
+    return t
+
+
 class ELBO(nn.Module):
     """
     :param generator: BayesianNet p(x, z).
@@ -45,7 +57,7 @@ class ELBO(nn.Module):
         that is used); run p on {latents} U observed; combine the two log-joints."""
         self.variational(observed)
         nodes_q = self.variational.nodes
-        _v_inputs = {k: v.tensor for k, v in nodes_q.items()}
+        _v_inputs = {k: latent_value(v) for k, v in nodes_q.items()}
         _observed = {**_v_inputs, **observed}
         self.generator(_observed)
         nodes_p = self.generator.nodes

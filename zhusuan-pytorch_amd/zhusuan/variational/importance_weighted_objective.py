@@ -5,6 +5,7 @@ import torch.nn as nn
 
 from ..framework.stochastic_tensor import StochasticTensor
 from .. import _ops
+from .elbo import latent_value
 from .._shapes import broadcast_shapes
 
 __all__ = ['ImportanceWeightedObjective']
@@ -52,7 +53,7 @@ class ImportanceWeightedObjective(nn.Module):
         nodes_q = self.variational.nodes
         _v_inputs = {}
         for k, v in nodes_q.items():
-            _v_inputs[k] = v.tensor
+            _v_inputs[k] = latent_value(v)
             if self.estimator == "vimco" and isinstance(v, StochasticTensor) and v.dist.is_reparameterized:
                 raise ValueError("with vimco estimator, the is_reparameterized must be false")
         _observed = {**_v_inputs, **observed}
