@@ -73,7 +73,7 @@ def cpu_baseline(budget_s=12.0, max_steps=40):
     # pick the intra-op thread count that is fastest on this host (all cores is often NOT: on a
     # 256-thread box the unfused elementwise passes run 50x slower with 256 torch threads than with 16-32)
     best = None
-    for nt in sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail}):
+    for nt in sorted({c for c in (4, 8, 16, 32, 64) if c <= avail} or {avail}):
         torch.set_num_threads(nt)
         step()
         t0 = time.perf_counter()

@@ -22,7 +22,7 @@ import zhusuan
 from examples import vae_mnist, iwae, bnn_vi
 
 
-def run_gpu(name, build, make_obs, evals_per_step, steps, graph=True):
+def run_gpu(name, build, make_obs, evals_per_step, steps, graph=True, forward_only=False):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = build(dev)
@@ -32,6 +32,9 @@ def run_gpu(name, build, make_obs, evals_per_step, steps, graph=True):
 
     def body():
         rng.begin_step()
+        if forward_only:                      # objective evaluation only (SURVEY 8d metric (i))
+            with torch.no_grad():
+                return model(obs).detach()
         for p in model.parameters():
             p.grad = None
         loss = model(obs)
@@ -108,6 +111,10 @@ def main():
                        args.steps, graph=False))
     res.append(run_gpu("C3 IWAE VIMCO B=256 K=50, Bernoulli from logits (sigmoid fused)",
                        lambda d: iwae.build(50, "vimco", device=d, fused_logits=True), bits(256), 12800, args.steps))
+    res.append(run_gpu("C3 IWAE VIMCO B=256 K=50, objective forward only", lambda d: iwae.build(50, "vimco", device=d), bits(256),
+                       12800, args.steps, forward_only=True))
+    res.append(run_gpu("C2 VAE SGVB B=512 K=1, objective forward only", lambda d: vae_mnist.build(512, device=d), bits(512), 512,
+                       args.steps, forward_only=True))
     res.append(run_gpu("C3 IWAE SGVB B=256 K=50", lambda d: iwae.build(50, "sgvb", device=d), bits(256), 12800, args.steps))
     bnn_obs = lambda B: (lambda dev: {"x": torch.randn(B, 13, device=dev), "y": torch.randn(B, device=dev)})
     res.append(run_gpu("C5/GPU BNN-VI B=512 K=10", lambda d: bnn_vi.build(n_particles=10, device=d), bnn_obs(512), 5120, args.steps))
