@@ -43,15 +43,18 @@ def run_gpu(name, build, make_obs, evals_per_step, steps, graph=True, forward_on
         return loss.detach()
 
     with zhusuan.device_rng(rng):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        step = body
+        if not graph:
             for _ in range(10):
                 body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        step = body
-        if graph:
+        else:
+            side = torch.cuda.Stream()          # warm up on the capture stream (AccumulateGrad stream affinity)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(10):
+                    body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = body()
@@ -101,8 +104,16 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--only", default=None, help="run only the GPU configs whose name contains this substring")
     args = ap.parse_args()
     res = []
+    real_run_gpu = run_gpu
+
+    def run_gpu_filtered(name, *a, **k):
+        if args.only and args.only not in name:
+            return {"config": name, "skipped": True}
+        return real_run_gpu(name, *a, **k)
+    globals()["run_gpu"] = run_gpu_filtered
     bits = lambda B: (lambda dev: {"x": (torch.rand(B, 784, device=dev) < 0.5).float()})
     res.append(run_gpu("C2 VAE SGVB B=512 K=1", lambda d: vae_mnist.build(512, device=d), bits(512), 512, args.steps))
     res.append(run_gpu("C1-shape VAE SGVB B=64 K=1", lambda d: vae_mnist.build(64, device=d), bits(64), 64, args.steps))

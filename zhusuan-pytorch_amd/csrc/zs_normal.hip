@@ -215,6 +215,68 @@ __global__ __launch_bounds__(256) void k_normal_sample_serial(
   }
 }
 
+// K1 forward for rows that cannot use 16-byte accesses (D % 4 != 0 or unaligned), D >= 8: one wave per
+// (k, r) row, one element per lane and pass, wavefront row sum.  (BNN weight matrix [1, 51]: the per-thread
+// serial kernel above took 21 us for ten rows of 51 elements.)
+template <bool HAS_EPS>
+__global__ __launch_bounds__(256) void k_normal_sample_waverow(
+    const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ eps,
+    uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float* __restrict__ z, float* __restrict__ lp,
+    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+  if (rs) { seed = rs[0]; call += rs[1]; }
+  const int lane = threadIdx.x & 63;
+  const int64_t rows = K * R, M = R * D;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    int64_t k, r;
+    divmod(row, R, k, r);
+    float acc = 0.f;
+    for (int64_t d = lane; d < D; d += 64) {
+      const int64_t m = r * D + d, i = k * M + m;
+      float e;
+      if (HAS_EPS) e = eps[i];
+      else e = f4_get(philox_normal4((uint64_t)(i >> 2), call, seed), (int)(i & 3));
+      const float mm = mu[m], s = sigma[m];
+      const float zz = mul_add_2round(mm, s, e);
+      z[i] = zz;
+      if (lp) {
+        const float l2 = log2_fast(s);
+        acc += normal_lp_term(zz - mm, l2 * ZS_LN2, exp2_fast(-2.0f * l2));
+      }
+    }
+    if (lp) {
+      acc = wave_sum(acc);
+      if (lane == 0) lp[k * sk + r * sr] = acc;
+    }
+  }
+}
+
+// K2 forward, same fallback shape: one wave per row, element-wise periodic addressing.
+__global__ __launch_bounds__(256) void k_normal_logprob_waverow(
+    const float* __restrict__ x, int64_t Px, const float* __restrict__ mu, int64_t Pm,
+    const float* __restrict__ sigma, int64_t Ps, float* __restrict__ lp,
+    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t rows = K * R;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    float acc = 0.f;
+    for (int64_t d = lane; d < D; d += 64) {
+      const int64_t i = row * D + d;
+      const float s = sigma[Ps == 1 ? 0 : mod_fast(i, Ps)];
+      const float l2 = log2_fast(s);
+      acc += normal_lp_term(x[Px == 1 ? 0 : mod_fast(i, Px)] - mu[Pm == 1 ? 0 : mod_fast(i, Pm)], l2 * ZS_LN2,
+                            exp2_fast(-2.0f * l2));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      int64_t k, r;
+      divmod(row, R, k, r);
+      lp[k * sk + r * sr] = acc;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // K1 backward (reparameterised): thread tile = 64 parameter float4 groups x 4 K-slices,
 // K-slice partials combined through LDS.
@@ -638,6 +700,14 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
       else     { if (lp) ZS_LAUNCH_LONG(false, true); else ZS_LAUNCH_LONG(false, false); }
 #undef ZS_LAUNCH_LONG
     }
+  } else if (D >= 8) {
+    const unsigned grid = grid_for(K * R, 4);
+    if (eps)
+      ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_waverow<true>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
+                offset, rng_state, z, lp, K, R, D, sk, sr);
+    else
+      ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_waverow<false>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
+                offset, rng_state, z, lp, K, R, D, sk, sr);
   } else {
     const unsigned grid = grid_for(K * R, 256);
     if (eps)
@@ -717,6 +787,9 @@ extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu
                 Px == 1 ? 0 : Px / D, (const float4*)mu, Pm == 1 ? 0 : Pm / D, (const float4*)sigma,
                 Ps == 1 ? 0 : Ps / D, lp, K, R, D4, rm.G, rm.rpw, rm.p2, sk, sr);
     }
+  } else if (D >= 8) {
+    ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_waverow, dim3(grid_for(K * R, 4)), dim3(256), st, x, Px, mu, Pm,
+              sigma, Ps, lp, K, R, D, sk, sr);
   } else {
     ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_serial, dim3(grid_for(K * R, 256)), dim3(256), st, x, Px, mu, Pm,
                        sigma, Ps, lp, K, R, D, sk, sr);
