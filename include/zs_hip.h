@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 3
+#define ZS_ABI_VERSION 4
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -177,6 +177,82 @@ int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float*
 int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state,
                          void* stream);
 
+/* ===========================================================================
+ * Widening: the reference's two other hand-written
+ * samplers, Logistic and Uniform, on the same Philox stream and row conventions.
+ * ===========================================================================*/
+
+/* ---------------------------------------------------------------------------
+ * L1  Logistic: fused sample + log-prob.
+ * Replaces Logistic._sample (zhusuan/distributions/logistic.py:52-67) and the
+ * log-density of the fresh sample Logistic._log_prob (logistic.py:69-83) with the
+ * group / trailing sums as for K1.
+ *
+ *   eps[k, m] = log(u) - log(1 - u),   u = u[k, m] uniform on (0, 1)        (logistic.py:64-65)
+ *   z[k, m]   = loc[m] + scale[m] * eps[k, m]                               (logistic.py:66)
+ *   lp[k, r]  = sum_d ( -t - 2*softplus(-t) - log(scale) ),  t = (z - loc) / scale   (logistic.py:81-82)
+ *
+ * u == NULL: u is drawn in-kernel, 24-bit uniforms of Philox4x32-10 with the
+ * counter convention of K1 (group = (k*M + m) / 4, word = (k*M + m) % 4).
+ * For the fresh sample t == eps, and -eps - 2*softplus(-eps) == log(u) + log(1 - u):
+ * the kernel reuses the two logarithms of the draw.
+ * -------------------------------------------------------------------------*/
+int zs_logistic_sample_logprob_f32(const float* loc, const float* scale, const float* u,
+                                   uint64_t seed, uint64_t offset, const uint64_t* rng_state,
+                                   float* z, float* lp,
+                                   int64_t K, int64_t M, int64_t D,
+                                   int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+
+/* Backward of L1 (Logistic is always reparameterised, logistic.py:36):
+ *   gloc[m]   = sum_k gz[k, m]
+ *   gscale[m] = sum_k gz[k, m] * eps[k, m]  -  (sum_k glp[k, r(m)]) / scale[m]
+ * gz or glp may be NULL.  u as in the forward call. */
+int zs_logistic_sample_logprob_bwd_f32(const float* scale, const float* u,
+                                       uint64_t seed, uint64_t offset, const uint64_t* rng_state,
+                                       const float* gz, const float* glp,
+                                       int64_t glp_stride_k, int64_t glp_stride_r,
+                                       float* gloc, float* gscale,
+                                       int64_t K, int64_t M, int64_t D, void* stream);
+
+/* L2  Logistic log-prob of a given value (logistic.py:69-83); problem [K, R, D], periodic operands. */
+int zs_logistic_logprob_f32(const float* x, int64_t Px, const float* loc, int64_t Pm,
+                            const float* scale, int64_t Ps, float* lp,
+                            int64_t K, int64_t R, int64_t D,
+                            int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+
+/* Backward of L2, element-wise partials of size K*R*D each (any may be NULL), with g = glp[k, r],
+ * t = (x - loc)/scale and h = tanh(t/2) (= 1 - 2*sigmoid(-t)):
+ *   gx = -g*h/scale,  gloc = +g*h/scale,  gscale = g*(h*t - 1)/scale. */
+int zs_logistic_logprob_bwd_f32(const float* x, int64_t Px, const float* loc, int64_t Pm,
+                                const float* scale, int64_t Ps,
+                                const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
+                                float* gx, float* gloc, float* gscale,
+                                int64_t K, int64_t R, int64_t D, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * U1  Uniform sample (zhusuan/distributions/uniform.py:51-70).  N elements, low / high periodic.
+ *   reparam != 0:  cache = u,                       out = u * (high - low) + low      (uniform.py:66-70)
+ *   reparam == 0:  cache = v = u*(high - low)+low,  out = v * (high - low) + low      (uniform.py:63-64,70:
+ *                  the reference scales the already scaled draw a second time; kept as is)
+ * `cache` is what the reference stores in sample_cache (uniform.py:69).  u == NULL: Philox draw as in L1.
+ * -------------------------------------------------------------------------*/
+int zs_uniform_sample_f32(const float* low, int64_t Pl, const float* high, int64_t Ph, const float* u,
+                          uint64_t seed, uint64_t offset, const uint64_t* rng_state,
+                          float* out, float* cache, int64_t N, int reparam, void* stream);
+
+/* U2  Uniform log-prob of a given value (uniform.py:72-85 -> torch.distributions.Uniform.log_prob):
+ *   lp[k, r] = sum_d ( log( (low <= x) * (high > x) ) - log(high - low) )      (-inf outside the support)
+ * Argument / support validation (ValueError in the reference) is the caller's job. */
+int zs_uniform_logprob_f32(const float* x, int64_t Px, const float* low, int64_t Pl,
+                           const float* high, int64_t Ph, float* lp,
+                           int64_t K, int64_t R, int64_t D,
+                           int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+
+/* Uniform (0, 1) draws of the kernels' Philox stream: out[i] = u01(word i%4 of group i/4). */
+int zs_philox_uniform_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state,
+                          void* stream);
+
+
 /* ---------------------------------------------------------------------------
  * float64 twins.  The reference accepts float64 parameters for Normal / Bernoulli
  * (zhusuan/distributions/utils.py:5,57-64); every entry point above exists with the suffix _f64,
@@ -196,6 +272,13 @@ int zs_bernoulli_sample_f64(const double* p, int64_t Pp, double* out, int64_t N,
 int zs_iw_reduce_f64(const double* logp, int64_t ld_p, const double* logq, int64_t ld_q, int64_t B, int64_t K, int estimator, double* cost_b, double* bound_b, double* coef_p, double* coef_q, void* stream);
 int zs_log_mean_exp_f64(const double* x, int64_t ld, int64_t B, int64_t K, double* out, void* stream);
 int zs_philox_normal_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
+int zs_logistic_sample_logprob_f64(const double* loc, const double* scale, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+int zs_logistic_sample_logprob_bwd_f64(const double* scale, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, const double* gz, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gloc, double* gscale, int64_t K, int64_t M, int64_t D, void* stream);
+int zs_logistic_logprob_f64(const double* x, int64_t Px, const double* loc, int64_t Pm, const double* scale, int64_t Ps, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+int zs_logistic_logprob_bwd_f64(const double* x, int64_t Px, const double* loc, int64_t Pm, const double* scale, int64_t Ps, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gloc, double* gscale, int64_t K, int64_t R, int64_t D, void* stream);
+int zs_uniform_sample_f64(const double* low, int64_t Pl, const double* high, int64_t Ph, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* out, double* cache, int64_t N, int reparam, void* stream);
+int zs_uniform_logprob_f64(const double* x, int64_t Px, const double* low, int64_t Pl, const double* high, int64_t Ph, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+int zs_philox_uniform_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Per-kernel timing for the benchmark harness (no reference counterpart).

@@ -95,6 +95,74 @@ def bernoulli_log_prob(probs, x, group_ndims=0):
 
 
 # ----------------------------------------------------------------------------
+# zhusuan/distributions/logistic.py, uniform.py   
+# ----------------------------------------------------------------------------
+def _repeat_leading(k, *params):
+    """The reference's ``p.repeat([n_samples, *len(first.shape) * [1]])`` (logistic.py:56-58, uniform.py:55-57):
+    every parameter is repeated with the FIRST parameter's number of axes."""
+    nd = params[0].dim()
+    return [p.repeat([k] + [1] * nd) for p in params]
+
+
+def logistic_sample(loc, scale, u, n_samples=None):
+    """Logistic._sample, logistic.py:52-67.  ``u`` replaces the uniform draw (:64) and has shape
+    ``[n_samples] + loc.shape`` (LOC's shape, :54-55,61)."""
+    k = 1 if n_samples is None else int(n_samples)
+    if k > 1:
+        lo, sc = _repeat_leading(k, loc, scale)
+    else:
+        lo, sc = loc, scale
+    epsilon = torch.log(u) - torch.log(1 - u)
+    return lo + sc * epsilon
+
+
+def logistic_log_prob(loc, scale, x, group_ndims=0):
+    """Logistic._log_prob (logistic.py:69-83) + group sum (base.py:175-176)."""
+    if x.dim() > loc.dim():
+        lo, sc = _repeat_leading(x.shape[0], loc, scale)
+    else:
+        lo, sc = loc, scale
+    z = (x - lo) / sc
+    lp = -z - 2. * torch.nn.Softplus()(-z) - torch.log(sc)
+    if group_ndims > 0:
+        lp = torch.sum(lp, [i for i in range(-group_ndims, 0)])
+    return lp
+
+
+def uniform_sample(low, high, u, n_samples=None, is_reparameterized=True):
+    """Uniform._sample, uniform.py:51-70.  Returns (sample, sample_cache).  ``u`` replaces the U(0,1) draw
+    behind torch.distributions.Uniform.sample(): reparameterised -> shape ``[n_samples] + low.shape`` (:66-67),
+    the cache holds u itself (:69); otherwise the draw has the broadcast shape of (low, high), is scaled into
+    [low, high) (:64), cached, and scaled AGAIN by the return statement (:70)."""
+    k = 1 if n_samples is None else int(n_samples)
+    if k > 1:
+        lo, hi = _repeat_leading(k, low, high)
+    else:
+        lo, hi = low, high
+    if not is_reparameterized:
+        with torch.no_grad():
+            cache = lo + u * (hi - lo)
+    else:
+        cache = u
+    return cache * (hi - lo) + lo, cache
+
+
+def uniform_log_prob(low, high, x, group_ndims=0):
+    """Uniform._log_prob (uniform.py:72-85): torch.distributions.Uniform(low, high).log_prob(x) =
+    log(lb * ub) - log(high - low) with lb = (low <= x), ub = (high > x); + group sum (base.py:175-176)."""
+    if x.dim() > low.dim():
+        lo, hi = _repeat_leading(x.shape[0], low, high)
+    else:
+        lo, hi = low, high
+    lb = lo.le(x).type_as(lo)
+    ub = hi.gt(x).type_as(lo)
+    lp = torch.log(lb.mul(ub)) - torch.log(hi - lo)
+    if group_ndims > 0:
+        lp = torch.sum(lp, [i for i in range(-group_ndims, 0)])
+    return lp
+
+
+# ----------------------------------------------------------------------------
 # zhusuan/framework/stochastic_tensor.py
 # ----------------------------------------------------------------------------
 def st_reduce(lp, reduce_mean_dims=None, reduce_sum_dims=None, multiplier=None):

@@ -18,6 +18,7 @@
  *   group sum  zhusuan/distributions/base.py:175-176, framework/stochastic_tensor.py:160-181
  *   IW / VIMCO zhusuan/variational/importance_weighted_objective.py:16-25,123-132,152-191
  *   LME        zhusuan/utils.py:6-21
+ *   Logistic   zhusuan/distributions/logistic.py:52-83;  Uniform  zhusuan/distributions/uniform.py:51-85
  * Serial loops, no threads, no SIMD intrinsics: clarity over speed.
  */
 #include <math.h>
@@ -69,6 +70,7 @@ const char* zs_error_string(int code) {
 #define SFXL(name) name##_f32_
 #define R_LOG logf
 #define R_EXP expf
+#define R_LOG1P log1pf
 #define R_C_NORM (-0.91893853320467274178f)
 #define R_EPS 1e-8f
 #include "zs_oracle_impl.inc"
@@ -77,6 +79,7 @@ const char* zs_error_string(int code) {
 #undef SFXL
 #undef R_LOG
 #undef R_EXP
+#undef R_LOG1P
 #undef R_C_NORM
 #undef R_EPS
 
@@ -85,6 +88,7 @@ const char* zs_error_string(int code) {
 #define SFXL(name) name##_f64_
 #define R_LOG log
 #define R_EXP exp
+#define R_LOG1P log1p
 #define R_C_NORM (-0.91893853320467274178)
 #define R_EPS 1e-8
 #include "zs_oracle_impl.inc"
@@ -93,6 +97,7 @@ const char* zs_error_string(int code) {
 #undef SFXL
 #undef R_LOG
 #undef R_EXP
+#undef R_LOG1P
 #undef R_C_NORM
 #undef R_EPS
 

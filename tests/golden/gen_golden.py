@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 REF = "/root/reference"
+sys.dont_write_bytecode = True   # the reference tree is read-only: no __pycache__ next to its sources
 OUT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REF)
 
@@ -228,6 +229,172 @@ def gen_bernoulli():
     out["ctor_logits"] = b.logits
     out["ctor_zero_logit_probs"] = Bernoulli(0.).probs
     save("g_bernoulli", **out)
+
+
+# --------------------------------------------------------------------------
+# G-L1 / G-U1: Logistic and Uniform
+# --------------------------------------------------------------------------
+class UniformQueue(object):
+    """Replaces the U(0,1) draws while the reference runs: ``torch.nn.init.uniform_`` (logistic.py:64) and
+    ``torch.rand`` (behind torch.distributions.Uniform.sample, uniform.py:64,66-67)."""
+
+    def __init__(self, u_list):
+        self.u = [torch.as_tensor(a) for a in u_list]
+        self.calls = []
+
+    def _uniform_(self, tensor, a=0., b=1.):
+        assert (a, b) == (0., 1.)
+        u = self.u.pop(0)
+        assert tuple(tensor.shape) == tuple(u.shape), (tuple(tensor.shape), tuple(u.shape))
+        self.calls.append(tuple(u.shape))
+        return u.clone()
+
+    def _rand(self, *size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        u = self.u.pop(0)
+        assert shape == tuple(u.shape), (shape, tuple(u.shape))
+        self.calls.append(shape)
+        return u.clone()
+
+    def __enter__(self):
+        self._o1, self._o2 = torch.nn.init.uniform_, torch.rand
+        torch.nn.init.uniform_ = self._uniform_
+        torch.rand = self._rand
+        return self
+
+    def __exit__(self, *a):
+        torch.nn.init.uniform_, torch.rand = self._o1, self._o2
+        assert not self.u, "unused draws: %d" % len(self.u)
+
+
+def gen_logistic():
+    from zhusuan.distributions import Logistic
+    rng = np.random.RandomState(707)
+    out = {}
+    case = 0
+    for shape in [(8, 4), (3, 5, 8)]:
+        for K in [None, 1, 5]:
+            for g in [0, 1, 2]:
+                loc = rng.standard_normal(shape).astype(F32)
+                sc = np.exp(0.4 * rng.standard_normal(shape) - 0.3).astype(F32)
+                ushape = shape if (K is None or K == 1) else (K,) + shape
+                u = rng.uniform(1e-4, 1 - 1e-4, ushape).astype(F32)
+                loc_t, sc_t = t(loc, True), t(sc, True)
+                d = Logistic(loc_t, sc_t, group_ndims=g)
+                with UniformQueue([u]):
+                    z = d.sample(K)
+                lp = d.log_prob(None)   # sample_cache, logistic.py:70-71
+                w = rng.standard_normal(tuple(lp.shape)).astype(F32)
+                wz = rng.standard_normal(tuple(z.shape)).astype(F32)
+                gl, gs = torch.autograd.grad((lp * t(w)).sum() + (z * t(wz)).sum(), [loc_t, sc_t])
+                p = "c%03d_" % case
+                out[p + "loc"], out[p + "scale"], out[p + "u"] = loc, sc, u
+                out[p + "K"] = np.array(-1 if K is None else K)
+                out[p + "g"] = np.array(g)
+                out[p + "z"], out[p + "lp"], out[p + "w"], out[p + "wz"] = z, lp, w, wz
+                out[p + "gloc"], out[p + "gscale"] = gl, gs
+                case += 1
+    out["n_cases"] = np.array(case)
+    save("g_logistic_sample", **out)
+
+    out = {}
+    case = 0
+    specs = [  # (loc shape, scale shape, given shape, group_ndims)
+        ((6, 4), (6, 4), (6, 4), 0),
+        ((6, 4), (6, 4), (3, 6, 4), 0),
+        ((6, 4), (6, 4), (3, 6, 4), 1),
+        ((5, 7), (5, 7), (4, 5, 7), 2),
+        ((1, 3), (2, 1), (2, 3), 0),
+        ((16,), (16,), (7, 16), 1),          # nice_mnist.py:29 style prior: loc/scale [D], data [B, D]
+        ((2,), (2, 2), (1,), 0),
+    ]
+    for ls, ss, gs, g in specs:
+        loc = rng.standard_normal(ls).astype(F32)
+        sc = np.exp(0.4 * rng.standard_normal(ss)).astype(F32)
+        x = (3.0 * rng.standard_normal(gs)).astype(F32)
+        if case == 0:
+            x.flat[:4] = [30.0, -30.0, 80.0, -80.0]      # softplus threshold / saturation
+        loc_t, sc_t, x_t = t(loc, True), t(sc, True), t(x, True)
+        d = Logistic(loc_t, sc_t, group_ndims=g)
+        lp = d.log_prob(x_t)
+        w = rng.standard_normal(tuple(lp.shape)).astype(F32)
+        gl, gsc, gx = torch.autograd.grad((lp * t(w)).sum(), [loc_t, sc_t, x_t])
+        p = "c%03d_" % case
+        out[p + "loc"], out[p + "scale"], out[p + "x"], out[p + "g"] = loc, sc, x, np.array(g)
+        out[p + "lp"], out[p + "w"] = lp, w
+        out[p + "gloc"], out[p + "gscale"], out[p + "gx"] = gl, gsc, gx
+        case += 1
+    out["n_cases"] = np.array(case)
+    # scipy-checked value of the reference's own test (test_logistic.py:69-77)
+    out["kat_lp"] = Logistic([2.], [1.]).log_prob([3.])
+    save("g_logistic_logprob", **out)
+
+
+def gen_uniform():
+    from zhusuan.distributions import Uniform
+    rng = np.random.RandomState(808)
+    out = {}
+    case = 0
+    for shape in [(8, 4), (3, 5, 8)]:
+        for K in [None, 1, 5]:
+            for reparam in [True, False]:
+                low = rng.standard_normal(shape).astype(F32)
+                high = (low + np.exp(0.5 * rng.standard_normal(shape))).astype(F32)
+                ushape = shape if (K is None or K == 1) else (K,) + shape
+                u = rng.uniform(0.0, 1.0, ushape).astype(F32)
+                low_t, high_t = t(low, True), t(high, True)
+                d = Uniform(low_t, high_t, is_reparameterized=reparam)
+                with UniformQueue([u]) as q:
+                    z = d.sample(K)
+                wz = rng.standard_normal(tuple(z.shape)).astype(F32)
+                glo, ghi = torch.autograd.grad((z * t(wz)).sum(), [low_t, high_t])
+                p = "c%03d_" % case
+                out[p + "low"], out[p + "high"], out[p + "u"] = low, high, u
+                out[p + "K"] = np.array(-1 if K is None else K)
+                out[p + "reparam"] = np.array(int(reparam))
+                out[p + "z"], out[p + "cache"], out[p + "wz"] = z, d.sample_cache, wz
+                out[p + "glow"], out[p + "ghigh"] = glo, ghi
+                out[p + "draw_shape"] = np.array(q.calls[0])
+                case += 1
+    out["n_cases"] = np.array(case)
+    # low-shaped draw shared along high-only broadcast axes (uniform.py:52-53,66-67)
+    low = rng.standard_normal((1, 3)).astype(F32)
+    high = (low.max() + np.exp(rng.standard_normal((2, 1)))).astype(F32)
+    u = rng.uniform(size=(2, 1, 3)).astype(F32)
+    d = Uniform(t(low), t(high))
+    with UniformQueue([u]) as q:
+        z = d.sample(2)
+    out["bc_low"], out["bc_high"], out["bc_u"], out["bc_z"] = low, high, u, z
+    out["bc_draw_shape"] = np.array(q.calls[0])
+    save("g_uniform_sample", **out)
+
+    out = {}
+    case = 0
+    specs = [((6, 4), (6, 4), (6, 4), 0), ((6, 4), (6, 4), (3, 6, 4), 0), ((6, 4), (6, 4), (3, 6, 4), 1),
+             ((5, 7), (5, 7), (4, 5, 7), 2), ((1, 3), (2, 1), (2, 3), 0), ((1,), (1,), (9,), 0)]
+    for ls, hs, gs, g in specs:
+        low = rng.standard_normal(ls).astype(F32)
+        high = (low.max() + np.exp(0.5 * rng.standard_normal(hs))).astype(F32)
+        full = np.broadcast_shapes(ls, hs, gs)
+        lo_b, hi_b = np.broadcast_to(low, full), np.broadcast_to(high, full)
+        # inside the support (the reference's torch.distributions validation raises outside it)
+        x_full = (lo_b + rng.uniform(0.05, 0.95, full) * (hi_b - lo_b)).astype(F32)
+        x = x_full if tuple(gs) == tuple(full) else x_full[(0,) * (len(full) - len(gs))]
+        if tuple(x.shape) != tuple(gs):
+            x = np.ascontiguousarray(np.broadcast_to(x_full.min(axis=tuple(range(len(full) - len(gs)))), gs))
+            x = np.maximum(x, lo_b.max() + 1e-3).astype(F32)
+        low_t, high_t = t(low, True), t(high, True)
+        d = Uniform(low_t, high_t, group_ndims=g)
+        lp = d.log_prob(t(x))
+        w = rng.standard_normal(tuple(lp.shape)).astype(F32)
+        glo, ghi = torch.autograd.grad((lp * t(w)).sum(), [low_t, high_t])
+        p = "c%03d_" % case
+        out[p + "low"], out[p + "high"], out[p + "x"], out[p + "g"] = low, high, x, np.array(g)
+        out[p + "lp"], out[p + "w"], out[p + "glow"], out[p + "ghigh"] = lp, w, glo, ghi
+        case += 1
+    out["n_cases"] = np.array(case)
+    out["kat_lp"] = Uniform(np.array([4.]), np.array([5.])).log_prob([4.5])   # test_uniform.py:80 (float64)
+    save("g_uniform_logprob", **out)
 
 
 # --------------------------------------------------------------------------
@@ -583,3 +750,5 @@ if __name__ == "__main__":
     gen_iwae()
     gen_bnn()
     gen_reference_tests()
+    gen_logistic()
+    gen_uniform()

@@ -1,8 +1,8 @@
 """The reference's OWN unittest files for this path, run unmodified against this package.
 
 Only where the reference checkout exists (the build container); skipped elsewhere.  The files
-(test/variational/test_elbo.py, test_iw.py, test/distributions/test_normal.py, test_bernoulli.py and their
-helper modules) are copied to a temporary directory at run time -- nothing of them is kept in this repository --
+(test/variational/test_elbo.py, test_iw.py, test/distributions/test_normal.py, test_bernoulli.py, test_logistic.py,
+test_uniform.py and their helper modules) are copied to a temporary directory at run time -- nothing of them is kept in this repository --
 and executed in a subprocess whose `zhusuan` is THIS package with the CPU oracle library as kernel back-end
 (tests/ref_plugin.py).  They use CPU tensors, so this is the host-logic / drop-in check: same constructor
 errors, shapes, dtypes (incl. float64), scipy known answers, analytic-KL gradient tests, vimco-vs-sgvb test.
@@ -26,7 +26,8 @@ def test_reference_unittests_pass_against_this_package(tmp_path):
     (work / "test").mkdir(parents=True)
     for rel in ["__init__.py", "variational/__init__.py", "variational/utils.py", "variational/test_elbo.py",
                 "variational/test_iw.py", "distributions/__init__.py", "distributions/utils.py",
-                "distributions/test_normal.py", "distributions/test_bernoulli.py"]:
+                "distributions/test_normal.py", "distributions/test_bernoulli.py", "distributions/test_logistic.py",
+                "distributions/test_uniform.py"]:
         dst = work / "test" / rel
         dst.parent.mkdir(parents=True, exist_ok=True)
         shutil.copyfile(os.path.join(REF, "test", rel), dst)
@@ -36,10 +37,11 @@ def test_reference_unittests_pass_against_this_package(tmp_path):
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests"), os.path.join(ROOT, "zhusuan-pytorch_amd"), str(work)])
     cmd = [sys.executable, "-m", "pytest", "-p", "ref_plugin", "-p", "no:cacheprovider", "--rootdir", str(work), "-q",
            "-W", "ignore", str(work / "test" / "variational"), str(work / "test" / "distributions" / "test_normal.py"),
-           str(work / "test" / "distributions" / "test_bernoulli.py")]
+           str(work / "test" / "distributions" / "test_bernoulli.py"), str(work / "test" / "distributions" / "test_logistic.py"),
+           str(work / "test" / "distributions" / "test_uniform.py")]
     r = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
     n_passed = int(r.stdout.strip().splitlines()[-1].split(" passed")[0].split()[-1])
-    assert n_passed >= 24, tail          # 3 (elbo) + 3 (iw) + 11 (normal) + 7 (bernoulli)
+    assert n_passed >= 42, tail          # 3 (elbo) + 3 (iw) + 11 (normal) + 7 (bernoulli) + 9 (logistic) + 9 (uniform)

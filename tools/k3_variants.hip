@@ -139,6 +139,35 @@ __global__ __launch_bounds__(256) void v3(const float4* __restrict__ p, const fl
   }
 }
 
+// V4: a 256-thread block owns one datapoint b and 4 particles per pass: x[b,:] is staged once in LDS and shared by the
+// 4 waves (halves the global-load instructions; p rows still stream 16 B per lane)
+__global__ __launch_bounds__(256) void v4(const float4* __restrict__ p, const float4* __restrict__ x, float* __restrict__ lp,
+                                          int K, int B, int D4) {
+  __shared__ float4 xs[256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int kgroups = (K + 3) / 4;
+  const long items = (long)B * kgroups;
+  for (long it = blockIdx.x; it < items; it += gridDim.x) {
+    const int kg = (int)(it / B), b = (int)(it - (long)kg * B);
+    __syncthreads();
+    if (threadIdx.x < D4) xs[threadIdx.x] = x[(long)b * D4 + threadIdx.x];
+    __syncthreads();
+    const int k = kg * 4 + w;
+    if (k < K) {
+      const float4* pr = p + ((long)k * B + b) * D4;
+      float4 pv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { int c = lane + 64 * u; ok[u] = c < D4; if (ok[u]) pv[u] = pr[c]; }
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (ok[u]) acc += term4(pv[u], xs[lane + 64 * u]);
+      acc = wsum(acc);
+      if (lane == 0) lp[(long)b * K + k] = acc * LN2;
+    }
+  }
+}
+
 // copy-rate reference: read p only (float4), trivial sum, same grid-stride structure -> the memory-side ceiling
 __global__ __launch_bounds__(256) void vread(const float4* __restrict__ p, float* __restrict__ lp, long n4) {
   float acc = 0.f;
@@ -202,6 +231,10 @@ int main(int argc, char** argv) {
       RUN("v0 wave/row grid 2048", (v0<256>), 2048, 256, P, (const float4*)x, lp, K, B, D4);
       RUN("v0 block512 grid 1024", (v0<512>), 1024, 512, P, (const float4*)x, lp, K, B, D4);
       RUN("v3 49-lane rows", v3, g0, 256, P, (const float4*)x, lp, K, B, D4);
+      { unsigned g = (unsigned)std::min<long>((long)B * ((K + 3) / 4), 4096);
+        RUN("v4 x via LDS, block=(b,4k)", v4, g, 256, P, (const float4*)x, lp, K, B, D4); }
+      { unsigned g = (unsigned)((long)B * ((K + 3) / 4));
+        RUN("v4 x via LDS, full grid", v4, g, 256, P, (const float4*)x, lp, K, B, D4); }
       { unsigned g = (unsigned)std::min<long>(((long)B * ((K + 4) / 5) + 3) / 4, 4096);
         RUN("v1 x-in-regs KC=5", (v1<5>), g, 256, P, (const float4*)x, lp, K, B, D4); }
       { unsigned g = (unsigned)std::min<long>(((long)B * ((K + 9) / 10) + 3) / 4, 4096);

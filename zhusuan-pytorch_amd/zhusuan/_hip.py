@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -36,6 +36,14 @@ PROTOTYPES = {
     "zs_iw_reduce_f32": [_p, _i64, _p, _i64, _i64, _i64, _int, _p, _p, _p, _p, _p],
     "zs_log_mean_exp_f32": [_p, _i64, _i64, _i64, _p, _p],
     "zs_philox_normal_f32": [_p, _i64, _u64, _u64, _p, _p],
+    # Logistic / Uniform
+    "zs_logistic_sample_logprob_f32": [_p, _p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "zs_logistic_sample_logprob_bwd_f32": [_p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p],
+    "zs_logistic_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "zs_logistic_logprob_bwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
+    "zs_uniform_sample_f32": [_p, _i64, _p, _i64, _p, _u64, _u64, _p, _p, _p, _i64, _int, _p],
+    "zs_uniform_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "zs_philox_uniform_f32": [_p, _i64, _u64, _u64, _p, _p],
 }
 
 

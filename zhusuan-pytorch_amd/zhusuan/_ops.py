@@ -292,6 +292,187 @@ class LogMeanExpRows(torch.autograd.Function):
         return g.unsqueeze(1) * torch.exp(x2d - out.unsqueeze(1)) / K
 
 
+# ------------------------------------------------------------------------------------------------
+# Logistic / Uniform
+# ------------------------------------------------------------------------------------------------
+class LogisticSampleLogProb(torch.autograd.Function):
+    """L1: z = loc + scale * (log u - log(1-u)) and the row-summed log-density of z in one pass.
+    Replaces Logistic._sample + Logistic._log_prob (zhusuan/distributions/logistic.py:52-83)."""
+
+    @staticmethod
+    def forward(ctx, loc, scale, u, seed, call, rng_state, K, has_k_axis, n_fold, kfast):
+        _hip.require_device(loc, scale, u)
+        sfx = _sfx(loc, scale, u)
+        shape = tuple(loc.shape)
+        M = loc.numel()
+        rest = shape[:len(shape) - n_fold]
+        D = _prod(shape[len(shape) - n_fold:])
+        R = _prod(rest)
+        lead = (K,) if has_k_axis else ()
+        z = torch.empty(lead + shape, dtype=loc.dtype, device=loc.device)
+        if M == 0:
+            ctx.meta = None
+            return z, torch.zeros(lead + rest, dtype=loc.dtype, device=loc.device)
+        buf, lp, sk, sr = _alloc_rows(K, has_k_axis, rest, kfast, loc)
+        _hip.lib().call("zs_logistic_sample_logprob" + sfx, _hip.ptr(loc), _hip.ptr(scale), _hip.ptr(u), seed, call,
+                        _hip.ptr(rng_state), _hip.ptr(z), _hip.ptr(buf), K, M, D, sk, sr, _hip.stream_for(loc))
+        ctx.meta = (seed, call, K, M, D, R)
+        ctx.rng_state = rng_state
+        ctx.save_for_backward(scale, u)
+        return z, lp
+
+    @staticmethod
+    def backward(ctx, gz, glp):
+        if ctx.meta is None:
+            return (None,) * 10
+        seed, call, K, M, D, R = ctx.meta
+        scale, u = ctx.saved_tensors
+        gloc = torch.empty_like(scale)
+        gscale = torch.empty_like(scale)
+        gsk = gsr = 0
+        if gz is not None:
+            gz = gz.contiguous()
+        if glp is not None:
+            glp, gsk, gsr = _kr_view(glp, K, R)
+        _hip.lib().call("zs_logistic_sample_logprob_bwd" + _sfx(scale), _hip.ptr(scale), _hip.ptr(u), seed, call,
+                        _hip.ptr(ctx.rng_state), _hip.ptr(gz), _hip.ptr(glp), gsk, gsr, _hip.ptr(gloc), _hip.ptr(gscale),
+                        K, M, D, _hip.stream_for(scale))
+        return (gloc, gscale) + (None,) * 8
+
+
+def _krd(full_shape, n_fold):
+    """[K, R, D] view of a log-prob problem of shape `full_shape` whose last `n_fold` axes are summed."""
+    full_shape = tuple(full_shape)
+    out_shape = full_shape[:len(full_shape) - n_fold]
+    D = _prod(full_shape[len(full_shape) - n_fold:])
+    has_k = len(out_shape) >= 2
+    K = out_shape[0] if has_k else 1
+    rest = out_shape[1:] if has_k else out_shape
+    return K, _prod(rest), D, has_k, rest
+
+
+def _fold_period(f, P, N, like):
+    """Sum the element-wise partial `f` (N values) over the repeats of an operand of period P."""
+    if f is None:
+        return None
+    if P != N:
+        f = f.view(N // P, P).sum(0)
+    return f.view(like.shape)
+
+
+class LogisticLogProb(torch.autograd.Function):
+    """L2: row-summed Logistic log-density of a given value, periodically broadcast operands
+    (logistic.py:69-83)."""
+
+    @staticmethod
+    def forward(ctx, x, loc, scale, full_shape, n_fold, periods, kfast):
+        _hip.require_device(x, loc, scale)
+        sfx = _sfx(x, loc, scale)
+        K, R, D, has_k, rest = _krd(full_shape, n_fold)
+        buf, lp, sk, sr = _alloc_rows(K, has_k, rest, kfast and n_fold > 0, x)
+        Px, Pm, Ps = periods
+        if K * R * D > 0:
+            _hip.lib().call("zs_logistic_logprob" + sfx, _hip.ptr(x), Px, _hip.ptr(loc), Pm, _hip.ptr(scale), Ps,
+                            _hip.ptr(buf), K, R, D, sk, sr, _hip.stream_for(x))
+        ctx.meta = (K, R, D, periods)
+        ctx.save_for_backward(x, loc, scale)
+        return lp
+
+    @staticmethod
+    def backward(ctx, glp):
+        K, R, D, (Px, Pm, Ps) = ctx.meta
+        x, loc, scale = ctx.saved_tensors
+        need = ctx.needs_input_grad[:3]
+        N = K * R * D
+        if N == 0 or not any(need):
+            return (None,) * 7
+        glp, gsk, gsr = _kr_view(glp, K, R)
+        outs = [torch.empty(N, dtype=x.dtype, device=x.device) if n else None for n in need]
+        _hip.lib().call("zs_logistic_logprob_bwd" + _sfx(x), _hip.ptr(x), Px, _hip.ptr(loc), Pm, _hip.ptr(scale), Ps,
+                        _hip.ptr(glp), gsk, gsr, _hip.ptr(outs[0]), _hip.ptr(outs[1]), _hip.ptr(outs[2]), K, R, D,
+                        _hip.stream_for(x))
+        return (_fold_period(outs[0], Px, N, x), _fold_period(outs[1], Pm, N, loc), _fold_period(outs[2], Ps, N, scale),
+                None, None, None, None)
+
+
+class UniformSample(torch.autograd.Function):
+    """U1: Uniform._sample (zhusuan/distributions/uniform.py:51-70).  Returns (sample, cache); `cache` is what the
+    reference keeps in sample_cache.  d sample / d low = 1 - cache, d sample / d high = cache (uniform.py:70)."""
+
+    @staticmethod
+    def forward(ctx, low, high, u, seed, call, rng_state, shape, periods, reparam):
+        _hip.require_device(low, high, u)
+        sfx = _sfx(low, high, u)
+        out = torch.empty(tuple(shape), dtype=low.dtype, device=low.device)
+        cache = torch.empty_like(out)
+        N = out.numel()
+        Pl, Ph = periods
+        if N:
+            _hip.lib().call("zs_uniform_sample" + sfx, _hip.ptr(low), Pl, _hip.ptr(high), Ph, _hip.ptr(u), seed, call,
+                            _hip.ptr(rng_state), _hip.ptr(out), _hip.ptr(cache), N, 1 if reparam else 0,
+                            _hip.stream_for(low))
+        ctx.meta = (N, Pl, Ph)
+        ctx.save_for_backward(cache, low, high)
+        ctx.mark_non_differentiable(cache)
+        return out, cache
+
+    @staticmethod
+    def backward(ctx, g, _gcache):
+        N, Pl, Ph = ctx.meta
+        cache, low, high = ctx.saved_tensors
+        if N == 0 or g is None:
+            return (None,) * 9
+        g = g.contiguous().view(-1)
+        c = cache.view(-1)
+        ghigh = g * c
+        glow = g - ghigh
+        return (_fold_period(glow, Pl, N, low), _fold_period(ghigh, Ph, N, high)) + (None,) * 7
+
+
+class UniformLogProb(torch.autograd.Function):
+    """U2: row-summed Uniform log-density (uniform.py:72-85).  Backward (torch.distributions.Uniform.log_prob:
+    only ``-log(high - low)`` carries gradient): d/d low = +g/(high - low), d/d high = -g/(high - low)."""
+
+    @staticmethod
+    def forward(ctx, x, low, high, full_shape, n_fold, periods, kfast):
+        _hip.require_device(x, low, high)
+        sfx = _sfx(x, low, high)
+        K, R, D, has_k, rest = _krd(full_shape, n_fold)
+        buf, lp, sk, sr = _alloc_rows(K, has_k, rest, kfast and n_fold > 0, x)
+        Px, Pl, Ph = periods
+        if K * R * D > 0:
+            _hip.lib().call("zs_uniform_logprob" + sfx, _hip.ptr(x), Px, _hip.ptr(low), Pl, _hip.ptr(high), Ph,
+                            _hip.ptr(buf), K, R, D, sk, sr, _hip.stream_for(x))
+        ctx.meta = (K, R, D, periods, tuple(full_shape))
+        ctx.save_for_backward(low, high)
+        return lp
+
+    @staticmethod
+    def backward(ctx, glp):
+        K, R, D, (Px, Pl, Ph), full_shape = ctx.meta
+        low, high = ctx.saved_tensors
+        N = K * R * D
+        if N == 0 or not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            return (None,) * 7
+        g, _, _ = _kr_view(glp, K, R)
+        g = g.reshape(K * R, 1).expand(K * R, D).reshape(-1)
+
+        def full(t, P):
+            return t.reshape(-1).repeat(N // P) if P != N else t.reshape(-1)
+        t = g / (full(high, Ph) - full(low, Pl))
+        return (None, _fold_period(t, Pl, N, low), _fold_period(-t, Ph, N, high), None, None, None, None)
+
+
+def philox_uniform(shape, device, seed, call, rng_state=None, dtype=torch.float32):
+    """U(0,1) draws from the kernels' Philox stream (the u that L1 / U1 would draw for the same ids)."""
+    out = torch.empty(tuple(shape), dtype=dtype, device=device)
+    _hip.require_device(out)
+    if out.numel():
+        _hip.lib().call("zs_philox_uniform" + _sfx(out), _hip.ptr(out), out.numel(), seed, call, _hip.ptr(rng_state),
+                        _hip.stream_for(out))
+    return out
+
+
 def philox_normal(shape, device, seed, call, rng_state=None, dtype=torch.float32):
     """Standard normals from the kernels' own Philox stream (the eps K1 would draw for the same ids)."""
     out = torch.empty(tuple(shape), dtype=dtype, device=device)

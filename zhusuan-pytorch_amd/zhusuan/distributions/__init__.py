@@ -1,10 +1,13 @@
-"""Distributions on the variational-inference hot path (Normal, Bernoulli).
+"""Distributions of the variational-inference hot path (Normal, Bernoulli) and, as the first widening step
+(SURVEY.md 8f rank 4), the reference's two other hand-written samplers (Logistic, Uniform).
 
-The reference also ships Logistic, Beta, Gamma, Laplace, Uniform, StudentT, Poisson, Exponential
-and FlowDistribution (zhusuan/distributions/__init__.py:3-13); they are off the hot path named by
-BASELINE.json and are not part of this build."""
+The reference also ships Beta, Gamma, Laplace, StudentT, Poisson, Exponential (thin wrappers of
+torch.distributions) and FlowDistribution (zhusuan/distributions/__init__.py:3-13); they are off the hot path
+named by BASELINE.json and are not part of this build."""
 from .base import Distribution
 from .normal import Normal
 from .bernoulli import Bernoulli
+from .logistic import Logistic
+from .uniform import Uniform
 
-__all__ = ['Distribution', 'Normal', 'Bernoulli']
+__all__ = ['Distribution', 'Normal', 'Bernoulli', 'Logistic', 'Uniform']

@@ -4,16 +4,18 @@ import torch
 import torch.nn as nn
 
 from .stochastic_tensor import StochasticTensor
-from ..distributions import Distribution, Normal, Bernoulli
+from ..distributions import Distribution, Normal, Bernoulli, Logistic, Uniform
 
 __all__ = ['BayesianNet']
 
-# bn.py:8-19 maps ten names; the eight families off the hot path are not part of this build.
+# bn.py:8-19 maps ten names; the six torch.distributions wrappers off the hot path are not part of this build.
 name_mapping = {
     "Normal": Normal,
     "Bernoulli": Bernoulli,
+    "Logistic": Logistic,
+    "Uniform": Uniform,
 }
-_OUT_OF_SCOPE = ("Beta", "Exponential", "Gamma", "Laplace", "Logistic", "Poisson", "StudentT", "Uniform")
+_OUT_OF_SCOPE = ("Beta", "Exponential", "Gamma", "Laplace", "Poisson", "StudentT")
 
 
 class BayesianNet(nn.Module):
@@ -90,7 +92,7 @@ class BayesianNet(nn.Module):
         if isinstance(distribution, str):
             if distribution in _OUT_OF_SCOPE:
                 raise NotImplementedError(
-                    "distribution '%s' is outside the hot path of the MI355X build (Normal, Bernoulli)" % distribution)
+                    "distribution '%s' is outside the hot path of the MI355X build (Normal, Bernoulli, Logistic, Uniform)" % distribution)
             _dist = name_mapping[distribution](device=self.device, **kwargs)
             self._nodes[name] = StochasticTensor(self, name, _dist, n_samples=n_samples, **kwargs)
         elif isinstance(distribution, Distribution):
@@ -134,3 +136,22 @@ class BayesianNet(nn.Module):
                                  group_ndims=group_ndims, device=self.device, **kwargs)
         self._nodes[name] = StochasticTensor(self, name, distribution, n_samples=n_samples, **kwargs)
         return self._nodes[name].tensor
+
+    def uniform(self, name, low, high, dtype=None, is_continuous=True, is_reparameterized=True, group_ndims=0,
+                n_samples=None, **kwargs):
+        """bn.py:408-432."""
+        if not isinstance(name, str):
+            raise ValueError("name of stochastic_node must be str")
+        distribution = Uniform(low=low, high=high, dtype=dtype, is_continuous=is_continuous,
+                               is_reparameterized=is_reparameterized, group_ndims=group_ndims,
+                               device=self.device, **kwargs)
+        self._nodes[name] = StochasticTensor(self, name, distribution, n_samples=n_samples, **kwargs)
+        return self._nodes[name].tensor
+
+    def logistic(self, name, loc, scale, dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):
+        """The reference's helper of this name builds a LAPLACE node (bn.py:336-358 constructs ``Laplace``), which
+        is outside this build; use ``stochastic_node('Logistic', name, loc=..., scale=...)`` or pass a Logistic
+        instance for a Logistic node."""
+        raise NotImplementedError(
+            "BayesianNet.logistic() creates a Laplace node in the reference (zhusuan/framework/bn.py:345); Laplace is "
+            "outside the MI355X build.  Use stochastic_node('Logistic', ...) for a Logistic node.")
