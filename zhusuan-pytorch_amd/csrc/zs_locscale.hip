@@ -4,10 +4,12 @@
 // HBM-bound streaming work, one code path for float and double (template parameter T):
 //   * a thread owns 4 consecutive flat elements = one Philox4x32 group = one 16-byte (fp32) access when the
 //     operands allow it (VEC), scalar accesses otherwise;
-//   * row sums ("span" kernel): a 256-thread workgroup owns a span of whole rows (<= 2048 elements), parks the
-//     per-element terms in LDS and then adds each row with G lanes -- the global accesses stay fully coalesced
-//     for ANY row length D (40, 51, 784 ...), unlike a lane-group-per-row mapping;
-//   * rows longer than the span: one workgroup per row, register accumulation + block reduction;
+//   * row sums ("wave tile" kernel): a wavefront owns a tile of whole rows (<= 1024 elements: rr consecutive rows
+//     r for kk consecutive particles k), parks the per-element terms in its private LDS slice, adds each row with
+//     G lanes and writes the results in OUTPUT order -- global reads stay 16 B per lane for ANY row length D
+//     (40, 51, 784 ...), K-fastest results leave as runs of kk consecutive floats, and there is no workgroup
+//     barrier (same-wave LDS traffic is ordered);
+//   * rows longer than a tile: one workgroup per row, register accumulation + block reduction;
 //   * D == 1 (no fold) with a contiguous result: terms go straight from registers to the result.
 #include "zs_common.h"
 #include "../../include/zs_hip.h"
@@ -15,8 +17,6 @@
 using namespace zs;
 
 namespace {
-
-constexpr int kSpan = 2048;
 
 template <typename T>
 struct alignas(sizeof(T) * 4) V4 {
@@ -64,17 +64,20 @@ __device__ __forceinline__ void ld4(const T* __restrict__ p, int64_t i0, int n, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) out[j] = v.v[j];
   } else {
+    // unconditional (clamped) loads: a guard per element would serialise them behind branches
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = j < n ? p[i0 + j] : (T)0;
+    for (int j = 0; j < 4; ++j) out[j] = p[i0 + (j < n ? j : 0)];
   }
 }
-template <typename T, bool VEC>
+// NT: non-temporal store for outputs that cannot stay in the 256 MB Infinity Cache (streaming-write rate 4.1 -> 5.3 TB/s,
+// zs_normal.hip).  Compile-time: with a run-time flag the compiler merges the two stores and drops the hint.
+template <typename T, bool VEC, bool NT = false>
 __device__ __forceinline__ void st4(T* __restrict__ p, int64_t i0, int n, const T in[4]) {
   if (VEC) {
-    V4<T> v;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v.v[j] = in[j];
-    *reinterpret_cast<V4<T>*>(p + i0) = v;
+    typedef T vec4_t __attribute__((ext_vector_type(4)));
+    const vec4_t v = {in[0], in[1], in[2], in[3]};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<vec4_t*>(p + i0));
+    else *reinterpret_cast<vec4_t*>(p + i0) = v;
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -82,8 +85,11 @@ __device__ __forceinline__ void st4(T* __restrict__ p, int64_t i0, int n, const 
   }
 }
 // periodic operand a[i % P]; VEC callers guarantee P % 4 == 0 (or P == 1) and i0 % 4 == 0
+// `im` / `RD`: index of i0 inside the [R*D] parameter plane and the plane size, known to the row kernels for free
+// (RD == 0: unknown); operands repeated over the particles (P == RD) then need no division.
 template <typename T, bool VEC>
-__device__ __forceinline__ void ldp4(const T* __restrict__ p, int64_t P, int64_t i0, int n, T out[4], T pad) {
+__device__ __forceinline__ void ldp4(const T* __restrict__ p, int64_t P, int64_t i0, int n, T out[4], T pad, int64_t im = 0,
+                                     int64_t RD = 0) {
   if (P == 1) {
     const T v = p[0];
 #pragma unroll
@@ -91,13 +97,35 @@ __device__ __forceinline__ void ldp4(const T* __restrict__ p, int64_t P, int64_t
     return;
   }
   if (VEC) {
-    const int64_t idx = i0 < P ? i0 : mod_fast(i0, P);
+    const int64_t idx = i0 < P ? i0 : (P == RD ? im : mod_fast(i0, P));
     ld4<T, true>(p, idx, 4, out);
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) out[j] = j < n ? p[(i0 + j) < P ? (i0 + j) : mod_fast(i0 + j, P)] : pad;
   }
 }
+// Operand classes: how a periodic operand is addressed is decided on the host and compiled in, because ANY branch
+// between two global loads (even a uniform one) makes the compiler wait for the first before issuing the second.
+enum { C_GEN = 0, C_FULL = 1, C_PLANE = 2, C_SCALAR = 3 };   // generic a[i % P] | a[i] | a[i % (R*D)] = a[im] | a[0]
+template <typename T, bool VEC, int CLS>
+__device__ __forceinline__ void ldc4(const T* __restrict__ p, int64_t P, int64_t i0, int n, T out[4], T pad, int64_t im,
+                                     int64_t RD) {
+  if (CLS == C_SCALAR) {
+    const T v = p[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = v;
+  } else if (CLS == C_FULL) {
+    ld4<T, VEC>(p, i0, n, out);
+  } else if (CLS == C_PLANE) {
+    ld4<T, VEC>(p, im, n, out);
+  } else {
+    ldp4<T, VEC>(p, P, i0, n, out, pad, im, RD);
+  }
+}
+inline int operand_class(int64_t P, int64_t N, int64_t RD) {
+  return P == N ? C_FULL : (P == 1 ? C_SCALAR : (P == RD ? C_PLANE : C_GEN));
+}
+
 // uniform (0,1) draws for flat elements i0 .. i0+3: supplied, or words of the Philox group(s)
 template <typename T, bool VEC>
 __device__ __forceinline__ void draw4(const T* __restrict__ u, int64_t i0, int n, uint64_t seed, uint64_t call, T out[4]) {
@@ -125,57 +153,110 @@ __device__ __forceinline__ void draw4(const T* __restrict__ u, int64_t i0, int n
 }
 
 // ---------------------------------------------------------------- functors: per-4-element work
+// Row functors expose load() (global reads only) and finish() (arithmetic + stores) separately so that the tile
+// kernel can issue the reads of all its groups before the first dependent instruction.
 template <typename T>
-struct LogisticSampleF {   // L1
+struct Regs3 {
+  T a[4], b[4], c[4];
+};
+template <typename T, bool HAS_U, int CP = C_GEN>
+struct LogisticSampleF {   // L1.  CP: C_PLANE inside the tile kernel (im known), C_GEN elsewhere
   const T* loc; const T* scale; const T* u; uint64_t seed, call; const uint64_t* rs; T* z; int64_t M;
+  static constexpr bool kStores = true;
   __device__ void prepare() { if (rs) { seed = rs[0]; call += rs[1]; } }
-  template <bool VEC>
-  __device__ __forceinline__ void eval(int64_t i0, int n, T t[4], bool want) const {
-    T a[4], b[4], uu[4], zz[4];
-    ldp4<T, VEC>(loc, M, i0, n, a, (T)0);
-    ldp4<T, VEC>(scale, M, i0, n, b, (T)1);
-    draw4<T, VEC>(u, i0, n, seed, call, uu);
+  template <int ACC>
+  __device__ __forceinline__ void load(int64_t i0, int n, int64_t im, int64_t RD, Regs3<T>& r) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
+    ldc4<T, VEC, CP>(loc, M, i0, n, r.a, (T)0, im, RD);
+    ldc4<T, VEC, CP>(scale, M, i0, n, r.b, (T)1, im, RD);
+    if (HAS_U) ld4<T, VEC>(u, i0, n, r.c);
+  }
+  template <int ACC>
+  __device__ __forceinline__ void finish(int64_t i0, int n, Regs3<T>& r, T t[4], bool want) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
+    T zz[4];
+    if (!HAS_U) draw4<T, VEC>(nullptr, i0, n, seed, call, r.c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const T lu = t_log(uu[j]), l1 = t_log((T)1 - uu[j]);
-      zz[j] = mul_add_2round(a[j], b[j], lu - l1);
+      const T lu = t_log(r.c[j]), l1 = t_log((T)1 - r.c[j]);
+      zz[j] = mul_add_2round(r.a[j], r.b[j], lu - l1);
       // log-density of the fresh sample: -eps - 2*softplus(-eps) = log(u) + log(1-u)
-      if (want) t[j] = (lu + l1) - t_log(b[j]);
+      if (want) t[j] = (lu + l1) - t_log(r.b[j]);
     }
-    st4<T, VEC>(z, i0, n, zz);
+    st4<T, VEC, NT>(z, i0, n, zz);
+  }
+  template <int ACC>
+  __device__ __forceinline__ void eval(int64_t i0, int n, T t[4], bool want, int64_t im, int64_t RD) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
+    Regs3<T> r;
+    load<ACC>(i0, n, im, RD, r);
+    finish<ACC>(i0, n, r, t, want);
   }
 };
 
-template <typename T>
+template <typename T, int CX = C_GEN, int CP = C_GEN>
 struct LogisticLogProbF {   // L2
+  static constexpr bool kStores = false;
   const T* x; int64_t Px; const T* loc; int64_t Pm; const T* scale; int64_t Ps;
   __device__ void prepare() {}
-  template <bool VEC>
-  __device__ __forceinline__ void eval(int64_t i0, int n, T t[4], bool) const {
-    T xv[4], a[4], b[4];
-    ldp4<T, VEC>(x, Px, i0, n, xv, (T)0);
-    ldp4<T, VEC>(loc, Pm, i0, n, a, (T)0);
-    ldp4<T, VEC>(scale, Ps, i0, n, b, (T)1);
+  template <int ACC>
+  __device__ __forceinline__ void load(int64_t i0, int n, int64_t im, int64_t RD, Regs3<T>& r) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
+    ldc4<T, VEC, CX>(x, Px, i0, n, r.c, (T)0, im, RD);
+    ldc4<T, VEC, CP>(loc, Pm, i0, n, r.a, (T)0, im, RD);
+    ldc4<T, VEC, CP>(scale, Ps, i0, n, r.b, (T)1, im, RD);
+  }
+  template <int ACC>
+  __device__ __forceinline__ void finish(int64_t, int, Regs3<T>& r, T t[4], bool) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = logistic_term(xv[j], a[j], b[j]);
+    for (int j = 0; j < 4; ++j) t[j] = logistic_term(r.c[j], r.a[j], r.b[j]);
+  }
+  template <int ACC>
+  __device__ __forceinline__ void eval(int64_t i0, int n, T t[4], bool want, int64_t im, int64_t RD) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
+    Regs3<T> r;
+    load<ACC>(i0, n, im, RD, r);
+    finish<ACC>(i0, n, r, t, want);
   }
 };
 
-template <typename T>
+template <typename T, int CX = C_GEN, int CP = C_GEN>
 struct UniformLogProbF {   // U2
+  static constexpr bool kStores = false;
   const T* x; int64_t Px; const T* low; int64_t Pl; const T* high; int64_t Ph;
   __device__ void prepare() {}
-  template <bool VEC>
-  __device__ __forceinline__ void eval(int64_t i0, int n, T t[4], bool) const {
-    T xv[4], lo[4], hi[4];
-    ldp4<T, VEC>(x, Px, i0, n, xv, (T)0);
-    ldp4<T, VEC>(low, Pl, i0, n, lo, (T)0);
-    ldp4<T, VEC>(high, Ph, i0, n, hi, (T)1);
+  template <int ACC>
+  __device__ __forceinline__ void load(int64_t i0, int n, int64_t im, int64_t RD, Regs3<T>& r) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
+    ldc4<T, VEC, CX>(x, Px, i0, n, r.c, (T)0, im, RD);
+    ldc4<T, VEC, CP>(low, Pl, i0, n, r.a, (T)0, im, RD);
+    ldc4<T, VEC, CP>(high, Ph, i0, n, r.b, (T)1, im, RD);
+  }
+  template <int ACC>
+  __device__ __forceinline__ void finish(int64_t, int, Regs3<T>& r, T t[4], bool) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool inside = (lo[j] <= xv[j]) && (hi[j] > xv[j]);   // torch Uniform.log_prob: lb * ub
-      t[j] = (inside ? (T)0 : (T)(-INFINITY)) - t_log(hi[j] - lo[j]);
+      const bool inside = (r.a[j] <= r.c[j]) && (r.b[j] > r.c[j]);   // torch Uniform.log_prob: lb * ub
+      t[j] = (inside ? (T)0 : (T)(-INFINITY)) - t_log(r.b[j] - r.a[j]);
     }
+  }
+  template <int ACC>
+  __device__ __forceinline__ void eval(int64_t i0, int n, T t[4], bool want, int64_t im, int64_t RD) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
+    Regs3<T> r;
+    load<ACC>(i0, n, im, RD, r);
+    finish<ACC>(i0, n, r, t, want);
   }
 };
 
@@ -184,8 +265,10 @@ struct UniformSampleF {   // U1
   const T* low; int64_t Pl; const T* high; int64_t Ph; const T* u; uint64_t seed, call; const uint64_t* rs;
   T* out; T* cache; int reparam;
   __device__ void prepare() { if (rs) { seed = rs[0]; call += rs[1]; } }
-  template <bool VEC>
+  template <int ACC>
   __device__ __forceinline__ void eval(int64_t i0, int n) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
     T lo[4], hi[4], uu[4], o[4], c[4];
     ldp4<T, VEC>(low, Pl, i0, n, lo, (T)0);
     ldp4<T, VEC>(high, Ph, i0, n, hi, (T)1);
@@ -196,8 +279,8 @@ struct UniformSampleF {   // U1
       c[j] = reparam ? uu[j] : mul_add_2round(lo[j], uu[j], w);   // uniform.py:63-67
       o[j] = mul_add_2round(lo[j], c[j], w);                      // uniform.py:70
     }
-    st4<T, VEC>(out, i0, n, o);
-    if (cache) st4<T, VEC>(cache, i0, n, c);
+    st4<T, VEC, NT>(out, i0, n, o);
+    if (cache) st4<T, VEC, NT>(cache, i0, n, c);
   }
 };
 
@@ -205,8 +288,10 @@ template <typename T>
 struct PhiloxUniformF {
   uint64_t seed, call; const uint64_t* rs; T* out;
   __device__ void prepare() { if (rs) { seed = rs[0]; call += rs[1]; } }
-  template <bool VEC>
+  template <int ACC>
   __device__ __forceinline__ void eval(int64_t i0, int n) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
     T uu[4];
     draw4<T, VEC>(nullptr, i0, n, seed, call, uu);
     st4<T, VEC>(out, i0, n, uu);
@@ -218,8 +303,10 @@ struct LogisticLogProbBwdF {   // element-wise partials of L2
   const T* x; int64_t Px; const T* loc; int64_t Pm; const T* scale; int64_t Ps;
   const T* glp; int64_t gsk, gsr; T* gx; T* gloc; T* gscale; int64_t R, D;
   __device__ void prepare() {}
-  template <bool VEC>
+  template <int ACC>
   __device__ __forceinline__ void eval(int64_t i0, int n) const {
+    constexpr bool VEC = ACC != 0, NT = ACC == 2;
+    (void)VEC, (void)NT;
     T xv[4], a[4], b[4], o1[4], o2[4], o3[4];
     ldp4<T, VEC>(x, Px, i0, n, xv, (T)0);
     ldp4<T, VEC>(loc, Pm, i0, n, a, (T)0);
@@ -245,62 +332,116 @@ struct LogisticLogProbBwdF {   // element-wise partials of L2
         o1[j] = o2[j] = o3[j] = (T)0;
       }
     }
-    if (gx) st4<T, VEC>(gx, i0, n, o1);
-    if (gloc) st4<T, VEC>(gloc, i0, n, o2);
-    if (gscale) st4<T, VEC>(gscale, i0, n, o3);
+    if (gx) st4<T, VEC, NT>(gx, i0, n, o1);
+    if (gloc) st4<T, VEC, NT>(gloc, i0, n, o2);
+    if (gscale) st4<T, VEC, NT>(gscale, i0, n, o3);
   }
 };
 
 // ---------------------------------------------------------------- kernels
 __device__ __forceinline__ int pad_idx(int e) { return e + (e >> 5); }
 
-// Row sums over spans of whole rows (D <= span).  rpb rows per workgroup pass, G lanes add one row.
-template <typename T, typename F, bool VEC>
-__global__ __launch_bounds__(256) void k_span_rows(F f, T* __restrict__ lp, int64_t rows, int64_t R, int64_t D, int rpb,
-                                                   int lgG, int64_t sk, int64_t sr, int direct) {
-  __shared__ T term[kSpan + kSpan / 32 + 1];
+constexpr int kTile = 1024;                         // elements of one wave tile
+constexpr int kTileRows = 256;                      // at most this many rows per tile
+constexpr int kTileLds = kTile + kTile / 32 + kTileRows;   // padded terms + the row results
+
+// Row sums over wave tiles.  Tile (rt, kt) = rows r0 .. r0+rr-1 of particles k0 .. k0+kk-1, i.e. kk segments of rr*D
+// contiguous elements; element e of the tile is (seg, off) = divmod(e, rr*D).  Tile-local row q = seg*rr + off/D lies
+// at term[q*D .. q*D+D).  Results are written in the order (rrow, seg): runs of kk consecutive k for the K-fastest
+// layout, runs of rr consecutive r for the row-major one (kk == 1).
+// MODE 0: scalar accesses, one LDS slot per element; 1: 16-byte accesses, one slot per element;
+// 2: 16-byte accesses and D % 4 == 0: a group of 4 elements never straddles a row, so only its partial sum is parked
+// (4x less LDS traffic, 4x fewer adds in the row pass); 3: as 2 with non-temporal stores of the functor's outputs.
+template <typename T, typename F, int MODE>
+__global__ __launch_bounds__(256) void k_wave_rows(F f, T* __restrict__ lp, int64_t K, int64_t R, int D, int rr, int kk, int lgG,
+                                                   int64_t sk, int64_t sr, int direct) {
+  constexpr bool VEC = MODE != 0, PART = MODE >= 2;
+  constexpr int ACC = MODE == 0 ? 0 : (MODE == 3 ? 2 : 1);
+  __shared__ T lds[4][kTileLds];
+  T* __restrict__ term = lds[threadIdx.x >> 6];
+  T* __restrict__ res = term + (kTile + kTile / 32);
   f.prepare();
   const bool want = lp != nullptr;
+  const int lane = threadIdx.x & 63;
   const int G = 1 << lgG;
-  const int64_t tiles = (rows + rpb - 1) / rpb;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t row0 = tile * rpb;
-    const int nrows = (int)((rows - row0 < rpb) ? (rows - row0) : rpb);
-    const int64_t e0 = row0 * D;
-    const int n = nrows * (int)D;
-    for (int e = threadIdx.x * 4; e < n; e += 1024) {
-      T t[4] = {(T)0, (T)0, (T)0, (T)0};
-      const int cnt = n - e < 4 ? n - e : 4;
-      f.template eval<VEC>(e0 + e, cnt, t, want);
+  const int seg_len = rr * D;                 // <= kTile
+  const int64_t RD = R * (int64_t)D;
+  const int64_t rtiles = (R + rr - 1) / rr, ktiles = (K + kk - 1) / kk;
+  const int64_t tiles = rtiles * ktiles;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  // this lane's (up to) 4 groups of a tile: (segment, offset) and LDS slot are the same for every tile
+  int segj[4], offj[4], ldsj[4];
+  int64_t soj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = lane * 4 + 256 * j;
+    segj[j] = (int)((uint32_t)e / (uint32_t)seg_len);
+    offj[j] = e - segj[j] * seg_len;
+    soj[j] = segj[j] * RD + offj[j];
+    ldsj[j] = PART ? pad_idx(e >> 2) : pad_idx(e);   // e % 4 == 0: the four slots e .. e+3 never straddle a pad
+  }
+  const int DD = PART ? D >> 2 : D, SL = PART ? seg_len >> 2 : seg_len;   // row / segment length in LDS slots
+  for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tiles; t += nwaves) {
+    int64_t kt, rt;
+    divmod(t, rtiles, kt, rt);
+    const int64_t r0 = rt * rr, k0 = kt * kk;
+    const int nr = (int)((R - r0 < rr) ? (R - r0) : rr);   // valid rows per segment
+    const int nk = (int)((K - k0 < kk) ? (K - k0) : kk);   // valid segments
+    const int seg_valid = nr * D;
+    const int64_t im0 = r0 * D;
+    const int64_t base = k0 * RD + im0;
+    Regs3<T> rg[4];
+    int cnt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // All global reads of the tile first, and UNCONDITIONALLY: a group outside the tile reads the tile's first
+      // elements instead.  (A divergent guard around the loads makes the compiler wait for each group's data before
+      // it issues the next group's loads: 34 % -> 69 % of the HBM roofline in tools/rows_variants.hip.)
+      const int c = seg_valid - offj[j];
+      cnt[j] = (segj[j] < nk && c > 0) ? (c < 4 ? c : 4) : 0;
+      const bool on = cnt[j] > 0;
+      f.template load<ACC>(base + (on ? soj[j] : 0), on ? cnt[j] : (VEC ? 4 : 1), im0 + (on ? offj[j] : 0), RD, rg[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (cnt[j] <= 0) continue;
+      T tv[4] = {(T)0, (T)0, (T)0, (T)0};
+      f.template finish<ACC>(base + soj[j], cnt[j], rg[j], tv, want);
       if (!want) continue;
       if (direct) {
-        st4<T, VEC>(lp, e0 + e, cnt, t);
+        st4<T, VEC>(lp, base + soj[j], cnt[j], tv);
+      } else if (PART) {
+        term[ldsj[j]] = (tv[0] + tv[1]) + (tv[2] + tv[3]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < cnt) term[pad_idx(e + j)] = t[j];
+        for (int q = 0; q < 4; ++q)
+          if (q < cnt[j]) term[ldsj[j] + q] = tv[q];
       }
     }
     if (want && !direct) {
-      __syncthreads();
-      const int q0 = threadIdx.x >> lgG, g = threadIdx.x & (G - 1);
-      for (int q = q0; q < nrows; q += 256 >> lgG) {
+      // same-wave LDS hand-off: the DS queue of a wave is in order, no workgroup barrier needed
+      __builtin_amdgcn_wave_barrier();
+      const int nrows = nk * nr;              // <= kTileRows
+      const int g = lane & (G - 1);
+      for (int w = lane >> lgG; w < nrows; w += 64 >> lgG) {     // w = rrow * nk + seg: output order, k fastest
+        const int rrow = (int)((uint32_t)w / (uint32_t)nk), seg = w - rrow * nk;
+        const int b0 = seg * SL + rrow * DD;
         T acc = (T)0;
-        const int base = q * (int)D;
-        for (int d = g; d < (int)D; d += G) acc += term[pad_idx(base + d)];
+        for (int d = g; d < DD; d += G) acc += term[pad_idx(b0 + d)];
         for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, ZS_WAVE);
-        if (g == 0) {
-          int64_t k, r;
-          divmod(row0 + q, R, k, r);
-          lp[k * sk + r * sr] = acc;
-        }
+        if (g == 0) res[w] = acc;
       }
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
+      for (int o = lane; o < nrows; o += 64) {
+        const int rrow = (int)((uint32_t)o / (uint32_t)nk), seg = o - rrow * nk;
+        lp[(k0 + seg) * sk + (r0 + rrow) * sr] = res[o];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
-// Rows longer than the span: one workgroup per row.
+// Rows longer than a tile: one workgroup per row.
 template <typename T, typename F, bool VEC>
 __global__ __launch_bounds__(256) void k_long_rows(F f, T* __restrict__ lp, int64_t rows, int64_t R, int64_t D, int64_t sk,
                                                    int64_t sr) {
@@ -313,7 +454,7 @@ __global__ __launch_bounds__(256) void k_long_rows(F f, T* __restrict__ lp, int6
     for (int64_t e = (int64_t)threadIdx.x * 4; e < D; e += 1024) {
       T t[4] = {(T)0, (T)0, (T)0, (T)0};
       const int cnt = D - e < 4 ? (int)(D - e) : 4;
-      f.template eval<VEC>(e0 + e, cnt, t, want);
+      f.template eval<(VEC ? 1 : 0)>(e0 + e, cnt, t, want, 0, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (j < cnt) acc += t[j];
@@ -332,13 +473,13 @@ __global__ __launch_bounds__(256) void k_long_rows(F f, T* __restrict__ lp, int6
   }
 }
 
-template <typename T, typename F, bool VEC>
+template <typename T, typename F, int ACC>
 __global__ __launch_bounds__(256) void k_elem(F f, int64_t N) {
   f.prepare();
   const int64_t groups = (N + 3) >> 2;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i0 = g << 2;
-    f.template eval<VEC>(i0, N - i0 < 4 ? (int)(N - i0) : 4);
+    f.template eval<ACC>(i0, N - i0 < 4 ? (int)(N - i0) : 4);
   }
 }
 
@@ -411,37 +552,69 @@ inline bool al(const void* p, size_t bytes) { return p == nullptr || (((uintptr_
 inline bool per4(int64_t P) { return P == 1 || (P & 3) == 0; }
 
 template <typename T, typename F>
-int launch_rows(int kid, F f, bool vec_ok, T* lp, int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, hipStream_t st) {
-  const int64_t rows = K * R, N = rows * D;
-  vec_ok = vec_ok && (N & 3) == 0 && al(lp, sizeof(T));
-  if (D > kSpan) {
+int launch_rows(int kid, F f, bool vec_ok, T* lp, int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, hipStream_t st,
+                double out_bytes = 0.0) {
+  const int64_t rows = K * R, RD = R * D, N = rows * D;
+  vec_ok = vec_ok && (N & 3) == 0;
+  if (D > kTile) {
     const bool vec = vec_ok && (D & 3) == 0;
     const dim3 grid(grid_for(rows, 1, 256u * 32u));
     if (vec) ZS_LAUNCH(kid, (k_long_rows<T, F, true>), grid, dim3(256), st, f, lp, rows, R, D, sk, sr);
     else ZS_LAUNCH(kid, (k_long_rows<T, F, false>), grid, dim3(256), st, f, lp, rows, R, D, sk, sr);
     return 0;
   }
-  int span = kSpan;                        // smaller spans for small problems: more workgroups than CUs
-  while (span > 256 && N / span < 1024) span >>= 1;
-  if (span < D) span = (int)D;
-  int rpb = span / (int)D;
-  if (rpb >= 4) rpb &= ~3;                 // spans start on a multiple of 4 elements
-  if (rpb > rows) rpb = (int)rows;
+  // tile geometry: rr rows x kk particles (see k_wave_rows)
+  const int d = (int)D;
+  const int rr0 = (d & 3) == 0 ? 1 : ((d & 1) == 0 ? 2 : 4);      // smallest rr with rr*D % 4 == 0
+  int rr = 0, kk = 1;
+  if (lp != nullptr && K > 1 && sk == 1) {                        // K-fastest result: runs of kk particles per row
+    rr = rr0 * ((32 + rr0 * d - 1) / (rr0 * d));                  // segments of >= 32 contiguous elements
+    if (rr > R) rr = (int)R;
+    int64_t k2 = kTile / (rr * d);
+    if (k2 > kTileRows / rr) k2 = kTileRows / rr;
+    if (k2 > K) k2 = K;
+    kk = (int)k2;
+    if (kk < 8) rr = 0;
+  }
+  if (rr == 0) {                                                  // row-major tiles
+    kk = 1;
+    rr = kTile / d;
+    if (rr > kTileRows) rr = kTileRows;
+    if (rr >= rr0) rr -= rr % rr0;
+    if (rr > R) rr = (int)R;
+    // small problems: more tiles than wave slots
+    while (rr >= 2 * rr0 && rr * d >= 512 && ((R + rr - 1) / rr) * K < 2048) rr = ((rr / 2) / rr0) * rr0;
+  }
   const bool direct = lp != nullptr && D == 1 && sr == 1 && (K == 1 || sk == R);
-  const bool vec = vec_ok && ((((int64_t)rpb * D) & 3) == 0 || rpb >= rows) && (!direct || al(lp, sizeof(T) * 4));
+  const bool vec = vec_ok && (K == 1 || (RD & 3) == 0) && ((((int64_t)rr * D) & 3) == 0 || rr >= R) &&
+                   (!direct || al(lp, sizeof(T) * 4));
+  const bool part = vec && (d & 3) == 0 && !direct && lp != nullptr;
+  const int nrows = rr * kk, dd = part ? d >> 2 : d;
   int lgG = 0;
-  while (lgG < 6 && (2 << lgG) * rpb <= 256 && (1 << lgG) < D) ++lgG;
-  const dim3 grid(grid_for((rows + rpb - 1) / rpb, 1, 256u * 32u));
-  if (vec) ZS_LAUNCH(kid, (k_span_rows<T, F, true>), grid, dim3(256), st, f, lp, rows, R, D, rpb, lgG, sk, sr, (int)direct);
-  else ZS_LAUNCH(kid, (k_span_rows<T, F, false>), grid, dim3(256), st, f, lp, rows, R, D, rpb, lgG, sk, sr, (int)direct);
+  while (lgG < 6 && (64 >> (lgG + 1)) >= nrows && (2 << lgG) <= dd) ++lgG;
+  const int64_t tiles = ((R + rr - 1) / rr) * ((K + kk - 1) / kk);
+  const dim3 grid(grid_for(tiles, 4, 256u * 16u));
+  // (MODE 3, non-temporal stores of z, is not used: with the strided 160-byte segments of a tile the partial lines are
+  // merged in L2 only when the stores are cacheable -- measured 58 % -> 42 % of the roofline at 1.4 GB with the hint.)
+  (void)out_bytes;
+  if (part)
+    ZS_LAUNCH(kid, (k_wave_rows<T, F, 2>), grid, dim3(256), st, f, lp, K, R, d, rr, kk, lgG, sk, sr, (int)direct);
+  else if (vec)
+    ZS_LAUNCH(kid, (k_wave_rows<T, F, 1>), grid, dim3(256), st, f, lp, K, R, d, rr, kk, lgG, sk, sr, (int)direct);
+  else
+    ZS_LAUNCH(kid, (k_wave_rows<T, F, 0>), grid, dim3(256), st, f, lp, K, R, d, rr, kk, lgG, sk, sr, (int)direct);
   return 0;
 }
 
 template <typename T, typename F>
-int launch_elem(int kid, F f, bool vec_ok, int64_t N, hipStream_t st) {
+int launch_elem(int kid, F f, bool vec_ok, double out_bytes, int64_t N, hipStream_t st) {
   const dim3 grid(grid_for((N + 3) / 4, 256));
-  if (vec_ok && (N & 3) == 0) ZS_LAUNCH(kid, (k_elem<T, F, true>), grid, dim3(256), st, f, N);
-  else ZS_LAUNCH(kid, (k_elem<T, F, false>), grid, dim3(256), st, f, N);
+  if (vec_ok && (N & 3) == 0) {
+    (void)out_bytes;   // non-temporal stores (ACC 2) measured no gain for the two-output sampler: not instantiated
+    ZS_LAUNCH(kid, (k_elem<T, F, 1>), grid, dim3(256), st, f, N);
+  } else {
+    ZS_LAUNCH(kid, (k_elem<T, F, 0>), grid, dim3(256), st, f, N);
+  }
   return 0;
 }
 
@@ -453,8 +626,23 @@ int logistic_sample(const T* loc, const T* scale, const T* u, uint64_t seed, uin
   if (!loc || !scale || !z) return ZS_EINVAL;
   const size_t A = sizeof(T) * 4;
   const bool vec = (M & 3) == 0 && al(loc, A) && al(scale, A) && al(u, A) && al(z, A);
-  LogisticSampleF<T> f = {loc, scale, u, seed, offset, rng_state, z, M};
-  launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream);
+  const double zbytes = (double)K * (double)M * sizeof(T);
+  // D <= kTile: the tile kernel knows the index inside the [R*D] parameter plane (C_PLANE); the long-row kernel does not
+  if (D <= kTile) {
+    if (u) {
+      LogisticSampleF<T, true, C_PLANE> f = {loc, scale, u, seed, offset, rng_state, z, M};
+      launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream, zbytes);
+    } else {
+      LogisticSampleF<T, false, C_PLANE> f = {loc, scale, u, seed, offset, rng_state, z, M};
+      launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream, zbytes);
+    }
+  } else if (u) {
+    LogisticSampleF<T, true> f = {loc, scale, u, seed, offset, rng_state, z, M};
+    launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream, zbytes);
+  } else {
+    LogisticSampleF<T, false> f = {loc, scale, u, seed, offset, rng_state, z, M};
+    launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream, zbytes);
+  }
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -486,6 +674,28 @@ inline int check3(int64_t K, int64_t R, int64_t D, int64_t P1, int64_t P2, int64
   return 0;
 }
 
+// The value streams in full while both parameters share one class (the cases the callers produce: parameters of the
+// full shape, repeated over the particles, or scalar); anything else, and rows longer than a tile (no plane index),
+// takes the generic a[i % P] functor.
+#define ZS_DISPATCH_CLASSES(FUNCTOR, KID, x, Px, a, Pa, b, Pb)                                                       \
+  do {                                                                                                               \
+    const int cx = operand_class(Px, N, R * D), ca = operand_class(Pa, N, R * D), cb = operand_class(Pb, N, R * D);  \
+    const hipStream_t st__ = (hipStream_t)stream;                                                                    \
+    if (D <= kTile && cx == C_FULL && ca == cb && ca == C_FULL) {                                                    \
+      FUNCTOR<T, C_FULL, C_FULL> f = {x, Px, a, Pa, b, Pb};                                                          \
+      launch_rows<T>(KID, f, vec, lp, K, R, D, sk, sr, st__);                                                        \
+    } else if (D <= kTile && cx == C_FULL && ca == cb && ca == C_PLANE) {                                            \
+      FUNCTOR<T, C_FULL, C_PLANE> f = {x, Px, a, Pa, b, Pb};                                                         \
+      launch_rows<T>(KID, f, vec, lp, K, R, D, sk, sr, st__);                                                        \
+    } else if (D <= kTile && cx == C_FULL && ca == cb && ca == C_SCALAR) {                                           \
+      FUNCTOR<T, C_FULL, C_SCALAR> f = {x, Px, a, Pa, b, Pb};                                                        \
+      launch_rows<T>(KID, f, vec, lp, K, R, D, sk, sr, st__);                                                        \
+    } else {                                                                                                         \
+      FUNCTOR<T> f = {x, Px, a, Pa, b, Pb};                                                                          \
+      launch_rows<T>(KID, f, vec, lp, K, R, D, sk, sr, st__);                                                        \
+    }                                                                                                                \
+  } while (0)
+
 template <typename T>
 int logistic_logprob(const T* x, int64_t Px, const T* loc, int64_t Pm, const T* scale, int64_t Ps, T* lp, int64_t K, int64_t R,
                      int64_t D, int64_t sk, int64_t sr, void* stream) {
@@ -496,8 +706,7 @@ int logistic_logprob(const T* x, int64_t Px, const T* loc, int64_t Pm, const T* 
   if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
   const size_t A = sizeof(T) * 4;
   const bool vec = per4(Px) && per4(Pm) && per4(Ps) && (Px == 1 || al(x, A)) && (Pm == 1 || al(loc, A)) && (Ps == 1 || al(scale, A));
-  LogisticLogProbF<T> f = {x, Px, loc, Pm, scale, Ps};
-  launch_rows<T>(KID_LOGISTIC_LOGPROB, f, vec, lp, K, R, D, sk, sr, (hipStream_t)stream);
+  ZS_DISPATCH_CLASSES(LogisticLogProbF, KID_LOGISTIC_LOGPROB, x, Px, loc, Pm, scale, Ps);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -514,7 +723,8 @@ int logistic_logprob_bwd(const T* x, int64_t Px, const T* loc, int64_t Pm, const
   const bool vec = per4(Px) && per4(Pm) && per4(Ps) && (Px == 1 || al(x, A)) && (Pm == 1 || al(loc, A)) &&
                    (Ps == 1 || al(scale, A)) && al(gx, A) && al(gloc, A) && al(gscale, A);
   LogisticLogProbBwdF<T> f = {x, Px, loc, Pm, scale, Ps, glp, gsk, gsr, gx, gloc, gscale, R, D};
-  launch_elem<T>(KID_LOGISTIC_LOGPROB_BWD, f, vec, N, (hipStream_t)stream);
+  launch_elem<T>(KID_LOGISTIC_LOGPROB_BWD, f, vec, (double)N * sizeof(T) * ((gx != nullptr) + (gloc != nullptr) + (gscale != nullptr)), N,
+                 (hipStream_t)stream);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -530,7 +740,7 @@ int uniform_sample(const T* low, int64_t Pl, const T* high, int64_t Ph, const T*
   const bool vec = per4(Pl) && per4(Ph) && (Pl == 1 || al(low, A)) && (Ph == 1 || al(high, A)) && al(u, A) && al(out, A) &&
                    al(cache, A);
   UniformSampleF<T> f = {low, Pl, high, Ph, u, seed, offset, rng_state, out, cache, reparam};
-  launch_elem<T>(KID_UNIFORM_SAMPLE, f, vec, N, (hipStream_t)stream);
+  launch_elem<T>(KID_UNIFORM_SAMPLE, f, vec, (double)N * sizeof(T) * (cache ? 2 : 1), N, (hipStream_t)stream);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -545,8 +755,7 @@ int uniform_logprob(const T* x, int64_t Px, const T* low, int64_t Pl, const T* h
   if (N % Px || N % Pl || N % Ph) return ZS_EINVAL;
   const size_t A = sizeof(T) * 4;
   const bool vec = per4(Px) && per4(Pl) && per4(Ph) && (Px == 1 || al(x, A)) && (Pl == 1 || al(low, A)) && (Ph == 1 || al(high, A));
-  UniformLogProbF<T> f = {x, Px, low, Pl, high, Ph};
-  launch_rows<T>(KID_UNIFORM_LOGPROB, f, vec, lp, K, R, D, sk, sr, (hipStream_t)stream);
+  ZS_DISPATCH_CLASSES(UniformLogProbF, KID_UNIFORM_LOGPROB, x, Px, low, Pl, high, Ph);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -557,7 +766,7 @@ int philox_uniform(T* out, int64_t N, uint64_t seed, uint64_t offset, const uint
   if (N == 0) return 0;
   if (!out) return ZS_EINVAL;
   PhiloxUniformF<T> f = {seed, offset, rng_state, out};
-  launch_elem<T>(KID_PHILOX_UNIFORM, f, al(out, sizeof(T) * 4), N, (hipStream_t)stream);
+  launch_elem<T>(KID_PHILOX_UNIFORM, f, al(out, sizeof(T) * 4), (double)N * sizeof(T), N, (hipStream_t)stream);
   ZS_CHECK_LAUNCH();
   return 0;
 }
