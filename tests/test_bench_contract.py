@@ -1,0 +1,70 @@
+"""bench.py / __graft_entry__ contract checks.
+
+CPU: the one-line JSON contract is documented in bench.py and the entry module exposes build() and smoke().
+GPU: a short bench run (single-rank path and the multi-rank code path forced on one rank) prints ONE JSON line with
+the required keys, a live roofline object for a hot-path kernel and no CPU fallback; smoke() passes.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def test_entry_points_exist():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    assert callable(g.build) and callable(g.smoke)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in REQUIRED:
+        assert '"%s"' % key in src, key
+    baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert baseline["metric"].split(" ")[0] in src          # the metric BASELINE.json names
+
+
+def _run_bench(*extra):
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", "29533")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3"] + list(extra),
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_single_rank():
+    rec = _run_bench()
+    for key in REQUIRED:
+        assert key in rec, key
+    cpu = rec["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert rec["n_gpus"] == 1 and rec["steps"] == 6 and rec["warmup"] == 3
+    assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["vs_baseline"] is None
+    assert rec["dtype"] == "f32" or rec["dtype"] == "fp32"
+    assert rec["value"] > 1e5 and abs(rec["value"] - 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
+    roof = rec["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-6
+    assert "workload" in rec["config"] and "model" not in rec["config"]
+
+
+@pytest.mark.gpu
+def test_bench_line_collective_path_on_one_rank():
+    rec = _run_bench("--no-cpu-baseline", "--force-collective-path")
+    assert rec["n_gpus"] == 1 and rec["value"] > 1e5
+
+
+@pytest.mark.gpu
+def test_smoke():
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
