@@ -507,3 +507,14 @@ def test_hip_f64_entry_points(hip64, orc64):
     pr = np.linspace(0.05, 0.95, 5)
     assert np.array_equal(hip64.bern_sample(pr, 1001, 5, 2), orc64.bern_sample(pr, 1001, 5, 2))
     np.testing.assert_allclose(hip64.philox(1001, 1, 2), orc64.philox(1001, 1, 2), rtol=0, atol=3e-5)
+
+
+def test_host_library_hook_is_refused_outside_pytest():
+    """The test hook that lets CPU tensors reach a kernel library must not be usable by product code."""
+    import subprocess
+    import sys as _sys
+    code = ("import sys; sys.path.insert(0, %r); from zhusuan import _hip\n"
+            "try:\n    _hip._install_host_library_for_tests(object())\n    print('INSTALLED')\n"
+            "except RuntimeError as e:\n    print('REFUSED', e)\n") % os.path.join(ROOT, "zhusuan-pytorch_amd")
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in r.stdout and "no CPU execution path" in r.stdout, r.stdout + r.stderr

@@ -123,8 +123,13 @@ def lib():
 
 def _install_host_library_for_tests(klib):
     """TESTS ONLY: route kernel calls on CPU tensors to ``klib`` (the C oracle built from
-    oracle/zs_oracle_c.c) so host logic can be exercised without a GPU.  Never called by the package."""
+    oracle/zs_oracle_c.c) so host logic can be exercised without a GPU.  Never called by the package, and
+    refused outside a pytest process: the product has no CPU path."""
     global _HOST_LIB
+    import sys
+    if klib is not None and "pytest" not in sys.modules:
+        raise RuntimeError("zhusuan: _install_host_library_for_tests is a test hook (pytest only); "
+                           "the MI355X build has no CPU execution path")
     _HOST_LIB = klib
 
 
