@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 4
+#define ZS_ABI_VERSION 5
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -252,6 +252,32 @@ int zs_uniform_logprob_f32(const float* x, int64_t Px, const float* low, int64_t
 int zs_philox_uniform_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state,
                           void* stream);
 
+/* ---------------------------------------------------------------------------
+ * R1  Score-function (REINFORCE / NVIL) epilogue of the ELBO, one launch.
+ * Replaces the ~20 whole-tensor scalar ops of ELBO.reinforce (zhusuan/variational/elbo.py:163-238).
+ * n values of log p(x,z) and log q(z|x); baseline (optional) has period Pb (1 or n).
+ *
+ *   l0_i = logp_i - logq_i
+ *   variance_reduction != 0:
+ *     resid_i = l0_i - baseline_i,  l_i = resid_i                    (baseline != NULL, elbo.py:209-215)
+ *     bc = mean_i(l_i) if do_mean else l_0 (n must be 1)              (elbo.py:217-220)
+ *     moving_mean -= (moving_mean - bc) * (1 - decay);  local_step += 1
+ *     moving_mean /= 1 - decay^local_step                             (in place, every call: elbo.py:221-224)
+ *     l_i -= moving_mean
+ *   signal_i = l_i                                                    (the detached learning signal)
+ *   c_i = -(logp_i + l_i * logq_i) + 0.5 * resid_i^2                  (second term only with a baseline)
+ *   cost[0] = mean_i(c_i) if do_mean, else cost[i] = c_i
+ *
+ * moving_mean (float, 1 element) and local_step (int32, 1 element) are DEVICE state, read and written by the kernel
+ * (the module buffers of elbo.py:45-49), so the call is hipGraph-capturable.  resid may be NULL when baseline is.
+ * Derivatives for the caller: d c_i / d logp_i = -1,  d c_i / d logq_i = -signal_i,  d c_i / d baseline_i = -resid_i.
+ * -------------------------------------------------------------------------*/
+int zs_reinforce_f32(const float* logp, const float* logq, const float* baseline, int64_t Pb, int64_t n,
+                     int variance_reduction, int do_mean, double decay,
+                     float* moving_mean, int32_t* local_step,
+                     float* signal, float* cost, float* resid, void* stream);
+
+
 
 /* ---------------------------------------------------------------------------
  * float64 twins.  The reference accepts float64 parameters for Normal / Bernoulli
@@ -279,6 +305,7 @@ int zs_logistic_logprob_bwd_f64(const double* x, int64_t Px, const double* loc, 
 int zs_uniform_sample_f64(const double* low, int64_t Pl, const double* high, int64_t Ph, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* out, double* cache, int64_t N, int reparam, void* stream);
 int zs_uniform_logprob_f64(const double* x, int64_t Px, const double* low, int64_t Pl, const double* high, int64_t Ph, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
 int zs_philox_uniform_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
+int zs_reinforce_f64(const double* logp, const double* logq, const double* baseline, int64_t Pb, int64_t n, int variance_reduction, int do_mean, double decay, float* moving_mean, int32_t* local_step, double* signal, double* cost, double* resid, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Per-kernel timing for the benchmark harness (no reference counterpart).

@@ -208,6 +208,36 @@ def elbo_sgvb(logpxz, logqz, reduce_mean=True):
     return -elbo
 
 
+def elbo_reinforce(logpxz, logqz, moving_mean, local_step, reduce_mean=True, baseline=None, variance_reduction=True,
+                   decay=0.8):
+    """ELBO.reinforce, elbo.py:163-238.  ``moving_mean`` (float32 [1]) and ``local_step`` (int32 [1]) are the module
+    buffers of elbo.py:45-49 and are updated IN PLACE, including the division of the moving mean by the bias factor
+    on every call (:224).  Returns the cost, or (loss, mean elbo) when a baseline is used."""
+    decay_tensor = torch.ones(size=[1], dtype=torch.float32) * decay
+    l_signal = (logpxz - logqz).detach()
+    baseline_cost = None
+    vector_mean = len(logqz.shape) > 0 and reduce_mean
+    if variance_reduction:
+        if baseline is not None:
+            baseline_cost = 0.5 * torch.square(l_signal.detach() - baseline)
+            if vector_mean:
+                baseline_cost = torch.mean(baseline_cost)
+            l_signal = l_signal - baseline
+        bc = torch.mean(l_signal) if vector_mean else l_signal
+        moving_mean -= (moving_mean - bc.detach()) * (1.0 - decay)
+        local_step += 1
+        bias_factor = 1 - torch.pow(decay_tensor, local_step)
+        moving_mean /= bias_factor
+        l_signal = l_signal.detach().clone()
+        l_signal -= moving_mean.detach()      # in place as in the reference: a 0-d l_signal raises here (:225)
+    l_signal = l_signal.detach()
+    cost = -(logpxz + l_signal * logqz)
+    if baseline_cost is not None:
+        loss = torch.mean(cost + baseline_cost) if vector_mean else cost + baseline_cost
+        return loss, torch.mean(logpxz - logqz)
+    return torch.mean(cost) if vector_mean else cost
+
+
 # ----------------------------------------------------------------------------
 # zhusuan/variational/importance_weighted_objective.py
 # ----------------------------------------------------------------------------

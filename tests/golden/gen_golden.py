@@ -552,6 +552,61 @@ def gen_elbo():
 
 
 # --------------------------------------------------------------------------
+# G-RF: ELBO.reinforce, three consecutive steps each (the moving mean is state)
+# --------------------------------------------------------------------------
+def gen_reinforce():
+    rng = np.random.RandomState(606)
+    out = {}
+    case = 0
+    specs = [  # (shape, baseline kind, variance_reduction, reduce_mean)
+        ((), None, False, True), ((1,), None, True, False), ((7,), None, True, True), ((4, 6), None, True, True),
+        ((7,), "tensor", True, True), ((7,), "scalar", True, True), ((1,), "scalar", True, False),
+        ((7,), "tensor", False, True), ((7,), None, False, False), ((300,), "tensor", True, True),
+    ]
+    # (a 0-d log-joint with variance reduction raises in the reference: `l_signal -= moving_mean` cannot broadcast a
+    #  [1] buffer into a 0-d tensor in place, elbo.py:225; so does a vector without reduce_mean, elbo.py:221)
+    for shape, bkind, vr, rm in specs:
+        e = ELBO(None, None, estimator="reinforce")
+        p = "c%03d_" % case
+        out[p + "vr"], out[p + "rm"] = np.array(int(vr)), np.array(int(rm))
+        out[p + "bkind"] = np.array({None: 0, "tensor": 1, "scalar": 2}[bkind])
+        for step in range(3):
+            a = (-90 + 3 * rng.standard_normal(shape)).astype(F32)
+            b = (-40 + rng.standard_normal(shape)).astype(F32)
+            a_t, b_t = t(a, True), t(b, True)
+            base_t = None
+            if bkind == "tensor":
+                base = (-50 + rng.standard_normal(shape)).astype(F32)
+                base_t = t(base, True)
+            elif bkind == "scalar":
+                base = np.asarray(-50 + rng.standard_normal(), F32)
+                base_t = t(base, True)
+            res = e.reinforce(a_t, b_t, reduce_mean=rm, baseline=base_t, variance_reduction=vr, decay=0.8)
+            q = p + "s%d_" % step
+            out[q + "logp"], out[q + "logq"] = a, b
+            if isinstance(res, tuple):
+                loss, elbo_mean = res
+                out[q + "elbo_mean"] = elbo_mean
+            else:
+                loss = res
+            w = rng.standard_normal(tuple(loss.shape)).astype(F32)
+            inputs = [a_t, b_t] + ([base_t] if (base_t is not None and vr) else [])
+            grads = torch.autograd.grad((loss * t(w)).sum(), inputs, allow_unused=True)
+            out[q + "loss"], out[q + "w"] = loss, w
+            out[q + "glogp"] = grads[0] if grads[0] is not None else np.zeros(shape, F32)
+            out[q + "glogq"] = grads[1]
+            if base_t is not None:
+                out[q + "baseline"] = base
+                if vr:
+                    out[q + "gbaseline"] = grads[2]
+            out[q + "moving_mean"] = e.moving_mean.clone()
+            out[q + "local_step"] = e.local_step.clone()
+        case += 1
+    out["n_cases"] = np.array(case)
+    save("g_elbo_reinforce", **out)
+
+
+# --------------------------------------------------------------------------
 # End-to-end callers
 # --------------------------------------------------------------------------
 def _load(path, name):
@@ -752,3 +807,4 @@ if __name__ == "__main__":
     gen_reference_tests()
     gen_logistic()
     gen_uniform()
+    gen_reinforce()

@@ -122,6 +122,67 @@ __global__ __launch_bounds__(256) void k_lanes(const float4* __restrict__ x, con
   }
 }
 
+
+// K2-krep style with U value rows in flight and LDS-staged row sums (the K1 tiling): a wave owns rpw = 64/G parameter
+// rows (G = D/4 lanes each) and walks the K particles U at a time; each lane parks its 4-element partial per particle,
+// every KB particles the wave reads them back transposed and writes the K-fastest result coalesced.
+#define KB 32
+#define LDW 65
+template <int U>
+__global__ __launch_bounds__(256) void k_krep(const float4* __restrict__ x, const float4* __restrict__ lo, const float4* __restrict__ hi,
+                                              float* __restrict__ lp, int64_t K, int64_t R, int D4, int64_t kchunk, int64_t sk, int64_t sr) {
+  __shared__ float stage[4][KB * LDW];
+  float* __restrict__ st = stage[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int G = D4, rpw = 64 / G;
+  const int rw = lane / G, lig = lane - rw * G;
+  const bool lane_on = rw < rpw;
+  const int64_t M4 = R * (int64_t)D4;
+  const int64_t row_tiles = (R + rpw - 1) / rpw, k_tiles = (K + kchunk - 1) / kchunk, total = row_tiles * k_tiles;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += nwaves) {
+    const int64_t kt = t / row_tiles, rt = t - kt * row_tiles;
+    const int64_t rbase = rt * rpw, r = rbase + rw;
+    const bool on = lane_on && r < R;
+    const int64_t m4 = on ? r * D4 + lig : 0;
+    const float4 lv = lo[m4], hv = hi[m4];
+    const float ls[4] = {lv.x, lv.y, lv.z, lv.w}, hs[4] = {hv.x, hv.y, hv.z, hv.w};
+    float c = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c -= __builtin_amdgcn_logf(hs[q] - ls[q]) * 0.6931472f;
+    const int64_t k0 = kt * kchunk, k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
+    for (int64_t kb0 = k0; kb0 < k1; kb0 += KB) {
+      const int kb = (int)((k1 - kb0 < KB) ? (k1 - kb0) : KB);
+      for (int kk = 0; kk < kb; kk += U) {
+        float4 xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t k = kb0 + kk + (kk + u < kb ? u : 0);      // clamped: unconditional loads
+          xv[u] = x[k * M4 + m4];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (kk + u < kb) {
+            const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+            float a = c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a += (ls[q] <= xs[q] && hs[q] > xs[q]) ? 0.f : -INFINITY;
+            st[(kk + u) * LDW + lane] = a;
+          }
+        }
+      }
+      const int nout = rpw * kb;
+      for (int o = lane; o < nout; o += 64) {
+        const int q = o / kb, kk = o - q * kb;
+        const float* __restrict__ src = st + kk * LDW + q * G;
+        float sum = 0.f;
+        for (int j = 0; j < G; ++j) sum += src[j];
+        if (rbase + q < R) lp[(kb0 + kk) * sk + (rbase + q) * sr] = sum;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_read(const float4* __restrict__ x, float* __restrict__ out, int64_t n4) {
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -159,6 +220,21 @@ int main() {
     timeit("read-only float4", 4.0 * n, [&] { hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, (const float4*)x, lp, n / 4); });
     timeit("K2-style lanes-per-row (no LDS), kfast out", bytes, [&] {
       hipLaunchKernelGGL(k_lanes, dim3(4096), dim3(256), 0, 0, (const float4*)x, (const float4*)lo, (const float4*)hi, lp, K, R, D / 4, (int64_t)1, K); });
+    {
+      const int rpw = 64 / (D / 4);
+      const int64_t row_tiles = (R + rpw - 1) / rpw;
+      for (int64_t kchunk : {50, 25}) {
+        const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 3) / 4, 4096);
+        char nm[128];
+        snprintf(nm, sizeof nm, "krep U=2 LDS-staged, kchunk=%ld", (long)kchunk);
+        timeit(nm, bytes, [&] { hipLaunchKernelGGL((k_krep<2>), dim3(grid), dim3(256), 0, 0, (const float4*)x, (const float4*)lo, (const float4*)hi, lp, K, R, D / 4, kchunk, (int64_t)1, K); });
+        snprintf(nm, sizeof nm, "krep U=4 LDS-staged, kchunk=%ld", (long)kchunk);
+        timeit(nm, bytes, [&] { hipLaunchKernelGGL((k_krep<4>), dim3(grid), dim3(256), 0, 0, (const float4*)x, (const float4*)lo, (const float4*)hi, lp, K, R, D / 4, kchunk, (int64_t)1, K); });
+        snprintf(nm, sizeof nm, "krep U=8 LDS-staged, kchunk=%ld", (long)kchunk);
+        timeit(nm, bytes, [&] { hipLaunchKernelGGL((k_krep<8>), dim3(grid), dim3(256), 0, 0, (const float4*)x, (const float4*)lo, (const float4*)hi, lp, K, R, D / 4, kchunk, (int64_t)1, K); });
+      }
+    }
     struct Geo { int rr, kk, lgG; const char* name; };
     const Geo geos[] = {{1, 25, 1, "tile rr=1 kk=25"}, {25, 1, 1, "tile rr=25 kk=1 (row-major reads)"}, {4, 6, 1, "tile rr=4 kk=6"}};
     for (const Geo& g : geos) {

@@ -1,0 +1,105 @@
+// R1: score-function (REINFORCE) epilogue of the ELBO in one launch (include/zs_hip.h; reference
+// zhusuan/variational/elbo.py:163-238).  The operands are the per-datapoint (or already batch-reduced) log-joints, so n
+// is small -- one 1024-thread workgroup walks them twice (mean of the learning signal, then the cost); the moving
+// mean and the step counter are device state that the kernel itself updates, which makes the objective capturable in
+// a hipGraph.  Sums are accumulated in double and combined in a fixed order: deterministic.
+#include "zs_common.h"
+#include "../../include/zs_hip.h"
+
+using namespace zs;
+
+namespace {
+
+__device__ __forceinline__ double block_sum_1024(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, ZS_WAVE);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_reinforce(const T* __restrict__ logp, const T* __restrict__ logq,
+                                                    const T* __restrict__ baseline, int64_t Pb, int64_t n, int vr, int do_mean,
+                                                    float decay, float* __restrict__ moving_mean, int32_t* __restrict__ local_step,
+                                                    T* __restrict__ signal, T* __restrict__ cost, T* __restrict__ resid) {
+  __shared__ double sh[16];
+  __shared__ float sh_mm;
+  const bool has_b = vr && baseline != nullptr;
+  float mm = 0.f;
+  if (vr) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      T l = logp[i] - logq[i];
+      if (has_b) l -= baseline[Pb == 1 ? 0 : i];
+      s += (double)l;
+    }
+    s = block_sum_1024(s, sh);
+    if (threadIdx.x == 0) {
+      const float bc = do_mean ? (float)(s / (double)n) : (float)s;   // !do_mean: n == 1 (checked by the host side)
+      float m = *moving_mean;
+      m -= (m - bc) * (1.0f - decay);                                   // elbo.py:221
+      const int32_t st = *local_step + 1;                               // elbo.py:222
+      const float bias = 1.0f - powf(decay, (float)st);                 // elbo.py:223
+      m /= bias;                                                        // elbo.py:224 (in place, kept)
+      *moving_mean = m;
+      *local_step = st;
+      sh_mm = m;
+    }
+    __syncthreads();
+    mm = sh_mm;
+  }
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const T lp = logp[i], lq = logq[i];
+    T l = lp - lq;
+    T bcost = (T)0;
+    if (has_b) {
+      l -= baseline[Pb == 1 ? 0 : i];
+      if (resid) resid[i] = l;
+      bcost = (T)0.5 * l * l;                                           // elbo.py:210-212
+    }
+    if (vr) l -= (T)mm;                                                 // elbo.py:225
+    if (signal) signal[i] = l;
+    const T c = -(lp + l * lq) + bcost;                                 // elbo.py:228
+    if (do_mean) acc += (double)c;
+    else cost[i] = c;
+  }
+  if (do_mean) {
+    acc = block_sum_1024(acc, sh);
+    if (threadIdx.x == 0) cost[0] = (T)(acc / (double)n);
+  }
+}
+
+template <typename T>
+int reinforce(const T* logp, const T* logq, const T* baseline, int64_t Pb, int64_t n, int vr, int do_mean, double decay,
+              float* moving_mean, int32_t* local_step, T* signal, T* cost, T* resid, void* stream) {
+  if (n < 0 || Pb < 1) return ZS_EINVAL;
+  if (baseline && Pb != 1 && Pb != n) return ZS_EINVAL;
+  if (vr && !do_mean && n > 1) return ZS_EINVAL;      // the moving mean is a single number (elbo.py:221)
+  if (n == 0) return 0;
+  if (!logp || !logq || !cost) return ZS_EINVAL;
+  if (vr && (!moving_mean || !local_step)) return ZS_EINVAL;
+  ZS_LAUNCH(KID_REINFORCE, (k_reinforce<T>), dim3(1), dim3(n >= 1024 ? 1024 : (n > 64 ? 256 : 64)), (hipStream_t)stream, logp, logq,
+            baseline, Pb, n, vr, do_mean, (float)decay, moving_mean, local_step, signal, cost, resid);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int zs_reinforce_f32(const float* logp, const float* logq, const float* baseline, int64_t Pb, int64_t n,
+                                int variance_reduction, int do_mean, double decay, float* moving_mean, int32_t* local_step,
+                                float* signal, float* cost, float* resid, void* stream) {
+  return reinforce<float>(logp, logq, baseline, Pb, n, variance_reduction, do_mean, decay, moving_mean, local_step, signal, cost, resid,
+                          stream);
+}
+extern "C" int zs_reinforce_f64(const double* logp, const double* logq, const double* baseline, int64_t Pb, int64_t n,
+                                int variance_reduction, int do_mean, double decay, float* moving_mean, int32_t* local_step,
+                                double* signal, double* cost, double* resid, void* stream) {
+  return reinforce<double>(logp, logq, baseline, Pb, n, variance_reduction, do_mean, decay, moving_mean, local_step, signal, cost,
+                           resid, stream);
+}

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -44,6 +44,8 @@ PROTOTYPES = {
     "zs_uniform_sample_f32": [_p, _i64, _p, _i64, _p, _u64, _u64, _p, _p, _p, _i64, _int, _p],
     "zs_uniform_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_philox_uniform_f32": [_p, _i64, _u64, _u64, _p, _p],
+    # ELBO.reinforce epilogue
+    "zs_reinforce_f32": [_p, _p, _p, _i64, _i64, _int, _int, ctypes.c_double, _p, _p, _p, _p, _p, _p],
 }
 
 

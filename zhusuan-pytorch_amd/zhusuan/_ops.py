@@ -473,6 +473,53 @@ def philox_uniform(shape, device, seed, call, rng_state=None, dtype=torch.float3
     return out
 
 
+class ReinforceEpilogue(torch.autograd.Function):
+    """R1: the score-function estimator's scalar epilogue in one launch (zhusuan/variational/elbo.py:163-238).
+    `moving_mean` (float32 [1]) and `local_step` (int32 [1]) are the module's buffers, updated by the kernel.
+    Returns the cost: 0-d when `do_mean`, else of logq's shape."""
+
+    @staticmethod
+    def forward(ctx, logp, logq, baseline, moving_mean, local_step, variance_reduction, do_mean, decay):
+        _hip.require_device(logp, logq, baseline, moving_mean, local_step)
+        sfx = _sfx(logp, logq, baseline)
+        shape = tuple(logq.shape)
+        n = logq.numel()
+        lp, lq = logp.contiguous(), logq.contiguous()
+        use_b = bool(variance_reduction) and baseline is not None
+        b, Pb = None, 1
+        if use_b:
+            if baseline.numel() == 1:
+                b = baseline.reshape(1)
+            else:
+                b, Pb = baseline.expand(shape).contiguous(), n
+        signal = torch.empty(shape, dtype=lq.dtype, device=lq.device)
+        resid = torch.empty(shape, dtype=lq.dtype, device=lq.device) if use_b else None
+        cost = torch.empty((() if do_mean else shape), dtype=lq.dtype, device=lq.device)
+        if n:
+            _hip.lib().call("zs_reinforce" + sfx, _hip.ptr(lp), _hip.ptr(lq), _hip.ptr(b), Pb, n,
+                            1 if variance_reduction else 0, 1 if do_mean else 0, float(decay),
+                            _hip.ptr(moving_mean), _hip.ptr(local_step), _hip.ptr(signal), _hip.ptr(cost), _hip.ptr(resid),
+                            _hip.stream_for(lq))
+        ctx.meta = (n, bool(do_mean), use_b, tuple(baseline.shape) if use_b else None)
+        ctx.save_for_backward(signal, resid)
+        return cost
+
+    @staticmethod
+    def backward(ctx, g):
+        n, do_mean, use_b, bshape = ctx.meta
+        signal, resid = ctx.saved_tensors
+        if n == 0:
+            return (None,) * 8
+        if do_mean:
+            g = g / n
+        glogp = (-g).expand(signal.shape) if ctx.needs_input_grad[0] else None
+        glogq = -(g * signal) if ctx.needs_input_grad[1] else None
+        gb = None
+        if use_b and ctx.needs_input_grad[2]:
+            gb = (-(g * resid)).sum_to_size(bshape)
+        return glogp, glogq, gb, None, None, None, None, None
+
+
 def philox_normal(shape, device, seed, call, rng_state=None, dtype=torch.float32):
     """Standard normals from the kernels' own Philox stream (the eps K1 would draw for the same ids)."""
     out = torch.empty(tuple(shape), dtype=dtype, device=device)

@@ -3,6 +3,8 @@
 import torch
 import torch.nn as nn
 
+from .. import _ops
+
 __all__ = ['ELBO', 'EvidenceLowerBoundObjective']
 
 
@@ -78,37 +80,29 @@ class ELBO(nn.Module):
         return -elbo
 
     def reinforce(self, logpxz, logqz, reduce_mean=True, baseline=None, variance_reduction=True, decay=0.8):
-        """Score-function estimator with moving-mean baseline (elbo.py:163-238), including the
-        reference's in-place division of ``moving_mean`` by the bias factor each step (:224)."""
-        dev = logqz.device
-        decay_tensor = torch.ones(size=[1], dtype=torch.float32, device=dev) * decay
-        l_signal = (logpxz - logqz).detach()
-        baseline_cost = None
+        """Score-function estimator with moving-mean baseline (elbo.py:163-238) as ONE kernel (R1,
+        ``zs_reinforce_f32``): learning signal, moving-mean update -- including the reference's in-place division of
+        ``moving_mean`` by the bias factor on every call (:224) -- cost and its mean.  The moving mean and the step
+        counter stay on the device, so the objective can be captured in a hipGraph."""
+        logpxz = torch.as_tensor(logpxz)
+        logqz = torch.as_tensor(logqz, device=logpxz.device)
+        if logpxz.shape != logqz.shape:
+            logpxz, logqz = torch.broadcast_tensors(logpxz, logqz)
+        vector = logqz.dim() > 0
+        do_mean = vector and bool(reduce_mean)
         if variance_reduction:
-            if baseline is not None:
-                baseline_cost = 0.5 * torch.square(l_signal.detach() - baseline)
-                if len(logqz.shape) > 0 and reduce_mean:
-                    baseline_cost = torch.mean(baseline_cost)
-                l_signal = l_signal - baseline
-            if len(logqz.shape) > 0 and reduce_mean:
-                bc = torch.mean(l_signal)
-            else:
-                bc = l_signal
-            self.moving_mean -= (self.moving_mean - bc.detach()) * (1.0 - decay)
-            self.local_step += 1
-            bias_factor = 1 - torch.pow(decay_tensor, self.local_step)
-            self.moving_mean /= bias_factor
-            l_signal = l_signal - self.moving_mean.detach()
-        l_signal = l_signal.detach()
-        cost = -(logpxz + l_signal * logqz)
-        if baseline_cost is not None:
-            if len(logqz.shape) > 0 and reduce_mean:
-                loss = torch.mean(cost + baseline_cost)
-            else:
-                loss = cost + baseline_cost
-            return loss, torch.mean(logpxz - logqz)
-        if len(logqz.shape) > 0 and reduce_mean:
-            cost = torch.mean(cost)
+            # shapes the reference's in-place buffer arithmetic cannot broadcast (elbo.py:221,225)
+            if not vector:
+                raise RuntimeError("output with shape [] doesn't match the broadcast shape [1]")
+            if not do_mean and logqz.numel() != 1:
+                raise RuntimeError("output with shape [1] doesn't match the broadcast shape %s" % list(logqz.shape))
+        use_b = bool(variance_reduction) and baseline is not None
+        if use_b:
+            baseline = torch.as_tensor(baseline, dtype=logqz.dtype, device=logqz.device)
+        cost = _ops.ReinforceEpilogue.apply(logpxz, logqz, baseline if use_b else None, self.moving_mean, self.local_step,
+                                            bool(variance_reduction), do_mean, float(decay))
+        if use_b:
+            return cost, torch.mean(logpxz - logqz)
         return cost
 
 
