@@ -174,41 +174,13 @@ def main():
             for _ in range(args.warmup):
                 step_body()
         else:
-            # The launch-bound inner loop (~130 kernels, most of them a few microseconds) becomes ONE hipGraph.
-            # All eager warm-up runs on the capture side stream: autograd's AccumulateGrad nodes remember
-            # the stream they were first used on, and a default-stream association breaks the capture.
+            # The launch-bound inner loop (~130 kernels, most of them a few microseconds) becomes ONE hipGraph
+            # (zhusuan.GraphedStep: warm-up on the capture stream, thread-local capture mode).  With a collective
+            # the step is two graphs around it: graph A = compute + pack, eager RCCL all-reduce of the bucket,
+            # graph B = optimizer.
             try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(max(args.warmup, 3)):
-                        step_body()
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                if not multi:
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                        static_loss = step_body()
-
-                    def step():
-                        graph.replay()
-                        return static_loss
-                else:
-                    # the collective stays OUTSIDE the graphs: graph A = compute + pack, eager RCCL all-reduce
-                    # of the bucket, graph B = optimizer
-                    graph_a = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph_a, capture_error_mode="thread_local"):
-                        static_local = compute_part()
-                    torch.cuda.synchronize()
-                    graph_b = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph_b, pool=graph_a.pool(), capture_error_mode="thread_local"):
-                        opt.step()
-
-                    def step():
-                        graph_a.replay()
-                        g = exchange_part(static_local)
-                        graph_b.replay()
-                        return g
+                step = zhusuan.GraphedStep(compute_part, opt.step, exchange=exchange_part if multi else None, rng=rng,
+                                           warmup=max(args.warmup, 3))
                 for _ in range(3):
                     step()
                 mode = "hipgraph"
@@ -232,6 +204,7 @@ def main():
         n_prof = min(args.steps, 50)
         klib.prof_enable(True)
         if mode == "hipgraph":
+            side = torch.cuda.Stream()       # eager launches next to captured graphs: stay off the default stream
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(n_prof):

@@ -1,0 +1,95 @@
+"""zhusuan.GraphedStep: a captured training step must train exactly like the eager one (same device-resident Philox
+state, same optimizer), with and without an eager exchange between two graphs; constructing it with restore=True has
+no side effect on parameters, optimizer state or RNG state."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import zhusuan as zs
+from examples import vae_mnist, iwae
+
+
+def test_graphed_step_needs_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        zs.GraphedStep(lambda: None)
+
+
+def _make(kind, dev, seed=5):
+    torch.manual_seed(seed)
+    if kind == "vae":
+        model = vae_mnist.build(32, device=dev)
+        B = 32
+    else:
+        model = iwae.build(5, "vimco", hidden=64, device=dev)
+        B = 16
+    x = (torch.rand(B, 784, device=dev) < 0.5).float()
+    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
+    rng = zs.DeviceRNG(dev, seed=123)
+    return model, opt, rng, {"x": x}
+
+
+def _compute(model, rng, obs):
+    def compute():
+        rng.begin_step()
+        for p in model.parameters():
+            p.grad = None
+        loss = model(obs)
+        loss.backward()
+        return loss.detach()
+    return compute
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["vae", "iwae"])
+@pytest.mark.parametrize("with_exchange", [False, True])
+def test_graphed_step_matches_eager(kind, with_exchange):
+    dev = torch.device("cuda:0")
+    model_e, opt_e, rng_e, obs = _make(kind, dev)
+    model_g, opt_g, rng_g, _ = _make(kind, dev)
+    for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+        assert torch.equal(pe, pg)
+    calls = []
+
+    def exchange(loss):
+        calls.append(1)
+        return loss
+    before = [p.detach().clone() for p in model_g.parameters()]
+    step = zs.GraphedStep(_compute(model_g, rng_g, obs), opt_g.step, exchange=exchange if with_exchange else None, rng=rng_g,
+                          warmup=3, restore=True)
+    assert len(step.graphs) == (2 if with_exchange else 1)
+    for b, p in zip(before, model_g.parameters()):
+        assert torch.equal(b, p), "restore=True must undo the warm-up steps"
+    assert torch.equal(rng_g.state, rng_e.state)
+    calls.clear()
+    comp_e = _compute(model_e, rng_e, obs)
+    le, lg = [], []
+    with zs.device_rng(rng_e):
+        for _ in range(6):
+            le.append(float(comp_e()))
+            opt_e.step()
+    for _ in range(6):
+        lg.append(float(step()))
+    np.testing.assert_allclose(lg, le, rtol=2e-5)
+    assert len(set(lg)) == 6                                   # fresh draws on every replay
+    if with_exchange:
+        assert len(calls) == 6
+    for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_graphed_forward_only():
+    dev = torch.device("cuda:0")
+    model, _, rng, obs = _make("iwae", dev)
+
+    def compute():
+        rng.begin_step()
+        with torch.no_grad():
+            return model(obs).detach()
+    step = zs.GraphedStep(compute, None, rng=rng)
+    vals = [float(step()) for _ in range(4)]
+    assert len(set(vals)) == 4 and all(np.isfinite(vals))

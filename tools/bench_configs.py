@@ -48,20 +48,17 @@ def run_gpu(name, build, make_obs, evals_per_step, steps, graph=True, forward_on
             for _ in range(10):
                 body()
         else:
-            side = torch.cuda.Stream()          # warm up on the capture stream (AccumulateGrad stream affinity)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(10):
-                    body()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = body()
-
-            def step():
-                g.replay()
-                return out
+            def compute():
+                rng.begin_step()
+                if forward_only:
+                    with torch.no_grad():
+                        return model(obs).detach()
+                for p in model.parameters():
+                    p.grad = None
+                loss = model(obs)
+                loss.backward()
+                return loss.detach()
+            step = zhusuan.GraphedStep(compute, None if forward_only else opt.step, rng=rng, warmup=10)
             for _ in range(3):
                 step()
         torch.cuda.synchronize()

@@ -15,3 +15,4 @@ from . import distributions
 from . import framework
 from .utils import *
 from ._rng import inject_epsilon, DeviceRNG, device_rng
+from .graph import GraphedStep

@@ -1,0 +1,145 @@
+"""hipGraph capture of a whole training step (the launch-bound small shapes).
+
+At the configuration sizes of the reference's examples a step is ~100-130 kernels of a few microseconds each, so the
+launch path, not the GPU, sets the pace.  ``GraphedStep`` records the step once and replays it:
+
+    rng = zhusuan.DeviceRNG(device, seed=0)                     # draws must come from device-resident state
+    opt = torch.optim.Adam(model.parameters(), 1e-3, capturable=True)
+
+    def compute():                                              # objective forward + backward
+        rng.begin_step()
+        for p in model.parameters():
+            p.grad = None
+        loss = model({'x': x})
+        loss.backward()
+        return loss.detach()
+
+    step = zhusuan.GraphedStep(compute, opt.step, rng=rng)
+    for _ in range(n):
+        loss = step()                                           # one graph launch
+
+With an ``exchange`` callable (the data-parallel all-reduce, see ``zhusuan.dataparallel``) the step is recorded as two
+graphs around it -- graph A = ``compute``, then ``exchange`` launched eagerly (the RCCL collective stays outside the
+graphs), then graph B = the optimizer.
+
+Capture rules that this class takes care of (each one cost a crash while bench.py was written):
+  * the eager warm-up runs on the capture side stream -- autograd's AccumulateGrad nodes remember the stream they were
+    first used on, and a default-stream association breaks the capture;
+  * ``capture_error_mode='thread_local'``, so that unrelated threads (e.g. a data loader) may keep calling HIP;
+  * nothing inside the step may copy from the host (``torch.as_tensor(python_scalar, device=...)`` does);
+  * the warm-up steps are real optimizer steps; with ``restore=True`` parameters, optimizer state and the RNG state are
+    put back afterwards, so that constructing a GraphedStep has no side effect on training.
+"""
+import torch
+
+from . import _rng
+
+__all__ = ['GraphedStep']
+
+
+def _optimizer_state_tensors(optimizer):
+    out = []
+    if optimizer is None:
+        return out
+    for group in optimizer.param_groups:
+        for p in group['params']:
+            st = optimizer.state.get(p, None)
+            if st:
+                for k in sorted(st.keys()):
+                    if isinstance(st[k], torch.Tensor):
+                        out.append(((id(p), k), st[k]))
+    return out
+
+
+class GraphedStep(object):
+    """
+    :param compute: callable() -> detached 0-d loss; must (re)compute every gradient of the step.
+    :param optimizer_step: callable() applying the update (e.g. ``opt.step`` of a ``capturable=True`` optimizer), or None.
+    :param exchange: optional callable(loss) -> loss run EAGERLY between the two graphs (gradient all-reduce).
+    :param rng: the ``zhusuan.DeviceRNG`` the step draws from (activated around warm-up, capture and every replay).
+    :param warmup: eager steps on the capture stream before recording (>= 2: allocator and autograd settle).
+    :param restore: undo the warm-up's effect on parameters / optimizer state / RNG state after recording.
+    :param optimizer: the optimizer object, needed only for ``restore`` (its state tensors are reset in place).
+    :param parameters: iterable of the tensors ``restore`` must put back (default: the optimizer's parameters).
+    """
+
+    def __init__(self, compute, optimizer_step=None, exchange=None, rng=None, warmup=3, restore=False, optimizer=None,
+                 parameters=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("zhusuan.GraphedStep needs a HIP device: the MI355X build has no CPU path")
+        self._compute, self._opt_step, self._exchange, self._rng = compute, optimizer_step, exchange, rng
+        self.graphs = []
+        if optimizer is None and optimizer_step is not None and hasattr(optimizer_step, '__self__') and \
+                isinstance(optimizer_step.__self__, torch.optim.Optimizer):
+            optimizer = optimizer_step.__self__
+        params = list(parameters) if parameters is not None else (
+            [p for g in optimizer.param_groups for p in g['params']] if optimizer is not None else [])
+        saved_params = saved_state = saved_rng = None
+        if restore:
+            saved_params = [p.detach().clone() for p in params]
+            saved_state = dict((key, t.detach().clone()) for key, t in _optimizer_state_tensors(optimizer))
+            saved_rng = (rng.state.clone(), rng._delta) if rng is not None else None
+
+        def eager_step():
+            loss = self._compute()
+            if self._exchange is not None:
+                loss = self._exchange(loss)
+            if self._opt_step is not None:
+                self._opt_step()
+            return loss
+
+        with self._rng_scope():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(int(warmup), 2)):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            if self._exchange is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._static_loss = eager_step()
+                self.graphs = [g]
+            else:
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                    self._static_loss = self._compute()
+                self.graphs = [ga]
+                if self._opt_step is not None:
+                    torch.cuda.synchronize()
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+                        self._opt_step()
+                    self.graphs.append(gb)
+            torch.cuda.synchronize()
+        if restore:
+            with torch.no_grad():
+                for p, s in zip(params, saved_params):
+                    p.copy_(s)
+                for key, t in _optimizer_state_tensors(optimizer):
+                    if key in saved_state:
+                        t.copy_(saved_state[key])
+                    else:
+                        t.zero_()          # state created by the warm-up: back to its initial value
+                if saved_rng is not None:
+                    rng.state.copy_(saved_rng[0])
+                    rng._delta = saved_rng[1]
+            torch.cuda.synchronize()
+
+    def _rng_scope(self):
+        if self._rng is not None:
+            return _rng.device_rng(self._rng)
+        import contextlib
+        return contextlib.nullcontext()
+
+    def __call__(self):
+        """Replay the recorded step; returns the (static) loss tensor of this step."""
+        if self._exchange is None:
+            self.graphs[0].replay()
+            return self._static_loss
+        self.graphs[0].replay()
+        loss = self._exchange(self._static_loss)
+        if len(self.graphs) > 1:
+            self.graphs[1].replay()
+        return loss
