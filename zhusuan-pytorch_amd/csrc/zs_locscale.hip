@@ -69,15 +69,16 @@ __device__ __forceinline__ void ld4(const T* __restrict__ p, int64_t i0, int n, 
     for (int j = 0; j < 4; ++j) out[j] = p[i0 + (j < n ? j : 0)];
   }
 }
-// NT: non-temporal store for outputs that cannot stay in the 256 MB Infinity Cache (streaming-write rate 4.1 -> 5.3 TB/s,
-// zs_normal.hip).  Compile-time: with a run-time flag the compiler merges the two stores and drops the hint.
-template <typename T, bool VEC, bool NT = false>
+// (Non-temporal stores were measured and rejected for these kernels: the strided 160-byte segments of a wave tile only
+// merge into full lines in L2 when the stores are cacheable -- 58 % -> 42 % of the roofline at 1.4 GB with the hint -- and
+// the two-output Uniform sampler gained nothing.)
+template <typename T, bool VEC>
 __device__ __forceinline__ void st4(T* __restrict__ p, int64_t i0, int n, const T in[4]) {
   if (VEC) {
-    typedef T vec4_t __attribute__((ext_vector_type(4)));
-    const vec4_t v = {in[0], in[1], in[2], in[3]};
-    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<vec4_t*>(p + i0));
-    else *reinterpret_cast<vec4_t*>(p + i0) = v;
+    V4<T> v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v.v[j] = in[j];
+    *reinterpret_cast<V4<T>*>(p + i0) = v;
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -162,20 +163,20 @@ struct Regs3 {
 template <typename T, bool HAS_U, int CP = C_GEN>
 struct LogisticSampleF {   // L1.  CP: C_PLANE inside the tile kernel (im known), C_GEN elsewhere
   const T* loc; const T* scale; const T* u; uint64_t seed, call; const uint64_t* rs; T* z; int64_t M;
-  static constexpr bool kStores = true;
+
   __device__ void prepare() { if (rs) { seed = rs[0]; call += rs[1]; } }
   template <int ACC>
   __device__ __forceinline__ void load(int64_t i0, int n, int64_t im, int64_t RD, Regs3<T>& r) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     ldc4<T, VEC, CP>(loc, M, i0, n, r.a, (T)0, im, RD);
     ldc4<T, VEC, CP>(scale, M, i0, n, r.b, (T)1, im, RD);
     if (HAS_U) ld4<T, VEC>(u, i0, n, r.c);
   }
   template <int ACC>
   __device__ __forceinline__ void finish(int64_t i0, int n, Regs3<T>& r, T t[4], bool want) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     T zz[4];
     if (!HAS_U) draw4<T, VEC>(nullptr, i0, n, seed, call, r.c);
 #pragma unroll
@@ -185,12 +186,12 @@ struct LogisticSampleF {   // L1.  CP: C_PLANE inside the tile kernel (im known)
       // log-density of the fresh sample: -eps - 2*softplus(-eps) = log(u) + log(1-u)
       if (want) t[j] = (lu + l1) - t_log(r.b[j]);
     }
-    st4<T, VEC, NT>(z, i0, n, zz);
+    st4<T, VEC>(z, i0, n, zz);
   }
   template <int ACC>
   __device__ __forceinline__ void eval(int64_t i0, int n, T t[4], bool want, int64_t im, int64_t RD) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     Regs3<T> r;
     load<ACC>(i0, n, im, RD, r);
     finish<ACC>(i0, n, r, t, want);
@@ -199,28 +200,27 @@ struct LogisticSampleF {   // L1.  CP: C_PLANE inside the tile kernel (im known)
 
 template <typename T, int CX = C_GEN, int CP = C_GEN>
 struct LogisticLogProbF {   // L2
-  static constexpr bool kStores = false;
   const T* x; int64_t Px; const T* loc; int64_t Pm; const T* scale; int64_t Ps;
   __device__ void prepare() {}
   template <int ACC>
   __device__ __forceinline__ void load(int64_t i0, int n, int64_t im, int64_t RD, Regs3<T>& r) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     ldc4<T, VEC, CX>(x, Px, i0, n, r.c, (T)0, im, RD);
     ldc4<T, VEC, CP>(loc, Pm, i0, n, r.a, (T)0, im, RD);
     ldc4<T, VEC, CP>(scale, Ps, i0, n, r.b, (T)1, im, RD);
   }
   template <int ACC>
   __device__ __forceinline__ void finish(int64_t, int, Regs3<T>& r, T t[4], bool) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
 #pragma unroll
     for (int j = 0; j < 4; ++j) t[j] = logistic_term(r.c[j], r.a[j], r.b[j]);
   }
   template <int ACC>
   __device__ __forceinline__ void eval(int64_t i0, int n, T t[4], bool want, int64_t im, int64_t RD) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     Regs3<T> r;
     load<ACC>(i0, n, im, RD, r);
     finish<ACC>(i0, n, r, t, want);
@@ -229,21 +229,20 @@ struct LogisticLogProbF {   // L2
 
 template <typename T, int CX = C_GEN, int CP = C_GEN>
 struct UniformLogProbF {   // U2
-  static constexpr bool kStores = false;
   const T* x; int64_t Px; const T* low; int64_t Pl; const T* high; int64_t Ph;
   __device__ void prepare() {}
   template <int ACC>
   __device__ __forceinline__ void load(int64_t i0, int n, int64_t im, int64_t RD, Regs3<T>& r) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     ldc4<T, VEC, CX>(x, Px, i0, n, r.c, (T)0, im, RD);
     ldc4<T, VEC, CP>(low, Pl, i0, n, r.a, (T)0, im, RD);
     ldc4<T, VEC, CP>(high, Ph, i0, n, r.b, (T)1, im, RD);
   }
   template <int ACC>
   __device__ __forceinline__ void finish(int64_t, int, Regs3<T>& r, T t[4], bool) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool inside = (r.a[j] <= r.c[j]) && (r.b[j] > r.c[j]);   // torch Uniform.log_prob: lb * ub
@@ -252,8 +251,8 @@ struct UniformLogProbF {   // U2
   }
   template <int ACC>
   __device__ __forceinline__ void eval(int64_t i0, int n, T t[4], bool want, int64_t im, int64_t RD) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     Regs3<T> r;
     load<ACC>(i0, n, im, RD, r);
     finish<ACC>(i0, n, r, t, want);
@@ -267,8 +266,8 @@ struct UniformSampleF {   // U1
   __device__ void prepare() { if (rs) { seed = rs[0]; call += rs[1]; } }
   template <int ACC>
   __device__ __forceinline__ void eval(int64_t i0, int n) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     T lo[4], hi[4], uu[4], o[4], c[4];
     ldp4<T, VEC>(low, Pl, i0, n, lo, (T)0);
     ldp4<T, VEC>(high, Ph, i0, n, hi, (T)1);
@@ -279,8 +278,8 @@ struct UniformSampleF {   // U1
       c[j] = reparam ? uu[j] : mul_add_2round(lo[j], uu[j], w);   // uniform.py:63-67
       o[j] = mul_add_2round(lo[j], c[j], w);                      // uniform.py:70
     }
-    st4<T, VEC, NT>(out, i0, n, o);
-    if (cache) st4<T, VEC, NT>(cache, i0, n, c);
+    st4<T, VEC>(out, i0, n, o);
+    if (cache) st4<T, VEC>(cache, i0, n, c);
   }
 };
 
@@ -290,8 +289,8 @@ struct PhiloxUniformF {
   __device__ void prepare() { if (rs) { seed = rs[0]; call += rs[1]; } }
   template <int ACC>
   __device__ __forceinline__ void eval(int64_t i0, int n) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     T uu[4];
     draw4<T, VEC>(nullptr, i0, n, seed, call, uu);
     st4<T, VEC>(out, i0, n, uu);
@@ -305,8 +304,8 @@ struct LogisticLogProbBwdF {   // element-wise partials of L2
   __device__ void prepare() {}
   template <int ACC>
   __device__ __forceinline__ void eval(int64_t i0, int n) const {
-    constexpr bool VEC = ACC != 0, NT = ACC == 2;
-    (void)VEC, (void)NT;
+    constexpr bool VEC = ACC != 0;
+    (void)VEC;
     T xv[4], a[4], b[4], o1[4], o2[4], o3[4];
     ldp4<T, VEC>(x, Px, i0, n, xv, (T)0);
     ldp4<T, VEC>(loc, Pm, i0, n, a, (T)0);
@@ -332,9 +331,9 @@ struct LogisticLogProbBwdF {   // element-wise partials of L2
         o1[j] = o2[j] = o3[j] = (T)0;
       }
     }
-    if (gx) st4<T, VEC, NT>(gx, i0, n, o1);
-    if (gloc) st4<T, VEC, NT>(gloc, i0, n, o2);
-    if (gscale) st4<T, VEC, NT>(gscale, i0, n, o3);
+    if (gx) st4<T, VEC>(gx, i0, n, o1);
+    if (gloc) st4<T, VEC>(gloc, i0, n, o2);
+    if (gscale) st4<T, VEC>(gscale, i0, n, o3);
   }
 };
 
@@ -351,12 +350,12 @@ constexpr int kTileLds = kTile + kTile / 32 + kTileRows;   // padded terms + the
 // layout, runs of rr consecutive r for the row-major one (kk == 1).
 // MODE 0: scalar accesses, one LDS slot per element; 1: 16-byte accesses, one slot per element;
 // 2: 16-byte accesses and D % 4 == 0: a group of 4 elements never straddles a row, so only its partial sum is parked
-// (4x less LDS traffic, 4x fewer adds in the row pass); 3: as 2 with non-temporal stores of the functor's outputs.
+// (4x less LDS traffic, 4x fewer adds in the row pass).
 template <typename T, typename F, int MODE>
 __global__ __launch_bounds__(256) void k_wave_rows(F f, T* __restrict__ lp, int64_t K, int64_t R, int D, int rr, int kk, int lgG,
                                                    int64_t sk, int64_t sr, int direct) {
-  constexpr bool VEC = MODE != 0, PART = MODE >= 2;
-  constexpr int ACC = MODE == 0 ? 0 : (MODE == 3 ? 2 : 1);
+  constexpr bool VEC = MODE != 0, PART = MODE == 2;
+  constexpr int ACC = VEC ? 1 : 0;
   __shared__ T lds[4][kTileLds];
   T* __restrict__ term = lds[threadIdx.x >> 6];
   T* __restrict__ res = term + (kTile + kTile / 32);
@@ -552,8 +551,7 @@ inline bool al(const void* p, size_t bytes) { return p == nullptr || (((uintptr_
 inline bool per4(int64_t P) { return P == 1 || (P & 3) == 0; }
 
 template <typename T, typename F>
-int launch_rows(int kid, F f, bool vec_ok, T* lp, int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, hipStream_t st,
-                double out_bytes = 0.0) {
+int launch_rows(int kid, F f, bool vec_ok, T* lp, int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, hipStream_t st) {
   const int64_t rows = K * R, RD = R * D, N = rows * D;
   vec_ok = vec_ok && (N & 3) == 0;
   if (D > kTile) {
@@ -594,9 +592,6 @@ int launch_rows(int kid, F f, bool vec_ok, T* lp, int64_t K, int64_t R, int64_t 
   while (lgG < 6 && (64 >> (lgG + 1)) >= nrows && (2 << lgG) <= dd) ++lgG;
   const int64_t tiles = ((R + rr - 1) / rr) * ((K + kk - 1) / kk);
   const dim3 grid(grid_for(tiles, 4, 256u * 16u));
-  // (MODE 3, non-temporal stores of z, is not used: with the strided 160-byte segments of a tile the partial lines are
-  // merged in L2 only when the stores are cacheable -- measured 58 % -> 42 % of the roofline at 1.4 GB with the hint.)
-  (void)out_bytes;
   if (part)
     ZS_LAUNCH(kid, (k_wave_rows<T, F, 2>), grid, dim3(256), st, f, lp, K, R, d, rr, kk, lgG, sk, sr, (int)direct);
   else if (vec)
@@ -607,10 +602,9 @@ int launch_rows(int kid, F f, bool vec_ok, T* lp, int64_t K, int64_t R, int64_t 
 }
 
 template <typename T, typename F>
-int launch_elem(int kid, F f, bool vec_ok, double out_bytes, int64_t N, hipStream_t st) {
+int launch_elem(int kid, F f, bool vec_ok, int64_t N, hipStream_t st) {
   const dim3 grid(grid_for((N + 3) / 4, 256));
   if (vec_ok && (N & 3) == 0) {
-    (void)out_bytes;   // non-temporal stores (ACC 2) measured no gain for the two-output sampler: not instantiated
     ZS_LAUNCH(kid, (k_elem<T, F, 1>), grid, dim3(256), st, f, N);
   } else {
     ZS_LAUNCH(kid, (k_elem<T, F, 0>), grid, dim3(256), st, f, N);
@@ -626,22 +620,21 @@ int logistic_sample(const T* loc, const T* scale, const T* u, uint64_t seed, uin
   if (!loc || !scale || !z) return ZS_EINVAL;
   const size_t A = sizeof(T) * 4;
   const bool vec = (M & 3) == 0 && al(loc, A) && al(scale, A) && al(u, A) && al(z, A);
-  const double zbytes = (double)K * (double)M * sizeof(T);
   // D <= kTile: the tile kernel knows the index inside the [R*D] parameter plane (C_PLANE); the long-row kernel does not
   if (D <= kTile) {
     if (u) {
       LogisticSampleF<T, true, C_PLANE> f = {loc, scale, u, seed, offset, rng_state, z, M};
-      launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream, zbytes);
+      launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream);
     } else {
       LogisticSampleF<T, false, C_PLANE> f = {loc, scale, u, seed, offset, rng_state, z, M};
-      launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream, zbytes);
+      launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream);
     }
   } else if (u) {
     LogisticSampleF<T, true> f = {loc, scale, u, seed, offset, rng_state, z, M};
-    launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream, zbytes);
+    launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream);
   } else {
     LogisticSampleF<T, false> f = {loc, scale, u, seed, offset, rng_state, z, M};
-    launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream, zbytes);
+    launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream);
   }
   ZS_CHECK_LAUNCH();
   return 0;
@@ -723,8 +716,7 @@ int logistic_logprob_bwd(const T* x, int64_t Px, const T* loc, int64_t Pm, const
   const bool vec = per4(Px) && per4(Pm) && per4(Ps) && (Px == 1 || al(x, A)) && (Pm == 1 || al(loc, A)) &&
                    (Ps == 1 || al(scale, A)) && al(gx, A) && al(gloc, A) && al(gscale, A);
   LogisticLogProbBwdF<T> f = {x, Px, loc, Pm, scale, Ps, glp, gsk, gsr, gx, gloc, gscale, R, D};
-  launch_elem<T>(KID_LOGISTIC_LOGPROB_BWD, f, vec, (double)N * sizeof(T) * ((gx != nullptr) + (gloc != nullptr) + (gscale != nullptr)), N,
-                 (hipStream_t)stream);
+  launch_elem<T>(KID_LOGISTIC_LOGPROB_BWD, f, vec, N, (hipStream_t)stream);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -740,7 +732,7 @@ int uniform_sample(const T* low, int64_t Pl, const T* high, int64_t Ph, const T*
   const bool vec = per4(Pl) && per4(Ph) && (Pl == 1 || al(low, A)) && (Ph == 1 || al(high, A)) && al(u, A) && al(out, A) &&
                    al(cache, A);
   UniformSampleF<T> f = {low, Pl, high, Ph, u, seed, offset, rng_state, out, cache, reparam};
-  launch_elem<T>(KID_UNIFORM_SAMPLE, f, vec, (double)N * sizeof(T) * (cache ? 2 : 1), N, (hipStream_t)stream);
+  launch_elem<T>(KID_UNIFORM_SAMPLE, f, vec, N, (hipStream_t)stream);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -766,7 +758,7 @@ int philox_uniform(T* out, int64_t N, uint64_t seed, uint64_t offset, const uint
   if (N == 0) return 0;
   if (!out) return ZS_EINVAL;
   PhiloxUniformF<T> f = {seed, offset, rng_state, out};
-  launch_elem<T>(KID_PHILOX_UNIFORM, f, al(out, sizeof(T) * 4), (double)N * sizeof(T), N, (hipStream_t)stream);
+  launch_elem<T>(KID_PHILOX_UNIFORM, f, al(out, sizeof(T) * 4), N, (hipStream_t)stream);
   ZS_CHECK_LAUNCH();
   return 0;
 }
