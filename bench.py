@@ -118,10 +118,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hook (tests/test_bench_contract.py): several ranks share GPU 0 and talk over gloo, so that the multi-rank
+    # control flow (shards, bucket, split graphs, max-over-ranks timing) can be exercised on a one-GPU box.  RCCL
+    # refuses two ranks on one device, so this is never a measurement mode.
+    share_device = os.environ.get("ZS_BENCH_SHARE_DEVICE") == "1"
+    dev_index = 0 if share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1 or (args.force_collective_path and "RANK" in os.environ):
-        dist.init_process_group("nccl", device_id=dev)
+        if share_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library("cublaslt" if args.blas == "hipblaslt" else "cublas")
