@@ -168,6 +168,12 @@ __global__ __launch_bounds__(256) void v4(const float4* __restrict__ p, const fl
   }
 }
 
+__global__ __launch_bounds__(256) void vproduce(const float4* __restrict__ q, float4* __restrict__ p, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = q[i]; v.x = 0.5f * v.x + 0.25f; v.y = 0.5f * v.y + 0.25f; v.z = 0.5f * v.z + 0.25f; v.w = 0.5f * v.w + 0.25f; p[i] = v;
+  }
+}
+
 // copy-rate reference: read p only (float4), trivial sum, same grid-stride structure -> the memory-side ceiling
 __global__ __launch_bounds__(256) void vread(const float4* __restrict__ p, float* __restrict__ lp, long n4) {
   float acc = 0.f;
@@ -204,8 +210,9 @@ int main(int argc, char** argv) {
   for (int bi = 0; bi < 3; ++bi) {
     const int B = Bs[bi];
     const long rows = (long)K * B, n = rows * D;
-    const int NBUF = (n * 4 > (256l << 20)) ? 1 : 3;   // rotate buffers for the small sizes as well as reuse one
-    float* p[3]; float *x, *lp;
+    // rotate buffers for the small sizes: 3 (all stay in the 256 MB Infinity Cache) and 10 (400 MB: every launch reads HBM)
+    const int NBUF = (n * 4 > (256l << 20)) ? 1 : 10;
+    float* p[10]; float *x, *lp;
     for (int i = 0; i < NBUF; ++i) CK(hipMalloc(&p[i], n * 4));
     CK(hipMalloc(&x, (long)B * D * 4)); CK(hipMalloc(&lp, rows * 4));
     std::vector<float> h(n);
@@ -217,12 +224,17 @@ int main(int argc, char** argv) {
     const double bytes = 4.0 * n + 4.0 * B * D + 4.0 * rows;
     printf("B=%d K=%d D=%d rows=%ld  p=%.1f MB  (NBUF=%d)\n", B, K, D, rows, n * 4 / 1e6, NBUF);
     Timer t;
-    for (int mode = 0; mode < 2; ++mode) {   // 0: same buffer every launch (cache-warm), 1: rotate buffers
-      if (mode == 1 && NBUF == 1) break;
-      printf(" mode=%s\n", mode ? "rotate" : "same-buffer");
-#define P (const float4*)p[mode ? (it % NBUF) : 0]
+    // 0: same buffer every launch (cache-warm), 1: rotate 3 buffers (cache-resident), 2: rotate 10 buffers (HBM),
+    // 3: the buffer has just been (re)written by an element-wise producer kernel, as p is by the sigmoid in the step
+    for (int mode = 0; mode < 4; ++mode) {
+      if (mode >= 1 && NBUF == 1) break;
+      const char* mnames[] = {"same-buffer", "rotate-3 (Infinity Cache)", "rotate-10 (HBM)", "freshly written by a producer kernel"};
+      printf(" mode=%s\n", mnames[mode]);
+#define P (const float4*)p[mode == 0 ? 0 : (mode == 1 ? it % 3 : (mode == 2 ? it % NBUF : 0))]
 #define RUN(name, kern, grid, block, ...) \
-      for (int it = 0; it < iters; ++it) t.launch([&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, a, b, 0, __VA_ARGS__); }); \
+      for (int it = 0; it < iters; ++it) { \
+        if (mode == 3) hipLaunchKernelGGL(vproduce, dim3(2048), dim3(256), 0, 0, (const float4*)p[1], (float4*)p[0], n / 4); \
+        t.launch([&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, a, b, 0, __VA_ARGS__); }); } \
       t.report(name, bytes);
       unsigned g0 = (unsigned)std::min<long>((rows + 3) / 4, 4096);
       RUN("read-only float4 (ref)", vread, 2048, 256, P, lp, n / 4);
