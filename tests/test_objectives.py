@@ -390,3 +390,14 @@ def test_reference_iw_objective_sgvb_vimco(dev):
                 self.normal("z", mean=torch.zeros(3, 2), std=torch.ones(3, 2), n_samples=4)
                 return self
         ImportanceWeightedObjective(_Net().to(dev), Q().to(dev), axis=0, estimator="vimco")({})
+
+
+def test_helpers_of_families_outside_the_build_raise_clearly(dev):
+    net = BayesianNet()
+    for helper in ("beta", "exponential", "gamma", "laplace", "poisson", "studentT"):
+        with pytest.raises(NotImplementedError, match="outside the hot path"):
+            getattr(net, helper)("n", 1.0)
+    d = Normal(mean=torch.zeros(3, device=dev), std=torch.ones(3, device=dev))
+    z = d.sample(2)
+    assert torch.equal(d._log_prob(sample=z), d._log_prob(z))          # the reference's keyword name
+    assert list(d._log_prob().shape) == [2, 3]                          # None -> cached sample

@@ -82,8 +82,10 @@ class Distribution(object):
         """log-prob of `given` (None = the cached sample) summed over the last `n_fold` axes."""
         raise NotImplementedError()
 
-    def _log_prob(self, given=None):
-        return self._log_prob_sum(given, 0)
+    def _log_prob(self, sample=None, **kwargs):
+        """Element-wise log-prob of `sample` (None = the cached sample), no group sum -- the reference's per-family
+        hook (normal.py:109, bernoulli.py:84, logistic.py:69, uniform.py:72)."""
+        return self._log_prob_sum(sample, 0)
 
     def prob(self, given):
         return self._prob(given)

@@ -155,3 +155,18 @@ class BayesianNet(nn.Module):
         raise NotImplementedError(
             "BayesianNet.logistic() creates a Laplace node in the reference (zhusuan/framework/bn.py:345); Laplace is "
             "outside the MI355X build.  Use stochastic_node('Logistic', ...) for a Logistic node.")
+
+
+def _outside(helper, family):
+    def method(self, name, *args, **kwargs):
+        raise NotImplementedError(
+            "BayesianNet.%s(): distribution '%s' is outside the hot path of the MI355X build "
+            "(Normal, Bernoulli, Logistic, Uniform)" % (helper, family))
+    method.__name__ = helper
+    method.__doc__ = "bn.py helper of the reference for the %s family: not part of this build." % family
+    return method
+
+
+for _helper, _family in (("beta", "Beta"), ("exponential", "Exponential"), ("gamma", "Gamma"), ("laplace", "Laplace"),
+                         ("poisson", "Poisson"), ("studentT", "StudentT")):
+    setattr(BayesianNet, _helper, _outside(_helper, _family))

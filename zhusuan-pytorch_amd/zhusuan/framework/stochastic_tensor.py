@@ -29,9 +29,18 @@ class StochasticTensor(object):
         self._dtype = dist.dtype
         self._n_samples = n_samples
         self._observation = observation
+        self._check_observation(observation)
         self._reduce_mean_dims = kwargs.get("reduce_mean_dims", None)
         self._reduce_sum_dims = kwargs.get("reduce_sum_dims", None)
         self._multiplier = kwargs.get("multiplier", None)
+
+    def _check_observation(self, observation):
+        """stochastic_tensor.py:62-68: an observation handed to the constructor is cast to the node's dtype."""
+        if observation is None:
+            return None
+        if observation.dtype != self.dtype:
+            observation = torch.as_tensor(observation, dtype=self.dtype)
+        return observation
 
     @property
     def bn(self):
