@@ -397,6 +397,10 @@ def test_helpers_of_families_outside_the_build_raise_clearly(dev):
     for helper in ("beta", "exponential", "gamma", "laplace", "poisson", "studentT"):
         with pytest.raises(NotImplementedError, match="outside the hot path"):
             getattr(net, helper)("n", 1.0)
+    import zhusuan.distributions as zd
+    for fam in ("Beta", "Exponential", "Gamma", "Laplace", "Poisson", "StudentT", "FlowDistribution"):
+        with pytest.raises(NotImplementedError, match="outside the variational-inference hot path"):
+            getattr(zd, fam)(1.0, 1.0)
     d = Normal(mean=torch.zeros(3, device=dev), std=torch.ones(3, device=dev))
     z = d.sample(2)
     assert torch.equal(d._log_prob(sample=z), d._log_prob(z))          # the reference's keyword name

@@ -9,5 +9,8 @@ from .normal import Normal
 from .bernoulli import Bernoulli
 from .logistic import Logistic
 from .uniform import Uniform
+from ._outside import Beta, Exponential, Gamma, Laplace, Poisson, StudentT, FlowDistribution
 
-__all__ = ['Distribution', 'Normal', 'Bernoulli', 'Logistic', 'Uniform']
+__all__ = ['Distribution', 'Normal', 'Bernoulli', 'Logistic', 'Uniform',
+           # placeholders that raise NotImplementedError when constructed:
+           'Beta', 'Exponential', 'Gamma', 'Laplace', 'Poisson', 'StudentT', 'FlowDistribution']
