@@ -63,6 +63,9 @@ class NormalSampleLogProb(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mu, sigma, eps, seed, call, rng_state, K, has_k_axis, n_fold, reparam, kfast):
+        # backward copes with an undefined gz / glp itself: do not let autograd fill a [K, B, D] tensor with zeros
+        # (a 2 MB memset per step when the sample reaches the generator detached, as in the VIMCO path)
+        ctx.set_materialize_grads(False)
         _hip.require_device(mu, sigma, eps)
         sfx = _sfx(mu, sigma, eps)
         lib = _hip.lib()
@@ -96,6 +99,8 @@ class NormalSampleLogProb(torch.autograd.Function):
         seed, call, K, M, D, R, reparam = ctx.meta
         lib = _hip.lib()
         sfx = _sfx(ctx.saved_tensors[0])
+        if gz is None and glp is None:
+            return (None,) * 11
         if reparam:
             mu, sigma, eps = ctx.saved_tensors
             gmu = torch.empty_like(mu)
@@ -238,6 +243,7 @@ class IWReduce(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logp, logq, estimator):
+        ctx.set_materialize_grads(False)     # the diagnostic `bound` never carries a gradient
         _hip.require_device(logp, logq)
         sfx = _sfx(logp, logq)
         B, K = logp.shape
@@ -264,6 +270,8 @@ class IWReduce(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_cost, g_bound):
         coef_p, coef_q = ctx.saved_tensors
+        if g_cost is None:
+            return None, None, None
         g = g_cost.unsqueeze(1)
         gp = g * coef_p if ctx.needs_input_grad[0] else None
         gq = g * coef_q if ctx.needs_input_grad[1] else None
@@ -301,6 +309,7 @@ class LogisticSampleLogProb(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, loc, scale, u, seed, call, rng_state, K, has_k_axis, n_fold, kfast):
+        ctx.set_materialize_grads(False)     # backward handles an undefined gz / glp (see NormalSampleLogProb)
         _hip.require_device(loc, scale, u)
         sfx = _sfx(loc, scale, u)
         shape = tuple(loc.shape)
@@ -326,6 +335,8 @@ class LogisticSampleLogProb(torch.autograd.Function):
         if ctx.meta is None:
             return (None,) * 10
         seed, call, K, M, D, R = ctx.meta
+        if gz is None and glp is None:
+            return (None,) * 10
         scale, u = ctx.saved_tensors
         gloc = torch.empty_like(scale)
         gscale = torch.empty_like(scale)
@@ -401,6 +412,7 @@ class UniformSample(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, low, high, u, seed, call, rng_state, shape, periods, reparam):
+        ctx.set_materialize_grads(False)
         _hip.require_device(low, high, u)
         sfx = _sfx(low, high, u)
         out = torch.empty(tuple(shape), dtype=low.dtype, device=low.device)
