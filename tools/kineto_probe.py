@@ -37,4 +37,13 @@ for e in prof.events():
         agg.setdefault(e.name[:70], []).append(d)
 for k, v in agg.items():
     print("%-72s n=%3d avg %.2f us min %.2f" % (k, len(v), sum(v) / len(v), min(v)))
+other = {}
+for e in prof.events():
+    if getattr(e, "device_type", None) is not None and "DeviceType.CUDA" in str(e.device_type):
+        d = getattr(e, "device_time", 0.0) or 0.0
+        other.setdefault(e.name[:90], []).append(d)
+tot = sum(sum(v) for v in other.values())
+for k, v in sorted(other.items(), key=lambda kv: -sum(kv[1]))[:45]:
+    print("%5.1f%% %6.1f/step %7.2f us  %s" % (100 * sum(v) / tot, len(v) / 20.0, sum(v) / len(v), k))
+print("device time per step %.1f us" % (tot / 20.0))
 print("n events", len(list(prof.events())))
