@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, GOLDEN
+from conftest import GOLDEN
 
 REF = "/root/reference"
 

@@ -1,8 +1,6 @@
 """zhusuan.GraphedStep: a captured training step must train exactly like the eager one (same device-resident Philox
 state, same optimizer), with and without an eager exchange between two graphs; constructing it with restore=True has
 no side effect on parameters, optimizer state or RNG state."""
-import copy
-
 import numpy as np
 import pytest
 import torch

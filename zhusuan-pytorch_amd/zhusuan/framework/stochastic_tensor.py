@@ -2,7 +2,6 @@
 Interface of zhusuan/framework/stochastic_tensor.py:5-181 of the reference."""
 import torch
 
-from ..distributions.base import Distribution
 from .._shapes import broadcast_shapes
 
 __all__ = ['StochasticTensor']
