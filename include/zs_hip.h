@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 5
+#define ZS_ABI_VERSION 6
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -169,6 +169,23 @@ int zs_iw_reduce_f32(const float* logp, int64_t ld_p, const float* logq, int64_t
                      int64_t B, int64_t K, int estimator,
                      float* cost_b, float* bound_b, float* coef_p, float* coef_q, void* stream);
 
+/* K4b  The whole importance-weighted objective in ONE launch: zs_iw_reduce plus what the callers of
+ * ImportanceWeightedObjective.sgvb / .vimco otherwise do with separate whole-tensor ops
+ * (importance_weighted_objective.py:97-98,131-132,191):
+ *   - the log-joint of the generator given as the sum of two terms, logp = logp_a + logp_b (logp_b may be NULL),
+ *     e.g. log p(x|z) + log p(z): rounded as (a + b) - logq, exactly like the reference's separate add;
+ *   - the batch mean of the per-datapoint costs, mean_cost[0] = (1/B) sum_b cost_b, formed deterministically
+ *     (per-workgroup partial sums in `workspace`, the last workgroup to finish adds them in index order);
+ *   - both coefficient matrices in one [2, B, K] buffer (coef[0] = d cost / d logp, coef[1] = d cost / d logq),
+ *     already scaled by 1/B when the mean is requested, so that backward is a single multiply by the incoming gradient.
+ * want_mean != 0 requires mean_cost, workspace (workspace_len >= number of workgroups; 4096 is always enough) and
+ * ticket (one uint32, zero before the first use; the kernel leaves it zero again).  cost_b / bound_b may be NULL. */
+int zs_iw_objective_f32(const float* logp_a, int64_t ld_a, const float* logp_b, int64_t ld_b,
+                        const float* logq, int64_t ld_q, int64_t B, int64_t K, int estimator, int want_mean,
+                        float* cost_b, float* bound_b, float* coef, float* mean_cost,
+                        float* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
+
+
 /* out[b] = log_mean_exp_k(x[b*ld + k])  (zhusuan/utils.py:6-21, K-fastest rows) */
 int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float* out, void* stream);
 
@@ -296,6 +313,7 @@ int zs_bernoulli_logits_logprob_f64(const double* logits, const double* x, int64
 int zs_bernoulli_logits_logprob_bwd_f64(const double* logits, const double* x, int64_t Px, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* glogits, int64_t K, int64_t R, int64_t D, void* stream);
 int zs_bernoulli_sample_f64(const double* p, int64_t Pp, double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 int zs_iw_reduce_f64(const double* logp, int64_t ld_p, const double* logq, int64_t ld_q, int64_t B, int64_t K, int estimator, double* cost_b, double* bound_b, double* coef_p, double* coef_q, void* stream);
+int zs_iw_objective_f64(const double* logp_a, int64_t ld_a, const double* logp_b, int64_t ld_b, const double* logq, int64_t ld_q, int64_t B, int64_t K, int estimator, int want_mean, double* cost_b, double* bound_b, double* coef, double* mean_cost, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
 int zs_log_mean_exp_f64(const double* x, int64_t ld, int64_t B, int64_t K, double* out, void* stream);
 int zs_philox_normal_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 int zs_logistic_sample_logprob_f64(const double* loc, const double* scale, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);

@@ -27,14 +27,14 @@ def declared_symbols():
 
 def test_header_symbols_exported_by_both_libraries():
     names = declared_symbols()
-    assert len(names) == 47 and set(_hip.PROTOTYPES) <= set(names)
+    assert len(names) == 49 and set(_hip.PROTOTYPES) <= set(names)
     hip = ctypes.CDLL(_hip.LIB_PATH)           # loads without a GPU; no compute call is made here
     orc = ctypes.CDLL(build_oracle_lib())
     for n in names:
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 5
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 6
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 
@@ -518,3 +518,82 @@ def test_host_library_hook_is_refused_outside_pytest():
             "except RuntimeError as e:\n    print('REFUSED', e)\n") % os.path.join(ROOT, "zhusuan-pytorch_amd")
     r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "REFUSED" in r.stdout and "no CPU execution path" in r.stdout, r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------ K4b: the whole IW objective in one launch
+def _iw_objective(raw, a, b, q, est, want_mean, ws_len=4096):
+    B, K = q.shape
+    cost_b, bound = raw.empty(B), raw.empty(B)
+    coef = raw.empty(2, B, K)
+    mean = raw.empty(1)
+    ws = torch.zeros(ws_len, dtype=raw.dtype, device=raw.dev)
+    ticket = torch.zeros(1, dtype=torch.int32, device=raw.dev)
+    raw.call("zs_iw_objective_f32", raw.t(a), K, raw.t(b), K, raw.t(q), K, B, K, est, int(want_mean), cost_b, bound, coef,
+             mean if want_mean else None, ws if want_mean else None, ws_len if want_mean else 0, ticket if want_mean else None)
+    assert int(ticket) == 0, "the kernel must leave the ticket at zero"
+    return dict(cost=cost_b.cpu().numpy(), bound=bound.cpu().numpy(), coef=coef.cpu().numpy(),
+                mean=mean.cpu().numpy() if want_mean else None)
+
+
+def test_c_oracle_iw_objective_is_reduce_plus_mean(orc):
+    rng = np.random.RandomState(5)
+    B, K = 37, 9
+    a = (-500 + 3 * rng.standard_normal((B, K))).astype(np.float32)
+    b = (-40 + rng.standard_normal((B, K))).astype(np.float32)
+    q = (-45 + rng.standard_normal((B, K))).astype(np.float32)
+    for est in (0, 1):
+        ref = orc.iw((a + b).astype(np.float32), q, est)
+        for want_mean in (False, True):
+            for bb in (b, None):
+                got = _iw_objective(orc, a if bb is not None else (a + b).astype(np.float32), bb, q, est, want_mean)
+                sc = 1.0 / B if want_mean else 1.0
+                np.testing.assert_array_equal(got["cost"], ref["cost"])
+                np.testing.assert_array_equal(got["bound"], ref["bound"])
+                np.testing.assert_allclose(got["coef"][0], ref["cp"] * sc, rtol=1e-6, atol=0)
+                np.testing.assert_allclose(got["coef"][1], ref["cq"] * sc, rtol=1e-6, atol=1e-12)
+                if want_mean:
+                    np.testing.assert_allclose(got["mean"][0], ref["cost"].astype(np.float64).mean(), rtol=1e-6)
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.call("zs_iw_objective_f32", orc.t(a), K, None, K, orc.t(q), K, B, K, 0, 1, None, None, None, None, None, 0, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K", [(1, 2), (3, 5), (256, 50), (5, 64), (4, 65), (3, 200), (20000, 50), (5000, 70), (2, 1000)])
+@pytest.mark.parametrize("est", [0, 1])
+def test_hip_iw_objective(hip, orc, B, K, est):
+    rng = np.random.RandomState(B + K + est)
+    a = (-500 + 3 * rng.standard_normal((B, K))).astype(np.float32)
+    b = (-40 + rng.standard_normal((B, K))).astype(np.float32)
+    q = (-45 + 2 * rng.standard_normal((B, K))).astype(np.float32)
+    base = hip.iw((a + b).astype(np.float32), q, est)                       # the two-launch form on the same device
+    for want_mean in (True, False):
+        got = _iw_objective(hip, a, b, q, est, want_mean)
+        ref = _iw_objective(orc, a, b, q, est, want_mean)
+        sc = 1.0 / B if want_mean else 1.0
+        np.testing.assert_array_equal(got["cost"], base["cost"])             # same kernel body: bit-identical rows
+        np.testing.assert_array_equal(got["bound"], base["bound"])
+        np.testing.assert_allclose(got["coef"][0], base["cp"] * np.float32(sc), rtol=2e-7, atol=0)
+        np.testing.assert_allclose(got["coef"][1], base["cq"] * np.float32(sc), rtol=2e-7, atol=1e-12)
+        np.testing.assert_allclose(got["bound"], ref["bound"], rtol=2e-6, atol=1e-4)
+        if want_mean:
+            exact = base["cost"].astype(np.float64).mean()
+            assert abs(got["mean"][0] - exact) <= 2e-6 * abs(exact)
+            again = _iw_objective(hip, a, b, q, est, True)
+            assert got["mean"][0] == again["mean"][0], "the batch mean must be deterministic"
+    # workspace too small for the grid is rejected, not overrun
+    if B >= 5000:
+        with pytest.raises(RuntimeError, match="code -1"):
+            _iw_objective(hip, a, b, q, est, True, ws_len=8)
+
+
+@pytest.mark.gpu
+def test_hip_iw_objective_f64(hip64, orc64):
+    rng = np.random.RandomState(11)
+    for B, K in [(7, 5), (300, 50), (3, 130)]:
+        a, b = -500 + 3 * rng.standard_normal((B, K)), -40 + rng.standard_normal((B, K))
+        q = -45 + 2 * rng.standard_normal((B, K))
+        for est in (0, 1):
+            got, ref = _iw_objective(hip64, a, b, q, est, True), _iw_objective(orc64, a, b, q, est, True)
+            np.testing.assert_allclose(got["mean"], ref["mean"], rtol=1e-10)
+            np.testing.assert_allclose(got["cost"], ref["cost"], rtol=1e-9, atol=1e-7)
+            np.testing.assert_allclose(got["coef"], ref["coef"], rtol=1e-6, atol=1e-9)

@@ -234,18 +234,32 @@ __device__ __forceinline__ int bmin_i(int v, int* sh) {
   return a < c ? a : c;
 }
 
+struct IwExt64 {   // extras of zs_iw_objective_f64 (zs_iw.hip: IwExt)
+  const double* logp_b;
+  int64_t ld_b;
+  double scale;
+  double* mean_cost;
+  double* partials;
+  unsigned* ticket;
+  double inv_B;
+};
+
 __global__ __launch_bounds__(256) void k64_iw_reduce(const double* __restrict__ logp, int64_t ld_p, const double* __restrict__ logq,
                                                      int64_t ld_q, int64_t B, int64_t K, int estimator, double* __restrict__ cost_b,
                                                      double* __restrict__ bound_b, double* __restrict__ coef_p,
-                                                     double* __restrict__ coef_q) {
+                                                     double* __restrict__ coef_q, IwExt64 ext) {
   __shared__ double shf[4];
   __shared__ int shi[4];
+  __shared__ bool last;
+  double my_cost = 0.0;
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const double* __restrict__ pp = logp + b * ld_p;
+    const double* __restrict__ pb = ext.logp_b ? ext.logp_b + b * ext.ld_b : nullptr;
     const double* __restrict__ qq = logq + b * ld_q;
+#define ZS_LW(k) ((pb ? pp[k] + pb[k] : pp[k]) - qq[k])
     double mx = -INFINITY, sl = 0.0;
     for (int64_t k = threadIdx.x; k < K; k += 256) {
-      const double l = pp[k] - qq[k];
+      const double l = ZS_LW(k);
       mx = fmax(mx, l);
       sl += l;
     }
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(256) void k64_iw_reduce(const double* __restrict__ 
     int jm = 0x7fffffff;
     double s = 0.0;
     for (int64_t k = threadIdx.x; k < K; k += 256) {
-      const double l = pp[k] - qq[k];
+      const double l = ZS_LW(k);
       if (l == m1 && (int)k < jm) jm = (int)k;
       s += exp(l - m1);
     }
@@ -263,17 +277,17 @@ __global__ __launch_bounds__(256) void k64_iw_reduce(const double* __restrict__ 
     if (estimator == ZS_IW_VIMCO) {
       double t = -INFINITY;
       for (int64_t k = threadIdx.x; k < K; k += 256)
-        if ((int)k != jstar) t = fmax(t, pp[k] - qq[k]);
+        if ((int)k != jstar) t = fmax(t, ZS_LW(k));
       m2 = bmax_d(t, shf);
       double s2 = 0.0;
       for (int64_t k = threadIdx.x; k < K; k += 256)
-        if ((int)k != jstar) s2 += exp((pp[k] - qq[k]) - m2);
+        if ((int)k != jstar) s2 += exp(ZS_LW(k) - m2);
       S2 = bsum_d(s2, shf);
     }
     const double logS = log(S), invKm1 = K > 1 ? 1.0 / (double)(K - 1) : 0.0;
     double ct = 0.0;
     for (int64_t k = threadIdx.x; k < K; k += 256) {
-      const double lq = qq[k], l = pp[k] - lq;
+      const double lq = qq[k], l = (pb ? pp[k] + pb[k] : pp[k]) - lq;
       const double e = exp(l - m1), wt = e / S;
       double c1 = -wt * l, cq = wt;
       if (estimator == ZS_IW_VIMCO) {
@@ -285,16 +299,38 @@ __global__ __launch_bounds__(256) void k64_iw_reduce(const double* __restrict__ 
         cq = wt - signal;
       }
       ct += c1;
-      if (coef_p) coef_p[b * K + k] = -wt;
-      if (coef_q) coef_q[b * K + k] = cq;
+      if (coef_p) coef_p[b * K + k] = -wt * ext.scale;
+      if (coef_q) coef_q[b * K + k] = cq * ext.scale;
     }
     const double cost = bsum_d(ct, shf);
+    my_cost += cost;
     if (threadIdx.x == 0) {
       if (cost_b) cost_b[b] = cost;
       if (bound_b) bound_b[b] = log(S / (double)K) + m1;
     }
   }
+#undef ZS_LW
+  if (ext.mean_cost) {   // deterministic batch mean: the last workgroup to arrive adds the partials in index order
+    if (threadIdx.x == 0) {
+      ext.partials[blockIdx.x] = my_cost;
+      __threadfence();
+      last = (atomicAdd(ext.ticket, 1u) == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {
+      __threadfence();
+      double s = 0.0;
+      for (unsigned i = threadIdx.x; i < gridDim.x; i += 64)
+        s += __hip_atomic_load(ext.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s = wsum_d(s);
+      if (threadIdx.x == 0) {
+        ext.mean_cost[0] = s * ext.inv_B;
+        *ext.ticket = 0u;
+      }
+    }
+  }
 }
+
 
 __global__ __launch_bounds__(256) void k64_lme(const double* __restrict__ x, int64_t ld, int64_t B, int64_t K, double* __restrict__ out) {
   __shared__ double shf[4];
@@ -440,18 +476,39 @@ extern "C" int zs_bernoulli_sample_f64(const double* p, int64_t Pp, double* out,
   return 0;
 }
 
-extern "C" int zs_iw_reduce_f64(const double* logp, int64_t ld_p, const double* logq, int64_t ld_q, int64_t B, int64_t K,
-                                int estimator, double* cost_b, double* bound_b, double* coef_p, double* coef_q, void* stream) {
+static int iw_launch64(int kid, const double* logp, int64_t ld_p, const double* logq, int64_t ld_q, int64_t B, int64_t K, int estimator,
+                       double* cost_b, double* bound_b, double* coef_p, double* coef_q, const IwExt64& ext, int64_t workspace_len,
+                       void* stream) {
   if (B < 0 || K < 1 || ld_p < K || ld_q < K) return ZS_EINVAL;
   if (estimator != ZS_IW_SGVB && estimator != ZS_IW_VIMCO) return ZS_EINVAL;
   if (estimator == ZS_IW_VIMCO && K < 2) return ZS_EINVAL;
   if (K > 0x7fffffff) return ZS_ENOTSUP;
+  if (ext.logp_b && ext.ld_b < K) return ZS_EINVAL;
   if (B == 0) return 0;
   if (!logp || !logq) return ZS_EINVAL;
-  ZS_LAUNCH(KID_IW_REDUCE, k64_iw_reduce, dim3(grid_for(B, 1)), dim3(256), ST, logp, ld_p, logq, ld_q, B, K, estimator, cost_b, bound_b,
-            coef_p, coef_q);
+  const unsigned grid = grid_for(B, 1);
+  if (ext.mean_cost && (!ext.partials || !ext.ticket || workspace_len < (int64_t)grid)) return ZS_EINVAL;
+  ZS_LAUNCH(kid, k64_iw_reduce, dim3(grid), dim3(256), ST, logp, ld_p, logq, ld_q, B, K, estimator, cost_b, bound_b, coef_p, coef_q, ext);
   ZS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int zs_iw_reduce_f64(const double* logp, int64_t ld_p, const double* logq, int64_t ld_q, int64_t B, int64_t K,
+                                int estimator, double* cost_b, double* bound_b, double* coef_p, double* coef_q, void* stream) {
+  const IwExt64 ext = {nullptr, 0, 1.0, nullptr, nullptr, nullptr, 0.0};
+  return iw_launch64(KID_IW_REDUCE, logp, ld_p, logq, ld_q, B, K, estimator, cost_b, bound_b, coef_p, coef_q, ext, 0, stream);
+}
+
+extern "C" int zs_iw_objective_f64(const double* logp_a, int64_t ld_a, const double* logp_b, int64_t ld_b, const double* logq,
+                                   int64_t ld_q, int64_t B, int64_t K, int estimator, int want_mean, double* cost_b,
+                                   double* bound_b, double* coef, double* mean_cost, double* workspace, int64_t workspace_len,
+                                   uint32_t* ticket, void* stream) {
+  if (want_mean && !mean_cost) return ZS_EINVAL;
+  if (B < 0 || K < 1) return ZS_EINVAL;
+  const double inv_B = B > 0 ? 1.0 / (double)B : 0.0;
+  const IwExt64 ext = {logp_b, ld_b, want_mean ? inv_B : 1.0, want_mean ? mean_cost : nullptr, workspace, ticket, inv_B};
+  return iw_launch64(KID_IW_OBJECTIVE, logp_a, ld_a, logq, ld_q, B, K, estimator, cost_b, bound_b, coef, coef ? coef + B * K : nullptr, ext,
+                     workspace_len, stream);
 }
 
 extern "C" int zs_log_mean_exp_f64(const double* x, int64_t ld, int64_t B, int64_t K, double* out, void* stream) {

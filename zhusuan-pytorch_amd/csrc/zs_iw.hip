@@ -24,6 +24,42 @@ struct IwRow {  // row-level scalars, uniform across the lanes that own the row
   float invK, invKm1;
 };
 
+// Extras of zs_iw_objective (all zero / NULL for zs_iw_reduce): second log-joint term, coefficient scale and the
+// deterministic batch mean (per-workgroup partials + last-workgroup-done ticket).
+struct IwExt {
+  const float* logp_b;
+  int64_t ld_b;
+  float scale;
+  float* mean_cost;
+  float* partials;
+  unsigned* ticket;
+  float inv_B;
+};
+
+// Called by every thread of a workgroup after its rows are done: `block_cost` = the workgroup's cost sum (valid in
+// thread 0).  The last workgroup to arrive adds the partials in index order with one wavefront.
+__device__ __forceinline__ void iw_finish_mean(const IwExt& ext, float block_cost) {
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    ext.partials[blockIdx.x] = block_cost;
+    __threadfence();
+    const unsigned t = atomicAdd(ext.ticket, 1u);
+    last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (last && threadIdx.x < 64) {
+    __threadfence();
+    float s = 0.f;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 64)
+      s += __hip_atomic_load(ext.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written by other workgroups
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+      ext.mean_cost[0] = s * ext.inv_B;
+      *ext.ticket = 0u;
+    }
+  }
+}
+
 // per-particle outputs given the row scalars.
 // Learning signal of VIMCO: signal_j = LME(l) - LME(l with l_j -> sub_j) = log(S) - log(S - e_j + t_j),
 // t_j = exp(sub_j - m1).  Formed as -log1p((t_j - e_j)/S) it carries no cancellation between two
@@ -54,15 +90,19 @@ __device__ __forceinline__ void iw_particle(const IwRow& r, float l, float lq, i
 __global__ __launch_bounds__(256) void k_iw_reduce_wave(
     const float* __restrict__ logp, int64_t ld_p, const float* __restrict__ logq, int64_t ld_q,
     int64_t B, int K, int estimator, float* __restrict__ cost_b, float* __restrict__ bound_b,
-    float* __restrict__ coef_p, float* __restrict__ coef_q) {
+    float* __restrict__ coef_p, float* __restrict__ coef_q, IwExt ext) {
+  __shared__ float wave_cost[4];
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const bool on = lane < K;
+  float my_cost = 0.f;
   for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < B; b += nwaves) {
     float lq = 0.f, l = -INFINITY;
     if (on) {
       lq = logq[b * ld_q + lane];
-      l = logp[b * ld_p + lane] - lq;
+      float lp = logp[b * ld_p + lane];
+      if (ext.logp_b) lp += ext.logp_b[b * ext.ld_b + lane];     // (a + b) - q, rounded like the reference's add
+      l = lp - lq;
     }
     IwRow r;
     r.m1 = wave_max(l);
@@ -80,14 +120,20 @@ __global__ __launch_bounds__(256) void k_iw_reduce_wave(
     float wt = 0.f, ct = 0.f, cq = 0.f;
     if (on) iw_particle(r, l, lq, lane, estimator, wt, ct, cq);
     const float cost = wave_sum(ct);
+    my_cost += cost;
     if (on) {
-      if (coef_p) coef_p[b * K + lane] = -wt;
-      if (coef_q) coef_q[b * K + lane] = cq;
+      if (coef_p) coef_p[b * K + lane] = -wt * ext.scale;
+      if (coef_q) coef_q[b * K + lane] = cq * ext.scale;
     }
     if (lane == 0) {
       if (cost_b) cost_b[b] = cost;
       if (bound_b) bound_b[b] = logf(r.S * r.invK) + r.m1;  // log(mean(exp(x - max))) + max, utils.py:18
     }
+  }
+  if (ext.mean_cost) {
+    if (lane == 0) wave_cost[threadIdx.x >> 6] = my_cost;
+    __syncthreads();
+    iw_finish_mean(ext, (wave_cost[0] + wave_cost[1]) + (wave_cost[2] + wave_cost[3]));
   }
 }
 
@@ -122,16 +168,19 @@ __device__ __forceinline__ int block_min_int(int v, int* sh) {
 __global__ __launch_bounds__(256) void k_iw_reduce_block(
     const float* __restrict__ logp, int64_t ld_p, const float* __restrict__ logq, int64_t ld_q,
     int64_t B, int64_t K, int estimator, float* __restrict__ cost_b, float* __restrict__ bound_b,
-    float* __restrict__ coef_p, float* __restrict__ coef_q) {
+    float* __restrict__ coef_p, float* __restrict__ coef_q, IwExt ext) {
   __shared__ float shf[4];
   __shared__ int shi[4];
+  float my_cost = 0.f;
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const float* __restrict__ pp = logp + b * ld_p;
+    const float* __restrict__ pb = ext.logp_b ? ext.logp_b + b * ext.ld_b : nullptr;
     const float* __restrict__ qq = logq + b * ld_q;
+#define ZS_LW(k) ((pb ? pp[k] + pb[k] : pp[k]) - qq[k])
     // pass 1: max, sum of l
     float mx = -INFINITY, sl = 0.f;
     for (int64_t k = threadIdx.x; k < K; k += 256) {
-      const float l = pp[k] - qq[k];
+      const float l = ZS_LW(k);
       mx = fmaxf(mx, l);
       sl += l;
     }
@@ -142,7 +191,7 @@ __global__ __launch_bounds__(256) void k_iw_reduce_block(
     int jm = 0x7fffffff;
     float s = 0.f;
     for (int64_t k = threadIdx.x; k < K; k += 256) {
-      const float l = pp[k] - qq[k];
+      const float l = ZS_LW(k);
       if (l == r.m1 && (int)k < jm) jm = (int)k;
       s += expf(l - r.m1);
     }
@@ -153,11 +202,11 @@ __global__ __launch_bounds__(256) void k_iw_reduce_block(
     if (estimator == ZS_IW_VIMCO) {
       float m2 = -INFINITY;
       for (int64_t k = threadIdx.x; k < K; k += 256)
-        if ((int)k != r.jstar) m2 = fmaxf(m2, pp[k] - qq[k]);
+        if ((int)k != r.jstar) m2 = fmaxf(m2, ZS_LW(k));
       r.m2 = block_max(m2, shf);
       float s2 = 0.f;
       for (int64_t k = threadIdx.x; k < K; k += 256)
-        if ((int)k != r.jstar) s2 += expf((pp[k] - qq[k]) - r.m2);
+        if ((int)k != r.jstar) s2 += expf(ZS_LW(k) - r.m2);
       r.S2 = block_sum(s2, shf);
     }
     r.logS = logf(r.S);
@@ -166,19 +215,22 @@ __global__ __launch_bounds__(256) void k_iw_reduce_block(
     float ct = 0.f;
     for (int64_t k = threadIdx.x; k < K; k += 256) {
       const float lq = qq[k];
-      const float l = pp[k] - lq;
+      const float l = (pb ? pp[k] + pb[k] : pp[k]) - lq;
       float wt, c1, cq;
       iw_particle(r, l, lq, (int)k, estimator, wt, c1, cq);
       ct += c1;
-      if (coef_p) coef_p[b * K + k] = -wt;
-      if (coef_q) coef_q[b * K + k] = cq;
+      if (coef_p) coef_p[b * K + k] = -wt * ext.scale;
+      if (coef_q) coef_q[b * K + k] = cq * ext.scale;
     }
     const float cost = block_sum(ct, shf);
+    my_cost += cost;
     if (threadIdx.x == 0) {
       if (cost_b) cost_b[b] = cost;
       if (bound_b) bound_b[b] = logf(r.S * r.invK) + r.m1;
     }
   }
+#undef ZS_LW
+  if (ext.mean_cost) iw_finish_mean(ext, my_cost);
 }
 
 __global__ __launch_bounds__(256) void k_philox_normal(float* __restrict__ out, int64_t N, uint64_t seed,
@@ -200,24 +252,46 @@ __global__ __launch_bounds__(256) void k_philox_normal(float* __restrict__ out, 
 
 }  // namespace
 
-extern "C" int zs_iw_reduce_f32(const float* logp, int64_t ld_p, const float* logq, int64_t ld_q, int64_t B,
-                                int64_t K, int estimator, float* cost_b, float* bound_b, float* coef_p,
-                                float* coef_q, void* stream) {
+static int iw_launch(int kid, const float* logp, int64_t ld_p, const float* logq, int64_t ld_q, int64_t B, int64_t K, int estimator,
+                     float* cost_b, float* bound_b, float* coef_p, float* coef_q, const IwExt& ext, int64_t workspace_len,
+                     void* stream) {
   if (B < 0 || K < 1 || ld_p < K || ld_q < K) return ZS_EINVAL;
   if (estimator != ZS_IW_SGVB && estimator != ZS_IW_VIMCO) return ZS_EINVAL;
   if (estimator == ZS_IW_VIMCO && K < 2) return ZS_EINVAL;
   if (K > 0x7fffffff) return ZS_ENOTSUP;
+  if (ext.logp_b && ext.ld_b < K) return ZS_EINVAL;
   if (B == 0) return 0;
   if (!logp || !logq) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = K <= 64 ? grid_for(B, 4) : grid_for(B, 1);
+  if (ext.mean_cost && (!ext.partials || !ext.ticket || workspace_len < (int64_t)grid)) return ZS_EINVAL;
   if (K <= 64)
-    ZS_LAUNCH(KID_IW_REDUCE, k_iw_reduce_wave, dim3(grid_for(B, 4)), dim3(256), st, logp, ld_p, logq, ld_q, B,
-                       (int)K, estimator, cost_b, bound_b, coef_p, coef_q);
+    ZS_LAUNCH(kid, k_iw_reduce_wave, dim3(grid), dim3(256), st, logp, ld_p, logq, ld_q, B, (int)K, estimator, cost_b, bound_b, coef_p,
+              coef_q, ext);
   else
-    ZS_LAUNCH(KID_IW_REDUCE, k_iw_reduce_block, dim3(grid_for(B, 1)), dim3(256), st, logp, ld_p, logq, ld_q, B, K,
-                       estimator, cost_b, bound_b, coef_p, coef_q);
+    ZS_LAUNCH(kid, k_iw_reduce_block, dim3(grid), dim3(256), st, logp, ld_p, logq, ld_q, B, K, estimator, cost_b, bound_b, coef_p,
+              coef_q, ext);
   ZS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int zs_iw_reduce_f32(const float* logp, int64_t ld_p, const float* logq, int64_t ld_q, int64_t B,
+                                int64_t K, int estimator, float* cost_b, float* bound_b, float* coef_p,
+                                float* coef_q, void* stream) {
+  const IwExt ext = {nullptr, 0, 1.0f, nullptr, nullptr, nullptr, 0.f};
+  return iw_launch(KID_IW_REDUCE, logp, ld_p, logq, ld_q, B, K, estimator, cost_b, bound_b, coef_p, coef_q, ext, 0, stream);
+}
+
+extern "C" int zs_iw_objective_f32(const float* logp_a, int64_t ld_a, const float* logp_b, int64_t ld_b, const float* logq,
+                                   int64_t ld_q, int64_t B, int64_t K, int estimator, int want_mean, float* cost_b,
+                                   float* bound_b, float* coef, float* mean_cost, float* workspace, int64_t workspace_len,
+                                   uint32_t* ticket, void* stream) {
+  if (want_mean && !mean_cost) return ZS_EINVAL;
+  if (B < 0 || K < 1) return ZS_EINVAL;
+  const float inv_B = B > 0 ? 1.0f / (float)B : 0.f;
+  const IwExt ext = {logp_b, ld_b, want_mean ? inv_B : 1.0f, want_mean ? mean_cost : nullptr, workspace, ticket, inv_B};
+  return iw_launch(KID_IW_OBJECTIVE, logp_a, ld_a, logq, ld_q, B, K, estimator, cost_b, bound_b, coef, coef ? coef + B * K : nullptr, ext,
+                   workspace_len, stream);
 }
 
 // log_mean_exp over K-fastest rows: the IW reduction with logq == 0 and only the bound requested
@@ -294,7 +368,7 @@ const char* const kKernelNames[zs::KID_COUNT] = {
     "zs_bernoulli_sample_f32", "zs_iw_reduce_f32", "zs_log_mean_exp_f32", "zs_philox_normal_f32",
     "zs_logistic_sample_logprob_f32", "zs_logistic_sample_logprob_bwd_f32", "zs_logistic_logprob_f32",
     "zs_logistic_logprob_bwd_f32", "zs_uniform_sample_f32", "zs_uniform_logprob_f32", "zs_philox_uniform_f32",
-    "zs_reinforce_f32"};
+    "zs_reinforce_f32", "zs_iw_objective_f32"};
 void prof_clear(ProfState& s) {
   for (int k = 0; k < zs::KID_COUNT; ++k) {
     for (auto& p : s.ev[k]) {

@@ -278,6 +278,76 @@ class IWReduce(torch.autograd.Function):
         return gp, gq, None
 
 
+_IW_WORKSPACE = {}     # (device, dtype) -> (partials [4096], ticket [1] int32): scratch of the deterministic batch mean
+
+
+def _iw_workspace(device, dtype):
+    key = (str(device), dtype)
+    ws = _IW_WORKSPACE.get(key)
+    if ws is None:
+        ws = (torch.zeros(4096, dtype=dtype, device=device), torch.zeros(1, dtype=torch.int32, device=device))
+        _IW_WORKSPACE[key] = ws
+    return ws
+
+
+def _rows_for_iw(t, K):
+    """[B, K] operand of the IW kernels with unit stride along K; returns (tensor, leading dimension)."""
+    B = t.shape[0]
+    if K > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    ld = t.stride(0) if B > 1 else K
+    if ld < K:
+        t, ld = t.contiguous(), K
+    return t, ld
+
+
+class IWObjective(torch.autograd.Function):
+    """K4b: the whole importance-weighted objective in one launch -- log w = (logp_a + logp_b) - logq, the per-datapoint
+    IWAE / VIMCO costs, their batch mean and both gradient-coefficient matrices (zhusuan/variational/
+    importance_weighted_objective.py:97-98,102-191).  Operands are K-fastest [B, K] matrices.
+    Returns (cost, bound_b): cost is the 0-d batch mean when `want_mean`, else the [B] costs; bound_b =
+    log_mean_exp(log w) per datapoint is a detached diagnostic.  Backward is ONE multiply of the [2, B, K] coefficient
+    buffer (already scaled by 1/B) with the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, logp_a, logp_b, logq, estimator, want_mean):
+        ctx.set_materialize_grads(False)
+        _hip.require_device(logp_a, logp_b, logq)
+        sfx = _sfx(logp_a, logp_b, logq)
+        B, K = logq.shape
+        pa, ld_a = _rows_for_iw(logp_a, K)
+        pb, ld_b = (None, K) if logp_b is None else _rows_for_iw(logp_b, K)
+        q, ld_q = _rows_for_iw(logq, K)
+        dt, dev = logq.dtype, logq.device
+        bound = torch.empty(B, dtype=dt, device=dev)
+        coef = torch.empty((2, B, K), dtype=dt, device=dev)
+        if want_mean:
+            cost = torch.empty((), dtype=dt, device=dev)
+            ws, ticket = _iw_workspace(dev, dt)
+            _hip.lib().call("zs_iw_objective" + sfx, _hip.ptr(pa), ld_a, _hip.ptr(pb), ld_b, _hip.ptr(q), ld_q, B, K, estimator, 1,
+                            None, _hip.ptr(bound), _hip.ptr(coef), _hip.ptr(cost), _hip.ptr(ws), ws.numel(), _hip.ptr(ticket),
+                            _hip.stream_for(q))
+        else:
+            cost = torch.empty(B, dtype=dt, device=dev)
+            _hip.lib().call("zs_iw_objective" + sfx, _hip.ptr(pa), ld_a, _hip.ptr(pb), ld_b, _hip.ptr(q), ld_q, B, K, estimator, 0,
+                            _hip.ptr(cost), _hip.ptr(bound), _hip.ptr(coef), None, None, 0, None, _hip.stream_for(q))
+        ctx.save_for_backward(coef)
+        ctx.has_b = logp_b is not None
+        ctx.want_mean = bool(want_mean)
+        ctx.mark_non_differentiable(bound)
+        return cost, bound
+
+    @staticmethod
+    def backward(ctx, g_cost, g_bound):
+        if g_cost is None:
+            return None, None, None, None, None
+        (coef,) = ctx.saved_tensors
+        gc = coef * (g_cost if ctx.want_mean else g_cost.reshape(1, -1, 1))
+        gp = gc[0]
+        return (gp if ctx.needs_input_grad[0] else None, gp if (ctx.has_b and ctx.needs_input_grad[1]) else None,
+                gc[1] if ctx.needs_input_grad[2] else None, None, None)
+
+
 class LogMeanExpRows(torch.autograd.Function):
     """log_mean_exp over the last (contiguous) axis of a 2-D tensor (zhusuan/utils.py:6-21)."""
 

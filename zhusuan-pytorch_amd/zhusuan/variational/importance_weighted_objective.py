@@ -48,7 +48,9 @@ class ImportanceWeightedObjective(nn.Module):
         return log_joint_
 
     def forward(self, observed, reduce_mean=True):
-        """importance_weighted_objective.py:79-100."""
+        """importance_weighted_objective.py:79-100.  The generator's log-joint is handed to the kernel as (up to) two
+        terms, so that its last addition (e.g. log p(x|z) + log p(z)), the subtraction of log q, the K-particle
+        reductions and the batch mean are ONE launch; the value is rounded exactly like the reference's separate ops."""
         self.variational(observed)
         nodes_q = self.variational.nodes
         _v_inputs = {}
@@ -58,18 +60,22 @@ class ImportanceWeightedObjective(nn.Module):
                 raise ValueError("with vimco estimator, the is_reparameterized must be false")
         _observed = {**_v_inputs, **observed}
         nodes_p = self.generator(_observed).nodes
-        logpxz = self.log_joint(nodes_p)
+        terms_p = [nodes_p[n].log_prob() for n in nodes_p.keys()]
         logqz = self.log_joint(nodes_q)
-        if self.estimator == 'sgvb':
-            return self.sgvb(logpxz, logqz, reduce_mean)
-        return self.vimco(logpxz, logqz, reduce_mean)
+        head = None
+        for t in terms_p[:-1]:                      # left-to-right, as log_joint sums them
+            head = t if head is None else head + t
+        if head is None:
+            return self._objective(terms_p[0], None, logqz, reduce_mean)
+        return self._objective(head, terms_p[-1], logqz, reduce_mean)
 
-    def _rows(self, logpxz, logqz):
-        """Both log-joints as K-fastest [B, K] matrices plus the shape of the non-particle axes.
+    def _rows(self, tensors):
+        """The given log-joint tensors as K-fastest [B, K] matrices plus K and the shape of the non-particle axes.
         Tensors produced by the log-prob kernels already have this layout, so no copy happens."""
-        logpxz = torch.as_tensor(logpxz)
-        logqz = torch.as_tensor(logqz, device=logpxz.device)
-        shape = broadcast_shapes(logpxz.shape, logqz.shape)
+        tensors = [torch.as_tensor(t) for t in tensors]
+        dev = tensors[0].device
+        tensors = [t if t.device == dev else t.to(dev) for t in tensors]
+        shape = broadcast_shapes(*[tuple(t.shape) for t in tensors])
         if len(shape) == 0:
             raise ValueError(_ERR_VIMCO)
         axis = self._axis % len(shape)
@@ -79,25 +85,27 @@ class ImportanceWeightedObjective(nn.Module):
         def rows(t):
             t = t.expand(shape) if tuple(t.shape) != tuple(shape) else t
             return t.movedim(axis, -1).reshape(-1, K)
-        return rows(logpxz), rows(logqz), K, rest
+        return [rows(t) for t in tensors], K, rest
+
+    def _objective(self, logp_a, logp_b, logqz, reduce_mean, estimator=None):
+        vimco = (estimator or self.estimator) == 'vimco'
+        try:
+            mats, K, rest = self._rows([logp_a, logqz] if logp_b is None else [logp_a, logp_b, logqz])
+        except (IndexError, ZeroDivisionError):
+            raise ValueError(_ERR_VIMCO)
+        if vimco and K < 2:
+            raise ValueError(_ERR_VIMCO)
+        a2, q2 = mats[0], mats[-1]
+        b2 = mats[1] if logp_b is not None else None
+        want_mean = True if vimco else bool(reduce_mean)      # vimco always returns the batch mean (:191)
+        cost, bound_b = _ops.IWObjective.apply(a2, b2, q2, _ops.ZS_IW_VIMCO if vimco else _ops.ZS_IW_SGVB, want_mean)
+        self.last_iw_bound = bound_b.reshape(rest)
+        return cost if want_mean else cost.reshape(rest)
 
     def sgvb(self, logpxz, logqz, reduce_mean=True):
-        """importance_weighted_objective.py:102-132 with compute_iw_term (:16-25) in one kernel."""
-        p2, q2, K, rest = self._rows(logpxz, logqz)
-        cost_b, bound_b = _ops.IWReduce.apply(p2, q2, _ops.ZS_IW_SGVB)
-        self.last_iw_bound = bound_b.reshape(rest)
-        if reduce_mean:
-            return torch.mean(cost_b)
-        return cost_b.reshape(rest)
+        """importance_weighted_objective.py:102-132 with compute_iw_term (:16-25), one kernel."""
+        return self._objective(logpxz, None, logqz, reduce_mean, 'sgvb')
 
     def vimco(self, logpxz, logqz, reduce_mean=True):
         """importance_weighted_objective.py:134-191.  Always returns the batch mean, like the reference."""
-        try:
-            p2, q2, K, rest = self._rows(logpxz, logqz)
-        except (IndexError, ZeroDivisionError):
-            raise ValueError(_ERR_VIMCO)
-        if K < 2:
-            raise ValueError(_ERR_VIMCO)
-        cost_b, bound_b = _ops.IWReduce.apply(p2, q2, _ops.ZS_IW_VIMCO)
-        self.last_iw_bound = bound_b.reshape(rest)
-        return cost_b.mean()
+        return self._objective(logpxz, None, logqz, reduce_mean, 'vimco')
