@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 6
+#define ZS_ABI_VERSION 7
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -294,6 +294,22 @@ int zs_reinforce_f32(const float* logp, const float* logq, const float* baseline
                      float* moving_mean, int32_t* local_step,
                      float* signal, float* cost, float* resid, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * S1  Scalar ELBO epilogue: out[0] = sum_t coef[t] * sum_i rows_t[i]  for up to ZS_MAX_TERMS dense vectors.
+ * Replaces, for objectives whose nodes all reduce to scalars (the VAE and BNN callers: reduce_mean_dims /
+ * reduce_sum_dims / multiplier of StochasticTensor.log_prob, zhusuan/framework/stochastic_tensor.py:160-181, then
+ * ELBO.log_joint + ELBO.sgvb, zhusuan/variational/elbo.py:58-79,155-161), the per-node mean / sum / multiply launches
+ * and the scalar adds, subtract and negation: one launch forward.  coef_out (n_terms values, optional) receives the
+ * coefficients, so that backward is one multiply of that vector by the incoming gradient (d out / d rows_t[i] = coef[t]).
+ * Unused slots: rows == NULL (n ignored).  One workgroup; sums are accumulated in double in a fixed order.
+ * -------------------------------------------------------------------------*/
+#define ZS_MAX_TERMS 6
+int zs_scalar_objective_f32(const float* r0, int64_t n0, double c0, const float* r1, int64_t n1, double c1,
+                            const float* r2, int64_t n2, double c2, const float* r3, int64_t n3, double c3,
+                            const float* r4, int64_t n4, double c4, const float* r5, int64_t n5, double c5,
+                            float* out, float* coef_out, void* stream);
+
+
 
 
 /* ---------------------------------------------------------------------------
@@ -324,6 +340,7 @@ int zs_uniform_sample_f64(const double* low, int64_t Pl, const double* high, int
 int zs_uniform_logprob_f64(const double* x, int64_t Px, const double* low, int64_t Pl, const double* high, int64_t Ph, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
 int zs_philox_uniform_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 int zs_reinforce_f64(const double* logp, const double* logq, const double* baseline, int64_t Pb, int64_t n, int variance_reduction, int do_mean, double decay, float* moving_mean, int32_t* local_step, double* signal, double* cost, double* resid, void* stream);
+int zs_scalar_objective_f64(const double* r0, int64_t n0, double c0, const double* r1, int64_t n1, double c1, const double* r2, int64_t n2, double c2, const double* r3, int64_t n3, double c3, const double* r4, int64_t n4, double c4, const double* r5, int64_t n5, double c5, double* out, double* coef_out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Per-kernel timing for the benchmark harness (no reference counterpart).

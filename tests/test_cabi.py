@@ -27,14 +27,14 @@ def declared_symbols():
 
 def test_header_symbols_exported_by_both_libraries():
     names = declared_symbols()
-    assert len(names) == 49 and set(_hip.PROTOTYPES) <= set(names)
+    assert len(names) == 51 and set(_hip.PROTOTYPES) <= set(names)
     hip = ctypes.CDLL(_hip.LIB_PATH)           # loads without a GPU; no compute call is made here
     orc = ctypes.CDLL(build_oracle_lib())
     for n in names:
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 6
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 7
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 
@@ -597,3 +597,44 @@ def test_hip_iw_objective_f64(hip64, orc64):
             np.testing.assert_allclose(got["mean"], ref["mean"], rtol=1e-10)
             np.testing.assert_allclose(got["cost"], ref["cost"], rtol=1e-9, atol=1e-7)
             np.testing.assert_allclose(got["coef"], ref["coef"], rtol=1e-6, atol=1e-9)
+
+
+# ------------------------------------------------------------------ S1: scalar ELBO epilogue
+def _scalar_objective(raw, vecs, coefs):
+    out, cv = raw.empty(1), raw.empty(6)
+    args = []
+    for j in range(6):
+        if j < len(vecs):
+            args += [raw.t(vecs[j]), int(np.asarray(vecs[j]).size), float(coefs[j])]
+        else:
+            args += [None, 0, 0.0]
+    raw.call("zs_scalar_objective_f32", *args, out, cv)
+    return float(out.cpu().numpy()[0]), cv.cpu().numpy()[:len(vecs)]
+
+
+def test_c_oracle_scalar_objective(orc):
+    rng = np.random.RandomState(3)
+    vecs = [rng.standard_normal(n).astype(np.float32) - 90 for n in (1, 7, 512, 3000)]
+    coefs = [-1.0, 1.0 / 7, -456.0 / 512, 0.25]
+    val, cv = _scalar_objective(orc, vecs, coefs)
+    exact = sum(c * v.astype(np.float64).sum() for c, v in zip(coefs, vecs))
+    assert abs(val - exact) <= 2e-7 * abs(exact)
+    np.testing.assert_allclose(cv, np.asarray(coefs, np.float32), rtol=0, atol=0)
+    with pytest.raises(RuntimeError, match="code -1"):
+        _scalar_objective(orc, [], [])
+
+
+@pytest.mark.gpu
+def test_hip_scalar_objective(hip, orc, hip64, orc64):
+    rng = np.random.RandomState(4)
+    for sizes in [(1,), (5, 1), (512, 512, 512), (64, 65, 1024, 1025, 100000, 3)]:
+        vecs = [rng.standard_normal(n) * 3 - 50 for n in sizes]
+        coefs = list(rng.standard_normal(len(sizes)))
+        exact = sum(c * np.asarray(v, np.float32).astype(np.float64).sum() for c, v in zip(coefs, vecs))
+        a, ca = _scalar_objective(hip, [v.astype(np.float32) for v in vecs], coefs)
+        b, cb = _scalar_objective(orc, [v.astype(np.float32) for v in vecs], coefs)
+        assert abs(a - exact) <= 3e-7 * max(1.0, abs(exact)) and abs(a - b) <= 3e-7 * max(1.0, abs(exact))
+        np.testing.assert_array_equal(ca, cb)
+        a64, _ = _scalar_objective(hip64, vecs, coefs)
+        exact64 = sum(c * v.sum() for c, v in zip(coefs, vecs))
+        assert abs(a64 - exact64) <= 1e-12 * max(1.0, abs(exact64))

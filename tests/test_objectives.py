@@ -405,3 +405,43 @@ def test_helpers_of_families_outside_the_build_raise_clearly(dev):
     z = d.sample(2)
     assert torch.equal(d._log_prob(sample=z), d._log_prob(z))          # the reference's keyword name
     assert list(d._log_prob().shape) == [2, 3]                          # None -> cached sample
+
+
+def test_scalar_sgvb_fast_path_is_taken_and_equals_the_unfused_objective(dev):
+    """VAE-shaped nets: every node reduces to a scalar, so ELBO.forward goes through ONE zs_scalar_objective launch;
+    its value and gradients must equal log_joint + sgvb evaluated node by node on the same draws."""
+    from zhusuan import _ops
+    from examples import vae_mnist
+    torch.manual_seed(0)
+    model = vae_mnist.build(16, device=dev)
+    x = (torch.rand(16, 784, device=dev) < 0.5).float()
+    eps = [np.random.RandomState(i).standard_normal((16, 40)).astype(np.float32) for i in range(4)]
+    calls = []
+    orig = _ops.ScalarObjective.apply
+
+    def spy(*a, **k):
+        calls.append(len(a) - 1)
+        return orig(*a, **k)
+    _ops.ScalarObjective.apply = spy
+    try:
+        with zs.inject_epsilon(eps[:2]):
+            loss = model({"x": x})
+    finally:
+        _ops.ScalarObjective.apply = orig
+    assert calls == [3]                                        # log p(x|z), log p(z), log q(z|x) in one launch
+    grads = torch.autograd.grad(loss, list(model.parameters()))
+    # the same objective, node by node (the reference's op sequence)
+    with zs.inject_epsilon(eps[:2]):
+        model.variational({"x": x})
+        nodes_q = model.variational.nodes
+        obs = {k: v.tensor for k, v in nodes_q.items()}
+        obs["x"] = x
+        model.generator(obs)
+        loss2 = model.sgvb(model.log_joint(model.generator.nodes), model.log_joint(nodes_q))
+    grads2 = torch.autograd.grad(loss2, list(model.parameters()))
+    np.testing.assert_allclose(float(loss), float(loss2), rtol=2e-6)
+    for a, b in zip(grads, grads2):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6)
+    # a node that keeps its batch axis switches the fast path off
+    plan = model.generator.nodes["x"]._scalar_term(rows=False)
+    assert plan is not None and abs(plan[1] - 1.0 / 16) < 1e-12

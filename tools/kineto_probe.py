@@ -10,16 +10,20 @@ from torch.profiler import profile, ProfilerActivity
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-model = iwae.build(50, "vimco", device=dev)
+import sys as _s
+KIND = _s.argv[1] if len(_s.argv) > 1 else "iwae"
+from examples import vae_mnist, bnn_vi
+model = iwae.build(50, "vimco", device=dev) if KIND == "iwae" else (vae_mnist.build(512, device=dev) if KIND == "vae" else bnn_vi.build(n_particles=10, device=dev))
 opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
 rng = zhusuan.DeviceRNG(dev, seed=1)
-x = (torch.rand(256, 784, device=dev) < 0.5).float()
+x = (torch.rand(256 if KIND == "iwae" else 512, 784, device=dev) < 0.5).float()
+obs = {"x": x} if KIND != "bnn" else {"x": torch.randn(512, 13, device=dev), "y": torch.randn(512, device=dev)}
 
 def compute():
     rng.begin_step()
     for p in model.parameters():
         p.grad = None
-    loss = model({"x": x}); loss.backward()
+    loss = model(obs); loss.backward()
     return loss.detach()
 step = zhusuan.GraphedStep(compute, opt.step, rng=rng, warmup=5)
 for _ in range(5): step()

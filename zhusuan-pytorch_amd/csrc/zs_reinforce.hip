@@ -1,3 +1,4 @@
+// Scalar epilogues of the ELBO.
 // R1: score-function (REINFORCE) epilogue of the ELBO in one launch (include/zs_hip.h; reference
 // zhusuan/variational/elbo.py:163-238).  The operands are the per-datapoint (or already batch-reduced) log-joints, so n
 // is small -- one 1024-thread workgroup walks them twice (mean of the learning signal, then the cost); the moving
@@ -102,4 +103,64 @@ extern "C" int zs_reinforce_f64(const double* logp, const double* logq, const do
                                 double* signal, double* cost, double* resid, void* stream) {
   return reinforce<double>(logp, logq, baseline, Pb, n, variance_reduction, do_mean, decay, moving_mean, local_step, signal, cost,
                            resid, stream);
+}
+
+// ---------------------------------------------------------------- S1: out = sum_t coef_t * sum_i rows_t[i]
+namespace {
+
+template <typename T>
+struct Terms {
+  const T* r[ZS_MAX_TERMS];
+  int64_t n[ZS_MAX_TERMS];
+  double c[ZS_MAX_TERMS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scalar_objective(Terms<T> t, T* __restrict__ out, T* __restrict__ coef_out) {
+  __shared__ double sh[16];
+  double total = 0.0;
+#pragma unroll
+  for (int j = 0; j < ZS_MAX_TERMS; ++j) {
+    if (t.r[j] == nullptr) continue;                       // uniform
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < t.n[j]; i += blockDim.x) s += (double)t.r[j][i];
+    s = block_sum_1024(s, sh);
+    total += t.c[j] * s;
+    if (coef_out && threadIdx.x == 0) coef_out[j] = (T)t.c[j];
+  }
+  if (threadIdx.x == 0) out[0] = (T)total;
+}
+
+template <typename T>
+int scalar_objective(const Terms<T>& t, T* out, T* coef_out, void* stream) {
+  int64_t nmax = 0;
+  bool any = false;
+  for (int j = 0; j < ZS_MAX_TERMS; ++j) {
+    if (!t.r[j]) continue;
+    if (t.n[j] < 0) return ZS_EINVAL;
+    any = true;
+    nmax = t.n[j] > nmax ? t.n[j] : nmax;
+  }
+  if (!out || !any) return ZS_EINVAL;
+  ZS_LAUNCH(KID_SCALAR_OBJECTIVE, (k_scalar_objective<T>), dim3(1), dim3(nmax >= 1024 ? 1024 : (nmax > 64 ? 256 : 64)),
+            (hipStream_t)stream, t, out, coef_out);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+#define ZS_TERMS(T) Terms<T> t = {{r0, r1, r2, r3, r4, r5}, {n0, n1, n2, n3, n4, n5}, {c0, c1, c2, c3, c4, c5}}
+extern "C" int zs_scalar_objective_f32(const float* r0, int64_t n0, double c0, const float* r1, int64_t n1, double c1, const float* r2,
+                                       int64_t n2, double c2, const float* r3, int64_t n3, double c3, const float* r4, int64_t n4,
+                                       double c4, const float* r5, int64_t n5, double c5, float* out, float* coef_out, void* stream) {
+  ZS_TERMS(float);
+  return scalar_objective<float>(t, out, coef_out, stream);
+}
+extern "C" int zs_scalar_objective_f64(const double* r0, int64_t n0, double c0, const double* r1, int64_t n1, double c1,
+                                       const double* r2, int64_t n2, double c2, const double* r3, int64_t n3, double c3,
+                                       const double* r4, int64_t n4, double c4, const double* r5, int64_t n5, double c5, double* out,
+                                       double* coef_out, void* stream) {
+  ZS_TERMS(double);
+  return scalar_objective<double>(t, out, coef_out, stream);
 }

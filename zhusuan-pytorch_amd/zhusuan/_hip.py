@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -48,6 +48,8 @@ PROTOTYPES = {
     "zs_reinforce_f32": [_p, _p, _p, _i64, _i64, _int, _int, ctypes.c_double, _p, _p, _p, _p, _p, _p],
     # the whole importance-weighted objective in one launch
     "zs_iw_objective_f32": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _i64, _p, _p],
+    # scalar ELBO epilogue: six (rows, n, coef) slots, out, coef_out, stream
+    "zs_scalar_objective_f32": [_p, _i64, ctypes.c_double] * 6 + [_p, _p, _p],
 }
 
 

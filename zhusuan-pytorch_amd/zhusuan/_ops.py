@@ -348,6 +348,58 @@ class IWObjective(torch.autograd.Function):
                 gc[1] if ctx.needs_input_grad[2] else None, None, None)
 
 
+MAX_TERMS = 6      # ZS_MAX_TERMS of include/zs_hip.h
+
+
+def _dense_flat(t):
+    """`t` as a flat view of its storage when it is dense (any permutation of a contiguous block), else a flat copy:
+    the scalar epilogue only needs the SUM of the elements, so their order is irrelevant."""
+    if t.dim() == 0:
+        return t.reshape(1)
+    if t.is_contiguous():
+        return t.reshape(-1)
+    try:
+        if t.storage_offset() == 0 and t.untyped_storage().nbytes() == t.numel() * t.element_size():
+            return torch.as_strided(t, (t.numel(),), (1,))
+    except RuntimeError:
+        pass
+    return t.contiguous().reshape(-1)
+
+
+class ScalarObjective(torch.autograd.Function):
+    """S1: ``sum_t coefs[t] * tensors[t].sum()`` in one launch; backward is one multiply of the coefficient vector by
+    the incoming gradient, handed to every operand as a stride-0 expansion (the log-prob kernels read their incoming
+    gradient through strides, so nothing is materialised)."""
+
+    @staticmethod
+    def forward(ctx, coefs, *tensors):
+        if not (1 <= len(tensors) <= MAX_TERMS) or len(coefs) != len(tensors):
+            raise ValueError("ScalarObjective takes 1..%d (coefficient, tensor) pairs" % MAX_TERMS)
+        _hip.require_device(*tensors)
+        sfx = _sfx(*tensors)
+        flats = [_dense_flat(t) for t in tensors]
+        dt, dev = tensors[0].dtype, tensors[0].device
+        out = torch.empty((), dtype=dt, device=dev)
+        cvec = torch.empty(len(tensors), dtype=dt, device=dev)
+        args = []
+        for j in range(MAX_TERMS):
+            if j < len(flats):
+                args += [_hip.ptr(flats[j]), flats[j].numel(), float(coefs[j])]
+            else:
+                args += [None, 0, 0.0]
+        _hip.lib().call("zs_scalar_objective" + sfx, *args, _hip.ptr(out), _hip.ptr(cvec), _hip.stream_for(tensors[0]))
+        ctx.save_for_backward(cvec)
+        ctx.shapes = [tuple(t.shape) for t in tensors]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (cvec,) = ctx.saved_tensors
+        gv = cvec * g
+        return (None,) + tuple(gv[j].expand(shape) if ctx.needs_input_grad[j + 1] else None
+                               for j, shape in enumerate(ctx.shapes))
+
+
 class LogMeanExpRows(torch.autograd.Function):
     """log_mean_exp over the last (contiguous) axis of a 2-D tensor (zhusuan/utils.py:6-21)."""
 

@@ -82,14 +82,8 @@ class StochasticTensor(object):
     def get_shape(self):
         return self.shape
 
-    def log_prob(self, sample=None):
-        """stochastic_tensor.py:160-181: dist.log_prob -> mean over reduce_mean_dims -> sum over
-        reduce_sum_dims -> drop those axes -> * multiplier.
-
-        Trailing axes that are only summed are folded into the log-prob kernel's row sum (together with
-        the distribution's group_ndims axes); the remaining reductions act on the already reduced,
-        small tensor.  Sums and means over distinct axes commute, so the value is the reference's up to
-        fp32 summation order."""
+    def _reduction_plan(self, sample=None):
+        """(value, ndim of dist.log_prob, mean dims, sum dims, trailing sum dims folded into the kernel)."""
         dist = self._dist
         g = dist.group_ndims
         x = dist.sample_cache if sample is None else sample
@@ -102,6 +96,36 @@ class StochasticTensor(object):
         extra = 0
         while nd - 1 - extra >= 0 and (nd - 1 - extra) in sum_dims and (nd - 1 - extra) not in mean_dims:
             extra += 1
+        return full, nd, mean_dims, sum_dims, extra
+
+    def _scalar_term(self, sample=None, rows=True):
+        """When the node's reductions collapse EVERY axis (the VAE / BNN callers), ``log_prob()`` is
+        ``coef * rows.sum()``: returns (rows, coef) so that the objective can fold all nodes into one launch
+        (zs_scalar_objective); None otherwise.  Means and sums over distinct axes commute, so
+        coef = multiplier / prod(sizes of the mean axes).  ``rows=False`` only answers the question (no kernel)."""
+        full, nd, mean_dims, sum_dims, extra = self._reduction_plan(sample)
+        if nd == 0 or set(mean_dims) | set(sum_dims) != set(range(nd)) or set(mean_dims) & set(sum_dims):
+            return None
+        coef = 1.0
+        for d in mean_dims:
+            coef /= float(full[d])
+        if self._multiplier:
+            coef *= float(self._multiplier)
+        if not rows:
+            return None, coef
+        return self._dist._log_prob_sum(sample, self._dist.group_ndims + extra), coef
+
+    def log_prob(self, sample=None):
+        """stochastic_tensor.py:160-181: dist.log_prob -> mean over reduce_mean_dims -> sum over
+        reduce_sum_dims -> drop those axes -> * multiplier.
+
+        Trailing axes that are only summed are folded into the log-prob kernel's row sum (together with
+        the distribution's group_ndims axes); the remaining reductions act on the already reduced,
+        small tensor.  Sums and means over distinct axes commute, so the value is the reference's up to
+        fp32 summation order."""
+        dist = self._dist
+        g = dist.group_ndims
+        full, nd, mean_dims, sum_dims, extra = self._reduction_plan(sample)
         lp = dist._log_prob_sum(sample, g + extra)
         rest_sum = [d for d in sum_dims if d < nd - extra]
         if mean_dims:

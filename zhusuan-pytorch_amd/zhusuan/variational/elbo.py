@@ -63,11 +63,35 @@ class ELBO(nn.Module):
         _observed = {**_v_inputs, **observed}
         self.generator(_observed)
         nodes_p = self.generator.nodes
+        if self.estimator == "sgvb":
+            fused = self._scalar_sgvb(nodes_p, nodes_q)
+            if fused is not None:
+                return fused
         logpxz = self.log_joint(nodes_p)
         logqz = self.log_joint(nodes_q)
         if self.estimator == "sgvb":
             return self.sgvb(logpxz, logqz, reduce_mean)
         return self.reinforce(logpxz, logqz, reduce_mean, **kwargs)
+
+    def _scalar_sgvb(self, nodes_p, nodes_q):
+        """When every node's log-probability reduces to a scalar (the VAE and BNN callers), the whole sgvb objective
+        -(sum_p log p - sum_q log q) is a weighted sum of the kernels' row results: ONE launch (S1,
+        ``zs_scalar_objective``) instead of a mean / sum / multiply per node plus the scalar adds, the subtraction and
+        the negation of elbo.py:58-79,155-161.  Returns None when some node keeps a non-scalar shape."""
+        plan = [(sign, nodes[name]) for sign, nodes in ((-1.0, nodes_p), (1.0, nodes_q)) for name in nodes.keys()]
+        if not plan or len(plan) > _ops.MAX_TERMS:
+            return None
+        for _, node in plan:                        # decide first (no kernel is launched by the question)
+            if not hasattr(node, '_scalar_term') or node._scalar_term(rows=False) is None:
+                return None
+        terms, coefs = [], []
+        for sign, node in plan:
+            rows, coef = node._scalar_term()
+            terms.append(rows)
+            coefs.append(sign * coef)
+        if len({t.dtype for t in terms}) != 1:
+            return None
+        return _ops.ScalarObjective.apply(tuple(coefs), *terms)
 
     def sgvb(self, logpxz, logqz, reduce_mean=True, log_det=None):
         """elbo.py:134-161."""
