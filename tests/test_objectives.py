@@ -445,3 +445,29 @@ def test_scalar_sgvb_fast_path_is_taken_and_equals_the_unfused_objective(dev):
     # a node that keeps its batch axis switches the fast path off
     plan = model.generator.nodes["x"]._scalar_term(rows=False)
     assert plan is not None and abs(plan[1] - 1.0 / 16) < 1e-12
+
+
+def test_subclass_hooks_are_honoured_by_the_fused_paths(dev):
+    """Overriding log_joint / sgvb / vimco (the reference's extension points) must switch the single-launch paths off."""
+    from examples import vae_mnist, iwae
+    torch.manual_seed(0)
+    x = (torch.rand(8, 784, device=dev) < 0.5).float()
+    seen = []
+
+    base = vae_mnist.build(8, device=dev)
+
+    class MyELBO(ELBO):
+        def sgvb(self, logpxz, logqz, reduce_mean=True, log_det=None):
+            seen.append("sgvb")
+            return super().sgvb(logpxz, logqz, reduce_mean, log_det)
+    m = MyELBO(base.generator, base.variational)
+    assert np.isfinite(float(m({"x": x}))) and seen == ["sgvb"]
+
+    ib = iwae.build(4, "sgvb", hidden=32, device=dev)
+
+    class MyIW(ImportanceWeightedObjective):
+        def log_joint(self, nodes):
+            seen.append("log_joint")
+            return super().log_joint(nodes)
+    m2 = MyIW(ib.generator, ib.variational, axis=0, estimator="sgvb")
+    assert np.isfinite(float(m2({"x": x}))) and seen.count("log_joint") == 2

@@ -63,8 +63,8 @@ class ELBO(nn.Module):
         _observed = {**_v_inputs, **observed}
         self.generator(_observed)
         nodes_p = self.generator.nodes
-        if self.estimator == "sgvb":
-            fused = self._scalar_sgvb(nodes_p, nodes_q)
+        if self.estimator == "sgvb" and type(self).sgvb is ELBO.sgvb and type(self).log_joint is ELBO.log_joint:
+            fused = self._scalar_sgvb(nodes_p, nodes_q)      # (a subclass that overrides either hook keeps its hooks)
             if fused is not None:
                 return fused
         logpxz = self.log_joint(nodes_p)

@@ -60,6 +60,12 @@ class ImportanceWeightedObjective(nn.Module):
                 raise ValueError("with vimco estimator, the is_reparameterized must be false")
         _observed = {**_v_inputs, **observed}
         nodes_p = self.generator(_observed).nodes
+        cls = type(self)
+        if (cls.log_joint is not ImportanceWeightedObjective.log_joint or cls.sgvb is not ImportanceWeightedObjective.sgvb
+                or cls.vimco is not ImportanceWeightedObjective.vimco):
+            # a subclass overrides one of the reference's hooks: keep calling them like the reference does (:97-100)
+            logpxz, logqz = self.log_joint(nodes_p), self.log_joint(nodes_q)
+            return self.sgvb(logpxz, logqz, reduce_mean) if self.estimator == 'sgvb' else self.vimco(logpxz, logqz, reduce_mean)
         terms_p = [nodes_p[n].log_prob() for n in nodes_p.keys()]
         logqz = self.log_joint(nodes_q)
         head = None
