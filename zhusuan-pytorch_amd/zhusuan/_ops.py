@@ -282,11 +282,17 @@ _IW_WORKSPACE = {}     # (device, dtype) -> (partials [4096], ticket [1] int32):
 
 
 def _iw_workspace(device, dtype):
+    """Scratch of K4b's batch mean, one per (device, dtype), shared by successive launches on one stream (the kernel
+    leaves the ticket at zero).  Objectives evaluated concurrently on several streams of one device must not share it:
+    not supported.  While a hipGraph is being captured a not-yet-cached workspace is allocated for that graph only --
+    caching a tensor that lives in a graph's private pool would dangle once the graph is destroyed."""
     key = (str(device), dtype)
     ws = _IW_WORKSPACE.get(key)
     if ws is None:
         ws = (torch.zeros(4096, dtype=dtype, device=device), torch.zeros(1, dtype=torch.int32, device=device))
-        _IW_WORKSPACE[key] = ws
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            _IW_WORKSPACE[key] = ws
     return ws
 
 
