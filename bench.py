@@ -156,6 +156,9 @@ def main():
                     help="run the multi-rank code path (bucket pack + all-reduce + split graphs) even with one rank")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python each step instead of replaying one captured hipGraph")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="eager launches only (--no-graph): all-reduce gradient buckets from autograd hooks while backward "
+                         "is still running (zhusuan.dataparallel.OverlappedBuckets)")
     ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "rocblas"],
                     help="BLAS library PyTorch uses for the MLPs' fp32 GEMMs (outside the hot path)")
     args = ap.parse_args()
@@ -197,6 +200,8 @@ def main():
     obs = {"x": x}
 
     multi = world > 1 or args.force_collective_path
+    overlap = multi and args.no_graph and args.overlap_allreduce
+    obuckets = dataparallel.OverlappedBuckets(model, n_buckets=2) if overlap else None
 
     def compute_part():
         """objective forward + backward (+ packing the flat [grads | loss] bucket when there is a collective)"""
@@ -218,7 +223,15 @@ def main():
         return bucket.flat[bucket.n_grad]
 
     def step_body():
-        g = exchange_part(compute_part())
+        if overlap:                       # buckets leave from autograd hooks during backward
+            rng.begin_step()
+            obuckets.zero()
+            loss = model(obs)
+            obuckets.begin(loss)
+            loss.backward()
+            g = obuckets.finish()
+        else:
+            g = exchange_part(compute_part())
         opt.step()
         return g
 
@@ -363,7 +376,8 @@ def main():
                        "global_batch": BATCH_PER_GPU * world, "particles": PARTICLES,
                        "parallelism": "dp%d (minibatch shards, one flat-bucket all-reduce of %d bytes)" % (world, bucket.nbytes()),
                        "bernoulli_path": "logits (sigmoid fused)" if args.fused_logits else "probs (reference default)",
-                       "mlp_gemm_library": args.blas, "launch_mode": mode if not (multi and mode == "hipgraph") else "hipgraph x2 around an eager all-reduce"},
+                       "mlp_gemm_library": args.blas, "launch_mode": (mode if not (multi and mode == "hipgraph") else "hipgraph x2 around an eager all-reduce")
+                       + (", all-reduce overlapped with backward (2 buckets)" if overlap else "")},
             "final_loss": final_loss,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,

@@ -71,19 +71,21 @@ def test_smoke():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_sharing_one_gpu_over_gloo():
+@pytest.mark.parametrize("extra", [[], ["--no-graph", "--overlap-allreduce"]])
+def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
     """The N = 2 control flow end to end (torch.distributed.run, shards, flat bucket, graph A -> all-reduce -> graph B,
     max-over-ranks timing, rank-0 JSON line) on a one-GPU box: both ranks on GPU 0, gloo instead of RCCL."""
     env = dict(os.environ)
     env["ZS_BENCH_SHARE_DEVICE"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    assert ("overlapped" in rec["config"]["launch_mode"]) == bool(extra)
     assert abs(rec["value"] - 2 * 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
     assert "graph capture failed" not in r.stderr, r.stderr[-2000:]

@@ -63,6 +63,49 @@ def _run_shard(rank, world, estimator):
     return float(g), flat, [p.detach().clone() for p in model.parameters()]
 
 
+def _run_shard_overlapped(rank, world, estimator, n_buckets):
+    import zhusuan as zs
+    from zhusuan import _hip, dataparallel
+    from examples import iwae
+    _hip._install_host_library_for_tests(host_kernel_library())
+    dev = torch.device("cpu")
+    model = iwae.build(n_samples=K, estimator=estimator, hidden=HID, device=dev)
+    H.load_params_into(model, 4242 if rank == 0 else 9999)
+    dataparallel.broadcast_parameters(model, src=0)
+    buckets = dataparallel.OverlappedBuckets(model, n_buckets=n_buckets)
+    x, e1, e2 = _data()
+    xs = dataparallel.shard_rows(torch.tensor(x), rank, world)
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    buckets.zero()
+    with zs.inject_epsilon([e1[:, sl], e2[:, sl]]):
+        loss = model({"x": xs})
+    buckets.begin(loss)
+    loss.backward()
+    launched_during_backward = [b["launched"] for b in buckets.buckets]
+    g = buckets.finish()
+    assert all(launched_during_backward), "every bucket must leave from its hook, before finish()"
+    for b in buckets.buckets:
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(b["params"], b["views"]))
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    return float(g), flat
+
+
+def _worker_overlapped(rank, world, port, estimator, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        loss, flat = _run_shard_overlapped(rank, world, estimator, 3)
+        torch.save({"loss": loss, "flat": flat}, os.path.join(out_dir, "o%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, estimator, out_dir):
     for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -118,3 +161,41 @@ def test_bucket_layout_and_sharding():
     assert torch.equal(dataparallel.shard_rows(x, 1, 3), x[2:4])
     with pytest.raises(ValueError, match="does not split evenly"):
         dataparallel.shard_rows(x, 0, 4)
+
+
+def test_overlapped_buckets_two_ranks_match_the_single_bucket(tmp_path):
+    """OverlappedBuckets (all-reduce launched from autograd hooks while backward is still running) must give exactly the
+    averaged gradients and objective of the one-bucket path."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_overlapped, args=(world, port, "vimco", str(tmp_path)), nprocs=world, join=True)
+    o0, o1 = torch.load(str(tmp_path / "o0.pt")), torch.load(str(tmp_path / "o1.pt"))
+    assert o0["loss"] == o1["loss"] and torch.equal(o0["flat"], o1["flat"])
+    loss, flat, _ = _run_shard(0, 1, "vimco")                      # single process, full minibatch
+    from zhusuan import _hip
+    _hip._install_host_library_for_tests(None)
+    assert abs(o0["loss"] - loss) <= 2e-6 * abs(loss)
+    np.testing.assert_allclose(o0["flat"].numpy(), flat.numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_overlapped_buckets_partition_and_hook_order():
+    from zhusuan import dataparallel
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Tanh(), torch.nn.Linear(4, 4), torch.nn.Tanh(), torch.nn.Linear(4, 2))
+    ob = dataparallel.OverlappedBuckets(net, n_buckets=2)
+    params = list(net.parameters())
+    assert [p for b in ob.buckets for p in b["params"]] == list(reversed(params))     # backward order
+    assert len(ob.buckets) == 2 and ob.nbytes() == 4 * (sum(p.numel() for p in params) + 1)
+    order = []
+    orig = ob._launch
+    ob._launch = lambda bi: (order.append(bi), orig(bi))[1]
+    ob.zero()
+    loss = net(torch.ones(5, 3)).sum()
+    ob.begin(loss)
+    loss.backward()
+    assert order == [0, 1]                                  # the last layers' bucket leaves first, during backward
+    ref = [p.grad.clone() for p in params]
+    g = ob.finish()                                         # no process group: nothing is sent, values unchanged
+    assert float(g) == float(loss)
+    for p, r in zip(params, ref):
+        assert torch.equal(p.grad, r)
+    ob.remove_hooks()

@@ -54,6 +54,114 @@ class GradientBucket(object):
         return self.flat.numel() * 4
 
 
+class OverlappedBuckets(object):
+    """Eager-mode variant: the gradient all-reduce OVERLAPS with backward.
+
+    Parameters are grouped, in the order backward produces their gradients (reverse registration order: the generator's
+    last layer first, the encoder last), into `n_buckets` flat fp32 buffers of similar size.  A post-accumulate-grad hook
+    per parameter counts arrivals; the moment a bucket is complete it is packed (one ``cat`` kernel) and its all-reduce
+    is launched asynchronously, so it travels over xGMI while autograd is still computing the remaining gradients.
+    ``finish()`` waits for the handles, applies 1/world and re-points every ``p.grad`` at its slice (no unpack copy).
+
+        buckets = dataparallel.OverlappedBuckets(model, n_buckets=2)
+        buckets.zero(); loss = model(obs); buckets.begin(loss); loss.backward()
+        global_loss = buckets.finish(); optimizer.step()
+
+    For steps recorded with ``zhusuan.GraphedStep`` use ``GradientBucket`` (hooks do not run on a graph replay)."""
+
+    def __init__(self, module, n_buckets=2, group=None):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("module has no trainable parameters")
+        self.group = group
+        order = list(reversed(params))
+        total = sum(p.numel() for p in order)
+        n_buckets = max(1, min(int(n_buckets), len(order)))
+        target = (total + n_buckets - 1) // n_buckets
+        self.buckets = []            # dicts: params, flat, views, pending, handle
+        cur, cur_n = [], 0
+        for p in order:
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= target and len(self.buckets) < n_buckets - 1:
+                self.buckets.append(self._make(cur))
+                cur, cur_n = [], 0
+        if cur:
+            self.buckets.append(self._make(cur))
+        self._loss_slot = self.buckets[0]["flat"][-1:]      # the first bucket to leave carries the objective
+        self._owner = {}
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self._owner[p] = bi
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._loss = None
+
+    def _make(self, params):
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n + (1 if not self.buckets else 0), dtype=torch.float32, device=params[0].device)
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return {"params": list(params), "flat": flat, "views": views, "n": n, "pending": len(params), "handle": None,
+                "launched": False}
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def zero(self):
+        for b in self.buckets:
+            b["pending"], b["handle"], b["launched"] = len(b["params"]), None, False
+            for p in b["params"]:
+                p.grad = None
+        self._loss = None
+
+    def begin(self, local_loss):
+        """Hand over the local objective before ``backward()`` so that it rides in the first bucket."""
+        self._loss = local_loss.detach()
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b["params"]]
+        if bi == 0:
+            loss = self._loss if self._loss is not None else torch.zeros((), device=b["flat"].device)
+            parts.append(loss.reshape(1).to(torch.float32))
+        torch.cat(parts, out=b["flat"])
+        b["launched"] = True
+        if self._active():
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        bi = self._owner[p]
+        b = self.buckets[bi]
+        b["pending"] -= 1
+        if b["pending"] == 0 and not b["launched"]:
+            self._launch(bi)
+
+    def finish(self):
+        """Wait for the collectives, average, alias ``p.grad`` to the buckets; returns the global objective (0-d)."""
+        world = dist.get_world_size(self.group) if self._active() else 1
+        for bi, b in enumerate(self.buckets):
+            if not b["launched"]:                 # parameters that received no gradient this step
+                self._launch(bi)
+            if b["handle"] is not None:
+                b["handle"].wait()
+            if world > 1:
+                b["flat"].mul_(1.0 / world)
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+        return self._loss_slot[0]
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def nbytes(self):
+        return sum(b["flat"].numel() * 4 for b in self.buckets)
+
+
 def shard_rows(x, rank, world_size):
     """Rows [rank*B/G, (rank+1)*B/G) of the minibatch (equal shards: the mean of the local means is then
     the global mean)."""
