@@ -118,17 +118,17 @@ struct Terms {
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scalar_objective(Terms<T> t, T* __restrict__ out, T* __restrict__ coef_out) {
   __shared__ double sh[16];
-  double total = 0.0;
+  double acc = 0.0;                                        // one weighted accumulation, ONE block reduction for all terms
 #pragma unroll
   for (int j = 0; j < ZS_MAX_TERMS; ++j) {
     if (t.r[j] == nullptr) continue;                       // uniform
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < t.n[j]; i += blockDim.x) s += (double)t.r[j][i];
-    s = block_sum_1024(s, sh);
-    total += t.c[j] * s;
+    acc += t.c[j] * s;
     if (coef_out && threadIdx.x == 0) coef_out[j] = (T)t.c[j];
   }
-  if (threadIdx.x == 0) out[0] = (T)total;
+  acc = block_sum_1024(acc, sh);
+  if (threadIdx.x == 0) out[0] = (T)acc;
 }
 
 template <typename T>
