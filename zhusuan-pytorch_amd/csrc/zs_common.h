@@ -111,6 +111,15 @@ __host__ __device__ __forceinline__ int next_pow2(int v) {
 struct Philox4 {
   uint32_t x, y, z, w;
 };
+// a ^ b ^ key in ONE VALU instruction: CDNA4's v_bitop3_b32 with the parity truth table 0x96 (gfx950 has no
+// v_xor3_b32, and the compiler emits two v_xor_b32 for the C expression: 38 of the 104 instructions of K1's inner loop
+// were xors).  `key` is a round key: uniform across the wavefront, so it stays in a scalar register.
+__device__ __forceinline__ uint32_t xor3_key(uint32_t a, uint32_t b, uint32_t key) {
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(key));
+  return r;
+}
+
 __device__ __forceinline__ Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) {
   uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32);
   uint32_t c2 = (uint32_t)call, c3 = (uint32_t)(call >> 32);
@@ -119,9 +128,9 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t group, uint64_t call, 
   for (int r = 0; r < 10; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n0 = xor3_key((uint32_t)(p1 >> 32), c1, k0);
     uint32_t n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
     uint32_t n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u;

@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
+# ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments); default: the in-tree library
+LIB_PATH = os.environ.get("ZS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
 ABI_VERSION = 7
 
 _p = ctypes.c_void_p
