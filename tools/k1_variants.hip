@@ -14,7 +14,7 @@ __device__ __forceinline__ Philox4 philox_r(uint64_t group, uint64_t call, uint6
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    uint32_t n0 = xor3_key((uint32_t)(p1 >> 32), c1, k0), n1 = (uint32_t)p1, n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1), n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   Philox4 o = {c0, c1, c2, c3};
@@ -164,11 +164,12 @@ __global__ __launch_bounds__(256) void k1lds(const float4* __restrict__ mu, cons
       const int kb = (int)((k1 - kb0 < KB) ? (k1 - kb0) : KB);
       for (int kk = 0; kk < kb; ++kk, g += M4) {
         float4 e;
-        if (MODE == 0) { Philox4 p = philox_r<10>((uint64_t)g, call, seed); e = bm4(p.x, p.y, p.z, p.w); }
+        if (MODE == 0 || MODE == 4) { Philox4 p = philox_r<10>((uint64_t)g, call, seed); e = bm4(p.x, p.y, p.z, p.w); }
+        else if (MODE == 5) { Philox4 p = philox_r<7>((uint64_t)g, call, seed); e = bm4(p.x, p.y, p.z, p.w); }
         else e = make_float4(0.1f * lane, 0.2f, -0.3f, 0.4f + (float)kk);
         float4 zz;
         zz.x = m.x + s.x * e.x; zz.y = m.y + s.y * e.y; zz.z = m.z + s.z * e.z; zz.w = m.w + s.w * e.w;
-        if (on) { if (NT) { typedef float f4v __attribute__((ext_vector_type(4))); f4v v = {zz.x, zz.y, zz.z, zz.w}; __builtin_nontemporal_store(v, (f4v*)&z[g]); } else z[g] = zz; }
+        if (on && (MODE != 4 || zz.x == 12345.678f)) { if (NT) { typedef float f4v __attribute__((ext_vector_type(4))); f4v v = {zz.x, zz.y, zz.z, zz.w}; __builtin_nontemporal_store(v, (f4v*)&z[g]); } else z[g] = zz; }
         const float d0 = zz.x - m.x, d1 = zz.y - m.y, d2 = zz.z - m.z, d3 = zz.w - m.w;
         st[kk * LDW + lane] = rowc - (hp[0] * (d0 * d0) + hp[1] * (d1 * d1) + hp[2] * (d2 * d2) + hp[3] * (d3 * d3));
       }
@@ -297,6 +298,8 @@ int main() {
     RUNL("philox10 + LDS-staged sums", 0, 0);
     RUNL("philox10 + LDS-staged sums, nt", 0, 1);
     RUNL("no rng + LDS-staged sums, nt", 3, 1);
+    RUNL("philox10 + LDS sums, NO z stores (VALU only)", 4, 1);
+    RUNL("philox7 + LDS-staged sums, nt", 5, 1);
     RUNX("xoshiro + shfl, nt stores", 2, 0, 1);
     RUNX("xoshiro, no reduce, nt stores", 2, 1, 1);
     RUNX("philox10, no reduce, nt stores", 0, 1, 1);
