@@ -120,12 +120,17 @@ __device__ __forceinline__ uint32_t xor3_key(uint32_t a, uint32_t b, uint32_t ke
   return r;
 }
 
+// Rounds of the generator.  10 = Philox4x32-10, the curand / torch / Random123 default and what the oracle implements;
+// anything else is for experiments only (tools/k1_launch_distribution.py with ZS_HIP_LIBRARY) and breaks RNG parity.
+#ifndef ZS_PHILOX_ROUNDS
+#define ZS_PHILOX_ROUNDS 10
+#endif
 __device__ __forceinline__ Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) {
   uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32);
   uint32_t c2 = (uint32_t)call, c3 = (uint32_t)(call >> 32);
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ZS_PHILOX_ROUNDS; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = xor3_key((uint32_t)(p1 >> 32), c1, k0);
