@@ -128,3 +128,63 @@ def test_end_to_end_step_is_deterministic_given_seed():
         vals.append((float(loss), float(sum(p.grad.double().abs().sum() for p in model.parameters()))))
     assert vals[0][0] == vals[1][0]                         # same Philox call ids -> bit-identical objective
     assert abs(vals[0][1] - vals[1][1]) <= 1e-6 * vals[0][1]
+
+
+# ------------------------------------------------------------------ widened rows at full sizes
+@pytest.mark.parametrize("B", [256, 4096])
+def test_logistic_uniform_properties(B):
+    from scipy import stats
+    from zhusuan.distributions import Logistic, Uniform
+    K, D = 50, 40
+    g = torch.Generator(device=DEV).manual_seed(B + 1)
+    loc = torch.randn(B, D, device=DEV, generator=g)
+    scale = torch.rand(B, D, device=DEV, generator=g) + 0.5
+    d = Logistic(loc, scale, group_ndims=1)
+    torch.manual_seed(7)
+    z = d.sample(K)
+    lp_fused = d.log_prob(None)                                   # L1: density of the fresh sample, same launch
+    assert z.shape == (K, B, D) and lp_fused.shape == (K, B) and lp_fused.stride() == (1, K)
+    lp_given = d.log_prob(z.clone())                              # L2 on the same values
+    torch.testing.assert_close(lp_given, lp_fused, rtol=1e-5, atol=2e-4)
+    elem = Logistic(loc, scale).log_prob(z)                       # D = 1 path, summed by torch
+    torch.testing.assert_close(elem.sum(-1), lp_fused, rtol=1e-5, atol=2e-4)
+    ref = stats.logistic.logpdf(z[:3, :5].double().cpu().numpy(), loc[:5].double().cpu().numpy(), scale[:5].double().cpu().numpy()).sum(-1)
+    np.testing.assert_allclose(lp_fused[:3, :5].cpu().numpy(), ref, rtol=2e-5, atol=2e-4)
+    # affine equivariance: sampling with the same Philox ids from (loc + c, s * scale) moves the sample accordingly
+    torch.manual_seed(7)
+    z2 = Logistic(loc + 2.0, 3.0 * scale, group_ndims=1).sample(K)
+    torch.testing.assert_close(z2, (z - loc) * 3.0 + loc + 2.0, rtol=2e-5, atol=2e-5)
+    # Uniform: inside the support the density is the constant -sum log(high - low); the sample stays inside
+    low, high = loc - scale, loc + scale
+    u = Uniform(low, high, group_ndims=1)
+    s = u.sample(K)
+    assert bool(((s >= low) & (s < high)).all())
+    lpu = u.log_prob(s)
+    torch.testing.assert_close(lpu, (-torch.log(high - low).sum(-1)).expand(K, B), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,K", [(256, 50), (2048, 50), (512, 10)])
+@pytest.mark.parametrize("est", ["sgvb", "vimco"])
+def test_iw_objective_fused_equals_composed(B, K, est):
+    """K4b (one launch: two-term log-joint, batch mean, scaled coefficients) against the same objective composed from
+    K4 + torch ops, values and gradients, at the BASELINE sizes."""
+    from zhusuan import _ops
+    g = torch.Generator(device=DEV).manual_seed(B + K)
+    a = (-540 + 5 * torch.randn(B, K, device=DEV, generator=g)).requires_grad_()
+    b = (-45 + torch.randn(B, K, device=DEV, generator=g)).requires_grad_()
+    q = (-50 + 2 * torch.randn(B, K, device=DEV, generator=g)).requires_grad_()
+    code = _ops.ZS_IW_VIMCO if est == "vimco" else _ops.ZS_IW_SGVB
+    fused, bound = _ops.IWObjective.apply(a, b, q, code, True)
+    gf = torch.autograd.grad(fused, [a, b, q])
+    cost_b, bound2 = _ops.IWReduce.apply(a + b, q, code)
+    comp = cost_b.mean()
+    gc = torch.autograd.grad(comp, [a, b, q])
+    torch.testing.assert_close(bound, bound2, rtol=0, atol=0)
+    torch.testing.assert_close(fused, comp, rtol=2e-6, atol=0)
+    for x, y in zip(gf, gc):
+        torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-10)
+    # adding a constant to both log p terms' sum and to log q leaves the weights, hence the sgvb gradients, unchanged
+    if est == "sgvb":
+        fused2, _ = _ops.IWObjective.apply(a + 3.0, b, q + 3.0, code, True)
+        g2 = torch.autograd.grad(fused2, [a, q])
+        torch.testing.assert_close(g2[0], gf[0], rtol=2e-4, atol=1e-7)
