@@ -3,6 +3,8 @@ captured from the reference's example models with identical weights, data and ep
 (SURVEY.md section 8a rows 12-14).  Parity bar of BASELINE.json: 1e-4 relative on the ELBO.
 "host" back-end on CPU (C oracle injected) and, marked gpu, the HIP library.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -142,3 +144,20 @@ def test_training_reduces_loss(dev):
         assert torch.isfinite(loss)
         bounds.append(float(model.last_iw_bound.mean()))
     assert np.mean(bounds[-5:]) > np.mean(bounds[:5]) + 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mod,args", [("examples.vae_mnist", ["--batch", "32", "--steps", "60"]),
+                                      ("examples.iwae", ["--batch", "16", "--particles", "8", "--steps", "60"]),
+                                      ("examples.iwae", ["--batch", "16", "--particles", "8", "--steps", "60", "--estimator", "sgvb",
+                                                         "--fused-logits"]),
+                                      ("examples.bnn_vi", ["--steps", "60"])])
+def test_example_scripts_run(mod, args):
+    """The counterparts of the reference's example scripts run as programs on the GPU (synthetic data)."""
+    import subprocess
+    import sys
+    from conftest import ROOT, PKG_ROOT
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG_ROOT, ROOT]))
+    r = subprocess.run([sys.executable, "-m", mod] + args, cwd=PKG_ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "ELBO-evals/s" in r.stdout and "nan" not in r.stdout.lower()
