@@ -379,6 +379,8 @@ def main():
                        "mlp_gemm_library": args.blas, "launch_mode": (mode if not (multi and mode == "hipgraph") else "hipgraph x2 around an eager all-reduce")
                        + (", all-reduce overlapped with backward (2 buckets)" if overlap else "")},
             "final_loss": final_loss,
+            **({"test_mode": "ranks share GPU 0 and reduce over gloo (ZS_BENCH_SHARE_DEVICE): control-flow test, NOT a measurement"}
+               if share_device else {}),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": pmc_traffic(dominant),

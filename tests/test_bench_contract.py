@@ -54,7 +54,7 @@ def test_bench_line_single_rank():
     roof = rec["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-6
-    assert "workload" in rec["config"] and "model" not in rec["config"]
+    assert "workload" in rec["config"] and "model" not in rec["config"] and "test_mode" not in rec
 
 
 @pytest.mark.gpu
@@ -87,5 +87,6 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert ("overlapped" in rec["config"]["launch_mode"]) == bool(extra)
+    assert "NOT a measurement" in rec["test_mode"]
     assert abs(rec["value"] - 2 * 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
     assert "graph capture failed" not in r.stderr, r.stderr[-2000:]
