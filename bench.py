@@ -7,8 +7,8 @@ One step = objective forward (sampling, log-probs, VIMCO reduction in HIP kernel
 hipBLASLt via PyTorch) + backward + [one all-reduce of the flat gradient bucket] + Adam.
 One ELBO-eval = one log-importance-weight log w[k, b], so a step does B*K evals per GPU.
 
-  python bench.py [--gpus N --steps K --warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py [--gpus N --steps K --warmup W]          (N > 1: this process only starts the N ranks, see launch_ranks)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form for N > 1)
 
 Rank 0 prints ONE JSON line (contract in the task description) with `roofline` -- the hot-path kernel that
 takes the most time (and moves the most bytes) per step, i.e. the backward of the Bernoulli log-prob row sum;
@@ -26,12 +26,66 @@ for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "t
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 BATCH_PER_GPU, PARTICLES, Z_DIM, X_DIM, HIDDEN = 256, 50, 40, 784, 500
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--fused-logits", action="store_true",
+                    help="decoder hands logits to Bernoulli(logits=...): sigmoid fused into the log-prob kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective-path", action="store_true",
+                    help="run the multi-rank code path (bucket pack + all-reduce + split graphs) even with one rank")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel from Python each step instead of replaying one captured hipGraph")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="eager launches only (--no-graph): all-reduce gradient buckets from autograd hooks while backward "
+                         "is still running (zhusuan.dataparallel.OverlappedBuckets)")
+    ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "rocblas"],
+                    help="BLAS library PyTorch uses for the MLPs' fp32 GEMMs (outside the hot path)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher around it: this process becomes the PARENT of N ranks.  It has
+    not imported torch or touched the GPU (and never will): it starts `python -m torch.distributed.run` with the
+    same arguments as a child process, one rank per GPU over RCCL, relays the child's output (rank 0 prints the one
+    JSON line) and exits with its return code.  Nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench: launching %d ranks: %s\n" % (n_ranks, " ".join(cmd)))
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+if __name__ == "__main__" and "RANK" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        raise SystemExit(launch_ranks(_a.gpus, sys.argv[1:]))
+
+import numpy as np                    # noqa: E402  (after the parent-only branch above: the parent never loads torch)
+import torch                          # noqa: E402
+import torch.distributed as dist      # noqa: E402
+
+
+def collective_library(share_device):
+    if share_device:
+        return "gloo (test mode)"
+    try:
+        return "RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                               # noqa: BLE001
+        return "RCCL (version unavailable)"
 
 
 def pmc_traffic(entry):
@@ -145,30 +199,13 @@ def device_kernel_times(run_steps, n_steps):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--fused-logits", action="store_true",
-                    help="decoder hands logits to Bernoulli(logits=...): sigmoid fused into the log-prob kernel")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-collective-path", action="store_true",
-                    help="run the multi-rank code path (bucket pack + all-reduce + split graphs) even with one rank")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="launch every kernel from Python each step instead of replaying one captured hipGraph")
-    ap.add_argument("--overlap-allreduce", action="store_true",
-                    help="eager launches only (--no-graph): all-reduce gradient buckets from autograd hooks while backward "
-                         "is still running (zhusuan.dataparallel.OverlappedBuckets)")
-    ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "rocblas"],
-                    help="BLAS library PyTorch uses for the MLPs' fp32 GEMMs (outside the hot path)")
-    args = ap.parse_args()
+    args = parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     # test hook (tests/test_bench_contract.py): several ranks share GPU 0 and talk over gloo, so that the multi-rank
     # control flow (shards, bucket, split graphs, max-over-ranks timing) can be exercised on a one-GPU box.  RCCL
     # refuses two ranks on one device, so this is never a measurement mode.
@@ -366,7 +403,9 @@ def main():
             "metric": "ELBO-evals/sec (batch x K particles), IWAE-MNIST VIMCO K=50",
             "value": BATCH_PER_GPU * PARTICLES * world * args.steps / elapsed,
             "unit": "ELBO-evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+            "collective_library": collective_library(share_device) if dist.is_initialized() else None,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

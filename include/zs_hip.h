@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 7
+#define ZS_ABI_VERSION 8
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -67,12 +67,20 @@ const char* zs_error_string(int code);
  * launch captured in a hipGraph draws fresh numbers on every replay once the
  * caller bumps rng_state[1] between replays (`seed` is then ignored).
  * lp == NULL: sample only.
+ * sigma_is_logstd != 0: the `sigma` operand holds log(sigma) -- the Normal(logstd=...) constructor,
+ * normal.py:56 `std = exp(logstd)` -- and the kernel forms sigma = exp(.) itself (here and in every
+ * Normal entry point below that takes the flag; their gsigma output is then d/d logstd = sigma * d/d sigma):
+ * the caller launches no exp forward and no multiply backward.
+ * rng_used (optional DEVICE pointer to two uint64): receives the resolved {seed, call} of this draw.  A backward
+ * call that may run after the caller has advanced the live rng_state (two objectives per step, a delayed or
+ * retained backward) passes it as ITS rng_state with offset 0 and regenerates exactly this draw.
  * -------------------------------------------------------------------------*/
 int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const float* eps,
                                  uint64_t seed, uint64_t offset, const uint64_t* rng_state,
                                  float* z, float* lp,
                                  int64_t K, int64_t M, int64_t D,
-                                 int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+                                 int64_t lp_stride_k, int64_t lp_stride_r,
+                                 int sigma_is_logstd, uint64_t* rng_used, void* stream);
 
 /* Backward of K1 for a reparameterised node (normal.py:104-105):
  *   gmu[m]    = sum_k gz[k, m]
@@ -83,7 +91,7 @@ int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float* eps,
                                      const float* gz, const float* glp,
                                      int64_t glp_stride_k, int64_t glp_stride_r,
                                      float* gmu, float* gsigma,
-                                     int64_t K, int64_t M, int64_t D, void* stream);
+                                     int64_t K, int64_t M, int64_t D, int sigma_is_logstd, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K2  Normal: log-prob of a given value (prior p(z), likelihood p(y|.)).
@@ -94,7 +102,7 @@ int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float* eps,
 int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu, int64_t Pm,
                           const float* sigma, int64_t Ps, float* lp,
                           int64_t K, int64_t R, int64_t D,
-                          int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+                          int64_t lp_stride_k, int64_t lp_stride_r, int sigma_is_logstd, void* stream);
 
 /* Backward of K2, element-wise partials of size K*R*D each (any may be NULL):
  *   gx = -g*prec*(x-mu),  gmu = +g*prec*(x-mu),  gsigma = g*(prec*(x-mu)^2 - 1)/sigma,
@@ -103,7 +111,7 @@ int zs_normal_logprob_bwd_f32(const float* x, int64_t Px, const float* mu, int64
                               const float* sigma, int64_t Ps,
                               const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
                               float* gx, float* gmu, float* gsigma,
-                              int64_t K, int64_t R, int64_t D, void* stream);
+                              int64_t K, int64_t R, int64_t D, int sigma_is_logstd, void* stream);
 
 /* Backward of K2 reduced over the K axis for parameters of period R*D
  * (mu, sigma of shape [R, D] repeated K times: the IWAE / non-reparameterised
@@ -112,7 +120,7 @@ int zs_normal_logprob_bwd_f32(const float* x, int64_t Px, const float* mu, int64
 int zs_normal_logprob_bwd_ksum_f32(const float* x, const float* mu, const float* sigma,
                                    const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
                                    float* gx, float* gmu, float* gsigma,
-                                   int64_t K, int64_t R, int64_t D, void* stream);
+                                   int64_t K, int64_t R, int64_t D, int sigma_is_logstd, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K3  Bernoulli: log-prob row sums.
@@ -212,13 +220,13 @@ int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, 
  * u == NULL: u is drawn in-kernel, 24-bit uniforms of Philox4x32-10 with the
  * counter convention of K1 (group = (k*M + m) / 4, word = (k*M + m) % 4).
  * For the fresh sample t == eps, and -eps - 2*softplus(-eps) == log(u) + log(1 - u):
- * the kernel reuses the two logarithms of the draw.
+ * the kernel reuses the two logarithms of the draw.  rng_used: as for K1.
  * -------------------------------------------------------------------------*/
 int zs_logistic_sample_logprob_f32(const float* loc, const float* scale, const float* u,
                                    uint64_t seed, uint64_t offset, const uint64_t* rng_state,
                                    float* z, float* lp,
                                    int64_t K, int64_t M, int64_t D,
-                                   int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+                                   int64_t lp_stride_k, int64_t lp_stride_r, uint64_t* rng_used, void* stream);
 
 /* Backward of L1 (Logistic is always reparameterised, logistic.py:36):
  *   gloc[m]   = sum_k gz[k, m]
@@ -318,11 +326,11 @@ int zs_scalar_objective_f32(const float* r0, int64_t n0, double c0, const float*
  * identical argument meaning, double* instead of float*.  They are plain (untuned) kernels: none of the
  * benchmark configurations uses float64.  Draws widen the same Philox / Box-Muller fp32 stream.
  * -------------------------------------------------------------------------*/
-int zs_normal_sample_logprob_f64(const double* mu, const double* sigma, const double* eps, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
-int zs_normal_sample_logprob_bwd_f64(const double* sigma, const double* eps, uint64_t seed, uint64_t offset, const uint64_t* rng_state, const double* gz, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gmu, double* gsigma, int64_t K, int64_t M, int64_t D, void* stream);
-int zs_normal_logprob_f64(const double* x, int64_t Px, const double* mu, int64_t Pm, const double* sigma, int64_t Ps, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
-int zs_normal_logprob_bwd_f64(const double* x, int64_t Px, const double* mu, int64_t Pm, const double* sigma, int64_t Ps, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gmu, double* gsigma, int64_t K, int64_t R, int64_t D, void* stream);
-int zs_normal_logprob_bwd_ksum_f64(const double* x, const double* mu, const double* sigma, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gmu, double* gsigma, int64_t K, int64_t R, int64_t D, void* stream);
+int zs_normal_sample_logprob_f64(const double* mu, const double* sigma, const double* eps, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, int sigma_is_logstd, uint64_t* rng_used, void* stream);
+int zs_normal_sample_logprob_bwd_f64(const double* sigma, const double* eps, uint64_t seed, uint64_t offset, const uint64_t* rng_state, const double* gz, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gmu, double* gsigma, int64_t K, int64_t M, int64_t D, int sigma_is_logstd, void* stream);
+int zs_normal_logprob_f64(const double* x, int64_t Px, const double* mu, int64_t Pm, const double* sigma, int64_t Ps, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, int sigma_is_logstd, void* stream);
+int zs_normal_logprob_bwd_f64(const double* x, int64_t Px, const double* mu, int64_t Pm, const double* sigma, int64_t Ps, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gmu, double* gsigma, int64_t K, int64_t R, int64_t D, int sigma_is_logstd, void* stream);
+int zs_normal_logprob_bwd_ksum_f64(const double* x, const double* mu, const double* sigma, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gmu, double* gsigma, int64_t K, int64_t R, int64_t D, int sigma_is_logstd, void* stream);
 int zs_bernoulli_logprob_f64(const double* p, const double* x, int64_t Px, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
 int zs_bernoulli_logprob_bwd_f64(const double* p, const double* x, int64_t Px, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gp, int64_t K, int64_t R, int64_t D, void* stream);
 int zs_bernoulli_logits_logprob_f64(const double* logits, const double* x, int64_t Px, double* lp, double* probs_out, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
@@ -332,7 +340,7 @@ int zs_iw_reduce_f64(const double* logp, int64_t ld_p, const double* logq, int64
 int zs_iw_objective_f64(const double* logp_a, int64_t ld_a, const double* logp_b, int64_t ld_b, const double* logq, int64_t ld_q, int64_t B, int64_t K, int estimator, int want_mean, double* cost_b, double* bound_b, double* coef, double* mean_cost, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
 int zs_log_mean_exp_f64(const double* x, int64_t ld, int64_t B, int64_t K, double* out, void* stream);
 int zs_philox_normal_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
-int zs_logistic_sample_logprob_f64(const double* loc, const double* scale, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
+int zs_logistic_sample_logprob_f64(const double* loc, const double* scale, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, uint64_t* rng_used, void* stream);
 int zs_logistic_sample_logprob_bwd_f64(const double* scale, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, const double* gz, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gloc, double* gscale, int64_t K, int64_t M, int64_t D, void* stream);
 int zs_logistic_logprob_f64(const double* x, int64_t Px, const double* loc, int64_t Pm, const double* scale, int64_t Ps, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
 int zs_logistic_logprob_bwd_f64(const double* x, int64_t Px, const double* loc, int64_t Pm, const double* scale, int64_t Ps, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gloc, double* gscale, int64_t K, int64_t R, int64_t D, void* stream);

@@ -71,6 +71,37 @@ def test_smoke():
 
 
 @pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent (which never loads torch) starts the two
+    ranks itself and relays rank 0's line.  Both ranks share GPU 0 over gloo here (one-GPU box)."""
+    env = dict(os.environ)
+    env["ZS_BENCH_SHARE_DEVICE"] = "1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["n_ranks_seen"] == 2 and "gloo" in rec["collective_library"]
+    assert abs(rec["value"] - 2 * 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
+
+
+def test_bench_parent_does_not_load_torch():
+    """The rank-launching parent must not initialise the GPU: it decides before torch is imported."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("raise SystemExit(launch_ranks(") < src.index("import torch")
+    r = subprocess.run([sys.executable, "-c",
+                        "import sys, runpy; sys.argv=['bench.py','--gpus','2'];\n"
+                        "import subprocess; subprocess.call=lambda *a, **k: (print('torch' in sys.modules), 0)[1]\n"
+                        "runpy.run_path(%r, run_name='__main__')" % os.path.join(ROOT, "bench.py")],
+                       cwd=ROOT, capture_output=True, text=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0 and r.stdout.strip().endswith("False"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--no-graph", "--overlap-allreduce"]])
 def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
     """The N = 2 control flow end to end (torch.distributed.run, shards, flat bucket, graph A -> all-reduce -> graph B,

@@ -34,7 +34,7 @@ def test_header_symbols_exported_by_both_libraries():
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 7
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 8
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 
@@ -85,45 +85,45 @@ class Raw(object):
             torch.cuda.synchronize()
 
     # each op returns a dict of numpy outputs
-    def normal_sample(self, mu, sigma, eps, K, D, seed=0, off=0, kfast=False, want_lp=True, rs=None):
+    def normal_sample(self, mu, sigma, eps, K, D, seed=0, off=0, kfast=False, want_lp=True, rs=None, ls=0, used=None):
         M = mu.size
         R = M // D
         z = self.empty(K, M)
         lp = self.empty(R, K) if kfast else self.empty(K, R)
         sk, sr = (1, K) if kfast else (R, 1)
         self.call("zs_normal_sample_logprob_f32", self.t(mu), self.t(sigma), self.t(eps), seed, off, rs, z,
-                  lp if want_lp else None, K, M, D, sk, sr)
+                  lp if want_lp else None, K, M, D, sk, sr, ls, used)
         lpn = lp.cpu().numpy()
         return dict(z=z.cpu().numpy(), lp=lpn.T if kfast else lpn)
 
-    def normal_sample_bwd(self, sigma, eps, gz, glp, K, D, seed=0, off=0, rs=None):
+    def normal_sample_bwd(self, sigma, eps, gz, glp, K, D, seed=0, off=0, rs=None, ls=0):
         M = sigma.size
         R = M // D
         gmu, gs = self.empty(M), self.empty(M)
         self.call("zs_normal_sample_logprob_bwd_f32", self.t(sigma), self.t(eps), seed, off, rs, self.t(gz), self.t(glp),
-                  R, 1, gmu, gs, K, M, D)
+                  R, 1, gmu, gs, K, M, D, ls)
         return dict(gmu=gmu.cpu().numpy(), gsigma=gs.cpu().numpy())
 
-    def normal_lp(self, x, mu, sigma, K, R, D, kfast=False):
+    def normal_lp(self, x, mu, sigma, K, R, D, kfast=False, ls=0):
         lp = self.empty(R, K) if kfast else self.empty(K, R)
         sk, sr = (1, K) if kfast else (R, 1)
         self.call("zs_normal_logprob_f32", self.t(x), x.size, self.t(mu), mu.size, self.t(sigma), sigma.size, lp,
-                  K, R, D, sk, sr)
+                  K, R, D, sk, sr, ls)
         lpn = lp.cpu().numpy()
         return dict(lp=lpn.T if kfast else lpn)
 
-    def normal_lp_bwd(self, x, mu, sigma, glp, K, R, D):
+    def normal_lp_bwd(self, x, mu, sigma, glp, K, R, D, ls=0):
         N = K * R * D
         gx, gm, gs = self.empty(N), self.empty(N), self.empty(N)
         self.call("zs_normal_logprob_bwd_f32", self.t(x), x.size, self.t(mu), mu.size, self.t(sigma), sigma.size,
-                  self.t(glp), R, 1, gx, gm, gs, K, R, D)
+                  self.t(glp), R, 1, gx, gm, gs, K, R, D, ls)
         return dict(gx=gx.cpu().numpy(), gmu=gm.cpu().numpy(), gsigma=gs.cpu().numpy())
 
-    def normal_lp_bwd_ksum(self, x, mu, sigma, glp, K, R, D, want_gx=True):
+    def normal_lp_bwd_ksum(self, x, mu, sigma, glp, K, R, D, want_gx=True, ls=0):
         gx = self.empty(K * R * D)
         gm, gs = self.empty(R * D), self.empty(R * D)
         self.call("zs_normal_logprob_bwd_ksum_f32", self.t(x), self.t(mu), self.t(sigma), self.t(glp), R, 1,
-                  gx if want_gx else None, gm, gs, K, R, D)
+                  gx if want_gx else None, gm, gs, K, R, D, ls)
         out = dict(gmu=gm.cpu().numpy(), gsigma=gs.cpu().numpy())
         if want_gx:
             out["gx"] = gx.cpu().numpy()
@@ -308,6 +308,93 @@ def test_hip_normal_logprob_periods(hip, orc, K, R, D):
              2e-4, 2e-4)
 
 
+def _logstd_case(K, R, D):
+    rng = np.random.RandomState(31 + K * 1000 + R * 10 + D)
+    M = R * D
+    mu = rng.standard_normal(M).astype(np.float32)
+    ls = (0.7 * rng.standard_normal(M) - 0.3).astype(np.float32)
+    eps = rng.standard_normal(K * M).astype(np.float32)
+    gz = rng.standard_normal(K * M).astype(np.float32)
+    glp = rng.standard_normal(K * R).astype(np.float32)
+    return mu, ls, eps, gz, glp
+
+
+def _check_logstd_against_sigma_form(lib, K, R, D, tol):
+    """sigma_is_logstd (Normal(logstd=...), normal.py:56): same results as handing over sigma = exp(logstd), with the
+    chain rule d/d logstd = sigma * d/d sigma applied to the gradients."""
+    mu, ls, eps, gz, glp = _logstd_case(K, R, D)
+    sd = np.exp(ls.astype(np.float64)).astype(np.float32)
+    M = R * D
+    a, b = lib.normal_sample(mu, ls, eps, K, D, ls=1), lib.normal_sample(mu, sd, eps, K, D)
+    np.testing.assert_allclose(a["z"], b["z"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(a["lp"], b["lp"], rtol=tol, atol=tol * max(1, D))
+    a, b = lib.normal_sample_bwd(ls, eps, gz, glp, K, D, ls=1), lib.normal_sample_bwd(sd, eps, gz, glp, K, D)
+    np.testing.assert_allclose(a["gmu"], b["gmu"], rtol=20 * tol, atol=20 * tol)
+    np.testing.assert_allclose(a["gsigma"], b["gsigma"] * sd, rtol=20 * tol, atol=20 * tol * np.sqrt(K))
+    x = (mu[None, :] + sd[None, :] * eps.reshape(K, M)).astype(np.float32).ravel()
+    for Ps, sel in [(M, slice(None)), (1, slice(0, 1))]:
+        a, b = lib.normal_lp(x, mu, ls[sel].copy(), K, R, D, ls=1), lib.normal_lp(x, mu, sd[sel].copy(), K, R, D)
+        np.testing.assert_allclose(a["lp"], b["lp"], rtol=tol, atol=tol * max(1, D))
+        a = lib.normal_lp_bwd(x, mu, ls[sel].copy(), glp, K, R, D, ls=1)
+        b = lib.normal_lp_bwd(x, mu, sd[sel].copy(), glp, K, R, D)
+        np.testing.assert_allclose(a["gx"], b["gx"], rtol=20 * tol, atol=20 * tol)
+        sd_full = np.tile(sd, K) if Ps == M else np.full(K * M, sd[0], np.float32)
+        np.testing.assert_allclose(a["gsigma"], b["gsigma"] * sd_full, rtol=20 * tol, atol=20 * tol)
+    a, b = lib.normal_lp_bwd_ksum(x, mu, ls, glp, K, R, D, ls=1), lib.normal_lp_bwd_ksum(x, mu, sd, glp, K, R, D)
+    np.testing.assert_allclose(a["gmu"], b["gmu"], rtol=20 * tol, atol=20 * tol * np.sqrt(K))
+    np.testing.assert_allclose(a["gsigma"], b["gsigma"] * sd, rtol=20 * tol, atol=20 * tol * np.sqrt(K))
+    np.testing.assert_allclose(a["gx"], b["gx"], rtol=20 * tol, atol=20 * tol)
+
+
+@pytest.mark.parametrize("K,R,D", [(1, 3, 4), (5, 6, 40), (3, 9, 7)])
+def test_c_oracle_normal_logstd_form(orc, K, R, D):
+    _check_logstd_against_sigma_form(orc, K, R, D, 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,D", NORMAL_SHAPES)
+def test_hip_normal_logstd_form(hip, orc, K, R, D):
+    """HIP kernels with log(sigma) operands: against their own sigma form and against the C oracle's logstd form."""
+    _check_logstd_against_sigma_form(hip, K, R, D, 1e-5)
+    mu, ls, eps, gz, glp = _logstd_case(K, R, D)
+    a, b = hip.normal_sample(mu, ls, eps, K, D, ls=1, kfast=True), orc.normal_sample(mu, ls, eps, K, D, ls=1, kfast=True)
+    np.testing.assert_allclose(a["z"], b["z"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(a["lp"], b["lp"], rtol=1e-5, atol=1e-5 * max(1, D))
+    _cmp(hip.normal_sample_bwd(ls, eps, gz, glp, K, D, ls=1), orc.normal_sample_bwd(ls, eps, gz, glp, K, D, ls=1), 1e-4,
+         1e-4 * np.sqrt(K))
+    _cmp(hip.normal_sample_bwd(ls, None, gz, glp, K, D, 77, 5, ls=1), orc.normal_sample_bwd(ls, None, gz, glp, K, D, 77, 5, ls=1),
+         2e-4, 2e-4 * np.sqrt(K))
+
+
+def _check_rng_used(lib, dev):
+    """rng_used: the sampling call publishes the Philox ids it resolved from the live rng_state; a backward that reads
+    them regenerates the forward's draw even after the live state has moved on (zhusuan.DeviceRNG.begin_step)."""
+    K, R, D = 6, 5, 8
+    mu, ls, eps, gz, glp = _logstd_case(K, R, D)
+    sd = np.exp(ls).astype(np.float32)
+    state = torch.tensor([1234, 1 << 16], dtype=torch.int64, device=dev)
+    used = torch.zeros(2, dtype=torch.int64, device=dev)
+    z_live = lib.normal_sample(mu, sd, None, K, D, off=3, rs=state, used=used)["z"]
+    assert used.cpu().tolist() == [1234, (1 << 16) + 3]
+    want = lib.normal_sample_bwd(sd, None, gz, glp, K, D, off=3, rs=state)
+    state[1] += 1 << 16                                      # begin_step() between forward and backward
+    stale = lib.normal_sample_bwd(sd, None, gz, glp, K, D, off=3, rs=state)
+    got = lib.normal_sample_bwd(sd, None, gz, glp, K, D, off=0, rs=used)
+    assert np.array_equal(got["gsigma"], want["gsigma"]) and np.array_equal(got["gmu"], want["gmu"])
+    assert not np.allclose(stale["gsigma"], want["gsigma"])  # the live state no longer reproduces the draw
+    z_again = lib.normal_sample(mu, sd, None, K, D, off=0, rs=used)["z"]
+    assert np.array_equal(z_again, z_live)
+
+
+def test_c_oracle_rng_used(orc):
+    _check_rng_used(orc, "cpu")
+
+
+@pytest.mark.gpu
+def test_hip_rng_used(hip):
+    _check_rng_used(hip, "cuda:0")
+
+
 BERN_SHAPES = [(1, 1, 1), (1, 5, 784), (50, 8, 784), (3, 4, 16), (2, 3, 783), (7, 2, 100), (2, 9, 260), (1, 300, 4)]
 
 
@@ -442,11 +529,11 @@ def test_hip_rng(hip, orc):
 @pytest.mark.gpu
 def test_hip_empty_and_unaligned(hip, orc):
     z = np.zeros(0, np.float32)
-    hip.call("zs_normal_sample_logprob_f32", hip.t(z), hip.t(z), None, 0, 0, None, hip.empty(0), hip.empty(0), 3, 0, 1, 1, 1)
+    hip.call("zs_normal_sample_logprob_f32", hip.t(z), hip.t(z), None, 0, 0, None, hip.empty(0), hip.empty(0), 3, 0, 1, 1, 1, 0, None)
     hip.call("zs_bernoulli_logprob_f32", hip.t(z), hip.t(np.ones(1, np.float32)), 1, hip.empty(0), 1, 0, 4, 1, 1)
     hip.call("zs_iw_reduce_f32", hip.t(np.ones(4, np.float32)), 4, hip.t(np.ones(4, np.float32)), 4, 0, 4, 0, None, None, None, None)
     with pytest.raises(RuntimeError, match="code -1"):
-        hip.call("zs_normal_sample_logprob_f32", None, None, None, 0, 0, None, None, None, 1, 4, 4, 1, 1)
+        hip.call("zs_normal_sample_logprob_f32", None, None, None, 0, 0, None, None, None, 1, 4, 4, 1, 1, 0, None)
     # operands offset by one float: the vector path must not be taken on misaligned pointers
     rng = np.random.RandomState(5)
     K, R, D = 3, 4, 8
@@ -510,13 +597,15 @@ def test_hip_f64_entry_points(hip64, orc64):
 
 
 def test_host_library_hook_is_refused_outside_pytest():
-    """The test hook that lets CPU tensors reach a kernel library must not be usable by product code."""
+    """The test hook that lets CPU tensors reach a kernel library must not be usable by product code: without the
+    token that tests/conftest.py puts in the environment it refuses -- even when pytest happens to be imported."""
     import subprocess
     import sys as _sys
-    code = ("import sys; sys.path.insert(0, %r); from zhusuan import _hip\n"
+    code = ("import sys, pytest; sys.path.insert(0, %r); from zhusuan import _hip\n"
             "try:\n    _hip._install_host_library_for_tests(object())\n    print('INSTALLED')\n"
             "except RuntimeError as e:\n    print('REFUSED', e)\n") % os.path.join(ROOT, "zhusuan-pytorch_amd")
-    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k != "ZS_TESTS_HOST_LIBRARY_TOKEN"}
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert "REFUSED" in r.stdout and "no CPU execution path" in r.stdout, r.stdout + r.stderr
 
 

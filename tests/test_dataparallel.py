@@ -199,3 +199,51 @@ def test_overlapped_buckets_partition_and_hook_order():
     for p, r in zip(params, ref):
         assert torch.equal(p.grad, r)
     ob.remove_hooks()
+
+
+def test_bucket_dtype_and_repack_without_zero():
+    """float64 models get a float64 bucket (mixed dtypes are refused), and pack() works when zero() was
+    skipped and autograd has accumulated IN PLACE into the views that alias the flat buffer."""
+    from zhusuan import dataparallel
+    lin = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2)).double()
+    bucket = dataparallel.GradientBucket(lin)
+    n = sum(p.numel() for p in lin.parameters())
+    assert bucket.flat.dtype == torch.float64 and bucket.nbytes() == 8 * (n + 1)
+    x = torch.ones(5, 3, dtype=torch.float64)
+    lin(x).sum().backward()
+    bucket.pack(torch.tensor(1.5, dtype=torch.float64))
+    first = bucket.flat.clone()
+    lin(x).sum().backward()                                  # no zero(): accumulates into the aliased views
+    bucket.pack(torch.tensor(2.5, dtype=torch.float64))      # used to raise (cat with overlapping out=)
+    assert torch.allclose(bucket.flat[:n], 2 * first[:n]) and float(bucket.flat[n]) == 2.5
+    ob = dataparallel.OverlappedBuckets(lin, n_buckets=2)
+    assert all(b["flat"].dtype == torch.float64 for b in ob.buckets)
+    ob.remove_hooks()
+    mixed = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2).double())
+    with pytest.raises(TypeError, match="share a dtype"):
+        dataparallel.GradientBucket(mixed)
+    with pytest.raises(TypeError, match="share a dtype"):
+        dataparallel.OverlappedBuckets(mixed)
+
+
+def test_overlapped_buckets_issue_collectives_in_bucket_order():
+    """A bucket that completes early (its parameters got their gradients first, or none at all) still leaves after
+    every earlier bucket: all ranks issue the same collective sequence."""
+    from zhusuan import dataparallel
+    a, b, c = torch.nn.Linear(2, 2), torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+    net = torch.nn.ModuleList([a, b, c])
+    ob = dataparallel.OverlappedBuckets(net, n_buckets=3)
+    assert len(ob.buckets) == 3                              # bucket 0 = c's parameters, 1 = b's, 2 = a's
+    order = []
+    orig = ob._launch
+    ob._launch = lambda bi: (order.append(bi), orig(bi))[1]
+    ob.zero()
+    x = torch.ones(4, 2)
+    loss = a(x).sum() + c(x).sum()                           # b receives no gradient; a's arrive in whatever order
+    ob.begin(loss)
+    loss.backward()
+    assert order in ([0], [])                                # bucket 2 (a) is complete but must wait for bucket 1 (b)
+    ob.finish()
+    assert order == [0, 1, 2]
+    assert all(torch.equal(p.grad, torch.zeros_like(p)) for p in b.parameters())
+    ob.remove_hooks()

@@ -185,8 +185,8 @@ def test_normal_sample_logprob_golden(dev):
         kw = dict(is_reparameterized=bool(g[p + "reparam"]), group_ndims=int(g[p + "g"]))
         exact = True
         if int(g[p + "use_logstd"]):
-            d = Normal(mean=mu, logstd=ls, **kw)     # std = exp(logstd) evaluated by torch ON THE DEVICE
-            exact = dev.type == "cpu"                # (device exp differs from the CPU's in the last ulp)
+            d = Normal(mean=mu, logstd=ls, **kw)     # std = exp(logstd) formed INSIDE the kernel (sigma_is_logstd):
+            exact = False                            # its exp differs from torch-CPU's vectorised exp in the last ulp
         else:
             # std = exp(ls) exactly as the reference run had it (stored: a CPU's vectorised exp can differ
             # in the last ulp from another CPU's), with the chain rule back to ls applied by hand below
@@ -389,6 +389,33 @@ def test_device_rng_state_drives_the_draws(dev):
         z = Normal(mean=m, std=s).sample(3)
         (gs,) = torch.autograd.grad(z.sum(), [s])
     close(gs, ((z.detach() - 0.0) / 2.0).sum(0), 1e-5, 1e-5)
+
+
+def test_device_rng_backward_after_begin_step(dev):
+    """a backward that runs after DeviceRNG.begin_step() (two objectives per step, retain_graph, delayed
+    backward) must regenerate the FORWARD's epsilon, not the one the advanced live state would give."""
+    from zhusuan.distributions import Logistic
+    m = torch.zeros([16, 8], device=dev, requires_grad=True)
+    s = torch.full([16, 8], 1.5, device=dev, requires_grad=True)
+    ls = torch.full([16, 8], 0.25, device=dev, requires_grad=True)
+    rng = zs.DeviceRNG(dev, seed=11)
+    with zs.device_rng(rng):
+        rng.begin_step()
+        z = Normal(mean=m, std=s).sample(4)
+        zl = Normal(mean=m, logstd=ls).sample(4)
+        sg = torch.full([16, 8], 0.5, device=dev, requires_grad=True)
+        zg = Logistic(loc=m, scale=sg).sample(4)
+        obj = (z * z).sum() + (zl * zl).sum() + (zg * zg).sum()
+        before = torch.autograd.grad(obj, [s, ls, sg, m], retain_graph=True)
+        rng.begin_step()
+        Normal(mean=m, std=s).sample(4)                  # the next step's draws move the live state further
+        after = torch.autograd.grad(obj, [s, ls, sg, m])
+    for a_, b_ in zip(before, after):
+        assert torch.equal(a_, b_)
+    # and the gradient is the one of the draw that was made: d sum(z^2) / d sigma = sum_k 2 z eps, eps = (z - m) / sigma
+    close(before[0], (2 * z.detach() * (z.detach() / 1.5)).sum(0), 1e-4, 1e-4)
+    close(before[1], (2 * zl.detach() * zl.detach()).sum(0), 1e-4, 1e-4)     # d/d logstd = sigma * d/d sigma
+    close(before[2], (2 * zg.detach() * (zg.detach() / 0.5)).sum(0), 1e-4, 1e-4)
 
 
 @pytest.mark.gpu

@@ -100,14 +100,14 @@ def test_oracle_uniform():
 
 # ------------------------------------------------------------------ raw C-ABI helpers
 class Raw2(Raw):
-    def logistic_sample(self, loc, scale, u, K, D, seed=0, off=0, kfast=False, want_lp=True, rs=None):
+    def logistic_sample(self, loc, scale, u, K, D, seed=0, off=0, kfast=False, want_lp=True, rs=None, used=None):
         M = loc.size
         R = M // D
         z = self.empty(K, M)
         lp = self.empty(R, K) if kfast else self.empty(K, R)
         sk, sr = (1, K) if kfast else (R, 1)
         self.call("zs_logistic_sample_logprob_f32", self.t(loc), self.t(scale), self.t(u), seed, off, rs, z,
-                  lp if want_lp else None, K, M, D, sk, sr)
+                  lp if want_lp else None, K, M, D, sk, sr, used)
         lpn = lp.cpu().numpy()
         return dict(z=z.cpu().numpy(), lp=lpn.T if kfast else lpn)
 
@@ -348,7 +348,7 @@ def test_hip_locscale_empty_unaligned_f64(hip, orc, hip64, orc64):
     u_b = torch.tensor(rng.uniform(0.01, 0.99, K * M + 1).astype(np.float32), device="cuda:0")
     z = torch.empty(K * M + 1, device="cuda:0")
     lp = torch.empty(K * R, device="cuda:0")
-    hip.call("zs_logistic_sample_logprob_f32", loc_b[1:], sc_b[1:], u_b[1:], 0, 0, None, z[1:], lp, K, M, D, R, 1)
+    hip.call("zs_logistic_sample_logprob_f32", loc_b[1:], sc_b[1:], u_b[1:], 0, 0, None, z[1:], lp, K, M, D, R, 1, None)
     ref = orc.logistic_sample(loc_b[1:].cpu().numpy(), sc_b[1:].cpu().numpy(), u_b[1:].cpu().numpy(), K, D)
     np.testing.assert_allclose(z[1:].cpu().numpy().reshape(K, M), ref["z"], rtol=1e-5, atol=4e-6)
     np.testing.assert_allclose(lp.cpu().numpy().reshape(K, R), ref["lp"], rtol=1e-5, atol=4e-5)

@@ -67,7 +67,17 @@ def test_bayesian_net_api(dev):
     net({"a": torch.ones(3, device=dev)})
     assert list(net.observed.keys()) == ["a"]
     v = net.stochastic_node("Normal", "a", mean=torch.zeros(3), std=torch.ones(3))
-    assert torch.equal(v, net.observed["a"]) and net.nodes["a"].is_observed()
+    assert torch.equal(v, net.observed["a"])
+    # stochastic_tensor.py:106-112: is_observed() reports the CONSTRUCTOR's observation, which BayesianNet never passes
+    # (bn.py:152-155) -- False here, exactly as in the reference; .tensor looks the name up in bn.observed instead
+    assert not net.nodes["a"].is_observed()
+    from zhusuan.framework import StochasticTensor
+    st = StochasticTensor(net, "a", net.nodes["a"].dist, observation=torch.ones(3, device=dev))
+    assert st.is_observed()
+    with pytest.raises(IndexError, match="Dimension out of range"):
+        net.sn(Normal(mean=torch.zeros(2, 3, device=dev), std=torch.ones(2, 3, device=dev)), "oob",
+               reduce_sum_dims=[2])
+        net.nodes["oob"].log_prob()
     z = net.sn(Normal(mean=torch.zeros(3, device=dev), std=torch.ones(3, device=dev)), "b", n_samples=4)
     assert list(z.shape) == [4, 3] and list(net.nodes["b"].shape) == [4, 3]
     assert net.snode("Bernoulli", "c", probs=torch.full([3], 0.5)).shape == (3,)

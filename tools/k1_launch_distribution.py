@@ -11,7 +11,7 @@ M = B * D
 mu = torch.randn(M, device=dev); sg = torch.rand(M, device=dev) + 0.5
 z = torch.empty(K * M, device=dev); lp = torch.empty(B * K, device=dev)
 other = torch.empty(K * M, device=dev)          # a second 0.7 GB tensor, touched between launches when asked to
-call = lambda off: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, off, None, P(z), P(lp), K, M, D, 1, K, st)
+call = lambda off: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, off, None, P(z), P(lp), K, M, D, 1, K, 0, None, st)
 for i in range(3): call(i)
 torch.cuda.synchronize()
 for mode in ("back-to-back", "sync between launches", "other tensor written between launches"):

@@ -12,6 +12,6 @@ M = B * D
 mu = torch.randn(M, device=dev); sg = torch.rand(M, device=dev) + 0.5
 z = torch.empty(K * M, device=dev); lp = torch.empty(B * K, device=dev)
 for i in range(5):
-    lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, i, None, P(z), P(lp), K, M, D, 1, K, st)
+    lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, i, None, P(z), P(lp), K, M, D, 1, K, 0, None, st)
 torch.cuda.synchronize()
 print("algorithmic bytes per launch", 4 * K * M + 4 * K * B + 8 * M)

@@ -70,24 +70,24 @@ def main():
         eps = torch.randn(K * M, device=dev)
         tag = "N=%d (B=%d)" % (N, B)
         timed("K1 normal sample+lp (Philox)", "zs_normal_sample_logprob_f32", 4 * N * D + 4 * N + 8 * M,
-              lambda: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, 2, None, P(z), P(lp), K, M, D, 1, K, st), tag)
+              lambda: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, 2, None, P(z), P(lp), K, M, D, 1, K, 0, None, st), tag)
         timed("K1 normal sample+lp (eps given)", "zs_normal_sample_logprob_f32", 8 * N * D + 4 * N + 8 * M,
-              lambda: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), P(eps), 0, 0, None, P(z), P(lp), K, M, D, 1, K, st), tag)
+              lambda: lib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), P(eps), 0, 0, None, P(z), P(lp), K, M, D, 1, K, 0, None, st), tag)
         timed("K2 normal logprob", "zs_normal_logprob_f32", 4 * N * D + 4 * N + 8 * M,
-              lambda: lib.call("zs_normal_logprob_f32", P(z), K * M, P(mu), M, P(sg), M, P(lp), K, B, D, 1, K, st), tag)
+              lambda: lib.call("zs_normal_logprob_f32", P(z), K * M, P(mu), M, P(sg), M, P(lp), K, B, D, 1, K, 0, st), tag)
         gz = torch.randn(K * M, device=dev)
         glp = torch.randn(B * K, device=dev)
         gmu, gsg = torch.empty(M, device=dev), torch.empty(M, device=dev)
         timed("K1 bwd (reparam, Philox)", "zs_normal_sample_logprob_bwd_f32", 4 * N * D + 4 * N + 12 * M,
-              lambda: lib.call("zs_normal_sample_logprob_bwd_f32", P(sg), None, 1, 2, None, P(gz), P(glp), 1, K, P(gmu), P(gsg), K, M, D, st), tag)
+              lambda: lib.call("zs_normal_sample_logprob_bwd_f32", P(sg), None, 1, 2, None, P(gz), P(glp), 1, K, P(gmu), P(gsg), K, M, D, 0, st), tag)
         timed("K2 bwd ksum (non-reparam)", "zs_normal_logprob_bwd_ksum_f32", 4 * N * D + 4 * N + 16 * M,
-              lambda: lib.call("zs_normal_logprob_bwd_ksum_f32", P(z), P(mu), P(sg), P(glp), 1, K, None, P(gmu), P(gsg), K, B, D, st), tag)
+              lambda: lib.call("zs_normal_logprob_bwd_ksum_f32", P(z), P(mu), P(sg), P(glp), 1, K, None, P(gmu), P(gsg), K, B, D, 0, st), tag)
         # ---------------- L1 / L2 / U1 / U2 (Logistic, Uniform): same shapes as K1 / K2
         u = eps.uniform_(1e-6, 1 - 1e-6)
         timed("L1 logistic sample+lp (Philox)", "zs_logistic_sample_logprob_f32", 4 * N * D + 4 * N + 8 * M,
-              lambda: lib.call("zs_logistic_sample_logprob_f32", P(mu), P(sg), None, 1, 2, None, P(z), P(lp), K, M, D, 1, K, st), tag)
+              lambda: lib.call("zs_logistic_sample_logprob_f32", P(mu), P(sg), None, 1, 2, None, P(z), P(lp), K, M, D, 1, K, None, st), tag)
         timed("L1 logistic sample+lp (u given)", "zs_logistic_sample_logprob_f32", 8 * N * D + 4 * N + 8 * M,
-              lambda: lib.call("zs_logistic_sample_logprob_f32", P(mu), P(sg), P(u), 0, 0, None, P(z), P(lp), K, M, D, 1, K, st), tag)
+              lambda: lib.call("zs_logistic_sample_logprob_f32", P(mu), P(sg), P(u), 0, 0, None, P(z), P(lp), K, M, D, 1, K, None, st), tag)
         timed("L2 logistic logprob", "zs_logistic_logprob_f32", 4 * N * D + 4 * N + 8 * M,
               lambda: lib.call("zs_logistic_logprob_f32", P(z), K * M, P(mu), M, P(sg), M, P(lp), K, B, D, 1, K, st), tag)
         timed("L1 bwd (Philox)", "zs_logistic_sample_logprob_bwd_f32", 4 * N * D + 4 * N + 12 * M,
@@ -96,7 +96,7 @@ def main():
         timed("U1 uniform sample (Philox)", "zs_uniform_sample_f32", 8 * N * D + 8 * M,
               lambda: lib.call("zs_uniform_sample_f32", P(mu), M, P(hi), M, None, 1, 2, None, P(z), P(gz), K * M, 1, st), tag)
         timed("U2 uniform logprob", "zs_uniform_logprob_f32", 4 * N * D + 4 * N + 8 * M,
-              lambda: lib.call("zs_uniform_logprob_f32", P(z), K * M, P(mu), M, P(hi), M, P(lp), K, B, D, 1, K, st), tag)
+              lambda: lib.call("zs_uniform_logprob_f32", P(z), K * M, P(mu), M, P(hi), M, P(lp), K, B, D, 1, K, 0, st), tag)
         del eps, gz, z, u, hi
         # ---------------- K4
         logp = torch.randn(B, K, device=dev) - 550

@@ -22,6 +22,7 @@ __device__ __forceinline__ double normal_term(double x, double mu, double sigma)
 __device__ __forceinline__ double bern_term(double p, double x) {
   return x * log(p + kEps) + (1.0 - x) * log((1.0 - p) + kEps);
 }
+__device__ __forceinline__ double sig_of(double v, bool ls) { return ls ? exp(v) : v; }   // Normal(logstd=...), normal.py:56
 __device__ __forceinline__ double sigmoid_d(double l) { return 1.0 / (1.0 + exp(-l)); }
 __device__ __forceinline__ double mul_add_2round(double m, double s, double e) {
 #pragma clang fp contract(off)   // two roundings like the reference's separate mul and add (normal.py:105)
@@ -37,8 +38,9 @@ __global__ __launch_bounds__(256) void k64_normal_sample(const double* __restric
                                                          const double* __restrict__ eps, uint64_t seed, uint64_t call,
                                                          const uint64_t* __restrict__ rs, double* __restrict__ z,
                                                          double* __restrict__ lp, int64_t K, int64_t R, int64_t D,
-                                                         int64_t sk, int64_t sr) {
+                                                         int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used) {
   if (rs) { seed = rs[0]; call += rs[1]; }
+  if (rng_used && blockIdx.x == 0 && threadIdx.x == 0) { rng_used[0] = seed; rng_used[1] = call; }
   const int64_t rows = K * R, M = R * D;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x) {
     int64_t k, r;
@@ -46,9 +48,10 @@ __global__ __launch_bounds__(256) void k64_normal_sample(const double* __restric
     double acc = 0.0;
     for (int64_t d = 0; d < D; ++d) {
       const int64_t m = r * D + d, i = k * M + m;
-      const double zz = mul_add_2round(mu[m], sigma[m], eps_at(eps, i, seed, call));
+      const double sg = sig_of(sigma[m], ls);
+      const double zz = mul_add_2round(mu[m], sg, eps_at(eps, i, seed, call));
       z[i] = zz;
-      if (lp) acc += normal_term(zz, mu[m], sigma[m]);
+      if (lp) acc += normal_term(zz, mu[m], sg);
     }
     if (lp) lp[k * sk + r * sr] = acc;
   }
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void k64_normal_sample_bwd(const double* __res
                                                              uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs,
                                                              const double* __restrict__ gz, const double* __restrict__ glp,
                                                              int64_t gsk, int64_t gsr, double* __restrict__ gmu,
-                                                             double* __restrict__ gsigma, int64_t K, int64_t M, int64_t D) {
+                                                             double* __restrict__ gsigma, int64_t K, int64_t M, int64_t D, bool ls) {
   if (rs) { seed = rs[0]; call += rs[1]; }
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = m / D;
@@ -72,20 +75,21 @@ __global__ __launch_bounds__(256) void k64_normal_sample_bwd(const double* __res
       if (glp) g += glp[k * gsk + r * gsr];
     }
     gmu[m] = a;
-    gsigma[m] = b - g / sigma[m];
+    const double sg = sig_of(sigma[m], ls);
+    gsigma[m] = ls ? b * sg - g : b - g / sg;
   }
 }
 
 __global__ __launch_bounds__(256) void k64_normal_logprob(const double* __restrict__ x, int64_t Px, const double* __restrict__ mu,
                                                           int64_t Pm, const double* __restrict__ sigma, int64_t Ps,
                                                           double* __restrict__ lp, int64_t K, int64_t R, int64_t D,
-                                                          int64_t sk, int64_t sr) {
+                                                          int64_t sk, int64_t sr, bool ls) {
   const int64_t rows = K * R;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x) {
     double acc = 0.0;
     for (int64_t d = 0; d < D; ++d) {
       const int64_t i = row * D + d;
-      acc += normal_term(x[mod_fast(i, Px)], mu[mod_fast(i, Pm)], sigma[mod_fast(i, Ps)]);
+      acc += normal_term(x[mod_fast(i, Px)], mu[mod_fast(i, Pm)], sig_of(sigma[mod_fast(i, Ps)], ls));
     }
     int64_t k, r;
     divmod(row, R, k, r);
@@ -93,26 +97,28 @@ __global__ __launch_bounds__(256) void k64_normal_logprob(const double* __restri
   }
 }
 
-__device__ __forceinline__ void normal_partials(double x, double mu, double sigma, double g, double& gx, double& gm, double& gs) {
+__device__ __forceinline__ void normal_partials(double x, double mu, double sigma, double g, double& gx, double& gm, double& gs,
+                                                bool ls) {
+  sigma = sig_of(sigma, ls);
   const double prec = exp(-2.0 * log(sigma));
   const double d = x - mu;
   const double t = g * prec * d;
   gx = -t;
   gm = t;
-  gs = g * (prec * d * d - 1.0) / sigma;
+  gs = ls ? g * (prec * d * d - 1.0) : g * (prec * d * d - 1.0) / sigma;   // d/d logstd = sigma * d/d sigma
 }
 
 __global__ __launch_bounds__(256) void k64_normal_logprob_bwd(const double* __restrict__ x, int64_t Px, const double* __restrict__ mu,
                                                               int64_t Pm, const double* __restrict__ sigma, int64_t Ps,
                                                               const double* __restrict__ glp, int64_t gsk, int64_t gsr,
                                                               double* __restrict__ gx, double* __restrict__ gmu,
-                                                              double* __restrict__ gsigma, int64_t N, int64_t R, int64_t D) {
+                                                              double* __restrict__ gsigma, int64_t N, int64_t R, int64_t D, bool ls) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t row, dd, k, r;
     divmod(i, D, row, dd);
     divmod(row, R, k, r);
     double a, b, c;
-    normal_partials(x[mod_fast(i, Px)], mu[mod_fast(i, Pm)], sigma[mod_fast(i, Ps)], glp[k * gsk + r * gsr], a, b, c);
+    normal_partials(x[mod_fast(i, Px)], mu[mod_fast(i, Pm)], sigma[mod_fast(i, Ps)], glp[k * gsk + r * gsr], a, b, c, ls);
     if (gx) gx[i] = a;
     if (gmu) gmu[i] = b;
     if (gsigma) gsigma[i] = c;
@@ -123,13 +129,13 @@ __global__ __launch_bounds__(256) void k64_normal_logprob_bwd_ksum(const double*
                                                                    const double* __restrict__ sigma, const double* __restrict__ glp,
                                                                    int64_t gsk, int64_t gsr, double* __restrict__ gx,
                                                                    double* __restrict__ gmu, double* __restrict__ gsigma,
-                                                                   int64_t K, int64_t M, int64_t D) {
+                                                                   int64_t K, int64_t M, int64_t D, bool ls) {
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = m / D;
     double sa = 0.0, sb = 0.0;
     for (int64_t k = 0; k < K; ++k) {
       double a, b, c;
-      normal_partials(x[k * M + m], mu[m], sigma[m], glp[k * gsk + r * gsr], a, b, c);
+      normal_partials(x[k * M + m], mu[m], sigma[m], glp[k * gsk + r * gsr], a, b, c, ls);
       if (gx) gx[k * M + m] = a;
       sa += b;
       sb += c;
@@ -352,12 +358,13 @@ __global__ __launch_bounds__(256) void k64_lme(const double* __restrict__ x, int
 
 extern "C" int zs_normal_sample_logprob_f64(const double* mu, const double* sigma, const double* eps, uint64_t seed,
                                             uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K,
-                                            int64_t M, int64_t D, int64_t sk, int64_t sr, void* stream) {
+                                            int64_t M, int64_t D, int64_t sk, int64_t sr, int sigma_is_logstd,
+                                            uint64_t* rng_used, void* stream) {
   if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
   if (M == 0) return 0;
   if (!mu || !sigma || !z) return ZS_EINVAL;
   ZS_LAUNCH(KID_NORMAL_SAMPLE, k64_normal_sample, dim3(grid_for(K * (M / D), 256)), dim3(256), ST, mu, sigma, eps, seed, offset,
-            rng_state, z, lp, K, M / D, D, sk, sr);
+            rng_state, z, lp, K, M / D, D, sk, sr, sigma_is_logstd != 0, rng_used);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -365,52 +372,53 @@ extern "C" int zs_normal_sample_logprob_f64(const double* mu, const double* sigm
 extern "C" int zs_normal_sample_logprob_bwd_f64(const double* sigma, const double* eps, uint64_t seed, uint64_t offset,
                                                 const uint64_t* rng_state, const double* gz, const double* glp, int64_t gsk,
                                                 int64_t gsr, double* gmu, double* gsigma, int64_t K, int64_t M, int64_t D,
-                                                void* stream) {
+                                                int sigma_is_logstd, void* stream) {
   if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
   if (M == 0) return 0;
   if (!sigma || !gmu || !gsigma) return ZS_EINVAL;
   ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, k64_normal_sample_bwd, dim3(grid_for(M, 256)), dim3(256), ST, sigma, eps, seed, offset, rng_state,
-            gz, glp, gsk, gsr, gmu, gsigma, K, M, D);
+            gz, glp, gsk, gsr, gmu, gsigma, K, M, D, sigma_is_logstd != 0);
   ZS_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int zs_normal_logprob_f64(const double* x, int64_t Px, const double* mu, int64_t Pm, const double* sigma, int64_t Ps,
-                                     double* lp, int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, void* stream) {
+                                     double* lp, int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, int sigma_is_logstd,
+                                     void* stream) {
   if (K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
   if (!x || !mu || !sigma || !lp) return ZS_EINVAL;
   if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
   ZS_LAUNCH(KID_NORMAL_LOGPROB, k64_normal_logprob, dim3(grid_for(K * R, 256)), dim3(256), ST, x, Px, mu, Pm, sigma, Ps, lp, K, R, D,
-            sk, sr);
+            sk, sr, sigma_is_logstd != 0);
   ZS_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int zs_normal_logprob_bwd_f64(const double* x, int64_t Px, const double* mu, int64_t Pm, const double* sigma,
                                          int64_t Ps, const double* glp, int64_t gsk, int64_t gsr, double* gx, double* gmu,
-                                         double* gsigma, int64_t K, int64_t R, int64_t D, void* stream) {
+                                         double* gsigma, int64_t K, int64_t R, int64_t D, int sigma_is_logstd, void* stream) {
   if (K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
   if (!x || !mu || !sigma || !glp) return ZS_EINVAL;
   if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
   ZS_LAUNCH(KID_NORMAL_LOGPROB_BWD, k64_normal_logprob_bwd, dim3(grid_for(N, 256)), dim3(256), ST, x, Px, mu, Pm, sigma, Ps, glp, gsk,
-            gsr, gx, gmu, gsigma, N, R, D);
+            gsr, gx, gmu, gsigma, N, R, D, sigma_is_logstd != 0);
   ZS_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int zs_normal_logprob_bwd_ksum_f64(const double* x, const double* mu, const double* sigma, const double* glp,
                                               int64_t gsk, int64_t gsr, double* gx, double* gmu, double* gsigma, int64_t K,
-                                              int64_t R, int64_t D, void* stream) {
+                                              int64_t R, int64_t D, int sigma_is_logstd, void* stream) {
   if (K < 1 || R < 0 || D < 1) return ZS_EINVAL;
   const int64_t M = R * D;
   if (M == 0) return 0;
   if (!x || !mu || !sigma || !glp) return ZS_EINVAL;
   ZS_LAUNCH(KID_NORMAL_LOGPROB_BWD_KSUM, k64_normal_logprob_bwd_ksum, dim3(grid_for(M, 256)), dim3(256), ST, x, mu, sigma, glp, gsk,
-            gsr, gx, gmu, gsigma, K, M, D);
+            gsr, gx, gmu, gsigma, K, M, D, sigma_is_logstd != 0);
   ZS_CHECK_LAUNCH();
   return 0;
 }

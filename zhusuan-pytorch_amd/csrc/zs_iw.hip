@@ -41,21 +41,22 @@ struct IwExt {
 __device__ __forceinline__ void iw_finish_mean(const IwExt& ext, float block_cost) {
   __shared__ bool last;
   if (threadIdx.x == 0) {
-    ext.partials[blockIdx.x] = block_cost;
-    __threadfence();
-    const unsigned t = atomicAdd(ext.ticket, 1u);
+    __hip_atomic_store(ext.partials + blockIdx.x, block_cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // release: the partial above is visible to whoever observes this increment; acquire: the last arrival sees all
+    const unsigned t = __hip_atomic_fetch_add(ext.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     last = (t == gridDim.x - 1);
   }
   __syncthreads();
   if (last && threadIdx.x < 64) {
-    __threadfence();
     float s = 0.f;
     for (unsigned i = threadIdx.x; i < gridDim.x; i += 64)
       s += __hip_atomic_load(ext.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written by other workgroups
     s = wave_sum(s);
     if (threadIdx.x == 0) {
       ext.mean_cost[0] = s * ext.inv_B;
-      *ext.ticket = 0u;
+      // hand the ticket back at zero for the next launch that uses this workspace (atomic, agent scope: the next
+      // launch may run on another CU / XCD)
+      __hip_atomic_store(ext.ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

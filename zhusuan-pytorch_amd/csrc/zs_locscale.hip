@@ -162,9 +162,13 @@ struct Regs3 {
 };
 template <typename T, bool HAS_U, int CP = C_GEN>
 struct LogisticSampleF {   // L1.  CP: C_PLANE inside the tile kernel (im known), C_GEN elsewhere
-  const T* loc; const T* scale; const T* u; uint64_t seed, call; const uint64_t* rs; T* z; int64_t M;
+  const T* loc; const T* scale; const T* u; uint64_t seed, call; const uint64_t* rs; T* z; int64_t M; uint64_t* used;
 
-  __device__ void prepare() { if (rs) { seed = rs[0]; call += rs[1]; } }
+  __device__ void prepare() {
+    if (rs) { seed = rs[0]; call += rs[1]; }
+    // resolved ids for the backward call, which may run after the caller has advanced the live rng_state
+    if (used && blockIdx.x == 0 && threadIdx.x == 0) { used[0] = seed; used[1] = call; }
+  }
   template <int ACC>
   __device__ __forceinline__ void load(int64_t i0, int n, int64_t im, int64_t RD, Regs3<T>& r) const {
     constexpr bool VEC = ACC != 0;
@@ -614,7 +618,7 @@ int launch_elem(int kid, F f, bool vec_ok, int64_t N, hipStream_t st) {
 
 template <typename T>
 int logistic_sample(const T* loc, const T* scale, const T* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, T* z,
-                    T* lp, int64_t K, int64_t M, int64_t D, int64_t sk, int64_t sr, void* stream) {
+                    T* lp, int64_t K, int64_t M, int64_t D, int64_t sk, int64_t sr, uint64_t* rng_used, void* stream) {
   if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
   if (M == 0) return 0;
   if (!loc || !scale || !z) return ZS_EINVAL;
@@ -623,17 +627,17 @@ int logistic_sample(const T* loc, const T* scale, const T* u, uint64_t seed, uin
   // D <= kTile: the tile kernel knows the index inside the [R*D] parameter plane (C_PLANE); the long-row kernel does not
   if (D <= kTile) {
     if (u) {
-      LogisticSampleF<T, true, C_PLANE> f = {loc, scale, u, seed, offset, rng_state, z, M};
+      LogisticSampleF<T, true, C_PLANE> f = {loc, scale, u, seed, offset, rng_state, z, M, rng_used};
       launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream);
     } else {
-      LogisticSampleF<T, false, C_PLANE> f = {loc, scale, u, seed, offset, rng_state, z, M};
+      LogisticSampleF<T, false, C_PLANE> f = {loc, scale, u, seed, offset, rng_state, z, M, rng_used};
       launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream);
     }
   } else if (u) {
-    LogisticSampleF<T, true> f = {loc, scale, u, seed, offset, rng_state, z, M};
+    LogisticSampleF<T, true> f = {loc, scale, u, seed, offset, rng_state, z, M, rng_used};
     launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream);
   } else {
-    LogisticSampleF<T, false> f = {loc, scale, u, seed, offset, rng_state, z, M};
+    LogisticSampleF<T, false> f = {loc, scale, u, seed, offset, rng_state, z, M, rng_used};
     launch_rows<T>(KID_LOGISTIC_SAMPLE, f, vec, lp, K, M / D, D, sk, sr, (hipStream_t)stream);
   }
   ZS_CHECK_LAUNCH();
@@ -768,8 +772,8 @@ int philox_uniform(T* out, int64_t N, uint64_t seed, uint64_t offset, const uint
 #define ZS_LOCSCALE_ENTRY(SFX, T)                                                                                                  \
   extern "C" int zs_logistic_sample_logprob##SFX(const T* loc, const T* scale, const T* u, uint64_t seed, uint64_t offset,         \
                                                  const uint64_t* rng_state, T* z, T* lp, int64_t K, int64_t M, int64_t D,          \
-                                                 int64_t sk, int64_t sr, void* stream) {                                           \
-    return logistic_sample<T>(loc, scale, u, seed, offset, rng_state, z, lp, K, M, D, sk, sr, stream);                             \
+                                                 int64_t sk, int64_t sr, uint64_t* rng_used, void* stream) {                       \
+    return logistic_sample<T>(loc, scale, u, seed, offset, rng_state, z, lp, K, M, D, sk, sr, rng_used, stream);                   \
   }                                                                                                                                \
   extern "C" int zs_logistic_sample_logprob_bwd##SFX(const T* scale, const T* u, uint64_t seed, uint64_t offset,                   \
                                                      const uint64_t* rng_state, const T* gz, const T* glp, int64_t gsk,            \

@@ -31,6 +31,20 @@ __device__ __forceinline__ float mul_add_2round(float m, float s, float e) {
   return m + prod;
 }
 
+// `sigma` operand given as log(sigma) (Normal(logstd=...), normal.py:56: std = exp(logstd)): the kernels form sigma
+// themselves instead of the caller launching an exp (and a multiply in backward).  Precise expf: it runs once per
+// parameter, not per particle.  d/d logstd = sigma * d/d sigma.
+__device__ __forceinline__ float sigma_of(float v, bool is_logstd) { return is_logstd ? expf(v) : v; }
+__device__ __forceinline__ float4 sigma_of(float4 v, bool is_logstd) {
+  if (is_logstd) { v.x = expf(v.x); v.y = expf(v.y); v.z = expf(v.z); v.w = expf(v.w); }
+  return v;
+}
+// resolved Philox ids of a draw, written once per launch for the backward call (which may run after the caller has
+// advanced the live rng_state)
+__device__ __forceinline__ void publish_rng(uint64_t* __restrict__ rng_used, uint64_t seed, uint64_t call) {
+  if (rng_used && blockIdx.x == 0 && threadIdx.x == 0) { rng_used[0] = seed; rng_used[1] = call; }
+}
+
 // ------------------------------------------------------------------------------------
 // K1 forward, rows of up to 256 elements (D4 <= 64): a wave owns `rpw` parameter rows (G = D4 lanes
 // each) and walks a chunk of the K particles, so log(sigma) and sigma^-2 are computed once per lane and
@@ -49,10 +63,11 @@ template <bool HAS_EPS, bool HAS_LP, bool NT>
 __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
     const float4* __restrict__ mu, const float4* __restrict__ sigma, const float4* __restrict__ eps,
     uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float4* __restrict__ z, float* __restrict__ lp,
-    int64_t K, int64_t R, int D4, int G, int rpw, int64_t kchunk, int64_t sk, int64_t sr) {
+    int64_t K, int64_t R, int D4, int G, int rpw, int64_t kchunk, int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used) {
   __shared__ float stage[4][ZS_K1_KB * ZS_K1_LDW];
   float* __restrict__ st = stage[threadIdx.x >> 6];
   if (rs) { seed = rs[0]; call += rs[1]; }
+  publish_rng(rng_used, seed, call);
   const int lane = threadIdx.x & 63;
   const int rw = lane / G, lig = lane - rw * G;
   const bool lane_on = rw < rpw;
@@ -71,7 +86,7 @@ __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = make_float4(1.f, 1.f, 1.f, 1.f);
     if (on) {
       m = mu[m4];
-      s = sigma[m4];
+      s = sigma_of(sigma[m4], ls);
     }
     // per-lane row constants, computed once and reused for every particle of the chunk:
     // rowc = sum_j (c - log sigma_j)  (normal.py:121-124),  hp_j = 0.5 * exp(-2 log sigma_j)
@@ -116,8 +131,13 @@ __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
         }
       }
       if (HAS_LP) {
-        // same-wave LDS hand-off: the DS queue is in order, no barrier needed between the writes above
-        // and these reads
+        // same-wave LDS hand-off (the slice is private to this wave, so no workgroup barrier): a wave-scope
+        // release/acquire fence pair orders the ds_write's above before the ds_read's below for the memory model, and
+        // wave_barrier keeps the compiler from moving either across it.  Both compile to no instructions beyond the
+        // s_waitcnt lgkmcnt the reads need anyway.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int nout = rpw * kb;
         for (int o = lane; o < nout; o += 64) {
           const int q = o / kb, kk = o - q * kb;
@@ -126,6 +146,10 @@ __global__ __launch_bounds__(256) void k_normal_sample_smallrow(
           for (int j = 0; j < G; ++j) sum += src[j];
           if (rbase + q < R) lp[(kb0 + kk) * sk + (rbase + q) * sr] = sum;
         }
+        // ... and the reads before the next batch of particles overwrites the slice
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
   }
@@ -136,8 +160,9 @@ template <bool HAS_EPS, bool HAS_LP>
 __global__ __launch_bounds__(256) void k_normal_sample_longrow(
     const float4* __restrict__ mu, const float4* __restrict__ sigma, const float4* __restrict__ eps,
     uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float4* __restrict__ z, float* __restrict__ lp,
-    int64_t K, int64_t R, int D4, int64_t sk, int64_t sr) {
+    int64_t K, int64_t R, int D4, int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used) {
   if (rs) { seed = rs[0]; call += rs[1]; }
+  publish_rng(rng_used, seed, call);
   const int lane = threadIdx.x & 63;
   const int64_t M4 = R * (int64_t)D4;
   const int64_t rows = K * R;
@@ -149,7 +174,7 @@ __global__ __launch_bounds__(256) void k_normal_sample_longrow(
     for (int c = lane; c < D4; c += 64) {
       const int64_t m4 = r * D4 + c;
       const int64_t g = k * M4 + m4;
-      const float4 m = mu[m4], s = sigma[m4];
+      const float4 m = mu[m4], s = sigma_of(sigma[m4], ls);
       float4 e;
       if (HAS_EPS) e = eps[g];
       else e = philox_normal4((uint64_t)g, call, seed);
@@ -181,8 +206,9 @@ template <bool HAS_EPS>
 __global__ __launch_bounds__(256) void k_normal_sample_serial(
     const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ eps,
     uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float* __restrict__ z, float* __restrict__ lp,
-    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used) {
   if (rs) { seed = rs[0]; call += rs[1]; }
+  publish_rng(rng_used, seed, call);
   const int64_t rows = K * R, M = R * D;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
        row += (int64_t)gridDim.x * blockDim.x) {
@@ -203,7 +229,7 @@ __global__ __launch_bounds__(256) void k_normal_sample_serial(
         }
         e = f4_get(n4, (int)(i & 3));
       }
-      const float mm = mu[m], s = sigma[m];
+      const float mm = mu[m], s = sigma_of(sigma[m], ls);
       const float zz = mul_add_2round(mm, s, e);
       z[i] = zz;
       if (lp) {
@@ -222,8 +248,9 @@ template <bool HAS_EPS>
 __global__ __launch_bounds__(256) void k_normal_sample_waverow(
     const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ eps,
     uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float* __restrict__ z, float* __restrict__ lp,
-    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used) {
   if (rs) { seed = rs[0]; call += rs[1]; }
+  publish_rng(rng_used, seed, call);
   const int lane = threadIdx.x & 63;
   const int64_t rows = K * R, M = R * D;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -236,7 +263,7 @@ __global__ __launch_bounds__(256) void k_normal_sample_waverow(
       float e;
       if (HAS_EPS) e = eps[i];
       else e = f4_get(philox_normal4((uint64_t)(i >> 2), call, seed), (int)(i & 3));
-      const float mm = mu[m], s = sigma[m];
+      const float mm = mu[m], s = sigma_of(sigma[m], ls);
       const float zz = mul_add_2round(mm, s, e);
       z[i] = zz;
       if (lp) {
@@ -255,7 +282,7 @@ __global__ __launch_bounds__(256) void k_normal_sample_waverow(
 __global__ __launch_bounds__(256) void k_normal_logprob_waverow(
     const float* __restrict__ x, int64_t Px, const float* __restrict__ mu, int64_t Pm,
     const float* __restrict__ sigma, int64_t Ps, float* __restrict__ lp,
-    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, bool ls) {
   const int lane = threadIdx.x & 63;
   const int64_t rows = K * R;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -263,7 +290,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_waverow(
     float acc = 0.f;
     for (int64_t d = lane; d < D; d += 64) {
       const int64_t i = row * D + d;
-      const float s = sigma[Ps == 1 ? 0 : mod_fast(i, Ps)];
+      const float s = sigma_of(sigma[Ps == 1 ? 0 : mod_fast(i, Ps)], ls);
       const float l2 = log2_fast(s);
       acc += normal_lp_term(x[Px == 1 ? 0 : mod_fast(i, Px)] - mu[Pm == 1 ? 0 : mod_fast(i, Pm)], l2 * ZS_LN2,
                             exp2_fast(-2.0f * l2));
@@ -285,7 +312,7 @@ template <bool HAS_EPS>
 __global__ __launch_bounds__(256) void k_normal_sample_bwd(
     const float4* __restrict__ sigma, const float4* __restrict__ eps, uint64_t seed, uint64_t call,
     const uint64_t* __restrict__ rs, const float4* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
-    float4* __restrict__ gmu, float4* __restrict__ gsigma, int64_t K, int64_t M4, int D4) {
+    float4* __restrict__ gmu, float4* __restrict__ gsigma, int64_t K, int64_t M4, int D4, bool ls) {
   __shared__ float4 red_a[4][64];
   __shared__ float4 red_b[4][64];
   __shared__ float red_g[4][64];
@@ -324,16 +351,18 @@ __global__ __launch_bounds__(256) void k_normal_sample_bwd(
       b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
       g += red_g[s][lane];
     }
-    const float4 s = sigma[m4];
+    const float4 s = sigma_of(sigma[m4], ls);
     gmu[m4] = a;
-    gsigma[m4] = make_float4(b.x - g / s.x, b.y - g / s.y, b.z - g / s.z, b.w - g / s.w);
+    // d/d sigma = sum_k gz*eps - (sum_k glp)/sigma ;  d/d logstd = sigma * that = sigma * sum_k gz*eps - sum_k glp
+    gsigma[m4] = ls ? make_float4(b.x * s.x - g, b.y * s.y - g, b.z * s.z - g, b.w * s.w - g)
+                    : make_float4(b.x - g / s.x, b.y - g / s.y, b.z - g / s.z, b.w - g / s.w);
   }
 }
 
 __global__ __launch_bounds__(256) void k_normal_sample_bwd_serial(
     const float* __restrict__ sigma, const float* __restrict__ eps, uint64_t seed, uint64_t call,
     const uint64_t* __restrict__ rs, const float* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
-    float* __restrict__ gmu, float* __restrict__ gsigma, int64_t K, int64_t M, int64_t D) {
+    float* __restrict__ gmu, float* __restrict__ gsigma, int64_t K, int64_t M, int64_t D, bool ls) {
   if (rs) { seed = rs[0]; call += rs[1]; }
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = m / D;
@@ -350,7 +379,8 @@ __global__ __launch_bounds__(256) void k_normal_sample_bwd_serial(
       if (glp) g += glp[k * gsk + r * gsr];
     }
     gmu[m] = a;
-    gsigma[m] = b - g / sigma[m];
+    const float sg = sigma_of(sigma[m], ls);
+    gsigma[m] = ls ? b * sg - g : b - g / sg;
   }
 }
 
@@ -369,7 +399,7 @@ __device__ __forceinline__ float4 ld_row4(const float4* __restrict__ p, int64_t 
 __global__ __launch_bounds__(256) void k_normal_logprob_rows(
     const float4* __restrict__ x, int64_t xr, const float4* __restrict__ mu, int64_t mr,
     const float4* __restrict__ sigma, int64_t sr_, float* __restrict__ lp,
-    int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t sk, int64_t sr) {
+    int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t sk, int64_t sr, bool ls) {
   const int lane = threadIdx.x & 63;
   const int rw = lane / G, lig = lane - rw * G;
   const bool lane_on = rw < rpw;
@@ -384,7 +414,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_rows(
       for (int c = lig; c < D4; c += G) {
         const float4 xv = ld_row4(x, row, xr, D4, c);
         const float4 m = ld_row4(mu, row, mr, D4, c);
-        const float4 s = ld_row4(sigma, row, sr_, D4, c);
+        const float4 s = sigma_of(ld_row4(sigma, row, sr_, D4, c), ls);
         const float sv[4] = {s.x, s.y, s.z, s.w};
         const float dv[4] = {xv.x - m.x, xv.y - m.y, xv.z - m.z, xv.w - m.w};
 #pragma unroll
@@ -410,7 +440,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_rows(
 __global__ __launch_bounds__(256) void k_normal_logprob_krep(
     const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
     float* __restrict__ lp, int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t kchunk,
-    int64_t sk, int64_t sr) {
+    int64_t sk, int64_t sr, bool ls) {
   const int lane = threadIdx.x & 63;
   const int rw = lane / G, lig = lane - rw * G;
   const bool lane_on = rw < rpw;
@@ -428,7 +458,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_krep(
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = make_float4(1.f, 1.f, 1.f, 1.f);
     if (on) {
       m = mu[m4];
-      s = sigma[m4];
+      s = sigma_of(sigma[m4], ls);
     }
     float rowc = 0.f, hp[4];
     {
@@ -477,7 +507,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_krep(
 __global__ __launch_bounds__(256) void k_normal_logprob_full(
     const float4* __restrict__ x, int x_scalar, const float4* __restrict__ mu, int mu_scalar,
     const float4* __restrict__ sigma, int sg_scalar, float* __restrict__ lp,
-    int64_t rows, int64_t R, int D4, int G, int rpw, int p2, int64_t sk, int64_t sr) {
+    int64_t rows, int64_t R, int D4, int G, int rpw, int p2, int64_t sk, int64_t sr, bool ls) {
   const int lane = threadIdx.x & 63;
   const int rw = lane / G, lig = lane - rw * G;
   const bool lane_on = rw < rpw;
@@ -487,7 +517,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_full(
   if (x_scalar) xs = *reinterpret_cast<const float*>(x);
   if (mu_scalar) ms = *reinterpret_cast<const float*>(mu);
   if (sg_scalar) {
-    ss = *reinterpret_cast<const float*>(sigma);
+    ss = sigma_of(*reinterpret_cast<const float*>(sigma), ls);
     const float l2 = log2_fast(ss);
     ls_s = l2 * ZS_LN2;
     hp_s = 0.5f * exp2_fast(-2.0f * l2);
@@ -506,7 +536,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_full(
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc += (ZS_NEG_HALF_LOG_2PI - ls_s) - hp_s * (dv[j] * dv[j]);
         } else {
-          const float4 sv4 = sigma[base + c];
+          const float4 sv4 = sigma_of(sigma[base + c], ls);
           const float sv[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -529,14 +559,14 @@ __global__ __launch_bounds__(256) void k_normal_logprob_full(
 __global__ __launch_bounds__(256) void k_normal_logprob_serial(
     const float* __restrict__ x, int64_t Px, const float* __restrict__ mu, int64_t Pm,
     const float* __restrict__ sigma, int64_t Ps, float* __restrict__ lp,
-    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr) {
+    int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, bool ls) {
   const int64_t rows = K * R;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows;
        row += (int64_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
     for (int64_t d = 0; d < D; ++d) {
       const int64_t i = row * D + d;
-      const float s = sigma[mod_fast(i, Ps)];
+      const float s = sigma_of(sigma[mod_fast(i, Ps)], ls);
       const float l2 = log2_fast(s);
       acc += normal_lp_term(x[mod_fast(i, Px)] - mu[mod_fast(i, Pm)], l2 * ZS_LN2, exp2_fast(-2.0f * l2));
     }
@@ -551,19 +581,19 @@ __global__ __launch_bounds__(256) void k_normal_logprob_bwd_elem(
     const float* __restrict__ x, int64_t Px, const float* __restrict__ mu, int64_t Pm,
     const float* __restrict__ sigma, int64_t Ps, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float* __restrict__ gx, float* __restrict__ gmu, float* __restrict__ gsigma,
-    int64_t N, int64_t R, int64_t D) {
+    int64_t N, int64_t R, int64_t D, bool ls) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / D;
     int64_t k, r;
     divmod(row, R, k, r);
     const float g = glp[k * gsk + r * gsr];
-    const float s = sigma[mod_fast(i, Ps)];
+    const float s = sigma_of(sigma[mod_fast(i, Ps)], ls);
     const float diff = x[mod_fast(i, Px)] - mu[mod_fast(i, Pm)];
     const float prec = exp2_fast(-2.0f * log2_fast(s));
     const float t = g * prec * diff;
     if (gx) gx[i] = -t;
     if (gmu) gmu[i] = t;
-    if (gsigma) gsigma[i] = g * (prec * diff * diff - 1.0f) / s;
+    if (gsigma) gsigma[i] = ls ? g * (prec * diff * diff - 1.0f) : g * (prec * diff * diff - 1.0f) / s;
   }
 }
 
@@ -572,7 +602,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_bwd_ksum(
     const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
     const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float4* __restrict__ gx, float4* __restrict__ gmu, float4* __restrict__ gsigma,
-    int64_t K, int64_t M4, int D4) {
+    int64_t K, int64_t M4, int D4, bool ls) {
   __shared__ float4 red[2][4][64];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int64_t m4 = (int64_t)blockIdx.x * 64 + lane;
@@ -580,14 +610,14 @@ __global__ __launch_bounds__(256) void k_normal_logprob_bwd_ksum(
   float4 am = make_float4(0.f, 0.f, 0.f, 0.f), as = am;
   if (on) {
     const int64_t r = (int64_t)((uint64_t)m4 >> 31 ? m4 / D4 : (int64_t)((uint32_t)m4 / (uint32_t)D4));
-    const float4 m = mu[m4], s = sigma[m4];
+    const float4 m = mu[m4], s = sigma_of(sigma[m4], ls);
     const float sv[4] = {s.x, s.y, s.z, s.w};
     const float mv[4] = {m.x, m.y, m.z, m.w};
     float pr[4], inv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       pr[j] = exp2_fast(-2.0f * log2_fast(sv[j]));
-      inv[j] = 1.0f / sv[j];
+      inv[j] = ls ? 1.0f : 1.0f / sv[j];     // d/d logstd = sigma * d/d sigma
     }
     float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t k = slice; k < K; k += 4) {
@@ -628,10 +658,11 @@ __global__ __launch_bounds__(256) void k_normal_logprob_bwd_ksum_serial(
     const float* __restrict__ x, const float* __restrict__ mu, const float* __restrict__ sigma,
     const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float* __restrict__ gx, float* __restrict__ gmu, float* __restrict__ gsigma,
-    int64_t K, int64_t M, int64_t D) {
+    int64_t K, int64_t M, int64_t D, bool ls) {
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = m / D;
-    const float s = sigma[m], mm = mu[m];
+    const float s = sigma_of(sigma[m], ls), mm = mu[m];
+    const float inv = ls ? 1.0f : 1.0f / s;
     const float prec = exp2_fast(-2.0f * log2_fast(s));
     float a = 0.f, b = 0.f;
     for (int64_t k = 0; k < K; ++k) {
@@ -639,7 +670,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_bwd_ksum_serial(
       const float diff = x[k * M + m] - mm;
       const float t = g * prec * diff;
       a += t;
-      b += g * (prec * diff * diff - 1.0f) / s;
+      b += g * (prec * diff * diff - 1.0f) * inv;
       if (gx) gx[k * M + m] = -t;
     }
     if (gmu) gmu[m] = a;
@@ -658,7 +689,9 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
                                             uint64_t seed, uint64_t offset, const uint64_t* rng_state,
                                             float* z, float* lp,
                                             int64_t K, int64_t M, int64_t D,
-                                            int64_t sk, int64_t sr, void* stream) {
+                                            int64_t sk, int64_t sr, int sigma_is_logstd, uint64_t* rng_used,
+                                            void* stream) {
+  const bool ls = sigma_is_logstd != 0;
   if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
   if (M == 0) return 0;
   if (!mu || !sigma || !z) return ZS_EINVAL;
@@ -681,7 +714,7 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
       const unsigned grid = grid_for(total, 4);
 #define ZS_LAUNCH_SMALL(E, L, T)                                                                          \
   ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_smallrow<E, L, T>), dim3(grid), dim3(256), st, m4, s4, e4, \
-            seed, offset, rng_state, (float4*)z, lp, K, R, D4, rm.G, rm.rpw, kchunk, sk, sr)
+            seed, offset, rng_state, (float4*)z, lp, K, R, D4, rm.G, rm.rpw, kchunk, sk, sr, ls, rng_used)
       const bool nt = (double)K * (double)M * 4.0 > 268435456.0;   // z cannot stay in the Infinity Cache
       if (nt) {
         if (eps) { if (lp) ZS_LAUNCH_SMALL(true, true, true); else ZS_LAUNCH_SMALL(true, false, true); }
@@ -695,7 +728,7 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
       const unsigned grid = grid_for(K * R, 4);
 #define ZS_LAUNCH_LONG(E, L)                                                                           \
   ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_longrow<E, L>), dim3(grid), dim3(256), st, m4, s4, e4, seed, \
-                     offset, rng_state, (float4*)z, lp, K, R, D4, sk, sr)
+                     offset, rng_state, (float4*)z, lp, K, R, D4, sk, sr, ls, rng_used)
       if (eps) { if (lp) ZS_LAUNCH_LONG(true, true); else ZS_LAUNCH_LONG(true, false); }
       else     { if (lp) ZS_LAUNCH_LONG(false, true); else ZS_LAUNCH_LONG(false, false); }
 #undef ZS_LAUNCH_LONG
@@ -704,18 +737,18 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
     const unsigned grid = grid_for(K * R, 4);
     if (eps)
       ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_waverow<true>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
-                offset, rng_state, z, lp, K, R, D, sk, sr);
+                offset, rng_state, z, lp, K, R, D, sk, sr, ls, rng_used);
     else
       ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_waverow<false>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
-                offset, rng_state, z, lp, K, R, D, sk, sr);
+                offset, rng_state, z, lp, K, R, D, sk, sr, ls, rng_used);
   } else {
     const unsigned grid = grid_for(K * R, 256);
     if (eps)
       ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_serial<true>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
-                         offset, rng_state, z, lp, K, R, D, sk, sr);
+                         offset, rng_state, z, lp, K, R, D, sk, sr, ls, rng_used);
     else
       ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_serial<false>), dim3(grid), dim3(256), st, mu, sigma, eps, seed,
-                         offset, rng_state, z, lp, K, R, D, sk, sr);
+                         offset, rng_state, z, lp, K, R, D, sk, sr, ls, rng_used);
   }
   ZS_CHECK_LAUNCH();
   return 0;
@@ -725,7 +758,8 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
                                                 uint64_t offset, const uint64_t* rng_state,
                                                 const float* gz, const float* glp,
                                                 int64_t gsk, int64_t gsr, float* gmu, float* gsigma,
-                                                int64_t K, int64_t M, int64_t D, void* stream) {
+                                                int64_t K, int64_t M, int64_t D, int sigma_is_logstd, void* stream) {
+  const bool ls = sigma_is_logstd != 0;
   if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
   if (M == 0) return 0;
   if (!sigma || !gmu || !gsigma) return ZS_EINVAL;
@@ -738,14 +772,14 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
     if (eps)
       ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<true>), dim3(grid), dim3(256), st, (const float4*)sigma,
                          (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
-                         (float4*)gsigma, K, M4, (int)(D / 4));
+                         (float4*)gsigma, K, M4, (int)(D / 4), ls);
     else
       ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<false>), dim3(grid), dim3(256), st, (const float4*)sigma,
                          (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
-                         (float4*)gsigma, K, M4, (int)(D / 4));
+                         (float4*)gsigma, K, M4, (int)(D / 4), ls);
   } else {
     ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, k_normal_sample_bwd_serial, dim3(grid_for(M, 256)), dim3(256), st, sigma, eps, seed,
-                       offset, rng_state, gz, glp, gsk, gsr, gmu, gsigma, K, M, D);
+                       offset, rng_state, gz, glp, gsk, gsr, gmu, gsigma, K, M, D, ls);
   }
   ZS_CHECK_LAUNCH();
   return 0;
@@ -753,7 +787,9 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
 
 extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu, int64_t Pm,
                                      const float* sigma, int64_t Ps, float* lp,
-                                     int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, void* stream) {
+                                     int64_t K, int64_t R, int64_t D, int64_t sk, int64_t sr, int sigma_is_logstd,
+                                     void* stream) {
+  const bool ls = sigma_is_logstd != 0;
   if (K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
@@ -777,22 +813,22 @@ extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu
       const int64_t kchunk = (K + kt - 1) / kt;
       const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
       ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_krep, dim3(grid_for(total, 4)), dim3(256), st, (const float4*)x,
-                (const float4*)mu, (const float4*)sigma, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr);
+                (const float4*)mu, (const float4*)sigma, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr, ls);
     } else if (simple) {
       ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_full, dim3(grid_for(tiles, 4)), dim3(256), st, (const float4*)x,
                 (int)(Px == 1 && N != 1), (const float4*)mu, (int)(Pm == 1 && N != 1), (const float4*)sigma,
-                (int)(Ps == 1 && N != 1), lp, rows, R, D4, rm.G, rm.rpw, rm.p2, sk, sr);
+                (int)(Ps == 1 && N != 1), lp, rows, R, D4, rm.G, rm.rpw, rm.p2, sk, sr, ls);
     } else {
       ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_rows, dim3(grid_for(tiles, 4)), dim3(256), st, (const float4*)x,
                 Px == 1 ? 0 : Px / D, (const float4*)mu, Pm == 1 ? 0 : Pm / D, (const float4*)sigma,
-                Ps == 1 ? 0 : Ps / D, lp, K, R, D4, rm.G, rm.rpw, rm.p2, sk, sr);
+                Ps == 1 ? 0 : Ps / D, lp, K, R, D4, rm.G, rm.rpw, rm.p2, sk, sr, ls);
     }
   } else if (D >= 8) {
     ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_waverow, dim3(grid_for(K * R, 4)), dim3(256), st, x, Px, mu, Pm,
-              sigma, Ps, lp, K, R, D, sk, sr);
+              sigma, Ps, lp, K, R, D, sk, sr, ls);
   } else {
     ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_serial, dim3(grid_for(K * R, 256)), dim3(256), st, x, Px, mu, Pm,
-                       sigma, Ps, lp, K, R, D, sk, sr);
+                       sigma, Ps, lp, K, R, D, sk, sr, ls);
   }
   ZS_CHECK_LAUNCH();
   return 0;
@@ -801,14 +837,15 @@ extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu
 extern "C" int zs_normal_logprob_bwd_f32(const float* x, int64_t Px, const float* mu, int64_t Pm,
                                          const float* sigma, int64_t Ps, const float* glp, int64_t gsk,
                                          int64_t gsr, float* gx, float* gmu, float* gsigma,
-                                         int64_t K, int64_t R, int64_t D, void* stream) {
+                                         int64_t K, int64_t R, int64_t D, int sigma_is_logstd, void* stream) {
+  const bool ls = sigma_is_logstd != 0;
   if (K < 1 || R < 0 || D < 1 || Px < 1 || Pm < 1 || Ps < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
   if (!x || !mu || !sigma || !glp) return ZS_EINVAL;
   if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
   ZS_LAUNCH(KID_NORMAL_LOGPROB_BWD, k_normal_logprob_bwd_elem, dim3(grid_for(N, 256)), dim3(256), (hipStream_t)stream, x,
-                     Px, mu, Pm, sigma, Ps, glp, gsk, gsr, gx, gmu, gsigma, N, R, D);
+                     Px, mu, Pm, sigma, Ps, glp, gsk, gsr, gx, gmu, gsigma, N, R, D, ls);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -816,7 +853,8 @@ extern "C" int zs_normal_logprob_bwd_f32(const float* x, int64_t Px, const float
 extern "C" int zs_normal_logprob_bwd_ksum_f32(const float* x, const float* mu, const float* sigma,
                                               const float* glp, int64_t gsk, int64_t gsr, float* gx,
                                               float* gmu, float* gsigma, int64_t K, int64_t R, int64_t D,
-                                              void* stream) {
+                                              int sigma_is_logstd, void* stream) {
+  const bool ls = sigma_is_logstd != 0;
   if (K < 1 || R < 0 || D < 1) return ZS_EINVAL;
   const int64_t M = R * D;
   if (M == 0) return 0;
@@ -828,10 +866,10 @@ extern "C" int zs_normal_logprob_bwd_ksum_f32(const float* x, const float* mu, c
     const int64_t M4 = M / 4;
     ZS_LAUNCH(KID_NORMAL_LOGPROB_BWD_KSUM, k_normal_logprob_bwd_ksum, dim3((unsigned)((M4 + 63) / 64)), dim3(256), st,
                        (const float4*)x, (const float4*)mu, (const float4*)sigma, glp, gsk, gsr, (float4*)gx,
-                       (float4*)gmu, (float4*)gsigma, K, M4, (int)(D / 4));
+                       (float4*)gmu, (float4*)gsigma, K, M4, (int)(D / 4), ls);
   } else {
     ZS_LAUNCH(KID_NORMAL_LOGPROB_BWD_KSUM, k_normal_logprob_bwd_ksum_serial, dim3(grid_for(M, 256)), dim3(256), st, x, mu, sigma,
-                       glp, gsk, gsr, gx, gmu, gsigma, K, M, D);
+                       glp, gsk, gsr, gx, gmu, gsigma, K, M, D, ls);
   }
   ZS_CHECK_LAUNCH();
   return 0;

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments); default: the in-tree library
 LIB_PATH = os.environ.get("ZS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -24,11 +24,11 @@ _int = ctypes.c_int
 
 # name -> argtypes ; every function returns int (0 = ok) unless noted
 PROTOTYPES = {
-    "zs_normal_sample_logprob_f32": [_p, _p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
-    "zs_normal_sample_logprob_bwd_f32": [_p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p],
-    "zs_normal_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
-    "zs_normal_logprob_bwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
-    "zs_normal_logprob_bwd_ksum_f32": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
+    "zs_normal_sample_logprob_f32": [_p, _p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p, _p],
+    "zs_normal_sample_logprob_bwd_f32": [_p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _int, _p],
+    "zs_normal_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _p],
+    "zs_normal_logprob_bwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p],
+    "zs_normal_logprob_bwd_ksum_f32": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p],
     "zs_bernoulli_logprob_f32": [_p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_bernoulli_logprob_bwd_f32": [_p, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
     "zs_bernoulli_logits_logprob_f32": [_p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
@@ -38,7 +38,7 @@ PROTOTYPES = {
     "zs_log_mean_exp_f32": [_p, _i64, _i64, _i64, _p, _p],
     "zs_philox_normal_f32": [_p, _i64, _u64, _u64, _p, _p],
     # Logistic / Uniform
-    "zs_logistic_sample_logprob_f32": [_p, _p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "zs_logistic_sample_logprob_f32": [_p, _p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p],
     "zs_logistic_sample_logprob_bwd_f32": [_p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p],
     "zs_logistic_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_logistic_logprob_bwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
@@ -128,14 +128,18 @@ def lib():
     return _LIB
 
 
+HOST_LIBRARY_TOKEN_ENV = "ZS_TESTS_HOST_LIBRARY_TOKEN"
+HOST_LIBRARY_TOKEN = "tests/conftest.py:host-library"
+
+
 def _install_host_library_for_tests(klib):
     """TESTS ONLY: route kernel calls on CPU tensors to ``klib`` (the C oracle built from
     oracle/zs_oracle_c.c) so host logic can be exercised without a GPU.  Never called by the package, and
-    refused outside a pytest process: the product has no CPU path."""
+    refused unless the environment carries the token that only tests/conftest.py sets (worker processes of
+    the multi-rank tests inherit it): the product has no CPU path."""
     global _HOST_LIB
-    import sys
-    if klib is not None and "pytest" not in sys.modules:
-        raise RuntimeError("zhusuan: _install_host_library_for_tests is a test hook (pytest only); "
+    if klib is not None and os.environ.get(HOST_LIBRARY_TOKEN_ENV) != HOST_LIBRARY_TOKEN:
+        raise RuntimeError("zhusuan: _install_host_library_for_tests is a test hook (tests/conftest.py only); "
                            "the MI355X build has no CPU execution path")
     _HOST_LIB = klib
 

@@ -57,12 +57,22 @@ def _kr_view(t, K, R):
     return v, v.stride(0), v.stride(1)
 
 
+def _rng_snapshot(rng_state, wanted):
+    """Two-word device buffer that a sampling kernel fills with the Philox ids it resolved from the live
+    ``rng_state``; the backward call reads it instead of the live state, which ``DeviceRNG.begin_step()`` may have
+    advanced in between (two objectives per step, a delayed or retained backward).  Costs no launch."""
+    if rng_state is None or not wanted:
+        return None
+    return torch.empty(2, dtype=torch.int64, device=rng_state.device)
+
+
 class NormalSampleLogProb(torch.autograd.Function):
     """K1: z = mu + sigma*eps and the row-summed log-density of z in one pass.
-    Replaces Normal._sample + Normal._log_prob (zhusuan/distributions/normal.py:89-126)."""
+    Replaces Normal._sample + Normal._log_prob (zhusuan/distributions/normal.py:89-126).  With `is_logstd` the
+    `sigma` operand is log(sigma) (Normal(logstd=...), normal.py:56) and its gradient is d/d logstd."""
 
     @staticmethod
-    def forward(ctx, mu, sigma, eps, seed, call, rng_state, K, has_k_axis, n_fold, reparam, kfast):
+    def forward(ctx, mu, sigma, eps, seed, call, rng_state, K, has_k_axis, n_fold, reparam, kfast, is_logstd=False):
         # backward copes with an undefined gz / glp itself: do not let autograd fill a [K, B, D] tensor with zeros
         # (a 2 MB memset per step when the sample reaches the generator detached, as in the VIMCO path)
         ctx.set_materialize_grads(False)
@@ -80,9 +90,13 @@ class NormalSampleLogProb(torch.autograd.Function):
             ctx.meta = None
             return z, lp
         buf, lp, sk, sr = _alloc_rows(K, has_k_axis, rest, kfast, mu)
+        used = _rng_snapshot(rng_state, reparam and eps is None)
         lib.call("zs_normal_sample_logprob" + sfx, _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(eps), seed, call,
-                 _hip.ptr(rng_state), _hip.ptr(z), _hip.ptr(buf), K, M, D, sk, sr, _hip.stream_for(mu))
-        ctx.meta = (seed, call, K, M, D, R, reparam)
+                 _hip.ptr(rng_state), _hip.ptr(z), _hip.ptr(buf), K, M, D, sk, sr, 1 if is_logstd else 0, _hip.ptr(used),
+                 _hip.stream_for(mu))
+        if used is not None:        # backward regenerates eps from the ids the kernel resolved, not from the live state
+            rng_state, call = used, 0
+        ctx.meta = (seed, call, K, M, D, R, reparam, 1 if is_logstd else 0)
         ctx.rng_state = rng_state
         if reparam:
             ctx.save_for_backward(mu, sigma, eps)
@@ -95,12 +109,12 @@ class NormalSampleLogProb(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gz, glp):
         if ctx.meta is None:
-            return (None,) * 11
-        seed, call, K, M, D, R, reparam = ctx.meta
+            return (None,) * 12
+        seed, call, K, M, D, R, reparam, ls = ctx.meta
         lib = _hip.lib()
         sfx = _sfx(ctx.saved_tensors[0])
         if gz is None and glp is None:
-            return (None,) * 11
+            return (None,) * 12
         if reparam:
             mu, sigma, eps = ctx.saved_tensors
             gmu = torch.empty_like(mu)
@@ -112,18 +126,18 @@ class NormalSampleLogProb(torch.autograd.Function):
                 glp, gsk, gsr = _kr_view(glp, K, R)
             lib.call("zs_normal_sample_logprob_bwd" + sfx, _hip.ptr(sigma), _hip.ptr(eps), seed, call,
                      _hip.ptr(ctx.rng_state), _hip.ptr(gz), _hip.ptr(glp), gsk, gsr, _hip.ptr(gmu), _hip.ptr(gsigma), K, M, D,
-                     _hip.stream_for(mu))
+                     ls, _hip.stream_for(mu))
         else:
             mu, sigma, z = ctx.saved_tensors
             if glp is None:
-                return (torch.zeros_like(mu), torch.zeros_like(sigma)) + (None,) * 9
+                return (torch.zeros_like(mu), torch.zeros_like(sigma)) + (None,) * 10
             gmu = torch.empty_like(mu)
             gsigma = torch.empty_like(sigma)
             glp, gsk, gsr = _kr_view(glp, K, R)
             lib.call("zs_normal_logprob_bwd_ksum" + sfx, _hip.ptr(z), _hip.ptr(mu), _hip.ptr(sigma),
-                     _hip.ptr(glp), gsk, gsr, None, _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D,
+                     _hip.ptr(glp), gsk, gsr, None, _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D, ls,
                      _hip.stream_for(mu))
-        return gmu, gsigma, None, None, None, None, None, None, None, None, None
+        return (gmu, gsigma) + (None,) * 10
 
 
 class NormalLogProb(torch.autograd.Function):
@@ -131,10 +145,11 @@ class NormalLogProb(torch.autograd.Function):
     Operands arrive contiguous; `periods` = (Px, Pm, Ps) in elements of the full [*full_shape] problem."""
 
     @staticmethod
-    def forward(ctx, x, mu, sigma, full_shape, n_fold, periods, kfast):
+    def forward(ctx, x, mu, sigma, full_shape, n_fold, periods, kfast, is_logstd=False):
         _hip.require_device(x, mu, sigma)
         sfx = _sfx(x, mu, sigma)
         lib = _hip.lib()
+        ls = 1 if is_logstd else 0
         full_shape = tuple(full_shape)
         out_shape = full_shape[:len(full_shape) - n_fold]
         D = _prod(full_shape[len(full_shape) - n_fold:])
@@ -146,21 +161,21 @@ class NormalLogProb(torch.autograd.Function):
         Px, Pm, Ps = periods
         if K * R * D > 0:
             lib.call("zs_normal_logprob" + sfx, _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
-                     _hip.ptr(buf), K, R, D, sk, sr, _hip.stream_for(x))
-        ctx.meta = (K, R, D, periods)
+                     _hip.ptr(buf), K, R, D, sk, sr, ls, _hip.stream_for(x))
+        ctx.meta = (K, R, D, periods, ls)
         ctx.save_for_backward(x, mu, sigma)
         return lp
 
     @staticmethod
     def backward(ctx, glp):
-        K, R, D, (Px, Pm, Ps) = ctx.meta
+        K, R, D, (Px, Pm, Ps), ls = ctx.meta
         x, mu, sigma = ctx.saved_tensors
         sfx = _sfx(x)
         need_x, need_mu, need_sigma = ctx.needs_input_grad[:3]
         N = K * R * D
         lib = _hip.lib()
         if N == 0 or not (need_x or need_mu or need_sigma):
-            return (None,) * 7
+            return (None,) * 8
         glp, gsk, gsr = _kr_view(glp, K, R)
         st = _hip.stream_for(x)
         gx = gmu = gsigma = None
@@ -170,7 +185,7 @@ class NormalLogProb(torch.autograd.Function):
             gmu = torch.empty_like(mu)
             gsigma = torch.empty_like(sigma)
             lib.call("zs_normal_logprob_bwd_ksum" + sfx, _hip.ptr(x), _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(glp),
-                     gsk, gsr, _hip.ptr(gx), _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D, st)
+                     gsk, gsr, _hip.ptr(gx), _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D, ls, st)
         else:
             def full():
                 return torch.empty(N, dtype=x.dtype, device=x.device)
@@ -178,7 +193,7 @@ class NormalLogProb(torch.autograd.Function):
             fm = full() if need_mu else None
             fs = full() if need_sigma else None
             lib.call("zs_normal_logprob_bwd" + sfx, _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
-                     _hip.ptr(glp), gsk, gsr, _hip.ptr(fx), _hip.ptr(fm), _hip.ptr(fs), K, R, D, st)
+                     _hip.ptr(glp), gsk, gsr, _hip.ptr(fx), _hip.ptr(fm), _hip.ptr(fs), K, R, D, ls, st)
 
             def fold(f, P, like):
                 if f is None:
@@ -188,7 +203,7 @@ class NormalLogProb(torch.autograd.Function):
                 return f.view(like.shape)
             gx, gmu, gsigma = fold(fx, Px, x), fold(fm, Pm, mu), fold(fs, Ps, sigma)
         return (gx if need_x else None, gmu if need_mu else None, gsigma if need_sigma else None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class BernoulliLogProb(torch.autograd.Function):
@@ -278,15 +293,16 @@ class IWReduce(torch.autograd.Function):
         return gp, gq, None
 
 
-_IW_WORKSPACE = {}     # (device, dtype) -> (partials [4096], ticket [1] int32): scratch of the deterministic batch mean
+_IW_WORKSPACE = {}     # (device, dtype, stream) -> (partials [4096], ticket [1] int32): scratch of the deterministic batch mean
 
 
 def _iw_workspace(device, dtype):
-    """Scratch of K4b's batch mean, one per (device, dtype), shared by successive launches on one stream (the kernel
-    leaves the ticket at zero).  Objectives evaluated concurrently on several streams of one device must not share it:
-    not supported.  While a hipGraph is being captured a not-yet-cached workspace is allocated for that graph only --
-    caching a tensor that lives in a graph's private pool would dangle once the graph is destroyed."""
-    key = (str(device), dtype)
+    """Scratch of K4b's batch mean: one per (device, dtype, STREAM).  Launches on one stream are ordered, so they can
+    share it (the kernel hands the ticket back at zero); objectives evaluated concurrently on different streams of a
+    device each get their own.  While a hipGraph is being captured a not-yet-cached workspace is allocated for that
+    graph only -- caching a tensor that lives in a graph's private pool would dangle once the graph is destroyed."""
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (str(device), dtype, stream)
     ws = _IW_WORKSPACE.get(key)
     if ws is None:
         ws = (torch.zeros(4096, dtype=dtype, device=device), torch.zeros(1, dtype=torch.int32, device=device))
@@ -451,8 +467,11 @@ class LogisticSampleLogProb(torch.autograd.Function):
             ctx.meta = None
             return z, torch.zeros(lead + rest, dtype=loc.dtype, device=loc.device)
         buf, lp, sk, sr = _alloc_rows(K, has_k_axis, rest, kfast, loc)
+        used = _rng_snapshot(rng_state, u is None)
         _hip.lib().call("zs_logistic_sample_logprob" + sfx, _hip.ptr(loc), _hip.ptr(scale), _hip.ptr(u), seed, call,
-                        _hip.ptr(rng_state), _hip.ptr(z), _hip.ptr(buf), K, M, D, sk, sr, _hip.stream_for(loc))
+                        _hip.ptr(rng_state), _hip.ptr(z), _hip.ptr(buf), K, M, D, sk, sr, _hip.ptr(used), _hip.stream_for(loc))
+        if used is not None:
+            rng_state, call = used, 0
         ctx.meta = (seed, call, K, M, D, R)
         ctx.rng_state = rng_state
         ctx.save_for_backward(scale, u)

@@ -9,8 +9,40 @@ import torch
 import torch.distributed as dist
 
 
+def _bucket_dtype(params):
+    """The one dtype of a flat gradient bucket: the parameters' (float32 in every benchmark config; float64 models work
+    too).  Mixed-precision parameter sets are refused -- one all-reduce needs one element type."""
+    dtypes = {p.dtype for p in params}
+    if len(dtypes) != 1:
+        raise TypeError("zhusuan.dataparallel: parameters of one bucket must share a dtype, got %s"
+                        % sorted(str(d) for d in dtypes))
+    return dtypes.pop()
+
+
+def _fill_flat(flat, params, views, tail):
+    """Write the gradients of `params` (and `tail`, a list of 1-element tensors) into `flat`, whose slices `views`
+    shadow the parameters.  One ``cat`` kernel when no gradient lives in the buffer yet; gradients that already alias
+    their slice (autograd accumulated in place into last step's views because zero() was skipped) are left where they
+    are and only the others are copied."""
+    aliased = [p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views)]
+    if not any(aliased):
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
+        torch.cat(parts + [t.detach().reshape(1).to(flat.dtype) for t in tail], out=flat)
+        return
+    dst = [v for p, v, a in zip(params, views, aliased) if not a and p.grad is not None]
+    src = [p.grad for p, a in zip(params, aliased) if not a and p.grad is not None]
+    if dst:
+        torch._foreach_copy_(dst, src)
+    for p, v in zip(params, views):
+        if p.grad is None:
+            v.zero_()
+    n = sum(p.numel() for p in params)
+    for i, t in enumerate(tail):
+        flat[n + i:n + i + 1].copy_(t.detach().reshape(1))
+
+
 class GradientBucket(object):
-    """One flat fp32 buffer [all gradients | objective] for the single all-reduce of a step.
+    """One flat buffer [all gradients | objective] (in the parameters' dtype) for the single all-reduce of a step.
 
     Per step: autograd produces the gradients as usual; ``all_reduce_mean`` packs them (one ``cat`` kernel
     straight into the persistent buffer), all-reduces the buffer, scales it by 1/world and re-points every
@@ -21,7 +53,7 @@ class GradientBucket(object):
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(n + 1, dtype=_bucket_dtype(self.params), device=dev)
         self.views = []
         off = 0
         for p in self.params:
@@ -35,9 +67,7 @@ class GradientBucket(object):
             p.grad = None
 
     def pack(self, local_loss):
-        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
-        parts.append(local_loss.detach().reshape(1).to(self.flat.dtype))
-        torch.cat(parts, out=self.flat)
+        _fill_flat(self.flat, self.params, self.views, [local_loss])
         for p, v in zip(self.params, self.views):
             p.grad = v
 
@@ -51,7 +81,7 @@ class GradientBucket(object):
         return self.flat[self.n_grad]
 
     def nbytes(self):
-        return self.flat.numel() * 4
+        return self.flat.numel() * self.flat.element_size()
 
 
 class OverlappedBuckets(object):
@@ -59,8 +89,11 @@ class OverlappedBuckets(object):
 
     Parameters are grouped, in the order backward produces their gradients (reverse registration order: the generator's
     last layer first, the encoder last), into `n_buckets` flat fp32 buffers of similar size.  A post-accumulate-grad hook
-    per parameter counts arrivals; the moment a bucket is complete it is packed (one ``cat`` kernel) and its all-reduce
-    is launched asynchronously, so it travels over xGMI while autograd is still computing the remaining gradients.
+    per parameter counts arrivals; the moment a bucket is complete -- and every EARLIER bucket has left: collectives
+    are issued in bucket order on every rank, whatever order the gradients arrive in (a parameter that receives no
+    gradient on some ranks only would otherwise reorder the collectives there and hang or mis-sum) -- it is packed
+    (one ``cat`` kernel) and its all-reduce is launched asynchronously, so it travels over xGMI while autograd is still
+    computing the remaining gradients.
     ``finish()`` waits for the handles, applies 1/world and re-points every ``p.grad`` at its slice (no unpack copy).
 
         buckets = dataparallel.OverlappedBuckets(model, n_buckets=2)
@@ -74,6 +107,7 @@ class OverlappedBuckets(object):
         if not params:
             raise ValueError("module has no trainable parameters")
         self.group = group
+        self._dtype = _bucket_dtype(params)
         order = list(reversed(params))
         total = sum(p.numel() for p in order)
         n_buckets = max(1, min(int(n_buckets), len(order)))
@@ -96,10 +130,11 @@ class OverlappedBuckets(object):
                 self._owner[p] = bi
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._loss = None
+        self._next = 0          # index of the next bucket allowed to leave
 
     def _make(self, params):
         n = sum(p.numel() for p in params)
-        flat = torch.zeros(n + (1 if not self.buckets else 0), dtype=torch.float32, device=params[0].device)
+        flat = torch.zeros(n + (1 if not self.buckets else 0), dtype=self._dtype, device=params[0].device)
         views, off = [], 0
         for p in params:
             views.append(flat[off:off + p.numel()].view_as(p))
@@ -116,6 +151,7 @@ class OverlappedBuckets(object):
             for p in b["params"]:
                 p.grad = None
         self._loss = None
+        self._next = 0
 
     def begin(self, local_loss):
         """Hand over the local objective before ``backward()`` so that it rides in the first bucket."""
@@ -123,11 +159,10 @@ class OverlappedBuckets(object):
 
     def _launch(self, bi):
         b = self.buckets[bi]
-        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b["params"]]
+        tail = []
         if bi == 0:
-            loss = self._loss if self._loss is not None else torch.zeros((), device=b["flat"].device)
-            parts.append(loss.reshape(1).to(torch.float32))
-        torch.cat(parts, out=b["flat"])
+            tail = [self._loss if self._loss is not None else torch.zeros((), dtype=self._dtype, device=b["flat"].device)]
+        _fill_flat(b["flat"], b["params"], b["views"], tail)
         b["launched"] = True
         if self._active():
             b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -136,15 +171,20 @@ class OverlappedBuckets(object):
         bi = self._owner[p]
         b = self.buckets[bi]
         b["pending"] -= 1
-        if b["pending"] == 0 and not b["launched"]:
-            self._launch(bi)
+        # fixed issue order: a complete bucket waits until every earlier one has been launched
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] <= 0:
+            if not self.buckets[self._next]["launched"]:
+                self._launch(self._next)
+            self._next += 1
 
     def finish(self):
         """Wait for the collectives, average, alias ``p.grad`` to the buckets; returns the global objective (0-d)."""
         world = dist.get_world_size(self.group) if self._active() else 1
-        for bi, b in enumerate(self.buckets):
+        for bi, b in enumerate(self.buckets):     # index order = issue order on every rank
             if not b["launched"]:                 # parameters that received no gradient this step
                 self._launch(bi)
+        self._next = len(self.buckets)
+        for bi, b in enumerate(self.buckets):
             if b["handle"] is not None:
                 b["handle"].wait()
             if world > 1:
@@ -159,7 +199,7 @@ class OverlappedBuckets(object):
         self._hooks = []
 
     def nbytes(self):
-        return sum(b["flat"].numel() * 4 for b in self.buckets)
+        return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
 
 
 def shard_rows(x, rank, world_size):

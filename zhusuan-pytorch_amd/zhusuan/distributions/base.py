@@ -12,6 +12,12 @@ __all__ = ['Distribution']
 
 
 class Distribution(object):
+    # True for families whose NON-reparameterised draw is a function with an identically zero derivative w.r.t. the
+    # parameters (Normal: torch.normal(mean, std), normal.py:102; Bernoulli: torch.bernoulli, bernoulli.py:80): the
+    # objectives may then hand the draw to the generator detached.  Uniform is NOT one of them: its draw is rescaled
+    # outside the no-grad region (uniform.py:63-70) and carries d/d low = 1 - u, d/d high = u.
+    _nonreparam_draw_has_zero_grad = False
+
     def __init__(self,
                  dtype,
                  is_continuous,

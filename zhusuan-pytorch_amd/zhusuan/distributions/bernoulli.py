@@ -11,6 +11,7 @@ __all__ = ['Bernoulli']
 
 
 class Bernoulli(Distribution):
+    _nonreparam_draw_has_zero_grad = True      # see Distribution
     """
     :param logits / probs: exactly one of them (ValueError otherwise, bernoulli.py:39-42).
         From ``probs`` the log-mass is ``x*log(p+1e-8) + (1-x)*log(1-p+1e-8)`` (bernoulli.py:94);

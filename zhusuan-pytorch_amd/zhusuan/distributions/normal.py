@@ -11,6 +11,7 @@ __all__ = ['Normal']
 
 
 class Normal(Distribution):
+    _nonreparam_draw_has_zero_grad = True      # see Distribution
     """
     :param mean: float tensor (or anything ``torch.as_tensor`` accepts); broadcastable against std.
     :param std / logstd: exactly one of them (ValueError otherwise, normal.py:51-54).
@@ -39,11 +40,17 @@ class Normal(Distribution):
                 "Either `std` or `logstd` should be passed. It is not allowed "
                 "that both are specified or both are not.")
         elif std is None:
-            self._std = torch.exp(torch.as_tensor(logstd, dtype=dtype).to(device))
+            # normal.py:56 computes std = exp(logstd) here.  The kernels take log(sigma) directly (sigma_is_logstd of
+            # include/zs_hip.h) and form exp() in registers, so constructing the node launches nothing; `std` is
+            # materialised only if somebody reads the property.
+            self._logstd_given = torch.as_tensor(logstd, dtype=dtype).to(device)
+            self._std_cache = None
         else:
-            self._std = torch.as_tensor(std, dtype=dtype).to(device)
-        check_broadcast(self._std, self._mean)
-        dtype = assert_same_log_float_dtype([(self._mean, "Normal.mean"), (self._std, "Normal.std")])
+            self._logstd_given = None
+            self._std_cache = torch.as_tensor(std, dtype=dtype).to(device)
+        scale = self._scale_operand()
+        check_broadcast(scale, self._mean)
+        dtype = assert_same_log_float_dtype([(self._mean, "Normal.mean"), (scale, "Normal.std")])
         super(Normal, self).__init__(dtype=dtype,
                                      is_continuous=is_continuous,
                                      is_reparameterized=is_reparameterized,
@@ -56,16 +63,26 @@ class Normal(Distribution):
     def mean(self):
         return self._mean
 
+    def _scale_operand(self):
+        """The tensor handed to the kernels as `sigma`: log(sigma) for Normal(logstd=...), else sigma."""
+        return self._std_cache if self._logstd_given is None else self._logstd_given
+
+    @property
+    def _std(self):
+        if self._std_cache is None:
+            self._std_cache = torch.exp(self._logstd_given)        # normal.py:56
+        return self._std_cache
+
     @property
     def std(self):
         return self._std
 
     @property
     def logstd(self):
-        return torch.log(self._std)
+        return torch.log(self._std)         # normal.py:77-79 (log of exp of the argument, as in the reference)
 
     def _batch_shape(self):
-        return torch.Size(broadcast_shapes(self._mean.shape, self._std.shape))
+        return torch.Size(broadcast_shapes(self._mean.shape, self._scale_operand().shape))
 
     def _sample(self, n_samples=1, epsilon=None):
         """normal.py:89-107.  The standard-normal draw has MEAN's shape (``[K] + mean.shape``), so it is
@@ -73,7 +90,8 @@ class Normal(Distribution):
         draw explicitly; otherwise it comes from the in-kernel Philox stream."""
         K = int(n_samples)
         has_k = K > 1
-        mean, std = self._mean, self._std
+        mean, std = self._mean, self._scale_operand()
+        is_logstd = self._logstd_given is not None
         bshape = tuple(self._batch_shape())
         lead = (K,) if has_k else ()
         eps_shape = lead + tuple(mean.shape)
@@ -102,7 +120,7 @@ class Normal(Distribution):
             sigma = std.expand(bshape).contiguous()
         n_fold = min(max(1, self._group_ndims), len(bshape))
         z, lp = _ops.NormalSampleLogProb.apply(mu, sigma, eps, seed, call, rng_state, K if has_k else 1, has_k, n_fold,
-                                               bool(self._is_reparameterized), True)
+                                               bool(self._is_reparameterized), True, is_logstd)
         self.sample_cache = z
         self._fused = (z, lp, n_fold)
         return z
@@ -120,5 +138,5 @@ class Normal(Distribution):
             raise ValueError("cannot sum %d trailing axes of a result of shape %s" % (n_fold, full))
         px, Px = _ops.periodic_operand(x, full)
         pm, Pm = _ops.periodic_operand(self._mean, full)
-        ps, Ps = _ops.periodic_operand(self._std, full)
-        return _ops.NormalLogProb.apply(px, pm, ps, full, n_fold, (Px, Pm, Ps), True)
+        ps, Ps = _ops.periodic_operand(self._scale_operand(), full)
+        return _ops.NormalLogProb.apply(px, pm, ps, full, n_fold, (Px, Pm, Ps), True, self._logstd_given is not None)

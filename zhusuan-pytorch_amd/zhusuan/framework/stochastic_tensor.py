@@ -8,7 +8,18 @@ __all__ = ['StochasticTensor']
 
 
 def _norm_dims(dims, nd):
-    return [int(d) % nd if nd else 0 for d in dims] if dims else []
+    """Axes of a reduction made non-negative.  An axis outside [-nd, nd) raises IndexError like the reference's
+    ``torch.mean`` / ``torch.sum`` (stochastic_tensor.py:162-165) instead of silently wrapping onto another axis."""
+    if not dims:
+        return []
+    out = []
+    for d in dims:
+        d = int(d)
+        lo, hi = (-nd, nd - 1) if nd else (-1, 0)
+        if not lo <= d <= hi:
+            raise IndexError("Dimension out of range (expected to be in range of [%d, %d], but got %d)" % (lo, hi, d))
+        out.append(d % nd if nd else 0)
+    return out
 
 
 class StochasticTensor(object):
@@ -58,7 +69,9 @@ class StochasticTensor(object):
         return self._dist
 
     def is_observed(self):
-        return self._name in self._bn.observed.keys()
+        """stochastic_tensor.py:106-112: whether an observation was handed to the CONSTRUCTOR (``.tensor`` looks the
+        name up in ``bn.observed`` instead, :121 -- the two differ and both are kept as in the reference)."""
+        return self._observation is not None
 
     @property
     def tensor(self):

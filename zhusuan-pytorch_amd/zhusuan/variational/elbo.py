@@ -9,13 +9,15 @@ __all__ = ['ELBO', 'EvidenceLowerBoundObjective']
 
 
 def latent_value(node):
-    """``node.tensor`` as handed to the generator.  A non-reparameterised draw carries a grad_fn whose
-    derivative is identically zero (``torch.normal(mean, std)``, normal.py:102); detaching it here changes no
-    gradient and lets autograd skip the dead branches through the generator (first decoder dgrad, prior
-    log-prob backward)."""
+    """``node.tensor`` as handed to the generator.  For Normal / Bernoulli a non-reparameterised draw carries a grad_fn
+    whose derivative is identically zero (``torch.normal(mean, std)``, normal.py:102); detaching it here changes no
+    gradient and lets autograd skip the dead branches through the generator (first decoder dgrad, prior log-prob
+    backward).  Families whose non-reparameterised draw still depends differentiably on the parameters (Uniform,
+    uniform.py:63-70) stay attached, so the pathwise gradient reaches low / high as in the reference."""
     t = node.tensor
     dist = getattr(node, 'dist', None)
-    if dist is not None and not dist.is_reparameterized and isinstance(t, torch.Tensor):
+    if (dist is not None and not dist.is_reparameterized and isinstance(t, torch.Tensor)
+            and getattr(dist, '_nonreparam_draw_has_zero_grad', False)):
         return t.detach()
     return t
 
