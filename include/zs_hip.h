@@ -362,6 +362,9 @@ int zs_scalar_objective_f64(const double* r0, int64_t n0, double c0, const doubl
 int zs_prof_enable(int on);
 int zs_prof_kernel_id(const char* entry_point);
 int zs_prof_query(int kernel_id, double* total_ms, double* min_ms, double* max_ms, int64_t* count);
+/* The individual durations (ms, launch order) of the recorded launches of one entry point: writes the first `capacity`
+ * of them to out_ms and returns how many were recorded (so the caller can take a median over back-to-back launches). */
+int64_t zs_prof_durations(int kernel_id, double* out_ms, int64_t capacity);
 
 #ifdef __cplusplus
 }

@@ -44,16 +44,19 @@ static void philox4(uint64_t group, uint64_t call, uint64_t seed, uint32_t out[4
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 static float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * 5.9604644775390625e-08f; }
+/* Box-Muller on the word pairs (0, 1) and (2, 3): radius from the 24-bit uniform u01(word) in (0, 1), angle
+ * 2*pi*t with t = (word >> 9) * 2^-23 in [0, 1) (the kernels' definition of the stream, csrc/zs_common.h) */
 static void philox_normal4(uint64_t group, uint64_t call, uint64_t seed, float n[4]) {
   uint32_t r[4];
   philox4(group, call, seed, r);
   const double two_pi = 6.283185307179586476925;
-  double u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]), u3 = u01(r[3]);
+  double u0 = u01(r[0]), u2 = u01(r[2]);
+  double t1 = (double)(r[1] >> 9) * 1.1920928955078125e-07, t3 = (double)(r[3] >> 9) * 1.1920928955078125e-07;
   double ra = sqrt(-2.0 * log(u0)), rb = sqrt(-2.0 * log(u2));
-  n[0] = (float)(ra * cos(two_pi * u1));
-  n[1] = (float)(ra * sin(two_pi * u1));
-  n[2] = (float)(rb * cos(two_pi * u3));
-  n[3] = (float)(rb * sin(two_pi * u3));
+  n[0] = (float)(ra * cos(two_pi * t1));
+  n[1] = (float)(ra * sin(two_pi * t1));
+  n[2] = (float)(rb * cos(two_pi * t3));
+  n[3] = (float)(rb * sin(two_pi * t3));
 }
 int zs_abi_version(void) { return ZS_ABI_VERSION; }
 const char* zs_error_string(int code) {
@@ -106,6 +109,11 @@ int zs_prof_enable(int on) { (void)on; return ZS_ENOTSUP; }
 int zs_prof_kernel_id(const char* entry_point) { (void)entry_point; return ZS_ENOTSUP; }
 int zs_prof_query(int kernel_id, double* total_ms, double* min_ms, double* max_ms, int64_t* count) {
   (void)kernel_id; (void)total_ms; (void)min_ms; (void)max_ms; (void)count;
+  return ZS_ENOTSUP;
+}
+
+int64_t zs_prof_durations(int kernel_id, double* out_ms, int64_t capacity) {
+  (void)kernel_id; (void)out_ms; (void)capacity;
   return ZS_ENOTSUP;
 }
 

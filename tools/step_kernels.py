@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""Per-step kernel table of one config: which kernels one training step launches, how often and for how long, split
+into hot-path kernels of this package (k_*) and everything else (the callers' GEMMs, torch element-wise glue, Adam).
+
+  python tools/step_kernels.py --config C5 [--steps 100] [--out profiles/r02_step_kernels_C5.json]
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_C5 -- python3 tools/step_kernels.py --config C5 --external
+
+Runs exactly `--steps` eager steps (no hipGraph: a replay hides nothing from a tracer, but eager keeps the launch order
+readable).  In-process the device timestamps come from torch.profiler (roctracer); with --external the process only
+runs the steps and an outside tracer (rocprofv3) does the counting: Calls / steps = launches per step.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import torch
+
+import zhusuan
+from examples import vae_mnist, iwae, bnn_vi
+
+
+def make(config, dev):
+    bits = lambda B: {"x": (torch.rand(B, 784, device=dev) < 0.5).float()}
+    if config == "C2":
+        return vae_mnist.build(512, device=dev), bits(512), 512
+    if config == "C3":
+        return iwae.build(50, "vimco", device=dev), bits(256), 12800
+    if config == "C3-logits":
+        return iwae.build(50, "vimco", device=dev, fused_logits=True), bits(256), 12800
+    if config == "C5":
+        return bnn_vi.build(n_particles=10, device=dev), {"x": torch.randn(512, 13, device=dev), "y": torch.randn(512, device=dev)}, 5120
+    raise SystemExit("unknown config %s" % config)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C5", choices=["C2", "C3", "C3-logits", "C5"])
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--external", action="store_true", help="an outside tracer counts; just run the steps")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model, obs, evals = make(args.config, dev)
+    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
+    rng = zhusuan.DeviceRNG(dev, seed=1)
+
+    def step():
+        rng.begin_step()
+        for p in model.parameters():
+            p.grad = None
+        loss = model(obs)
+        loss.backward()
+        opt.step()
+
+    with zhusuan.device_rng(rng):
+        if args.external:
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            return
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+    acc = {}
+    for e in prof.events():
+        d = getattr(e, "device_time", None) or getattr(e, "cuda_time", 0.0)
+        if d and d > 0:
+            a = acc.setdefault(e.name, [0, 0.0])
+            a[0] += 1
+            a[1] += float(d)
+    rows = []
+    for name, (n, tot) in acc.items():
+        hot = "k_" in name and ("zs" in name or name.lstrip("void ").startswith(("(anonymous namespace)::k_", "k_")))
+        rows.append({"kernel": name[:140], "hot_path": bool(hot), "launches_per_step": n / args.steps,
+                     "avg_us": tot / n, "us_per_step": tot / args.steps})
+    rows.sort(key=lambda r: -r["us_per_step"])
+    hot = [r for r in rows if r["hot_path"]]
+    glue = [r for r in rows if not r["hot_path"]]
+    summary = {"config": args.config, "steps": args.steps, "launch_mode": "eager",
+               "hot_path": {"launches_per_step": sum(r["launches_per_step"] for r in hot), "us_per_step": sum(r["us_per_step"] for r in hot)},
+               "other": {"launches_per_step": sum(r["launches_per_step"] for r in glue), "us_per_step": sum(r["us_per_step"] for r in glue)},
+               "kernels": rows}
+    print("%s: hot-path %.1f launches / %.1f us per step; other %.1f launches / %.1f us per step" % (
+        args.config, summary["hot_path"]["launches_per_step"], summary["hot_path"]["us_per_step"],
+        summary["other"]["launches_per_step"], summary["other"]["us_per_step"]))
+    for r in rows:
+        print("  %-5s %5.2f x %8.2f us  %s" % ("HOT" if r["hot_path"] else "", r["launches_per_step"], r["avg_us"], r["kernel"][:110]))
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(summary, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,16 @@ bool prof_begin_launch(int kid, hipEvent_t* start, hipEvent_t* stop);  // define
       hipLaunchKernelGGL(kern, grid, block, 0, st, __VA_ARGS__);                               \
   } while (0)
 
+// same, with `smem` bytes of dynamic LDS
+#define ZS_LAUNCH_SMEM(kid, kern, grid, block, smem, st, ...)                                  \
+  do {                                                                                         \
+    hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                 \
+    if (zs::prof_begin_launch(kid, &e0__, &e1__))                                              \
+      hipExtLaunchKernelGGL(kern, grid, block, smem, st, e0__, e1__, 0, __VA_ARGS__);          \
+    else                                                                                       \
+      hipLaunchKernelGGL(kern, grid, block, smem, st, __VA_ARGS__);                            \
+  } while (0)
+
 // ---------------------------------------------------------------- math
 // v_log_f32 / v_exp_f32 are base-2 and 1-ulp; natural log/exp are one multiply away.
 __device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }
@@ -125,18 +135,35 @@ __device__ __forceinline__ uint32_t xor3_key(uint32_t a, uint32_t b, uint32_t ke
 #ifndef ZS_PHILOX_ROUNDS
 #define ZS_PHILOX_ROUNDS 10
 #endif
+// Measured issue costs on gfx950 (tools/valu_rates.hip, cycles per wave64 instruction per SIMD with the chip full):
+// v_fma / v_bitop3 / v_mul_hi 4.3, v_xor_b32 2.5, v_mad_u64_u32 ~6, v_log / v_sqrt / v_sin / v_cos 8.  The generator is
+// what bounds the fused sampling kernel, so every instruction here is counted.
+//
+// (seed, call) are uniform across a launch: in the first round the product 0xCD9E8D57 * lo(call) and the key xors are
+// scalar-unit work, and the second round still has one uniform counter word.  Those two rounds are therefore written as
+// plain C (the compiler keeps uniform values in SGPRs: one v_mad_u64_u32 and three plain xors instead of two
+// multiplies and two three-input xors fed by v_mov copies); rounds 3..10 use the one-instruction three-input xor.
 __device__ __forceinline__ Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) {
   uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32);
   uint32_t c2 = (uint32_t)call, c3 = (uint32_t)(call >> 32);
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < ZS_PHILOX_ROUNDS; ++r) {
-    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = xor3_key((uint32_t)(p1 >> 32), c1, k0);
-    uint32_t n1 = (uint32_t)p1;
-    uint32_t n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
-    uint32_t n3 = (uint32_t)p0;
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0, n2;
+    // readfirstlane pins a uniform xor to the scalar unit (the optimiser otherwise re-associates it into two v_xor)
+    if (r == 0) {                                  // uniform here: p1 (both halves), k0, c3, k1
+      n0 = __builtin_amdgcn_readfirstlane((uint32_t)(p1 >> 32) ^ k0) ^ c1;   // one v_xor with the lane's c1 = hi(group)
+      n2 = (uint32_t)(p0 >> 32) ^ __builtin_amdgcn_readfirstlane(c3 ^ k1);   // one v_xor
+    } else if (r == 1) {                           // uniform here: c1 (= lo(p1) of round 0), k0, k1
+      n0 = (uint32_t)(p1 >> 32) ^ __builtin_amdgcn_readfirstlane(c1 ^ k0);   // one v_xor
+      n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
+    } else {
+      n0 = xor3_key((uint32_t)(p1 >> 32), c1, k0);
+      n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
+    }
+    const uint32_t n1 = (uint32_t)p1, n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
@@ -144,22 +171,36 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t group, uint64_t call, 
   Philox4 o = {c0, c1, c2, c3};
   return o;
 }
-// 24-bit uniform strictly inside (0, 1)
-__device__ __forceinline__ float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * 5.9604644775390625e-08f; }
+// 24-bit uniform strictly inside (0, 1): (m + 0.5) * 2^-24 with m = v >> 8.  One fma after the conversion; the result is
+// bit-identical to ((float)m + 0.5f) * 2^-24 (scaling by a power of two is exact).
+__device__ __forceinline__ float u01(uint32_t v) {
+  return __builtin_fmaf((float)(v >> 8), 5.9604644775390625e-08f, 2.98023223876953125e-08f);
+}
 
-// Four standard normals for Philox group `group` (Box-Muller on (x,y) and (z,w)).
-// v_sin_f32 / v_cos_f32 take their argument in revolutions, so sin(2*pi*u) = v_sin(u).
+// Angle of a Box-Muller pair, in revolutions, from one Philox word: the word's upper 23 bits become the mantissa of a
+// float in [1, 2) -- ONE instruction, v_alignbit_b32 ({0x7F, w} >> 9 = 0x3F800000 | (w >> 9)) -- and v_sin_f32 /
+// v_cos_f32 take revolutions, so the integer part drops out: cos(2*pi*(1 + t)) = cos(2*pi*t), t = (w >> 9) * 2^-23.
+// (Shift, convert and scale would be three instructions per angle; the kernel is bound by VALU issue.)
+__device__ __forceinline__ float angle_rev(uint32_t w) {
+  return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, w, 9));
+}
+
+// Four standard normals for Philox group `group`: Box-Muller on (x, y) and (z, w) --
+//   radius from the 24-bit uniform u01(x) strictly inside (0, 1), angle 2*pi*t from the upper 23 bits of y.
+// (The logarithm is taken of the scaled uniform itself: log2(m + 0.5) - 24 would save nothing after the fma in u01 and
+// cancels catastrophically for u close to 1, i.e. for radii close to 0.)
 __device__ __forceinline__ float4 philox_normal4(uint64_t group, uint64_t call, uint64_t seed) {
   Philox4 r = philox4x32_10(group, call, seed);
-  float u0 = u01(r.x), u1 = u01(r.y), u2 = u01(r.z), u3 = u01(r.w);
+  const float u0 = u01(r.x), u2 = u01(r.z);
+  const float a1 = angle_rev(r.y), a3 = angle_rev(r.w);
   // raw v_sqrt_f32 (1 ulp): the IEEE fix-up sequence of sqrtf() costs ~20 extra instructions per root
-  float ra = __builtin_amdgcn_sqrtf(-2.0f * ZS_LN2 * log2_fast(u0));
-  float rb = __builtin_amdgcn_sqrtf(-2.0f * ZS_LN2 * log2_fast(u2));
+  const float ra = __builtin_amdgcn_sqrtf(-2.0f * ZS_LN2 * log2_fast(u0));
+  const float rb = __builtin_amdgcn_sqrtf(-2.0f * ZS_LN2 * log2_fast(u2));
   float4 n;
-  n.x = ra * __builtin_amdgcn_cosf(u1);
-  n.y = ra * __builtin_amdgcn_sinf(u1);
-  n.z = rb * __builtin_amdgcn_cosf(u3);
-  n.w = rb * __builtin_amdgcn_sinf(u3);
+  n.x = ra * __builtin_amdgcn_cosf(a1);
+  n.y = ra * __builtin_amdgcn_sinf(a1);
+  n.z = rb * __builtin_amdgcn_cosf(a3);
+  n.w = rb * __builtin_amdgcn_sinf(a3);
   return n;
 }
 

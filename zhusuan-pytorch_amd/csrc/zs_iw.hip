@@ -442,6 +442,23 @@ extern "C" int zs_prof_query(int kernel_id, double* total_ms, double* min_ms, do
   return 0;
 }
 
+extern "C" int64_t zs_prof_durations(int kernel_id, double* out_ms, int64_t capacity) {
+  ProfState& s = prof_state();
+  if (kernel_id < 0 || kernel_id >= zs::KID_COUNT || capacity < 0 || (capacity > 0 && !out_ms)) return ZS_EINVAL;
+  std::lock_guard<std::mutex> g(s.mu);
+  int64_t n = 0;
+  for (auto& p : s.ev[kernel_id]) {
+    if (n < capacity) {
+      if (hipEventSynchronize(p.second) != hipSuccess) return ZS_EINVAL;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.first, p.second) != hipSuccess) return ZS_EINVAL;
+      out_ms[n] = ms;
+    }
+    ++n;
+  }
+  return n;
+}
+
 extern "C" int zs_abi_version(void) { return ZS_ABI_VERSION; }
 
 extern "C" const char* zs_error_string(int code) {

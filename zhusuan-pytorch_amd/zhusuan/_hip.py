@@ -89,6 +89,21 @@ class KernelLibrary(object):
         self.cdll.zs_prof_query.restype = _int
         self.cdll.zs_prof_query.argtypes = [_int] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.POINTER(_i64)]
 
+    def prof_durations(self, entry_point):
+        """Durations (ms, launch order) of the launches recorded for `entry_point`."""
+        kid = self.cdll.zs_prof_kernel_id(entry_point.encode())
+        if kid < 0:
+            raise RuntimeError("unknown entry point %s" % entry_point)
+        f = self.cdll.zs_prof_durations
+        f.restype = _i64
+        f.argtypes = [_int, ctypes.POINTER(ctypes.c_double), _i64]
+        n = f(kid, None, 0)
+        if n < 0:
+            raise RuntimeError("zs_prof_durations failed with code %d" % n)
+        buf = (ctypes.c_double * max(n, 1))()
+        f(kid, buf, n)
+        return [buf[i] for i in range(n)]
+
     def prof_enable(self, on):
         """Record the kernels' own start/stop events for every launch (include/zs_hip.h, zs_prof_*)."""
         rc = self.cdll.zs_prof_enable(1 if on else 0)
