@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--max-rows", type=int, default=1 << 22)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--x-dim", type=int, default=784)
     ap.add_argument("--only", default=None, help="only kernels whose name contains this substring")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -110,8 +111,8 @@ def main():
         cp, cq = torch.empty(B, K, device=dev), torch.empty(B, K, device=dev)
         timed("K4 iw reduce (vimco)", "zs_iw_reduce_f32", 16 * N + 8 * B,
               lambda: lib.call("zs_iw_reduce_f32", P(logp), K, P(logq), K, B, K, 1, P(cost), P(bound), P(cp), P(cq), st), tag)
-        # ---------------- K3: X = 784
-        X = 784
+        # ---------------- K3: X = 784 (--x-dim: experiments on the row length)
+        X = args.x_dim
         if N * X * 4 * 2 > 200e9:
             continue
         p = torch.rand(N * X, device=dev) * 0.96 + 0.02

@@ -3,6 +3,7 @@
 // lane), re-reads the observation row x[b, :] from L2, and reduces each row on the wavefront.
 #include "zs_common.h"
 #include "../../include/zs_hip.h"
+#include <stdlib.h>
 
 using namespace zs;
 
@@ -292,58 +293,83 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
 // K3 backward for big problems with a shared observation (same tiling as k_bern_logprob_xreuse): the wave keeps
 // x[b, :] in registers, streams JC particle rows of p past it and writes the gradient rows, non-temporally when
 // the tensor cannot stay in the Infinity Cache.
-template <bool LOGITS, bool NT>
+template <bool LOGITS, bool NT, int U>
 __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
     const float4* __restrict__ p, const float4* __restrict__ x, int64_t xrows, int64_t J, int64_t JC,
     const float* __restrict__ glp, int64_t gsk, int64_t gsr, float4* __restrict__ gp, int64_t R, int D4) {
+  (void)U;
   const int lane = threadIdx.x & 63;
   const int64_t jchunks = (J + JC - 1) / JC;
   const int64_t items = xrows * jchunks;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
+  // column of each of the lane's four 16-byte pieces, clamped into the row: every load is issued unconditionally (a
+  // guarded load puts an exec-mask change -- and with it a wait for the previous load -- between two loads); only the
+  // stores are predicated
+  int col[4];
+  bool ok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = lane + 64 * u;
+    ok[u] = c < D4;
+    col[u] = ok[u] ? c : D4 - 1;
+  }
   for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += nwaves) {
     int64_t jc, r0;
     divmod(it, xrows, jc, r0);
     const float4* __restrict__ xrow = x + r0 * D4;
     float4 xv[4];
-    bool ok[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = lane + 64 * u;
-      ok[u] = c < D4;
-      xv[u] = ok[u] ? xrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int u = 0; u < 4; ++u) xv[u] = xrow[col[u]];
     const int64_t j0 = jc * JC, j1 = (j0 + JC < J) ? j0 + JC : J;
-    for (int64_t j = j0; j < j1; ++j) {
-      const int64_t row = j * xrows + r0;
+    // rolling prefetch: the loads of particle row j + 1 are in flight while row j is computed and stored, so a wave
+    // always has one row (3 KB at 784 pixels) outstanding
+    float4 nx[4];
+    float gn;
+    {
+      const int64_t row = j0 * xrows + r0;
       int64_t k, r;
       divmod(row, R, k, r);
-      const float g = glp[k * gsk + r * gsr];
+      gn = glp[k * gsk + r * gsr];
       const float4* __restrict__ prow = p + row * D4;
-      float4* __restrict__ grow = gp + row * D4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) nx[u] = prow[col[u]];
+    }
+    for (int64_t j = j0; j < j1; ++j) {
       float4 pv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ok[u]) pv[u] = prow[lane + 64 * u];
+      for (int u = 0; u < 4; ++u) pv[u] = nx[u];
+      const float g = gn;
+      const int64_t row = j * xrows + r0;
+      {
+        const int64_t rown = (j + 1 < j1 ? j + 1 : j) * xrows + r0;    // last iteration: a harmless re-read
+        int64_t k, r;
+        divmod(rown, R, k, r);
+        gn = glp[k * gsk + r * gsr];
+        const float4* __restrict__ prow = p + rown * D4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nx[u] = prow[col[u]];
+      }
+      float4* __restrict__ grow = gp + row * D4;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
+        float4 o;
+        if (LOGITS) {
+          const float a = sigmoid_fast(pv[u].x), b = sigmoid_fast(pv[u].y), c = sigmoid_fast(pv[u].z),
+                      d = sigmoid_fast(pv[u].w);
+          o.x = g * bern_dp(a, xv[u].x) * a * (1.0f - a);
+          o.y = g * bern_dp(b, xv[u].y) * b * (1.0f - b);
+          o.z = g * bern_dp(c, xv[u].z) * c * (1.0f - c);
+          o.w = g * bern_dp(d, xv[u].w) * d * (1.0f - d);
+        } else {
+          o.x = g * bern_dp(pv[u].x, xv[u].x);
+          o.y = g * bern_dp(pv[u].y, xv[u].y);
+          o.z = g * bern_dp(pv[u].z, xv[u].z);
+          o.w = g * bern_dp(pv[u].w, xv[u].w);
+        }
         if (ok[u]) {
-          float4 o;
-          if (LOGITS) {
-            const float a = sigmoid_fast(pv[u].x), b = sigmoid_fast(pv[u].y), c = sigmoid_fast(pv[u].z),
-                        d = sigmoid_fast(pv[u].w);
-            o.x = g * bern_dp(a, xv[u].x) * a * (1.0f - a);
-            o.y = g * bern_dp(b, xv[u].y) * b * (1.0f - b);
-            o.z = g * bern_dp(c, xv[u].z) * c * (1.0f - c);
-            o.w = g * bern_dp(d, xv[u].w) * d * (1.0f - d);
-          } else {
-            o.x = g * bern_dp(pv[u].x, xv[u].x);
-            o.y = g * bern_dp(pv[u].y, xv[u].y);
-            o.z = g * bern_dp(pv[u].z, xv[u].z);
-            o.w = g * bern_dp(pv[u].w, xv[u].w);
-          }
           if (NT) {
-            const zs_f4v v = {o.x, o.y, o.z, o.w};
-            __builtin_nontemporal_store(v, reinterpret_cast<zs_f4v*>(&grow[lane + 64 * u]));
+            const zs_f4v vv = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(vv, reinterpret_cast<zs_f4v*>(&grow[lane + 64 * u]));
           } else {
             grow[lane + 64 * u] = o;
           }
@@ -389,6 +415,27 @@ __global__ __launch_bounds__(256) void k_bern_sample(const float* __restrict__ p
   }
 }
 
+// Work items of the shared-observation kernels: (observation row, chunk of JC particles).  One item per wave and one
+// wave slot per item in the grid, so the hardware dispatcher evens out the CUs (a capped grid striding over the items
+// left waves with 1 or 2 of them at the 1 M-row sweep point: 64 % of the roofline instead of 67-71 %).  JC is the largest
+// chunk that still gives every resident wave slot (256 CUs x 32) about sixteen items, divides J with little waste
+// (equal items), and is at least 4 rows so that the observation row in registers is amortised.
+inline int64_t pick_jc(int64_t J, int64_t xrows) {
+  static const int jc_env = getenv("ZS_K3_JC") ? atoi(getenv("ZS_K3_JC")) : 0;     // experiments only
+  if (jc_env > 0) return jc_env < J ? jc_env : J;
+  const int64_t target = 256ll * 32 * 16;
+  for (int64_t jc = J; jc >= 1; --jc) {
+    const int64_t chunks = (J + jc - 1) / jc;
+    if ((chunks * jc - J) * 8 > J) continue;          // unequal last chunk: skip
+    if (xrows * chunks >= target || jc <= 4) return jc;
+  }
+  return 1;
+}
+inline unsigned grid_for_items(int64_t items) {         // 4 waves per workgroup, one item per wave
+  const int64_t b = (items + 3) / 4;
+  return (unsigned)(b < 1 ? 1 : (b > 0x7fffffffll ? 0x7fffffffll : b));
+}
+
 template <bool LOGITS>
 int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* probs_out, int64_t K, int64_t R,
                int64_t D, int64_t sk, int64_t sr, hipStream_t st) {
@@ -408,11 +455,9 @@ int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* pro
       const int64_t J = rows / xrows;
       if (D4 <= 256 && J >= 2 && rows > 32768) {
         // big problem with a shared observation: x row in registers, JC particles per wave
-        int64_t JC = rows / 4096;          // keep >= ~4096 waves in the grid
-        if (JC < 1) JC = 1;
-        if (JC > J) JC = J;
+        const int64_t JC = pick_jc(J, xrows);
         const int64_t items = xrows * ((J + JC - 1) / JC);
-        const unsigned grid = grid_for(items, 4);
+        const unsigned grid = grid_for_items(items);
         if (rows >= 400000) {
           if (probs_out) ZS_LAUNCH(kid, (k_bern_logprob_xreuse<LOGITS, true, 2>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, lp, po, R, D4, sk, sr);
           else ZS_LAUNCH(kid, (k_bern_logprob_xreuse<LOGITS, false, 2>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, lp, po, R, D4, sk, sr);
@@ -460,19 +505,26 @@ int launch_bwd(const float* p, const float* x, int64_t Px, const float* glp, int
     const int kid = LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD;
     const int64_t rows = K * R, xrows = Px / D;
     const int64_t J = rows / xrows;
-    const bool nt = (double)N * 4.0 > 268435456.0;
-    if (D4 >= 64 && D4 <= 256 && J >= 2 && rows > 32768) {
-      int64_t JC = rows / 4096;
-      if (JC < 1) JC = 1;
-      if (JC > J) JC = J;
-      const unsigned grid = grid_for(xrows * ((J + JC - 1) / JC), 4);
-      if (nt) ZS_LAUNCH(kid, (k_bern_logprob_bwd_xreuse<LOGITS, true>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, glp, gsk, gsr, (float4*)gp, R, D4);
-      else ZS_LAUNCH(kid, (k_bern_logprob_bwd_xreuse<LOGITS, false>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, glp, gsk, gsr, (float4*)gp, R, D4);
+    static const int nt_env = getenv("ZS_K3_NT") ? atoi(getenv("ZS_K3_NT")) : -1;     // experiments only
+    const bool nt = nt_env >= 0 ? nt_env != 0 : (double)N * 4.0 > 268435456.0;
+    static const int xr_env = getenv("ZS_K3_XREUSE") ? atoi(getenv("ZS_K3_XREUSE")) : 1;     // experiments only
+    static const int cap_env = getenv("ZS_K3_GRIDCAP") ? atoi(getenv("ZS_K3_GRIDCAP")) : 4096;
+    if (xr_env && D4 >= 64 && D4 <= 256 && J >= 2 && rows > 32768) {
+      const int64_t JC = pick_jc(J, xrows);
+      const unsigned grid = grid_for_items(xrows * ((J + JC - 1) / JC));
+      static const int u_env = getenv("ZS_K3_BWD_U") ? atoi(getenv("ZS_K3_BWD_U")) : 0;     // experiments only
+      const bool two = u_env ? u_env == 2 : rows >= 400000;
+#define ZS_LAUNCH_BWD_X(T, UU)                                                                                         \
+  ZS_LAUNCH(kid, (k_bern_logprob_bwd_xreuse<LOGITS, T, UU>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, \
+            xrows, J, JC, glp, gsk, gsr, (float4*)gp, R, D4)
+      if (nt) { if (two) ZS_LAUNCH_BWD_X(true, 2); else ZS_LAUNCH_BWD_X(true, 1); }
+      else    { if (two) ZS_LAUNCH_BWD_X(false, 2); else ZS_LAUNCH_BWD_X(false, 1); }
+#undef ZS_LAUNCH_BWD_X
     } else if (nt) {
-      ZS_LAUNCH(kid, (k_bern_logprob_bwd_rows<LOGITS, true>), dim3(grid_for(tiles, 4)), dim3(256), st,
+      ZS_LAUNCH(kid, (k_bern_logprob_bwd_rows<LOGITS, true>), dim3(grid_for(tiles, 4, (unsigned)cap_env)), dim3(256), st,
                 (const float4*)p, (const float4*)x, xrows, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
     } else {
-      ZS_LAUNCH(kid, (k_bern_logprob_bwd_rows<LOGITS, false>), dim3(grid_for(tiles, 4)), dim3(256), st,
+      ZS_LAUNCH(kid, (k_bern_logprob_bwd_rows<LOGITS, false>), dim3(grid_for(tiles, 4, (unsigned)cap_env)), dim3(256), st,
                 (const float4*)p, (const float4*)x, xrows, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
     }
   } else {
