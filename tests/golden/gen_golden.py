@@ -638,13 +638,30 @@ def grad_stats(module):
     return names, np.array(norms), np.array(sums), heads
 
 
-def _pack_grads(out, prefix, module):
+GRAD_FULL_MAX = 32768      # gradients up to this many elements are stored whole, larger ones every GRAD_STRIDE-th element
+GRAD_STRIDE = 97           # (prime: the sample walks through every row and column residue of the weight matrices)
+
+
+def _pack_grads(out, prefix, module, elementwise=False, stride=None, tag=""):
+    """Per-parameter gradient norms / sums / first 8 elements; with `elementwise` also the gradient itself ("gfull_*")
+    or, for the large weight matrices, a strided sample of it ("gstride_*"), so that the tests can compare element by
+    element (a norm cannot see a sign or a permutation error inside a tensor)."""
     names, norms, sums, heads = grad_stats(module)
     out[prefix + "grad_names"] = np.array(names)
-    out[prefix + "grad_norms"] = norms
-    out[prefix + "grad_sums"] = sums
+    out[prefix + "grad_norms" + tag] = norms
+    out[prefix + "grad_sums" + tag] = sums
     for n, h in zip(names, heads):
-        out[prefix + "ghead_" + n] = h
+        out[prefix + "ghead%s_" % tag + n] = h
+    if elementwise or stride:
+        absmax = []
+        for name, p in module.named_parameters():
+            g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().reshape(-1).numpy()
+            absmax.append(float(np.abs(g).max()))
+            if g.size <= (GRAD_FULL_MAX if elementwise else 1024):
+                out[prefix + "gfull%s_" % tag + name] = g.copy()
+            else:
+                out[prefix + "gstride%s_" % tag + name] = g[::(GRAD_STRIDE if elementwise else stride)].copy()
+        out[prefix + "grad_absmax" + tag] = np.array(absmax)
 
 
 def gen_vae():
@@ -668,7 +685,7 @@ def gen_vae():
         out["logpz"] = gen.nodes["z"].log_prob()
         out["logpx"] = gen.nodes["x"].log_prob()
         out["logqz"] = var.nodes["z"].log_prob()
-        _pack_grads(out, "", model)
+        _pack_grads(out, "", model, elementwise=full)
         if full:
             out["x"], out["e1"], out["e2"] = x, e1, e2
             out["z"] = var.nodes["z"].dist.sample_cache
@@ -676,49 +693,73 @@ def gen_vae():
         save("g_vae_" + tag, **out)
 
 
+GRAD_STRIDE_BIG = 997      # config-shape goldens: every 997th element of every gradient
+
+
 def gen_iwae():
     iw = _load(os.path.join(REF, "examples/variational_autoencoder/iwae.py"), "ref_iwae")
     for est in ["sgvb", "vimco"]:
-        for tag, B, K, hidden, full in [("small", 8, 5, 32, True), ("c3", 256, 50, 500, False)]:
-            iw.hidden_dim = hidden
-            iw.reparameterization = (est == "sgvb")
-            rng = np.random.RandomState(700 + B + K)
-            x_dim, z_dim = 784, 40
-            gen = iw.Generator(x_dim, z_dim, K)
-            var = iw.Variational(x_dim, z_dim, K)
-            model = ImportanceWeightedObjective(gen, var, axis=0, estimator=est)
-            fill_params(model, 2000 + B + K)
-            x = (rng.uniform(size=(B, x_dim)) < 0.5).astype(F32)
-            e1 = rng.standard_normal((K, B, z_dim)).astype(F32)
-            e2 = rng.standard_normal((K, B, z_dim)).astype(F32)
-            with EpsQueue([e1, e2]) as q:
-                loss = model({"x": t(x)})
-            model.zero_grad()
-            loss.backward()
-            logpxz = gen.nodes["z"].log_prob() + gen.nodes["x"].log_prob()
-            logqz = var.nodes["z"].log_prob()
-            log_w = (logpxz - logqz).detach()
-            out = {"B": np.array(B), "K": np.array(K), "hidden": np.array(hidden),
-                   "seed_params": np.array(2000 + B + K), "seed_data": np.array(700 + B + K),
-                   "loss": loss, "iw_bound": zhusuan.log_mean_exp(log_w, 0).mean(),
-                   "draws": np.array([c[1] for c in q.calls]),
-                   "draw_kinds": np.array([c[0] for c in q.calls])}
-            _pack_grads(out, "", model)
-            if full:
-                out["x"], out["e1"], out["e2"] = x, e1, e2
-                out["z"] = var.nodes["z"].dist.sample_cache
-                out["log_w"] = log_w
-                out["logqz"] = logqz
-                out["logpz"] = gen.nodes["z"].log_prob()
-                out["logpx"] = gen.nodes["x"].log_prob()
-            else:
-                out["log_w_col0"] = log_w[:, 0]
+        # c4g: the GLOBAL batch of BASELINE config 4 (8 GPUs x 256) evaluated by the reference in one process
+        for tag, B, K, hidden, full in [("small", 8, 5, 32, True), ("c3", 256, 50, 500, False), ("c4g", 2048, 50, 500, False)]:
+            if tag == "c4g" and est != "vimco":
+                continue
+            out = {}
+            # Two passes of the SAME reference code: float32 (the parity target) and float64 (torch default dtype
+            # switched, identical weights / data / epsilon values).  VIMCO's learning signal subtracts two ~|log w|-sized
+            # numbers, so the reference's own fp32 gradients are only ~1e-4..1e-3-accurate; the
+            # float64 run tells the tests how far a correct fp32 implementation may sit from the fp32 reference.
+            for dt, sfx in [(torch.float32, ""), (torch.float64, "64")]:
+                torch.set_default_dtype(dt)
+                try:
+                    iw.hidden_dim = hidden
+                    iw.reparameterization = (est == "sgvb")
+                    rng = np.random.RandomState(700 + B + K)
+                    x_dim, z_dim = 784, 40
+                    gen = iw.Generator(x_dim, z_dim, K)
+                    var = iw.Variational(x_dim, z_dim, K)
+                    model = ImportanceWeightedObjective(gen, var, axis=0, estimator=est)
+                    fill_params(model, 2000 + B + K)
+                    x = (rng.uniform(size=(B, x_dim)) < 0.5).astype(F32)
+                    e1 = rng.standard_normal((K, B, z_dim)).astype(F32)
+                    e2 = rng.standard_normal((K, B, z_dim)).astype(F32)
+                    with EpsQueue([torch.tensor(e1, dtype=dt), torch.tensor(e2, dtype=dt)]) as q:
+                        loss = model({"x": torch.tensor(x, dtype=dt)})
+                    assert loss.dtype == dt
+                    model.zero_grad()
+                    loss.backward()
+                    logpxz = gen.nodes["z"].log_prob() + gen.nodes["x"].log_prob()
+                    logqz = var.nodes["z"].log_prob()
+                    log_w = (logpxz - logqz).detach()
+                    out["loss" + sfx] = loss
+                    out["iw_bound" + sfx] = zhusuan.log_mean_exp(log_w, 0).mean()
+                    _pack_grads(out, "", model, elementwise=full, stride=None if full else GRAD_STRIDE_BIG, tag=sfx)
+                    if sfx == "64":
+                        continue
+                    out.update({"B": np.array(B), "K": np.array(K), "hidden": np.array(hidden),
+                                "seed_params": np.array(2000 + B + K), "seed_data": np.array(700 + B + K),
+                                "draws": np.array([c[1] for c in q.calls]),
+                                "draw_kinds": np.array([c[0] for c in q.calls])})
+                    if full:
+                        out["x"], out["e1"], out["e2"] = x, e1, e2
+                        out["z"] = var.nodes["z"].dist.sample_cache
+                    if tag != "c4g":  # every log-importance-weight and its three terms ([K, B]: 51 KB each at the C3 shape)
+                        out["log_w"] = log_w
+                        out["logqz"] = logqz
+                        out["logpz"] = gen.nodes["z"].log_prob()
+                        out["logpx"] = gen.nodes["x"].log_prob()
+                    else:             # global batch: scalars, gradient statistics and a thin slice of log w
+                        out["log_w_col0"] = log_w[:, 0]
+                        out["log_w_row0_every16"] = log_w[0, ::16]
+                        out["bound_b_every16"] = zhusuan.log_mean_exp(log_w, 0)[::16]
+                finally:
+                    torch.set_default_dtype(torch.float32)
             save("g_iwae_%s_%s" % (est, tag), **out)
 
 
 def gen_bnn():
     bnn = _load(os.path.join(REF, "examples/bayesian_neural_nets/bnn_vi.py"), "ref_bnn")
-    for tag, B, K, full in [("small", 16, 4, True), ("c5", 512, 10, False)]:
+    # c5g: the GLOBAL batch of BASELINE config 5 (8 GPUs x 512) evaluated by the reference in one process
+    for tag, B, K, full in [("small", 16, 4, True), ("c5", 512, 10, False), ("c5g", 4096, 10, False)]:
         rng = np.random.RandomState(800 + B + K)
         layer_sizes = [13, 50, 1]
         net = bnn.Net(layer_sizes, K)
@@ -760,6 +801,69 @@ def gen_bnn():
             for i, e in enumerate(eps):
                 out["eps%d" % i] = e
         save("g_bnn_" + tag, **out)
+
+
+def gen_uniform_latent():
+    """A non-reparameterised Uniform latent under VIMCO and under REINFORCE: the reference draws it without
+    gradient but rescales the draw OUTSIDE the no-grad region (uniform.py:63-70), so the value handed to the generator
+    carries d/d low = 1 - u, d/d high = u and the generator's log-joint back-propagates into low / high.  Also pins the
+    reference's quirk that sample_cache (the value log q is evaluated at) is the once-scaled draw while the returned
+    sample is scaled twice."""
+    from zhusuan.distributions import Uniform
+    B, K, D = 6, 4, 3
+
+    class Q(BayesianNet):
+        def __init__(self):
+            super().__init__()
+            self.low = torch.nn.Parameter(torch.zeros(D))
+            self.logw = torch.nn.Parameter(torch.zeros(D))
+
+        def forward(self, observed):
+            self.observe(observed)
+            low = self.low.unsqueeze(0).expand(B, D)
+            high = low + torch.exp(self.logw).unsqueeze(0).expand(B, D)
+            self.sn(Uniform(low, high, is_reparameterized=False), "z", n_samples=K, reduce_sum_dims=[2])
+            return self
+
+    class P(BayesianNet):
+        def __init__(self):
+            super().__init__()
+            self.scale = torch.nn.Parameter(torch.ones(D))
+
+        def forward(self, observed):
+            self.observe(observed)
+            z = self.normal("z", mean=torch.zeros(B, D), std=3. * torch.ones(B, D), n_samples=K, reduce_sum_dims=[2])
+            self.normal("x", mean=z * self.scale, std=torch.ones(B, D), reduce_sum_dims=[2])
+            return self
+
+    rng = np.random.RandomState(909)
+    out = {"B": np.array(B), "K": np.array(K), "D": np.array(D)}
+    low0 = (0.3 * rng.standard_normal(D)).astype(F32)
+    logw0 = (0.2 * rng.standard_normal(D)).astype(F32)
+    scale0 = (1.0 + 0.1 * rng.standard_normal(D)).astype(F32)
+    x = rng.standard_normal((B, D)).astype(F32)
+    u1 = rng.uniform(0.02, 0.98, (K, B, D)).astype(F32)
+    u2 = rng.uniform(0.02, 0.98, (K, B, D)).astype(F32)
+    out.update(low=low0, logw=logw0, scale=scale0, x=x, u1=u1, u2=u2)
+    for est in ["vimco", "reinforce"]:
+        q, pnet = Q(), P()
+        with torch.no_grad():
+            q.low.copy_(t(low0)); q.logw.copy_(t(logw0)); pnet.scale.copy_(t(scale0))
+        if est == "vimco":
+            model = ImportanceWeightedObjective(pnet, q, axis=0, estimator="vimco")
+        else:
+            model = ELBO(pnet, q, estimator="reinforce")
+        with UniformQueue([u1, u2]) as uq:
+            res = model({"x": t(x)})
+        loss = res[0] if isinstance(res, tuple) else res
+        model.zero_grad()
+        loss.backward()
+        out[est + "_loss"] = loss
+        out[est + "_g_low"], out[est + "_g_logw"], out[est + "_g_scale"] = q.low.grad, q.logw.grad, pnet.scale.grad
+        out[est + "_z_used"] = pnet.nodes["z"].tensor if False else pnet.observed["z"]
+        out[est + "_logq"] = q.nodes["z"].log_prob()
+        out[est + "_draws"] = np.array([list(c) for c in uq.calls])
+    save("g_uniform_latent", **out)
 
 
 def gen_reference_tests():
@@ -808,3 +912,4 @@ if __name__ == "__main__":
     gen_logistic()
     gen_uniform()
     gen_reinforce()
+    gen_uniform_latent()

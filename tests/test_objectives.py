@@ -481,3 +481,60 @@ def test_subclass_hooks_are_honoured_by_the_fused_paths(dev):
             return super().log_joint(nodes)
     m2 = MyIW(ib.generator, ib.variational, axis=0, estimator="sgvb")
     assert np.isfinite(float(m2({"x": x}))) and seen.count("log_joint") == 2
+
+
+# ------------------------------------------------------------------ non-reparameterised Uniform latent
+@pytest.mark.parametrize("est", ["vimco", "reinforce"])
+def test_uniform_latent_keeps_its_pathwise_gradient(dev, est):
+    """Uniform(is_reparameterized=False) as a latent: the reference draws it under no_grad but rescales OUTSIDE
+    (uniform.py:63-70), so the value the generator sees carries d/d low = 1 - u, d/d high = u and the generator's
+    log-joint back-propagates into low / high -- the objectives must not detach it (they do detach Normal / Bernoulli
+    draws, whose derivative is identically zero).  Golden from the real reference: tests/golden/gen_golden.py
+    gen_uniform_latent (loss, log q, the value handed to the generator, gradients of all three parameters)."""
+    from zhusuan.distributions import Uniform
+    from zhusuan.framework import BayesianNet
+    g = load_golden("g_uniform_latent")
+    B, K, D = int(g["B"]), int(g["K"]), int(g["D"])
+
+    class Q(BayesianNet):
+        def __init__(self):
+            super().__init__()
+            self.low = torch.nn.Parameter(torch.tensor(g["low"]))
+            self.logw = torch.nn.Parameter(torch.tensor(g["logw"]))
+
+        def forward(self, observed):
+            self.observe(observed)
+            low = self.low.unsqueeze(0).expand(B, D)
+            high = low + torch.exp(self.logw).unsqueeze(0).expand(B, D)
+            self.sn(Uniform(low, high, is_reparameterized=False), "z", n_samples=K, reduce_sum_dims=[2])
+            return self
+
+    class P(BayesianNet):
+        def __init__(self):
+            super().__init__()
+            self.scale = torch.nn.Parameter(torch.tensor(g["scale"]))
+
+        def forward(self, observed):
+            self.observe(observed)
+            z = self.normal("z", mean=torch.zeros(B, D, device=dev), std=3. * torch.ones(B, D, device=dev), n_samples=K,
+                            reduce_sum_dims=[2])
+            self.normal("x", mean=z * self.scale, std=torch.ones(B, D, device=dev), reduce_sum_dims=[2])
+            return self
+
+    q, p = Q().to(dev), P().to(dev)
+    if est == "vimco":
+        model = ImportanceWeightedObjective(p, q, axis=0, estimator="vimco")
+    else:
+        model = ELBO(p, q, estimator="reinforce")
+    model = model.to(dev)
+    with zs.inject_epsilon([g["u1"], g["u2"]]):                      # the uniform draws of the two .tensor reads
+        res = model({"x": torch.tensor(g["x"], device=dev)})
+    loss = res[0] if isinstance(res, tuple) else res
+    close(loss, g[est + "_loss"], 2e-5, 1e-6)
+    close(p.observed["z"], g[est + "_z_used"], 1e-6, 1e-6)           # the twice-scaled draw (uniform.py:70)
+    assert p.observed["z"].requires_grad                               # ... still attached to low / high
+    close(q.nodes["z"].log_prob(), g[est + "_logq"], 1e-5, 1e-6)
+    loss.backward()
+    close(q.low.grad, g[est + "_g_low"], 1e-3, 1e-5)
+    close(q.logw.grad, g[est + "_g_logw"], 1e-3, 1e-5)
+    close(p.scale.grad, g[est + "_g_scale"], 1e-3, 1e-5)

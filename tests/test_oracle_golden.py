@@ -232,12 +232,10 @@ def test_iwae_end_to_end(est, tag, B, K, hidden):
     _check_grads(g, [(n, gr) for (n, _), gr in zip(spec, grads)])
     if tag == "small":
         assert np.array_equal(aux["z"].detach().numpy(), g["z"])
-        close(aux["log_w"], g["log_w"], 1e-5, 1e-4)
-    else:
-        close(aux["log_w"][:, 0], g["log_w_col0"], 1e-5, 1e-4)
+    close(aux["log_w"], g["log_w"], 1e-5, 1e-4)          # every log-importance-weight, small and config shape
 
 
-@pytest.mark.parametrize("tag,B,K", [("small", 16, 4), ("c5", 512, 10)])
+@pytest.mark.parametrize("tag,B,K", [("small", 16, 4), ("c5", 512, 10), ("c5g", 4096, 10)])
 def test_bnn_end_to_end(tag, B, K):
     g = load_golden("g_bnn_" + tag)
     assert int(g["n_draws"]) == 4 and tuple(g["draws_w0"]) == (K, 50, 14) and tuple(g["draws_w1"]) == (K, 1, 51)
