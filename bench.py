@@ -4,16 +4,25 @@
 Workload (BASELINE.json configs[2] / per-GPU shape of configs[3]): IWAE on MNIST-shaped synthetic bits,
 VIMCO estimator, batch 256 per GPU, K = 50 particles, latent 40, x 784, hidden 500, fp32.
 One step = objective forward (sampling, log-probs, VIMCO reduction in HIP kernels; MLPs in
-hipBLASLt via PyTorch) + backward + [one all-reduce of the flat gradient bucket] + Adam.
+hipBLASLt via PyTorch) + backward + [all-reduce of the flat gradient buckets] + Adam.
 One ELBO-eval = one log-importance-weight log w[k, b], so a step does B*K evals per GPU.
 
   python bench.py [--gpus N --steps K --warmup W]          (N > 1: this process only starts the N ranks, see launch_ranks)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form for N > 1)
 
-Rank 0 prints ONE JSON line (contract in the task description) with `roofline` -- the hot-path kernel that
-takes the most time (and moves the most bytes) per step, i.e. the backward of the Bernoulli log-prob row sum;
-every hot-path kernel's own figures are under `hip_kernels` -- and `cpu_baseline` (the CPU oracle,
-oracle/zs_oracle.py, timed on this host's cores on the same workload).
+Timing: trials of EXACTLY `--steps` steps, each bracketed by torch.cuda.synchronize() + a barrier on both sides and
+reduced with MAX over the ranks; trials repeat until at least MIN_TIMED_SECONDS have been timed (so that `--steps 20` is
+not a 24 ms sample) and the MEDIAN trial is reported.
+
+Rank 0 prints ONE JSON line (contract in the task description) with
+  `roofline`      the hot-path kernel that moves the most bytes per step (the backward of the Bernoulli log-prob row
+                  sum), timed live in the launch mode of the timed region;
+  `hip_kernels`   every hot-path kernel's own figures at the config size, `hbm_resident` the same kernels on working
+                  sets beyond the 256 MiB Infinity Cache measured in the same run;
+  `cpu_baseline`  the CPU oracle (oracle/zs_oracle.py) on the same workload on this host's cores (calibrated thread
+                  count, plus a 1-thread figure);
+  `extra_configs` the other single-GPU BASELINE configs (VAE B=512, BNN B=512 K=10, IWAE with the sigmoid fused), each
+                  with its own CPU baselines.
 """
 import argparse
 import json
@@ -28,6 +37,7 @@ for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "t
 
 BATCH_PER_GPU, PARTICLES, Z_DIM, X_DIM, HIDDEN = 256, 50, 40, 784, 500
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MIN_TIMED_SECONDS = 0.5
 
 
 def parse_args(argv=None):
@@ -38,10 +48,14 @@ def parse_args(argv=None):
     ap.add_argument("--fused-logits", action="store_true",
                     help="decoder hands logits to Bernoulli(logits=...): sigmoid fused into the log-prob kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip extra_configs and the HBM-resident kernel figures")
     ap.add_argument("--force-collective-path", action="store_true",
                     help="run the multi-rank code path (bucket pack + all-reduce + split graphs) even with one rank")
     ap.add_argument("--no-graph", action="store_true",
-                    help="launch every kernel from Python each step instead of replaying one captured hipGraph")
+                    help="launch every kernel from Python each step instead of replaying captured hipGraphs")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="multi-rank, graphs: ONE bucket all-reduced after the whole backward (graph A -> all-reduce -> "
+                         "graph B) instead of the staged step whose decoder-gradient all-reduce overlaps the encoder's backward")
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="eager launches only (--no-graph): all-reduce gradient buckets from autograd hooks while backward "
                          "is still running (zhusuan.dataparallel.OverlappedBuckets)")
@@ -79,6 +93,16 @@ import torch                          # noqa: E402
 import torch.distributed as dist      # noqa: E402
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (the K = 50 MNIST workload it is quoted on is the IWAE / VIMCO example:
+    config.workload names it)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, ValueError, KeyError):
+        return "ELBO-evals/sec (batch\u00d7K particles) VAE-MNIST K=50 @1/2/4/8 GPU"
+
+
 def collective_library(share_device):
     if share_device:
         return "gloo (test mode)"
@@ -88,44 +112,115 @@ def collective_library(share_device):
         return "RCCL (version unavailable)"
 
 
-def pmc_traffic(entry):
-    """HBM bytes per launch of `entry` from the PMC passes committed under profiles/ (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs of this same bench command, gfx950 FETCH_SIZE x2 correction
-    applied; see profiles/r01_pmc_traffic.json).  Counters cannot be read from inside this process."""
+def pmc_traffic(entry, fused_logits, abi_version):
+    """HBM bytes per launch of `entry` from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs of this bench command, gfx950 FETCH_SIZE x2 correction applied).  Counters cannot be
+    read from inside this process, so the figure is NOT measured in this run: it is returned with its provenance, and
+    only when the profile was taken with the same kernel library ABI and the same Bernoulli path (None otherwise)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
-            k = json.load(f)["kernels"].get(entry)
-        return k["hbm_bytes_corrected"] if k else None
+            doc = json.load(f)
+        if doc.get("abi_version") != abi_version or bool(doc.get("fused_logits", False)) != bool(fused_logits):
+            return None, {"source": os.path.relpath(files[-1], ROOT), "measured_in_this_run": False,
+                          "note": "profile does not match this run (kernel library ABI or Bernoulli path): not reported"}
+        k = doc["kernels"].get(entry)
+        if not k:
+            return None, None
+        return k["hbm_bytes_corrected"], {"source": os.path.relpath(files[-1], ROOT), "measured_in_this_run": False,
+                                          "tool": doc.get("tool"), "traffic_over_algorithmic": k.get("traffic_over_algorithmic")}
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
-def cpu_baseline(budget_s=12.0, max_steps=40):
-    """The CPU oracle (torch-CPU restatement of the reference's op sequence, pinned to the reference by
-    tests/test_oracle_golden.py) on the same workload: forward + backward + Adam, all host cores."""
+# ------------------------------------------------------------------------------------------------ workloads
+def make_workload(name, dev, seed_rank=0, fused_logits=False):
+    """(model, observations, ELBO-evals per step, description) of a BASELINE config on one GPU."""
+    from examples import iwae, vae_mnist, bnn_vi
+    rs = np.random.RandomState(1234 + seed_rank)
+    bits = lambda B: torch.tensor((rs.uniform(size=(B, X_DIM)) < 0.5).astype(np.float32), device=dev)
+    if name in ("c3", "c3_logits"):
+        model = iwae.build(n_samples=PARTICLES, estimator="vimco", x_dim=X_DIM, z_dim=Z_DIM, hidden=HIDDEN, device=dev,
+                           fused_logits=fused_logits or name == "c3_logits")
+        return model, {"x": bits(BATCH_PER_GPU)}, BATCH_PER_GPU * PARTICLES, \
+            "IWAE-MNIST VIMCO, batch=256, K=50" + (", Bernoulli from logits (sigmoid fused)" if name == "c3_logits" else "")
+    if name == "c2":
+        return vae_mnist.build(512, device=dev), {"x": bits(512)}, 512, "VAE-MNIST SGVB, batch=512, K=1 (BASELINE configs[1])"
+    if name == "c5":
+        x = torch.tensor(rs.standard_normal((512, 13)).astype(np.float32), device=dev)
+        y = torch.tensor(rs.standard_normal(512).astype(np.float32), device=dev)
+        return bnn_vi.build(n_particles=10, device=dev), {"x": x, "y": y}, 5120, \
+            "BNN-VI [13,50,1], batch=512 per GPU, K=10 (per-GPU shape of BASELINE configs[4])"
+    raise ValueError(name)
+
+
+def cpu_step_fn(name):
+    """One full training step (fwd + bwd + Adam) of the CPU oracle on workload `name`; returns (step, evals per step)."""
     from oracle import zs_oracle as O
     import helpers as H
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    spec = H.iwae_param_spec(hidden=HIDDEN)
-    p = H.make_params(spec, 1)
-    params = [p[n] for n, _ in spec]
-    opt = torch.optim.Adam(params, 1e-3)
     rng = np.random.RandomState(1234)
-    x = torch.tensor((rng.uniform(size=(BATCH_PER_GPU, X_DIM)) < 0.5).astype(np.float32))
+    if name in ("c3", "c3_logits"):
+        spec = H.iwae_param_spec(hidden=HIDDEN)
+        p = H.make_params(spec, 1)
+        opt = torch.optim.Adam([p[n] for n, _ in spec], 1e-3)
+        x = torch.tensor((rng.uniform(size=(BATCH_PER_GPU, X_DIM)) < 0.5).astype(np.float32))
 
-    def step():
-        torch.randn(PARTICLES, BATCH_PER_GPU, Z_DIM)      # the draw the objective discards (SURVEY 7.4-1)
-        eps = torch.randn(PARTICLES, BATCH_PER_GPU, Z_DIM)
-        loss, _ = O.iwae_loss(p, x, eps, PARTICLES, "vimco")
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-    # pick the intra-op thread count that is fastest on this host (all cores is often NOT: on a
-    # 256-thread box the unfused elementwise passes run 50x slower with 256 torch threads than with 16-32)
+        def step():
+            torch.randn(PARTICLES, BATCH_PER_GPU, Z_DIM)      # the draw the objective discards (SURVEY 7.4-1)
+            eps = torch.randn(PARTICLES, BATCH_PER_GPU, Z_DIM)
+            loss, _ = O.iwae_loss(p, x, eps, PARTICLES, "vimco")
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        return step, BATCH_PER_GPU * PARTICLES
+    if name == "c2":
+        spec = H.vae_param_spec()
+        p = H.make_params(spec, 1)
+        opt = torch.optim.Adam([p[n] for n, _ in spec], 1e-3)
+        x = torch.tensor((rng.uniform(size=(512, X_DIM)) < 0.5).astype(np.float32))
+
+        def step():
+            torch.randn(512, Z_DIM)
+            loss, _ = O.vae_loss(p, x, torch.randn(512, Z_DIM))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        return step, 512
+    if name == "c5":
+        wm, wl, yl = H.bnn_params(512, 10)
+        opt = torch.optim.Adam(wm + wl + [yl], 1e-3)
+        xb, yb = torch.randn(512, 13), torch.randn(512)
+
+        def step():
+            torch.randn(10, 50, 14)
+            torch.randn(10, 1, 51)
+            eps = [torch.randn(10, 50, 14), torch.randn(10, 1, 51)]
+            loss, _ = O.bnn_loss(wm, wl, yl, xb, yb, eps, 10)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        return step, 5120
+    raise ValueError(name)
+
+
+def cpu_baseline(name="c3", budget_s=8.0, one_thread_budget_s=5.0, max_steps=40):
+    """The CPU oracle (torch-CPU restatement of the reference's op sequence, pinned to the reference by
+    tests/test_oracle_golden.py) on workload `name`: forward + backward + Adam on this host's cores, at the fastest
+    intra-op thread count (calibrated: all cores is often NOT the fastest -- on a 256-thread box the unfused elementwise
+    passes run 50x slower with 256 torch threads than with 16-32) and with ONE thread."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    step, evals = cpu_step_fn(name)
+
+    def timed(budget):
+        step()
+        n, t0 = 0, time.perf_counter()
+        while n < max_steps and (n < 2 or (time.perf_counter() - t0) < budget):
+            step()
+            n += 1
+        return n, time.perf_counter() - t0
     best = None
     for nt in sorted({c for c in (4, 8, 16, 32, 64) if c <= avail} or {avail}):
         torch.set_num_threads(nt)
@@ -138,16 +233,122 @@ def cpu_baseline(budget_s=12.0, max_steps=40):
         if dt > 3.0:
             break
     torch.set_num_threads(best[0])
-    step()
-    n, t0 = 0, time.perf_counter()
-    while n < max_steps and (time.perf_counter() - t0) < budget_s:
-        step()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": BATCH_PER_GPU * PARTICLES * n / dt, "unit": "ELBO-evals/s", "cores": torch.get_num_threads(),
-            "kind": "port", "ms_per_step": 1e3 * dt / n, "host_cpus_available": avail,
-            "sample": "%d full training steps (fwd+bwd+Adam) of the same IWAE-VIMCO B=%d K=%d workload, torch-CPU "
-                      "fp32 oracle, %.1f s" % (n, BATCH_PER_GPU, PARTICLES, dt)}
+    n, dt = timed(budget_s)
+    rec = {"value": evals * n / dt, "unit": "ELBO-evals/s", "cores": torch.get_num_threads(), "kind": "port",
+           "ms_per_step": 1e3 * dt / n, "host_cpus_available": avail,
+           "sample": "%d full training steps (fwd+bwd+Adam) of the same workload, torch-CPU fp32 oracle, %.1f s" % (n, dt)}
+    torch.set_num_threads(1)
+    n1, dt1 = timed(one_thread_budget_s)
+    rec["one_thread"] = {"value": evals * n1 / dt1, "unit": "ELBO-evals/s", "cores": 1, "ms_per_step": 1e3 * dt1 / n1,
+                         "sample": "%d steps, %.1f s" % (n1, dt1)}
+    torch.set_num_threads(best[0])
+    return rec
+
+
+# ------------------------------------------------------------------------------------------------ timing helpers
+def timed_trials(step, steps, world, dev, min_seconds=MIN_TIMED_SECONDS, max_trials=200):
+    """Trials of exactly `steps` steps, each bracketed by synchronize + barrier and reduced with MAX over the ranks;
+    enough trials to cover `min_seconds` (every rank derives the same count from the first, rank-reduced, trial).
+    Returns (list of elapsed seconds per trial, last loss)."""
+    def one():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, last
+    first, last = one()
+    n = int(min(max_trials, max(3, np.ceil(min_seconds / max(first, 1e-6)))))
+    trials = [first]
+    for _ in range(n - 1):
+        el, last = one()
+        trials.append(el)
+    return trials, last
+
+
+def run_single_gpu_config(name, dev, steps, warmup):
+    """A BASELINE config other than the headline one on this GPU: full training steps replayed from one hipGraph."""
+    import zhusuan
+    torch.manual_seed(0)
+    model, obs, evals, label = make_workload(name, dev)
+    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
+    rng = zhusuan.DeviceRNG(dev, seed=1)
+
+    def compute():
+        rng.begin_step()
+        for p in model.parameters():
+            p.grad = None
+        loss = model(obs)
+        loss.backward()
+        return loss.detach()
+    with zhusuan.device_rng(rng):
+        step = zhusuan.GraphedStep(compute, opt.step, rng=rng, warmup=max(3, min(warmup, 10)))
+        for _ in range(3):
+            step()
+        trials, last = timed_trials(step, steps, 1, dev, min_seconds=0.3)
+    med = float(np.median(trials))
+    assert np.isfinite(float(last))
+    return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
+            "launch_mode": "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last)}
+
+
+def hbm_resident_kernels(klib, dev, launches=20):
+    """The streaming kernels on working sets that cannot sit in the 256 MiB Infinity Cache (the config-size figures in
+    `hip_kernels` can: 41 / 81 MB), in this same process: K3 forward / backward at N = 131 050 rows x 784 (420 / 831 MB),
+    K1 with in-kernel Philox at N = 4 194 300 rows x 40 (715 MB).  Median of `launches` back-to-back launches, HIP
+    events bound to each dispatch."""
+    import ctypes
+    from zhusuan import _hip
+    P = _hip.ptr
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out = {}
+
+    def timed(entry, nbytes, fn, rows, width):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        klib.prof_enable(True)
+        for _ in range(launches):
+            fn()
+        torch.cuda.synchronize()
+        klib.prof_enable(False)
+        d = sorted(1e3 * v for v in klib.prof_durations(entry))
+        med = d[len(d) // 2]
+        out[entry] = {"rows": rows, "row_length": width, "algorithmic_bytes": nbytes, "median_us": med, "min_us": d[0],
+                      "launches": len(d), "GBps": nbytes / med / 1e3, "frac_of_hbm_peak": nbytes / med / 1e3 / HBM_PEAK_GBS}
+    K = PARTICLES
+    B, X = 2621, X_DIM
+    N = K * B
+    p = torch.rand(N * X, device=dev) * 0.96 + 0.02
+    x = (torch.rand(B * X, device=dev) < 0.5).float()
+    lp = torch.empty(B * K, device=dev)
+    glp = torch.randn(B * K, device=dev)
+    gp = torch.empty(N * X, device=dev)
+    timed("zs_bernoulli_logprob_f32", 4 * N * X + 4 * B * X + 4 * N,
+          lambda: klib.call("zs_bernoulli_logprob_f32", P(p), P(x), B * X, P(lp), K, B, X, 1, K, st), N, X)
+    timed("zs_bernoulli_logprob_bwd_f32", 8 * N * X + 4 * B * X + 4 * N,
+          lambda: klib.call("zs_bernoulli_logprob_bwd_f32", P(p), P(x), B * X, P(glp), 1, K, P(gp), K, B, X, st), N, X)
+    del p, gp, x
+    B, D = 83886, Z_DIM
+    N, M = K * B, B * D
+    mu, sg = torch.randn(M, device=dev), torch.rand(M, device=dev) + 0.5
+    z, lp = torch.empty(K * M, device=dev), torch.empty(B * K, device=dev)
+    timed("zs_normal_sample_logprob_f32", 4 * N * D + 4 * N + 8 * M,
+          lambda: klib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, 2, None, P(z), P(lp), K, M, D, 1, K, 0, None, st),
+          N, D)
+    del mu, sg, z, lp
+    torch.cuda.empty_cache()
+    return out
 
 
 # kernel-name fragment -> C-ABI entry point (most specific first); logits forms carry <true, ...> as first template argument
@@ -207,10 +408,12 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     # test hook (tests/test_bench_contract.py): several ranks share GPU 0 and talk over gloo, so that the multi-rank
-    # control flow (shards, bucket, split graphs, max-over-ranks timing) can be exercised on a one-GPU box.  RCCL
+    # control flow (shards, buckets, staged graphs, max-over-ranks timing) can be exercised on a one-GPU box.  RCCL
     # refuses two ranks on one device, so this is never a measurement mode.
     share_device = os.environ.get("ZS_BENCH_SHARE_DEVICE") == "1"
     dev_index = 0 if share_device else local_rank
+    if not share_device and torch.cuda.device_count() <= dev_index:
+        raise SystemExit("bench: rank %d needs GPU %d, this node exposes %d" % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1 or (args.force_collective_path and "RANK" in os.environ):
@@ -223,22 +426,21 @@ def main():
         torch.backends.cuda.preferred_blas_library("cublaslt" if args.blas == "hipblaslt" else "cublas")
     import zhusuan  # noqa: F401
     from zhusuan import _hip, dataparallel
-    from examples import iwae
 
     torch.manual_seed(0)
-    model = iwae.build(n_samples=PARTICLES, estimator="vimco", x_dim=X_DIM, z_dim=Z_DIM, hidden=HIDDEN,
-                       device=dev, fused_logits=args.fused_logits)
+    model, obs, evals_per_step, _ = make_workload("c3", dev, seed_rank=rank, fused_logits=args.fused_logits)
     dataparallel.broadcast_parameters(model)
-    bucket = dataparallel.GradientBucket(model)
     opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
     rng = zhusuan.DeviceRNG(dev, seed=1000 + rank)          # per-rank Philox stream, state in device memory
-    rs = np.random.RandomState(1234 + rank)
-    x = torch.tensor((rs.uniform(size=(BATCH_PER_GPU, X_DIM)) < 0.5).astype(np.float32), device=dev)
-    obs = {"x": x}
 
     multi = world > 1 or args.force_collective_path
-    overlap = multi and args.no_graph and args.overlap_allreduce
-    obuckets = dataparallel.OverlappedBuckets(model, n_buckets=2) if overlap else None
+    hooks = multi and args.no_graph and args.overlap_allreduce
+    staged = multi and not args.no_graph and not args.no_overlap
+    bucket = dataparallel.GradientBucket(model)
+    obuckets = dataparallel.OverlappedBuckets(model, n_buckets=2) if hooks else None
+    # backward reaches the decoder's (generator's) parameters first, then the encoder's: two stages, two buckets
+    sbuckets = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()]) if staged else None
+    held = {}
 
     def compute_part():
         """objective forward + backward (+ packing the flat [grads | loss] bucket when there is a collective)"""
@@ -251,7 +453,7 @@ def main():
         return loss.detach()
 
     def exchange_part(loss):
-        """the ONE collective of a step: all-reduce of the flat bucket over RCCL/xGMI, then 1/world"""
+        """one collective after the whole backward: all-reduce of the flat bucket over RCCL/xGMI, then 1/world"""
         if not multi:
             return loss
         if dist.is_initialized():
@@ -260,7 +462,8 @@ def main():
         return bucket.flat[bucket.n_grad]
 
     def step_body():
-        if overlap:                       # buckets leave from autograd hooks during backward
+        """the step launched eagerly (also what the HIP-event kernel timing pass runs)"""
+        if hooks:                         # buckets leave from autograd hooks during backward
             rng.begin_step()
             obuckets.zero()
             loss = model(obs)
@@ -272,6 +475,22 @@ def main():
         opt.step()
         return g
 
+    # the staged step (default with more than one rank): decoder backward | all-reduce bucket 0 (asynchronous, on
+    # RCCL's stream) | encoder backward, overlapping it | all-reduce bucket 1, wait | 1/world + Adam
+    def stage_forward_and_decoder_backward():
+        rng.begin_step()
+        sbuckets.zero()
+        held["loss"] = model(obs)
+        sbuckets.backward_stage(held["loss"], 0)
+        return held["loss"].detach()
+
+    def stage_encoder_backward():
+        sbuckets.backward_stage(held["loss"], 1)
+
+    def stage_update():
+        sbuckets.scale()
+        opt.step()
+
     klib = _hip.lib()
     mode = "eager"
     with zhusuan.device_rng(rng):
@@ -280,36 +499,40 @@ def main():
             for _ in range(args.warmup):
                 step_body()
         else:
-            # The launch-bound inner loop (~130 kernels, most of them a few microseconds) becomes ONE hipGraph
-            # (zhusuan.GraphedStep: warm-up on the capture stream, thread-local capture mode).  With a collective
-            # the step is two graphs around it: graph A = compute + pack, eager RCCL all-reduce of the bucket,
-            # graph B = optimizer.
+            # The launch-bound inner loop (~130 kernels, most of them a few microseconds) is replayed from hipGraphs
+            # (warm-up on the capture stream, thread-local capture mode): ONE graph with a single rank; with a
+            # collective, graphs around the eagerly launched RCCL calls.
             try:
-                step = zhusuan.GraphedStep(compute_part, opt.step, exchange=exchange_part if multi else None, rng=rng,
-                                           warmup=max(args.warmup, 3))
+                if staged:
+                    stages = [("graph", stage_forward_and_decoder_backward), ("eager", lambda: sbuckets.launch(0)),
+                              ("graph", stage_encoder_backward), ("eager", lambda: (sbuckets.launch(1), sbuckets.wait())),
+                              ("graph", stage_update)]
+                    gs = zhusuan.GraphedStages(stages, rng=rng, warmup=max(args.warmup, 3))
+
+                    def step():
+                        gs()
+                        return sbuckets.loss()
+                    mode = "hipgraph x3, all-reduce of the decoder's gradients overlapped with the encoder's backward"
+                else:
+                    step = zhusuan.GraphedStep(compute_part, opt.step, exchange=exchange_part if multi else None, rng=rng,
+                                               warmup=max(args.warmup, 3))
+                    mode = "hipgraph x2 around an eager all-reduce" if multi else "hipgraph"
                 for _ in range(3):
                     step()
-                mode = "hipgraph"
             except Exception as e:                      # noqa: BLE001  (report, fall back to eager launches)
                 sys.stderr.write("bench: graph capture failed (%r); running eager\n" % (e,))
                 torch.cuda.synchronize()
-                step = step_body
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            last = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
+                step, mode = step_body, "eager"
+        if hooks:
+            mode = "eager, all-reduce overlapped with backward from autograd hooks (2 buckets)"
+        trials, last = timed_trials(step, args.steps, world, dev)
+        elapsed = float(np.median(trials))
         final_loss = float(last)
         # per-kernel durations: the same steps launched eagerly with start/stop HIP events bound to each
         # kernel dispatch on its stream (events cannot ride inside a graph replay)
         n_prof = min(args.steps, 50)
         klib.prof_enable(True)
-        if mode == "hipgraph":
+        if mode != "eager" and not hooks:
             side = torch.cuda.Stream()       # eager launches next to captured graphs: stay off the default stream
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -336,10 +559,6 @@ def main():
             run_steps(n_dev)
             dev_times = {}
         torch.cuda.synchronize()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     assert np.isfinite(final_loss)
 
     if rank == 0:
@@ -381,6 +600,8 @@ def main():
                     rec["algorithmic_bytes"] = algo[name]
                     rec["GBps"] = algo[name] / (rec["avg_us"] * 1e-6) / 1e9
                     rec["frac_of_hbm_peak"] = rec["GBps"] / HBM_PEAK_GBS
+                    rec["working_set"] = "%.1f MB: inside the 256 MiB Infinity Cache (see hbm_resident for the same kernel " \
+                                         "beyond it)" % (algo[name] / 1e6)
                 per_kernel[name] = rec
         # the dominant hot-path kernel of the step = the one that moves the most bytes per step (it is also the
         # one with the most time per step; bytes are used because they do not move when a profiler is attached)
@@ -399,37 +620,74 @@ def main():
                       "of the same workload launched eagerly right after the timed region" % n_prof)
         algo_bytes = algo[dominant]
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(dominant, args.fused_logits, _hip.ABI_VERSION)
+        nbytes = sbuckets.nbytes() if staged else (obuckets.nbytes() if hooks else bucket.nbytes())
         out = {
-            "metric": "ELBO-evals/sec (batch x K particles), IWAE-MNIST VIMCO K=50",
-            "value": BATCH_PER_GPU * PARTICLES * world * args.steps / elapsed,
+            "metric": baseline_metric(),
+            "value": evals_per_step * world * args.steps / elapsed,
             "unit": "ELBO-evals/s",
             "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "collective_library": collective_library(share_device) if dist.is_initialized() else None,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "trials": len(trials), "timed_seconds_total": float(sum(trials)),
+            "trial_ms_per_step": {"min": 1e3 * min(trials) / args.steps, "median": 1e3 * elapsed / args.steps,
+                                  "max": 1e3 * max(trials) / args.steps},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "IWAE-MNIST VIMCO, batch=%d per GPU (global %d), K=%d, latent=%d, x=%d, hidden=%d, "
                                    "full training step (fwd+bwd+all-reduce+Adam)" % (
                                        BATCH_PER_GPU, BATCH_PER_GPU * world, PARTICLES, Z_DIM, X_DIM, HIDDEN),
                        "global_batch": BATCH_PER_GPU * world, "particles": PARTICLES,
-                       "parallelism": "dp%d (minibatch shards, one flat-bucket all-reduce of %d bytes)" % (world, bucket.nbytes()),
+                       "parallelism": "dp%d (minibatch shards; %s, %d bytes per step)" % (
+                           world, "two flat buckets (decoder | encoder gradients + objective)" if (staged or hooks)
+                           else "one flat bucket [gradients | objective]", nbytes),
                        "bernoulli_path": "logits (sigmoid fused)" if args.fused_logits else "probs (reference default)",
-                       "mlp_gemm_library": args.blas, "launch_mode": (mode if not (multi and mode == "hipgraph") else "hipgraph x2 around an eager all-reduce")
-                       + (", all-reduce overlapped with backward (2 buckets)" if overlap else "")},
+                       "mlp_gemm_library": args.blas, "launch_mode": mode,
+                       "timing": "median of %d trials of %d steps, each bracketed by synchronize + barrier, max over ranks"
+                                 % (len(trials), args.steps)},
             "final_loss": final_loss,
             **({"test_mode": "ranks share GPU 0 and reduce over gloo (ZS_BENCH_SHARE_DEVICE): control-flow test, NOT a measurement"}
                if share_device else {}),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": pmc_traffic(dominant),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": 1e3 * k_ms if k_ms else None,
                          "min_launch_us": 1e3 * k_min_ms, "launches_timed": k_count,
-                         "eager_event_avg_us": 1e3 * ev_ms, "timing": timing},
+                         "eager_event_avg_us": 1e3 * ev_ms, "timing": timing,
+                         "working_set_note": "%.0f MB per launch: resident in the 256 MiB Infinity Cache between the producer "
+                                             "kernel and this one; hbm_resident holds the same kernel on a working set beyond it"
+                                             % (algo_bytes / 1e6)},
             "hip_kernels": per_kernel,
         }
+        extras = world == 1 and not args.no_extras and not args.force_collective_path
+        if extras:
+            try:
+                out["hbm_resident"] = hbm_resident_kernels(klib, dev)
+                dom = out["hbm_resident"].get(dominant)
+                if dom:
+                    out["roofline"]["hbm_resident"] = {"frac": dom["frac_of_hbm_peak"], "achieved": dom["GBps"],
+                                                       "median_launch_us": dom["median_us"], "rows": dom["rows"],
+                                                       "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
+            except Exception as e:                                  # noqa: BLE001
+                out["hbm_resident"] = {"error": repr(e)}
+            del model, opt, bucket
+            torch.cuda.empty_cache()
+            out["extra_configs"] = {}
+            for name in ("c2", "c5", "c3_logits"):
+                try:
+                    out["extra_configs"][name] = run_single_gpu_config(name, dev, args.steps, args.warmup)
+                except Exception as e:                              # noqa: BLE001
+                    out["extra_configs"][name] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline("c3")
+            if extras:
+                for name, b1, b2 in (("c2", 2.5, 2.0), ("c5", 2.0, 1.5)):
+                    if "error" not in out["extra_configs"].get(name, {"error": 1}):
+                        out["extra_configs"][name]["cpu_baseline"] = cpu_baseline(name, budget_s=b1, one_thread_budget_s=b2,
+                                                                                  max_steps=2000)
+                if "error" not in out["extra_configs"].get("c3_logits", {"error": 1}):
+                    out["extra_configs"]["c3_logits"]["cpu_baseline"] = "same workload as the headline line: see cpu_baseline"
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

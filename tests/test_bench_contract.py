@@ -24,8 +24,7 @@ def test_entry_points_exist():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in REQUIRED:
         assert '"%s"' % key in src, key
-    baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    assert baseline["metric"].split(" ")[0] in src          # the metric BASELINE.json names
+    assert 'json.load(f)["metric"]' in src and "BASELINE.json" in src     # the line carries BASELINE.json's metric verbatim
 
 
 def _run_bench(*extra):
@@ -55,12 +54,32 @@ def test_bench_line_single_rank():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-6
     assert "workload" in rec["config"] and "model" not in rec["config"] and "test_mode" not in rec
+    assert rec["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    # a 6-step trial is ~7 ms: the timed region is repeated until it covers at least half a second, median reported
+    assert rec["trials"] >= 3 and rec["timed_seconds_total"] >= 0.45
+    assert rec["trial_ms_per_step"]["min"] <= rec["ms_per_step"] <= rec["trial_ms_per_step"]["max"]
+    assert roof["traffic_source"] is None or roof["traffic_source"]["measured_in_this_run"] is False
+    # the same kernels on working sets beyond the Infinity Cache, measured in this run
+    hb = rec["hbm_resident"]
+    for k in ("zs_bernoulli_logprob_f32", "zs_bernoulli_logprob_bwd_f32", "zs_normal_sample_logprob_f32"):
+        assert hb[k]["algorithmic_bytes"] > 256 * 2 ** 20 and 0.2 < hb[k]["frac_of_hbm_peak"] < 1.0
+    assert 0.2 < roof["hbm_resident"]["frac"] < 1.0
+    # the other single-GPU configs, each with its CPU baselines (calibrated thread count and one thread)
+    for name in ("c2", "c5", "c3_logits"):
+        ex = rec["extra_configs"][name]
+        assert ex["value"] > 1e5 and ex["ms_per_step"] > 0 and ex["launch_mode"] == "hipgraph", ex
+    for name in ("c2", "c5"):
+        cb = rec["extra_configs"][name]["cpu_baseline"]
+        assert cb["value"] > 0 and cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0
+    assert cpu["one_thread"]["cores"] == 1 and cpu["one_thread"]["value"] > 0
 
 
 @pytest.mark.gpu
-def test_bench_line_collective_path_on_one_rank():
-    rec = _run_bench("--no-cpu-baseline", "--force-collective-path")
+@pytest.mark.parametrize("extra", [[], ["--no-overlap"]])
+def test_bench_line_collective_path_on_one_rank(extra):
+    rec = _run_bench("--no-cpu-baseline", "--force-collective-path", *extra)
     assert rec["n_gpus"] == 1 and rec["value"] > 1e5
+    assert ("hipgraph x3" in rec["config"]["launch_mode"]) == (not extra)
 
 
 @pytest.mark.gpu
@@ -102,7 +121,7 @@ def test_bench_parent_does_not_load_torch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--no-graph", "--overlap-allreduce"]])
+@pytest.mark.parametrize("extra", [[], ["--no-overlap"], ["--no-graph", "--overlap-allreduce"]])
 def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
     """The N = 2 control flow end to end (torch.distributed.run, shards, flat bucket, graph A -> all-reduce -> graph B,
     max-over-ranks timing, rank-0 JSON line) on a one-GPU box: both ranks on GPU 0, gloo instead of RCCL."""
@@ -117,7 +136,10 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
-    assert ("overlapped" in rec["config"]["launch_mode"]) == bool(extra)
+    # default: three hipGraphs, the decoder-gradient all-reduce overlapping the encoder's backward; --no-overlap: two graphs
+    # around one all-reduce; --no-graph --overlap-allreduce: eager launches, buckets leaving from autograd hooks
+    assert ("overlapped" in rec["config"]["launch_mode"]) == (extra != ["--no-overlap"])
+    assert ("hipgraph x3" in rec["config"]["launch_mode"]) == (extra == [])
     assert "NOT a measurement" in rec["test_mode"]
     assert abs(rec["value"] - 2 * 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
     assert "graph capture failed" not in r.stderr, r.stderr[-2000:]

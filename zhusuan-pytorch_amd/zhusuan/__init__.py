@@ -15,4 +15,4 @@ from . import distributions
 from . import framework
 from .utils import *
 from ._rng import inject_epsilon, DeviceRNG, device_rng
-from .graph import GraphedStep
+from .graph import GraphedStep, GraphedStages

@@ -202,6 +202,91 @@ class OverlappedBuckets(object):
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
 
 
+class StagedBuckets(object):
+    """Backward in STAGES, one flat bucket per stage, so that the all-reduce of an early stage's gradients travels
+    while the later stages are still being computed -- also when the step is replayed from hipGraphs, where autograd
+    hooks (``OverlappedBuckets``) do not run.
+
+    ``stage_params`` lists the parameters in the order backward reaches them, e.g. for the VAE / IWAE objectives
+    ``[generator.parameters(), variational.parameters()]``: the decoder's gradients are complete before the encoder's
+    backward has started.  Per step (each numbered piece is one stage of ``zhusuan.GraphedStages``; run them back to
+    back for an eager step):
+
+        b = dataparallel.StagedBuckets([gen.parameters(), var.parameters()])
+        b.zero(); loss = model(obs); b.backward_stage(loss, 0)     # 1 (graph)  decoder backward, bucket 0 packed
+        b.launch(0)                                                # 2 (eager)  asynchronous all-reduce of bucket 0
+        b.backward_stage(loss, 1)                                  # 3 (graph)  encoder backward, bucket 1 packed
+        b.launch(1); b.wait()                                      # 4 (eager)
+        b.scale(); optimizer.step()                                # 5 (graph)  1/world, update
+        global_loss = b.loss()
+
+    The objective rides in bucket 0 (the first to leave).  Every ``p.grad`` ends up aliasing its slice of a bucket."""
+
+    def __init__(self, stage_params, group=None):
+        self.group = group
+        self.stages = []
+        for i, params in enumerate(stage_params):
+            params = [p for p in params if p.requires_grad]
+            if not params:
+                raise ValueError("stage %d has no trainable parameters" % i)
+            n = sum(p.numel() for p in params)
+            flat = torch.zeros(n + (1 if i == 0 else 0), dtype=_bucket_dtype(params), device=params[0].device)
+            views, off = [], 0
+            for p in params:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self.stages.append({"params": params, "flat": flat, "views": views, "n": n, "handle": None})
+        seen = set()
+        for st in self.stages:
+            for p in st["params"]:
+                if id(p) in seen:
+                    raise ValueError("a parameter appears in two stages")
+                seen.add(id(p))
+
+    def _world(self):
+        active = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.get_world_size(self.group) if active else 1
+
+    def zero(self):
+        for st in self.stages:
+            st["handle"] = None
+            for p in st["params"]:
+                p.grad = None
+
+    def backward_stage(self, loss, i):
+        """Gradients of stage i's parameters only (autograd prunes everything that does not lead to them), packed into
+        bucket i.  All but the last stage keep the autograd graph alive for the stages that follow."""
+        st = self.stages[i]
+        last = i == len(self.stages) - 1
+        torch.autograd.backward(loss, inputs=st["params"], retain_graph=not last)
+        _fill_flat(st["flat"], st["params"], st["views"], [loss] if i == 0 else [])
+        for p, v in zip(st["params"], st["views"]):
+            p.grad = v
+
+    def launch(self, i):
+        """Start the all-reduce of bucket i without waiting for it (a no-op with one rank)."""
+        st = self.stages[i]
+        if self._world() > 1:
+            st["handle"] = dist.all_reduce(st["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self):
+        for st in self.stages:
+            if st["handle"] is not None:
+                st["handle"].wait()
+                st["handle"] = None
+
+    def scale(self):
+        w = self._world()
+        if w > 1:
+            torch._foreach_mul_([st["flat"] for st in self.stages], 1.0 / w)
+
+    def loss(self):
+        return self.stages[0]["flat"][self.stages[0]["n"]]
+
+    def nbytes(self):
+        return sum(st["flat"].numel() * st["flat"].element_size() for st in self.stages)
+
+
 def shard_rows(x, rank, world_size):
     """Rows [rank*B/G, (rank+1)*B/G) of the minibatch (equal shards: the mean of the local means is then
     the global mean)."""

@@ -34,7 +34,7 @@ import torch
 
 from . import _rng
 
-__all__ = ['GraphedStep']
+__all__ = ['GraphedStep', 'GraphedStages']
 
 
 def _optimizer_state_tensors(optimizer):
@@ -143,3 +143,79 @@ class GraphedStep(object):
         if len(self.graphs) > 1:
             self.graphs[1].replay()
         return loss
+
+
+class GraphedStages(object):
+    """A training step recorded as SEVERAL hipGraphs with eagerly executed pieces in between -- the shape of a
+    data-parallel step whose gradient all-reduce overlaps with backward:
+
+        stages = [("graph", forward_and_decoder_backward),      # returns the detached loss
+                  ("eager", launch_all_reduce_of_bucket_0),     # asynchronous: RCCL runs it on its own stream ...
+                  ("graph", encoder_backward),                  # ... while this graph replays on the compute stream
+                  ("eager", launch_bucket_1_and_wait_for_both),
+                  ("graph", scale_and_optimizer_step)]
+        step = zhusuan.GraphedStages(stages, rng=rng)
+        loss = step()
+
+    Collectives stay outside the graphs (an RCCL call captured into a graph ties the replay to one communicator state;
+    launched eagerly it is an ordinary stream-ordered operation).  All graphs share one memory pool: later stages read
+    what earlier ones produced (the autograd graph of the forward pass lives across the stage boundary, so the first
+    backward stage must keep it: ``retain_graph=True``).  Warm-up, capture stream and thread-local capture mode as for
+    ``GraphedStep``.  The value returned by the FIRST graph stage is the step's (static) loss tensor."""
+
+    def __init__(self, stages, rng=None, warmup=3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("zhusuan.GraphedStages needs a HIP device: the MI355X build has no CPU path")
+        kinds = [k for k, _ in stages]
+        if not stages or any(k not in ("graph", "eager") for k in kinds) or "graph" not in kinds:
+            raise ValueError("stages: a list of ('graph' | 'eager', callable) with at least one graph stage")
+        self._stages = [(k, f) for k, f in stages]
+        self._rng = rng
+        self._plan = []
+        self._static_loss = None
+
+        def eager_pass():
+            first = None
+            for kind, fn in self._stages:
+                out = fn()
+                if kind == "graph" and first is None:
+                    first = out
+            return first
+
+        with self._rng_scope():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(int(warmup), 2)):
+                    eager_pass()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            pool = None
+            for kind, fn in self._stages:
+                if kind == "eager":
+                    fn()                              # every rank runs the same sequence: collectives stay matched
+                    self._plan.append(fn)
+                    continue
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    out = fn()
+                if pool is None:
+                    pool = g.pool()
+                    self._static_loss = out
+                self._plan.append(g)
+                torch.cuda.synchronize()
+        self.graphs = [g for g in self._plan if isinstance(g, torch.cuda.CUDAGraph)]
+
+    def _rng_scope(self):
+        if self._rng is not None:
+            return _rng.device_rng(self._rng)
+        import contextlib
+        return contextlib.nullcontext()
+
+    def __call__(self):
+        for item in self._plan:
+            if isinstance(item, torch.cuda.CUDAGraph):
+                item.replay()
+            else:
+                item()
+        return self._static_loss
