@@ -1,12 +1,20 @@
-# Round-end GPU verification: build + smoke, the gpu test-suite, the bench line and its rocprofv3 kernel-trace summary.
-# Run through gpurun from the repository root:  gpurun --timeout 2400 -- 'bash tools/gpu_final_check.sh'
+# Round-end GPU verification: build + smoke, the gpu test-suite, the bench line, its rocprofv3 kernel-trace summary and the
+# PMC traffic passes.  Run through gpurun from the repository root:  gpurun --timeout 2400 -- 'bash tools/gpu_final_check.sh r02'
 cd "$(dirname "$0")/.." || exit 1
 ROOT=$(pwd)
+TAG=${1:-r02}
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4
-python bench.py --steps 200 --warmup 20 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err; echo "bench rc=$?"
+python bench.py --steps 200 --warmup 20 > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/bench_n1.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -o bench -- python3 "$ROOT/bench.py" --steps 200 --warmup 20 --no-cpu-baseline > "$ROOT/gpurun_out/bench_prof.json" 2> "$ROOT/gpurun_out/bench_prof.err"; echo "rocprof rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -o bench -- python3 "$ROOT/bench.py" --steps 200 --warmup 20 --no-cpu-baseline --no-extras > "$ROOT/gpurun_out/bench_prof.json" 2> "$ROOT/gpurun_out/bench_prof.err"; echo "rocprof rc=$?"
 rm -f "$ROOT/gpurun_out/prof/bench_kernel_trace.csv"     # 8 MB of per-dispatch rows; the stats file is the summary
+cp "$ROOT/gpurun_out/prof/bench_kernel_stats.csv" "$ROOT/gpurun_out/${TAG}_bench_n1_kernel_stats.csv"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$ROOT/gpurun_out/pmc_$c" -o pmc -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-extras > "$ROOT/gpurun_out/pmc_$c.log" 2>&1
+  echo "pmc $c rc=$?"
+  rm -f "$ROOT/gpurun_out/pmc_$c/pmc_kernel_trace.csv"
+done
+cd "$ROOT" && python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE --out gpurun_out/${TAG}_pmc_traffic.json
 ls "$ROOT/gpurun_out/prof"

@@ -274,23 +274,29 @@ __global__ __launch_bounds__(1024) void k_normal_sample_tile(
   }
 }
 
-// K1 forward, long rows (D4 > 64): one wave per (k, r) row, lanes stride over the row.
-template <bool HAS_EPS, bool HAS_LP>
+// K1 forward, long rows (D4 > 64): WPR waves per (k, r) row, lanes stride over the row.  WPR = 1: one wave per row
+// (many rows).  WPR = 4: the whole workgroup on one row -- for the few long rows of a weight-matrix node (BNN:
+// K = 10 rows of 700 elements; with one wave per row each lane walked three dependent load -> generate -> store rounds:
+// 6.1 us for 28 KB), partials combined through LDS.
+template <bool HAS_EPS, bool HAS_LP, int WPR>
 __global__ __launch_bounds__(256) void k_normal_sample_longrow(
     const float4* __restrict__ mu, const float4* __restrict__ sigma, const float4* __restrict__ eps,
     uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float4* __restrict__ z, float* __restrict__ lp,
     int64_t K, int64_t R, int D4, int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used) {
+  __shared__ float part[4];
   if (rs) { seed = rs[0]; call += rs[1]; }
   publish_rng(rng_used, seed, call);
   const int lane = threadIdx.x & 63;
+  constexpr int TPR = 64 * WPR;                       // threads per row
+  const int tin = WPR == 1 ? lane : (int)threadIdx.x;
   const int64_t M4 = R * (int64_t)D4;
   const int64_t rows = K * R;
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+  const int64_t stride = (int64_t)gridDim.x * (4 / WPR);
+  for (int64_t row = (int64_t)blockIdx.x * (4 / WPR) + (WPR == 1 ? (threadIdx.x >> 6) : 0); row < rows; row += stride) {
     int64_t k, r;
     divmod(row, R, k, r);
     float acc = 0.f;
-    for (int c = lane; c < D4; c += 64) {
+    for (int c = tin; c < D4; c += TPR) {
       const int64_t m4 = r * D4 + c;
       const int64_t g = k * M4 + m4;
       const float4 m = mu[m4], s = sigma_of(sigma[m4], ls);
@@ -315,7 +321,14 @@ __global__ __launch_bounds__(256) void k_normal_sample_longrow(
     }
     if (HAS_LP) {
       acc = wave_sum(acc);
-      if (lane == 0) lp[k * sk + r * sr] = acc;
+      if (WPR == 1) {
+        if (lane == 0) lp[k * sk + r * sr] = acc;
+      } else {                                           // `row` is uniform across the workgroup: barriers are safe
+        if (lane == 0) part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) lp[k * sk + r * sr] = (part[0] + part[1]) + (part[2] + part[3]);
+        __syncthreads();
+      }
     }
   }
 }
@@ -478,25 +491,43 @@ __global__ __launch_bounds__(256) void k_normal_sample_bwd(
   }
 }
 
+// K1 backward for rows without 16-byte access (any D / alignment; the BNN's [1, 51] weight matrix): the same tiling as
+// the vector kernel -- 64 elements x 4 K-slices per workgroup, slices combined through LDS -- with scalar accesses (a
+// thread per element walking all K particles took 6.3 us for 51 elements x 10 particles: ten dependent rounds of load,
+// generate, accumulate).
 __global__ __launch_bounds__(256) void k_normal_sample_bwd_serial(
     const float* __restrict__ sigma, const float* __restrict__ eps, uint64_t seed, uint64_t call,
     const uint64_t* __restrict__ rs, const float* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float* __restrict__ gmu, float* __restrict__ gsigma, int64_t K, int64_t M, int64_t D, bool ls) {
+  __shared__ float red[3][4][64];
   if (rs) { seed = rs[0]; call += rs[1]; }
-  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int64_t m = (int64_t)blockIdx.x * 64 + lane;
+  const bool on = m < M;
+  float a = 0.f, b = 0.f, g = 0.f;
+  if (on) {
     const int64_t r = m / D;
-    float a = 0.f, b = 0.f, g = 0.f;
-    for (int64_t k = 0; k < K; ++k) {
+    for (int64_t k = slice; k < K; k += 4) {
       const int64_t i = k * M + m;
       if (gz) {
         float e;
         if (eps) e = eps[i];
         else e = f4_get(philox_normal4((uint64_t)(i >> 2), call, seed), (int)(i & 3));
-        a += gz[i];
-        b += gz[i] * e;
+        const float gv = gz[i];
+        a += gv;
+        b += gv * e;
       }
       if (glp) g += glp[k * gsk + r * gsr];
     }
+  }
+  red[0][slice][lane] = a;
+  red[1][slice][lane] = b;
+  red[2][slice][lane] = g;
+  __syncthreads();
+  if (slice == 0 && on) {
+    a = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    b = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    g = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
     gmu[m] = a;
     const float sg = sigma_of(sigma[m], ls);
     gsigma[m] = ls ? b * sg - g : b - g / sg;
@@ -549,6 +580,59 @@ __global__ __launch_bounds__(256) void k_normal_logprob_rows(
     divmod(row, R, k, r);
       lp[k * sk + r * sr] = acc;
     }
+  }
+}
+
+// K2 forward, few long rows (D4 > 64, fewer rows than SIMDs -- a weight-matrix node's prior, K rows of 700 elements): the
+// whole workgroup on one row, every lane one or two 16-byte pieces, partials combined through LDS (one wave per row
+// walked three dependent rounds of loads: 6.3 us for 28 KB).
+// MS / SS: mu / sigma given as one scalar (decided on the host: a run-time scalar-or-row branch between two loads makes
+// the compiler wait for the first load before it issues the second, and the three loads of a piece went out one after
+// the other -- 6.9 us; with the operand classes compiled in they go out together).
+template <bool MS, bool SS>
+__global__ __launch_bounds__(256) void k_normal_logprob_blockrow(
+    const float4* __restrict__ x, int64_t xr, const float4* __restrict__ mu, int64_t mr,
+    const float4* __restrict__ sigma, int64_t sr_, float* __restrict__ lp,
+    int64_t K, int64_t R, int D4, int64_t sk, int64_t sr, bool ls) {
+  __shared__ float part[4];
+  const int64_t rows = K * R;
+  float ms = 0.f, l2s = 0.f, ps = 1.f;
+  if (MS) ms = *reinterpret_cast<const float*>(mu);
+  if (SS) {
+    l2s = log2_fast(sigma_of(*reinterpret_cast<const float*>(sigma), ls));
+    ps = exp2_fast(-2.0f * l2s);
+  }
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {       // uniform across the workgroup
+    const float4* __restrict__ xrow = x + mod_fast(row, xr) * D4;
+    const float4* __restrict__ mrow = MS ? nullptr : mu + mod_fast(row, mr) * D4;
+    const float4* __restrict__ srow = SS ? nullptr : sigma + mod_fast(row, sr_) * D4;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < D4; c += 256) {
+      const float4 xv = xrow[c];
+      const float4 m = MS ? make_float4(ms, ms, ms, ms) : mrow[c];
+      float4 s = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (!SS) s = sigma_of(srow[c], ls);
+      const float sv[4] = {s.x, s.y, s.z, s.w};
+      const float dv[4] = {xv.x - m.x, xv.y - m.y, xv.z - m.z, xv.w - m.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (SS) {
+          acc += normal_lp_term(dv[j], l2s * ZS_LN2, ps);
+        } else {
+          const float l2 = log2_fast(sv[j]);
+          acc += normal_lp_term(dv[j], l2 * ZS_LN2, exp2_fast(-2.0f * l2));
+        }
+      }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int64_t k, r;
+      divmod(row, R, k, r);
+      lp[k * sk + r * sr] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+    __syncthreads();
   }
 }
 
@@ -912,12 +996,18 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
       }
 #undef ZS_LAUNCH_SMALL
     } else {
-      const unsigned grid = grid_for(K * R, 4);
-#define ZS_LAUNCH_LONG(E, L)                                                                           \
-  ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_longrow<E, L>), dim3(grid), dim3(256), st, m4, s4, e4, seed, \
+      const bool few = K * R < 2048;                      // fewer rows than the chip has SIMDs: a workgroup per row
+      const unsigned grid = few ? grid_for(K * R, 1) : grid_for(K * R, 4);
+#define ZS_LAUNCH_LONG(E, L, W)                                                                           \
+  ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_longrow<E, L, W>), dim3(grid), dim3(256), st, m4, s4, e4, seed, \
                      offset, rng_state, (float4*)z, lp, K, R, D4, sk, sr, ls, rng_used)
-      if (eps) { if (lp) ZS_LAUNCH_LONG(true, true); else ZS_LAUNCH_LONG(true, false); }
-      else     { if (lp) ZS_LAUNCH_LONG(false, true); else ZS_LAUNCH_LONG(false, false); }
+      if (few) {
+        if (eps) { if (lp) ZS_LAUNCH_LONG(true, true, 4); else ZS_LAUNCH_LONG(true, false, 4); }
+        else     { if (lp) ZS_LAUNCH_LONG(false, true, 4); else ZS_LAUNCH_LONG(false, false, 4); }
+      } else {
+        if (eps) { if (lp) ZS_LAUNCH_LONG(true, true, 1); else ZS_LAUNCH_LONG(true, false, 1); }
+        else     { if (lp) ZS_LAUNCH_LONG(false, true, 1); else ZS_LAUNCH_LONG(false, false, 1); }
+      }
 #undef ZS_LAUNCH_LONG
     }
   } else if (D >= 8) {
@@ -965,7 +1055,7 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
                          (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
                          (float4*)gsigma, K, M4, (int)(D / 4), ls);
   } else {
-    ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, k_normal_sample_bwd_serial, dim3(grid_for(M, 256)), dim3(256), st, sigma, eps, seed,
+    ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, k_normal_sample_bwd_serial, dim3((unsigned)((M + 63) / 64)), dim3(256), st, sigma, eps, seed,
                        offset, rng_state, gz, glp, gsk, gsr, gmu, gsigma, K, M, D, ls);
   }
   ZS_CHECK_LAUNCH();
@@ -1005,6 +1095,15 @@ extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu
       ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_full, dim3(grid_for(tiles, 4)), dim3(256), st, (const float4*)x,
                 (int)(Px == 1 && N != 1), (const float4*)mu, (int)(Pm == 1 && N != 1), (const float4*)sigma,
                 (int)(Ps == 1 && N != 1), lp, rows, R, D4, rm.G, rm.rpw, rm.p2, sk, sr, ls);
+    } else if (D4 > 64 && rows < 2048 && Px != 1 && (Pm != 1 || Ps == 1)) {
+#define ZS_LAUNCH_BLOCKROW(MSC, SSC)                                                                              \
+  ZS_LAUNCH(KID_NORMAL_LOGPROB, (k_normal_logprob_blockrow<MSC, SSC>), dim3((unsigned)rows), dim3(256), st,        \
+            (const float4*)x, Px / D, (const float4*)mu, Pm == 1 ? 1 : Pm / D, (const float4*)sigma,             \
+            Ps == 1 ? 1 : Ps / D, lp, K, R, D4, sk, sr, ls)
+      if (Pm == 1) ZS_LAUNCH_BLOCKROW(true, true);
+      else if (Ps == 1) ZS_LAUNCH_BLOCKROW(false, true);
+      else ZS_LAUNCH_BLOCKROW(false, false);
+#undef ZS_LAUNCH_BLOCKROW
     } else {
       ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_rows, dim3(grid_for(tiles, 4)), dim3(256), st, (const float4*)x,
                 Px == 1 ? 0 : Px / D, (const float4*)mu, Pm == 1 ? 0 : Pm / D, (const float4*)sigma,
