@@ -866,6 +866,64 @@ def gen_uniform_latent():
     save("g_uniform_latent", **out)
 
 
+def gen_seeded():
+    """The reference's example models run from ``torch.manual_seed`` with NO draw injected: what a user's seeded run of
+    the reference produces.  The build's seed-compatible mode (``zhusuan.reference_rng()``: host draws from the same CPU
+    stream, call for call) must reproduce these numbers -- which also pins the draw ORDER (two draws per latent, the
+    second one used; the BNN's w0#1, w1#1, w0#2, w1#2)."""
+    out = {}
+    seed = 4321
+    vae = _load(os.path.join(REF, "examples/variational_autoencoder/vae_mnist.py"), "ref_vae_s")
+    B = 8
+    rng = np.random.RandomState(600 + B)
+    model = ELBO(vae.Generator(784, 40, B), vae.Variational(784, 40, B))
+    fill_params(model, 1000 + B)
+    x = (rng.uniform(size=(B, 784)) < 0.5).astype(F32)
+    torch.manual_seed(seed)
+    loss = model({"x": t(x)})
+    model.zero_grad()
+    loss.backward()
+    out["vae_loss"], out["vae_z"] = loss, model.variational.nodes["z"].dist.sample_cache
+    out["vae_grad_norms"] = grad_stats(model)[1]
+    iw = _load(os.path.join(REF, "examples/variational_autoencoder/iwae.py"), "ref_iwae_s")
+    B, K, hidden = 8, 5, 32
+    for est in ["sgvb", "vimco"]:
+        iw.hidden_dim = hidden
+        iw.reparameterization = (est == "sgvb")
+        rng = np.random.RandomState(700 + B + K)
+        model = ImportanceWeightedObjective(iw.Generator(784, 40, K), iw.Variational(784, 40, K), axis=0, estimator=est)
+        fill_params(model, 2000 + B + K)
+        x = (rng.uniform(size=(B, 784)) < 0.5).astype(F32)
+        torch.manual_seed(seed)
+        loss = model({"x": t(x)})
+        model.zero_grad()
+        loss.backward()
+        out["iwae_%s_loss" % est], out["iwae_%s_z" % est] = loss, model.variational.nodes["z"].dist.sample_cache
+        out["iwae_%s_grad_norms" % est] = grad_stats(model)[1]
+    bnn = _load(os.path.join(REF, "examples/bayesian_neural_nets/bnn_vi.py"), "ref_bnn_s")
+    B, K = 16, 4
+    rng = np.random.RandomState(800 + B + K)
+    net, var = bnn.Net([13, 50, 1], K), bnn.Variational([13, 50, 1], K)
+    model = ELBO(net, var)
+    prng = np.random.RandomState(3000 + B + K)
+    with torch.no_grad():
+        for p in var.w_means:
+            p.copy_(torch.tensor((0.1 * prng.standard_normal(tuple(p.shape))).astype(F32)))
+        for p in var.w_logstds:
+            p.copy_(torch.tensor((-1.0 + 0.1 * prng.standard_normal(tuple(p.shape))).astype(F32)))
+        net.y_logstd.fill_(0.3)
+    x = rng.standard_normal((B, 13)).astype(F32)
+    y = rng.standard_normal((B,)).astype(F32)
+    torch.manual_seed(seed)
+    loss = model({"x": t(x), "y": t(y)})
+    model.zero_grad()
+    loss.backward()
+    out["bnn_loss"] = loss
+    out["bnn_g_w_mean_0"], out["bnn_g_w_logstd_1"] = var.w_means[0].grad, var.w_logstds[1].grad
+    out["seed"] = np.array(seed)
+    save("g_seeded", **out)
+
+
 def gen_reference_tests():
     """Values of the reference's own statistical tests (test/variational/test_elbo.py, test_iw.py)
     so the build can re-run them against identical expectations."""
@@ -913,3 +971,4 @@ if __name__ == "__main__":
     gen_uniform()
     gen_reinforce()
     gen_uniform_latent()
+    gen_seeded()

@@ -213,3 +213,56 @@ def test_example_scripts_run(mod, args):
     r = subprocess.run([sys.executable, "-m", mod] + args, cwd=PKG_ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "ELBO-evals/s" in r.stdout and "nan" not in r.stdout.lower()
+
+
+# ------------------------------------------------------------------ seed-compatible mode
+def test_seeded_runs_reproduce_the_reference(dev):
+    """``torch.manual_seed(s)`` + ``zhusuan.reference_rng()``: every draw is made on the host from torch's CPU generator
+    with the reference's own call, in the reference's order, so a seeded run reproduces the seeded run of the reference
+    (golden: tests/golden/gen_golden.py gen_seeded, no draw injected there)."""
+    g = load_golden("g_seeded")
+    seed = int(g["seed"])
+    B = 8
+    model = vae_mnist.build(batch_size=B, device=dev)
+    H.load_params_into(model, 1000 + B)
+    x, _, _ = H.vae_data(B)
+    torch.manual_seed(seed)
+    with zs.reference_rng():
+        loss = model({"x": T(x, dev)})
+    assert rel(loss, g["vae_loss"]) < 2e-5
+    _check_z(model.variational.nodes["z"].dist.sample_cache, g["vae_z"], dev)
+    model.zero_grad()
+    loss.backward()
+    norms = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+    np.testing.assert_allclose(norms, g["vae_grad_norms"], rtol=1e-3, atol=1e-6)
+    B, K = 8, 5
+    for est in ("sgvb", "vimco"):
+        model = iwae.build(n_samples=K, estimator=est, hidden=32, device=dev)
+        H.load_params_into(model, 2000 + B + K)
+        x, _, _ = H.iwae_data(B, K)
+        torch.manual_seed(seed)
+        with zs.reference_rng():
+            loss = model({"x": T(x, dev)})
+        assert rel(loss, g["iwae_%s_loss" % est]) < 5e-5, est
+        _check_z(model.variational.nodes["z"].dist.sample_cache, g["iwae_%s_z" % est], dev)
+        model.zero_grad()
+        loss.backward()
+        norms = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+        np.testing.assert_allclose(norms, g["iwae_%s_grad_norms" % est], rtol=1e-3, atol=1e-6)
+    B, K = 16, 4
+    model = bnn_vi.build(n_particles=K, device=dev)
+    wm, wl, yl = H.bnn_params(B, K)
+    with torch.no_grad():
+        for i in range(2):
+            model.variational.w_means[i].copy_(wm[i])
+            model.variational.w_logstds[i].copy_(wl[i])
+        model.generator.y_logstd.copy_(yl)
+    x, y, _ = H.bnn_data(B, K)
+    torch.manual_seed(seed)
+    with zs.reference_rng():
+        loss = model({"x": T(x, dev), "y": T(y, dev)})
+    assert rel(loss, g["bnn_loss"]) < 2e-5
+    model.zero_grad()
+    loss.backward()
+    np.testing.assert_allclose(model.variational.w_means[0].grad.cpu().numpy(), g["bnn_g_w_mean_0"], rtol=1e-3, atol=5e-5)
+    np.testing.assert_allclose(model.variational.w_logstds[1].grad.cpu().numpy(), g["bnn_g_w_logstd_1"], rtol=1e-3, atol=5e-5)

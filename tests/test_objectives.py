@@ -87,8 +87,8 @@ def test_bayesian_net_api(dev):
         net.normal(5, mean=0., std=1.)
     with pytest.raises(ValueError, match="must be str"):
         net.bernoulli(5, probs=0.5)
-    with pytest.raises(NotImplementedError, match="outside the hot path"):
-        net.stochastic_node("Gamma", "e", alpha=1., beta=1.)
+    e = net.stochastic_node("Gamma", "e", alpha=torch.ones(3, device=dev), beta=torch.ones(3, device=dev))   # pass-through
+    assert list(e.shape) == [3] and bool((e > 0).all())
     net.cache["k"] = 1
     assert net.cache == {"k": 1}
     net.observe({})
@@ -402,15 +402,34 @@ def test_reference_iw_objective_sgvb_vimco(dev):
         ImportanceWeightedObjective(_Net().to(dev), Q().to(dev), axis=0, estimator="vimco")({})
 
 
-def test_helpers_of_families_outside_the_build_raise_clearly(dev):
-    net = BayesianNet()
-    for helper in ("beta", "exponential", "gamma", "laplace", "poisson", "studentT"):
-        with pytest.raises(NotImplementedError, match="outside the hot path"):
-            getattr(net, helper)("n", 1.0)
+def test_torch_distribution_pass_through_families(dev):
+    """Beta / Exponential / Gamma / Laplace / Poisson / StudentT: off the hot path, thin pass-throughs of torch.distributions
+    with the reference's conventions (leading sample axis by repeat, sample_cache, group sum, never reparameterised); the
+    reference's own unit tests for them run in tests/test_reference_suite.py.  Here: they work on the test device, through
+    the BayesianNet helpers too, and log-probs equal torch.distributions'."""
     import zhusuan.distributions as zd
-    for fam in ("Beta", "Exponential", "Gamma", "Laplace", "Poisson", "StudentT", "FlowDistribution"):
-        with pytest.raises(NotImplementedError, match="outside the variational-inference hot path"):
-            getattr(zd, fam)(1.0, 1.0)
+    one, two = torch.ones(4, 3, device=dev), torch.full((4, 3), 2.0, device=dev)
+    cases = [("beta", zd.Beta, (two, one), torch.distributions.Beta), ("exponential", zd.Exponential, (two,), torch.distributions.Exponential),
+             ("gamma", zd.Gamma, (two, one), torch.distributions.Gamma), ("laplace", zd.Laplace, (one, two), torch.distributions.Laplace),
+             ("poisson", zd.Poisson, (two,), torch.distributions.Poisson), ("studentT", zd.StudentT, (two, one, two), torch.distributions.StudentT)]
+    net = BayesianNet()
+    net._device = dev
+    for helper, cls, params, tcls in cases:
+        d = cls(*params, group_ndims=1)
+        assert not d.is_reparameterized and tuple(d.batch_shape) == (4, 3)
+        z = d.sample(5)
+        assert tuple(z.shape) == (5, 4, 3) and d.sample_cache is z and str(z.device) == str(torch.device(dev))
+        lp = d.log_prob(z)
+        close(lp, tcls(*params).log_prob(z).sum(-1), 1e-6, 1e-6)
+        assert tuple(d.sample().shape) == (4, 3)
+        v = getattr(net, helper)("n_" + helper, *params, n_samples=2, reduce_sum_dims=[2])
+        assert tuple(v.shape) == (2, 4, 3) and tuple(net.nodes["n_" + helper].log_prob().shape) == (2, 4)
+    with pytest.raises(NotImplementedError, match="outside the variational-inference hot path"):
+        zd.FlowDistribution(1.0, 1.0)
+    with pytest.raises(RuntimeError):
+        zd.Beta(torch.ones(2, 3), torch.ones(4, 5))                    # not broadcastable (reference: check_broadcast)
+    with pytest.warns(UserWarning, match="convert"):
+        zd.Poisson(torch.tensor([1, 2, 3]))                            # poisson.py:29-31: integer rate is converted
     d = Normal(mean=torch.zeros(3, device=dev), std=torch.ones(3, device=dev))
     z = d.sample(2)
     assert torch.equal(d._log_prob(sample=z), d._log_prob(z))          # the reference's keyword name

@@ -14,5 +14,5 @@ __version__ = '0.0.1+mi355x'
 from . import distributions
 from . import framework
 from .utils import *
-from ._rng import inject_epsilon, DeviceRNG, device_rng
+from ._rng import inject_epsilon, DeviceRNG, device_rng, reference_rng
 from .graph import GraphedStep, GraphedStages

@@ -14,6 +14,16 @@ epsilon tensors in explicitly:
 Each ``Normal._sample`` call pops the next tensor (shape ``[n_samples] + mean.shape``), in the
 order the reference would have called ``torch.normal`` -- remember that objectives draw every
 latent twice and use the second draw (elbo.py:122, importance_weighted_objective.py:85).
+
+Seed-compatible mode: inside ``zhusuan.reference_rng()`` every draw is made on the HOST from
+torch's default CPU generator with exactly the call the reference makes at that point, then copied to the device, so
+
+    torch.manual_seed(s)
+    with zhusuan.reference_rng():
+        loss = model({'x': x})
+
+consumes the CPU stream like the reference run under the same seed (two draws per latent, the second one used) and
+yields the reference's numbers.  It costs a host draw and a copy per sample: a reproduction mode, not the fast path.
 """
 import contextlib
 
@@ -37,9 +47,46 @@ def inject_epsilon(eps_list, strict=True):
         _queue = prev
 
 
-def pop_injected(shape, device, dtype=torch.float32):
-    """Next injected epsilon (moved to `device`, cast to `dtype`) or None when no injection is active."""
+_reference_stream = False
+
+
+@contextlib.contextmanager
+def reference_rng():
+    """Draw like the reference: on the CPU, from torch's default generator (``torch.manual_seed``), call for call."""
+    global _reference_stream
+    prev = _reference_stream
+    _reference_stream = True
+    try:
+        yield
+    finally:
+        _reference_stream = prev
+
+
+def reference_stream_active():
+    return _reference_stream and _queue is None
+
+
+def _host_draw(kind, shape, dtype):
+    """The reference's own host call for a draw of `kind`:
+    'normal'        torch.normal(0., 1., size=shape)                          normal.py:104  (== mean + std * it for :102)
+    'uniform_init'  torch.nn.init.uniform_(torch.empty(shape, dtype), 0, 1)   logistic.py:64
+    'rand'          torch.rand(shape, dtype)                                  uniform.py:64,66-67 (torch.distributions.Uniform.sample)"""
+    shape = tuple(shape)
+    if kind == "normal":
+        return torch.normal(0., 1., size=shape).to(dtype)
+    if kind == "uniform_init":
+        return torch.nn.init.uniform_(torch.empty(shape, dtype=dtype), 0., 1.)
+    if kind == "rand":
+        return torch.rand(shape, dtype=dtype)
+    raise ValueError(kind)
+
+
+def pop_injected(shape, device, dtype=torch.float32, kind="normal"):
+    """Next injected epsilon (moved to `device`, cast to `dtype`); inside ``reference_rng()`` a host draw of `kind`;
+    None when neither is active (the kernels then draw from their Philox stream)."""
     if _queue is None:
+        if _reference_stream:
+            return _host_draw(kind, shape, dtype).to(device).contiguous()
         return None
     if not _queue:
         raise RuntimeError("inject_epsilon: the model drew more Normal samples than epsilons were supplied")

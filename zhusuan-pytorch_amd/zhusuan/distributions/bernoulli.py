@@ -76,6 +76,10 @@ class Bernoulli(Distribution):
         K = int(n_samples)
         p = self.probs.contiguous()
         shape = ((K,) if K > 1 else ()) + tuple(p.shape)
+        if _rng.reference_stream_active():       # zhusuan.reference_rng(): torch.bernoulli on the host, as the reference
+            s = torch.bernoulli(p.detach().cpu().expand(shape)).to(p.device)
+            self.sample_cache = s
+            return s
         seed, call, rng_state = _rng.next_call(p.device)
         s = _ops.bernoulli_sample(p, max(p.numel(), 1), shape, seed, call, rng_state)
         self.sample_cache = s

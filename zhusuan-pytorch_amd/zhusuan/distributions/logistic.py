@@ -67,7 +67,7 @@ class Logistic(Distribution):
         u_shape = lead + tuple(loc.shape)
         u = uniform
         if u is None:
-            u = _rng.pop_injected(u_shape, loc.device, loc.dtype)
+            u = _rng.pop_injected(u_shape, loc.device, loc.dtype, kind="uniform_init")
         else:
             u = torch.as_tensor(u, dtype=loc.dtype).to(loc.device)
             if tuple(u.shape) != u_shape:

@@ -94,7 +94,9 @@ class Normal(Distribution):
         is_logstd = self._logstd_given is not None
         bshape = tuple(self._batch_shape())
         lead = (K,) if has_k else ()
-        eps_shape = lead + tuple(mean.shape)
+        # reparameterised: torch.normal(0, 1, size=[K] + mean.shape) (normal.py:90-92,104); otherwise
+        # torch.normal(mean_rep, std_rep) (normal.py:102): one independent draw per element of the BROADCAST shape
+        eps_shape = lead + (tuple(mean.shape) if self._is_reparameterized else bshape)
         eps = epsilon
         if eps is None:
             eps = _rng.pop_injected(eps_shape, mean.device, mean.dtype)
@@ -114,8 +116,10 @@ class Normal(Distribution):
             if eps is None:
                 s, c, rs = _rng.next_call(mean.device)
                 eps = _ops.philox_normal(eps_shape, mean.device, s, c, rs, mean.dtype)
-            pad = (1,) * (len(bshape) - mean.dim())
-            eps = eps.reshape(lead + pad + tuple(mean.shape)).expand(lead + bshape).contiguous()
+            if self._is_reparameterized:
+                pad = (1,) * (len(bshape) - mean.dim())
+                eps = eps.reshape(lead + pad + tuple(mean.shape)).expand(lead + bshape)
+            eps = eps.contiguous()
             mu = mean.expand(bshape).contiguous()
             sigma = std.expand(bshape).contiguous()
         n_fold = min(max(1, self._group_ndims), len(bshape))

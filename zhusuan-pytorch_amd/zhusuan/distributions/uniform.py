@@ -78,7 +78,7 @@ class Uniform(Distribution):
         u_shape = lead + (tuple(low.shape) if reparam else bshape)
         u = uniform
         if u is None:
-            u = _rng.pop_injected(u_shape, low.device, low.dtype)
+            u = _rng.pop_injected(u_shape, low.device, low.dtype, kind="rand")
         else:
             u = torch.as_tensor(u, dtype=low.dtype).to(low.device)
             if tuple(u.shape) != u_shape:

@@ -4,18 +4,25 @@ import torch
 import torch.nn as nn
 
 from .stochastic_tensor import StochasticTensor
-from ..distributions import Distribution, Normal, Bernoulli, Logistic, Uniform
+from ..distributions import (Distribution, Normal, Bernoulli, Logistic, Uniform, Beta, Exponential, Gamma, Laplace, Poisson,
+                             StudentT)
 
 __all__ = ['BayesianNet']
 
-# bn.py:8-19 maps ten names; the six torch.distributions wrappers off the hot path are not part of this build.
+# bn.py:8-19: the ten names (Normal / Bernoulli / Logistic / Uniform run on the HIP kernels, the other six are
+# torch.distributions pass-throughs off the hot path)
 name_mapping = {
     "Normal": Normal,
     "Bernoulli": Bernoulli,
+    "Beta": Beta,
+    "Exponential": Exponential,
+    "Gamma": Gamma,
+    "Laplace": Laplace,
     "Logistic": Logistic,
+    "Poisson": Poisson,
+    "StudentT": StudentT,
     "Uniform": Uniform,
 }
-_OUT_OF_SCOPE = ("Beta", "Exponential", "Gamma", "Laplace", "Poisson", "StudentT")
 
 
 class BayesianNet(nn.Module):
@@ -90,9 +97,6 @@ class BayesianNet(nn.Module):
         """Add (or overwrite) node `name`; returns its current value (observation or fresh sample),
         bn.py:139-158."""
         if isinstance(distribution, str):
-            if distribution in _OUT_OF_SCOPE:
-                raise NotImplementedError(
-                    "distribution '%s' is outside the hot path of the MI355X build (Normal, Bernoulli, Logistic, Uniform)" % distribution)
             _dist = name_mapping[distribution](device=self.device, **kwargs)
             self._nodes[name] = StochasticTensor(self, name, _dist, n_samples=n_samples, **kwargs)
         elif isinstance(distribution, Distribution):
@@ -149,24 +153,39 @@ class BayesianNet(nn.Module):
         return self._nodes[name].tensor
 
     def logistic(self, name, loc, scale, dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):
-        """The reference's helper of this name builds a LAPLACE node (bn.py:336-358 constructs ``Laplace``), which
-        is outside this build; use ``stochastic_node('Logistic', name, loc=..., scale=...)`` or pass a Logistic
-        instance for a Logistic node."""
-        raise NotImplementedError(
-            "BayesianNet.logistic() creates a Laplace node in the reference (zhusuan/framework/bn.py:345); Laplace is "
-            "outside the MI355X build.  Use stochastic_node('Logistic', ...) for a Logistic node.")
+        """As in the reference, the helper of this name builds a LAPLACE node (bn.py:336-358 constructs ``Laplace``).
+        For a Logistic node use ``stochastic_node('Logistic', name, loc=..., scale=...)`` or pass a Logistic instance."""
+        return self._family_node(Laplace, name, n_samples, dict(loc=loc, scale=scale, dtype=dtype, is_continuous=is_continuous,
+                                                                group_ndims=group_ndims), kwargs)
 
+    def _family_node(self, cls, name, n_samples, params, kwargs):
+        if not isinstance(name, str):
+            raise ValueError("name of stochastic_node must be str")
+        distribution = cls(device=self.device, **params, **kwargs)
+        self._nodes[name] = StochasticTensor(self, name, distribution, n_samples=n_samples, **kwargs)
+        return self._nodes[name].tensor
 
-def _outside(helper, family):
-    def method(self, name, *args, **kwargs):
-        raise NotImplementedError(
-            "BayesianNet.%s(): distribution '%s' is outside the hot path of the MI355X build "
-            "(Normal, Bernoulli, Logistic, Uniform)" % (helper, family))
-    method.__name__ = helper
-    method.__doc__ = "bn.py helper of the reference for the %s family: not part of this build." % family
-    return method
+    # the torch.distributions pass-through families (bn.py:242-406): plain torch ops, off the hot path
+    def beta(self, name, alpha, beta, dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):
+        return self._family_node(Beta, name, n_samples, dict(alpha=alpha, beta=beta, dtype=dtype, is_continuous=is_continuous,
+                                                             group_ndims=group_ndims), kwargs)
 
+    def exponential(self, name, rate, dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):
+        return self._family_node(Exponential, name, n_samples, dict(rate=rate, dtype=dtype, is_continuous=is_continuous,
+                                                                    group_ndims=group_ndims), kwargs)
 
-for _helper, _family in (("beta", "Beta"), ("exponential", "Exponential"), ("gamma", "Gamma"), ("laplace", "Laplace"),
-                         ("poisson", "Poisson"), ("studentT", "StudentT")):
-    setattr(BayesianNet, _helper, _outside(_helper, _family))
+    def gamma(self, name, alpha, beta, dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):
+        return self._family_node(Gamma, name, n_samples, dict(alpha=alpha, beta=beta, dtype=dtype, is_continuous=is_continuous,
+                                                              group_ndims=group_ndims), kwargs)
+
+    def laplace(self, name, loc, scale, dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):
+        return self._family_node(Laplace, name, n_samples, dict(loc=loc, scale=scale, dtype=dtype, is_continuous=is_continuous,
+                                                                group_ndims=group_ndims), kwargs)
+
+    def poisson(self, name, rate, dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):
+        return self._family_node(Poisson, name, n_samples, dict(rate=rate, dtype=dtype, is_continuous=is_continuous,
+                                                                group_ndims=group_ndims), kwargs)
+
+    def studentT(self, name, df, loc=0., scale=1., dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):
+        return self._family_node(StudentT, name, n_samples, dict(df=df, loc=loc, scale=scale, dtype=dtype,
+                                                                 is_continuous=is_continuous, group_ndims=group_ndims), kwargs)
