@@ -217,7 +217,7 @@ int zs_philox_normal_f32(float* out, int64_t N, uint64_t seed, uint64_t offset, 
  *   z[k, m]   = loc[m] + scale[m] * eps[k, m]                               (logistic.py:66)
  *   lp[k, r]  = sum_d ( -t - 2*softplus(-t) - log(scale) ),  t = (z - loc) / scale   (logistic.py:81-82)
  *
- * u == NULL: u is drawn in-kernel, 24-bit uniforms of Philox4x32-10 with the
+ * u == NULL: u is drawn in-kernel, uniforms (w >> 9 + 0.5) * 2^-23 (strictly inside (0, 1)) of Philox4x32-10 words w with the
  * counter convention of K1 (group = (k*M + m) / 4, word = (k*M + m) % 4).
  * For the fresh sample t == eps, and -eps - 2*softplus(-eps) == log(u) + log(1 - u):
  * the kernel reuses the two logarithms of the draw.  rng_used: as for K1.

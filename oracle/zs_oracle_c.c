@@ -43,8 +43,9 @@ static void philox4(uint64_t group, uint64_t call, uint64_t seed, uint32_t out[4
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-static float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * 5.9604644775390625e-08f; }
-/* Box-Muller on the word pairs (0, 1) and (2, 3): radius from the 24-bit uniform u01(word) in (0, 1), angle
+/* uniform strictly inside (0, 1): the 2^23 midpoints (m + 0.5) * 2^-23, m = v >> 9, every one exact in fp32 */
+static float u01(uint32_t v) { return ((float)(v >> 9) + 0.5f) * 1.1920928955078125e-07f; }
+/* Box-Muller on the word pairs (0, 1) and (2, 3): radius from the uniform u01(word) in (0, 1), angle
  * 2*pi*t with t = (word >> 9) * 2^-23 in [0, 1) (the kernels' definition of the stream, csrc/zs_common.h) */
 static void philox_normal4(uint64_t group, uint64_t call, uint64_t seed, float n[4]) {
   uint32_t r[4];

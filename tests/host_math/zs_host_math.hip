@@ -1,0 +1,187 @@
+// The kernels' per-element arithmetic (csrc/zs_common.h, csrc/zs_iw_math.h: __host__ __device__) compiled for the HOST
+// and run under AddressSanitizer + UndefinedBehaviorSanitizer (tests/test_sanitizers.py):
+//     hipcc -x hip --cuda-host-only -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all ...
+// Every function is checked against a double-precision restatement of the reference formula it implements, over edge
+// values (p in {0, 1}, sigma from 1e-6 to 1e6, uniforms at both ends of their range, |log w| ~ 550, a dominating
+// arg-max particle).  GPU sanitizers are not available on this pool, so this is where signed overflow, an invalid shift,
+// an out-of-range float -> int cast or a stray pointer in these helpers would show.  Prints "host math ok: N checks".
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "../../zhusuan-pytorch_amd/csrc/zs_common.h"
+#include "../../zhusuan-pytorch_amd/csrc/zs_iw_math.h"
+
+static long n_checks = 0;
+static int n_fail = 0;
+static void expect(bool ok, const char* what, double got, double want) {
+  ++n_checks;
+  if (!ok) {
+    if (n_fail < 20) fprintf(stderr, "FAIL %s: got %.9g want %.9g\n", what, got, want);
+    ++n_fail;
+  }
+}
+static bool close_rel(double got, double want, double rtol, double atol) { return fabs(got - want) <= rtol * fabs(want) + atol; }
+
+// Random123 known answers for philox4x32-10 (counter words c0..c3, key words k0 k1)
+static void test_philox_kat() {
+  struct { uint64_t group, call, seed; uint32_t out[4]; } kat[] = {
+      {0ull, 0ull, 0ull, {0x6627e8d5u, 0xe169c58du, 0xbc57ac4cu, 0x9b00dbd8u}},
+      {0xffffffffffffffffull, 0xffffffffffffffffull, 0xffffffffffffffffull, {0x408f276du, 0x41c83b0eu, 0xa20bc7c6u, 0x6d5451fdu}},
+      {0x85a308d3243f6a88ull, 0x0370734413198a2eull, 0x299f31d0a4093822ull, {0xd16cfe09u, 0x94fdccebu, 0x5001e420u, 0x24126ea1u}}};
+  for (auto& k : kat) {
+    const zs::Philox4 r = zs::philox4x32_10(k.group, k.call, k.seed);
+    expect(r.x == k.out[0] && r.y == k.out[1] && r.z == k.out[2] && r.w == k.out[3], "philox4x32_10 known answer", r.x, k.out[0]);
+  }
+}
+
+static void test_uniform_and_normal() {
+  const uint32_t words[] = {0u, 1u, 255u, 256u, 0x7fffffffu, 0x80000000u, 0xfffffeffu, 0xffffff00u, 0xffffffffu, 0x12345678u};
+  for (uint32_t w : words) {
+    const double want = ((double)(w >> 9) + 0.5) * 1.1920928955078125e-07;
+    const float u = zs::u01(w);
+    expect(u > 0.0f && u < 1.0f && (double)u == want, "u01 exact and strictly inside (0,1)", u, want);
+    expect(isfinite(logf(u)) && isfinite(logf(1.0f - u)), "log u, log(1 - u) finite (Logistic draw)", u, want);
+    const float a = zs::angle_rev(w);
+    expect(a >= 1.0f && a < 2.0f && close_rel(a - 1.0, (double)(w >> 9) * 1.1920928955078125e-07, 0, 1e-7), "angle_rev", a, 0);
+  }
+  // Box-Muller against the oracle's definition (oracle/zs_oracle_c.c:philox_normal4), many groups, two (seed, call) pairs
+  double s1 = 0, s2 = 0;
+  long n = 0;
+  for (uint64_t g = 0; g < 20000; ++g) {
+    const uint64_t group = g * 0x9E3779B97F4A7C15ull + (g << 40), call = g % 7 ? 3 : (1ull << 33) + 5, seed = 0x1234ABCDull + (g % 3);
+    const zs::Philox4 r = zs::philox4x32_10(group, call, seed);
+    const float4 nrm = zs::philox_normal4(group, call, seed);
+    const double two_pi = 6.283185307179586476925;
+    const double u0 = ((double)(r.x >> 9) + 0.5) * 1.1920928955078125e-07, u2 = ((double)(r.z >> 9) + 0.5) * 1.1920928955078125e-07;
+    const double t1 = (double)(r.y >> 9) * 1.1920928955078125e-07, t3 = (double)(r.w >> 9) * 1.1920928955078125e-07;
+    const double ra = sqrt(-2.0 * log(u0)), rb = sqrt(-2.0 * log(u2));
+    const double want[4] = {ra * cos(two_pi * t1), ra * sin(two_pi * t1), rb * cos(two_pi * t3), rb * sin(two_pi * t3)};
+    const float got[4] = {nrm.x, nrm.y, nrm.z, nrm.w};
+    for (int j = 0; j < 4; ++j) {
+      expect(close_rel(got[j], want[j], 2e-6, 2e-6) && isfinite(got[j]), "philox_normal4 vs double Box-Muller", got[j], want[j]);
+      s1 += got[j];
+      s2 += (double)got[j] * got[j];
+      ++n;
+    }
+  }
+  expect(fabs(s1 / n) < 0.02 && fabs(s2 / n - 1.0) < 0.02, "philox_normal4 moments", s1 / n, 0);
+}
+
+static void test_normal_bernoulli_terms() {
+  const float sig[] = {1e-6f, 1e-3f, 0.5f, 1.0f, 3.0f, 1e3f, 1e6f};
+  const float dif[] = {0.0f, 1e-8f, -0.3f, 2.5f, -40.0f};
+  for (float s : sig)
+    for (float d : dif) {
+      const float l2 = zs::log2_fast(s);
+      const float got = zs::normal_lp_term(d, l2 * ZS_LN2, zs::exp2_fast(-2.0f * l2));
+      const double ls = log((double)s), want = -0.91893853320467274178 - ls - 0.5 * exp(-2.0 * ls) * (double)d * d;   // normal.py:121-124
+      expect(close_rel(got, want, 3e-6, 3e-6) || !isfinite(want), "normal_lp_term", got, want);
+    }
+  const float ps[] = {0.0f, 1e-9f, 1e-4f, 0.25f, 0.5f, 0.75f, 1.0f - 1e-7f, 1.0f};
+  const float xs[] = {0.0f, 1.0f, 0.25f};
+  for (float p : ps)
+    for (float x : xs) {
+      const float a = p + 1e-8f, b = (1.0f - p) + 1e-8f;                 // the fp32 adds of bernoulli.py:94
+      const double want = (double)x * log((double)a) + (1.0 - (double)x) * log((double)b);
+      const float got = zs::bern_lp2_term(p, x) * ZS_LN2;
+      expect(close_rel(got, want, 3e-6, 3e-6), "bern_lp2_term", got, want);
+      const double dwant = (double)x / (double)a - (1.0 - (double)x) / (double)b;
+      const float dgot = zs::bern_dp(p, x);
+      expect(close_rel(dgot, dwant, 3e-6, 1e-6), "bern_dp", dgot, dwant);
+    }
+  for (float l = -30.0f; l <= 30.0f; l += 0.37f)
+    expect(close_rel(zs::sigmoid_fast(l), 1.0 / (1.0 + exp(-(double)l)), 3e-6, 1e-30), "sigmoid_fast", zs::sigmoid_fast(l), 0);
+  int64_t q, r;
+  const int64_t as[] = {0, 1, 12799, (1ll << 31) - 1, 1ll << 31, (1ll << 40) + 12345}, bs[] = {1, 7, 256, 83886, (1ll << 31) + 3};
+  for (int64_t a : as)
+    for (int64_t b : bs) {
+      zs::divmod(a, b, q, r);
+      expect(q == a / b && r == a % b && zs::mod_fast(a, b) == a % b, "divmod / mod_fast", (double)q, (double)(a / b));
+    }
+}
+
+// float64 restatement of importance_weighted_objective.py:16-25,123-132,152-191 for one row
+static void iw_truth(const std::vector<double>& l, const std::vector<double>& lq, int est, std::vector<double>& wt,
+                     std::vector<double>& cq, double& cost) {
+  const int K = (int)l.size();
+  double m = -INFINITY, S = 0, sumL = 0;
+  for (double v : l) m = v > m ? v : m;
+  for (double v : l) { S += exp(v - m); sumL += v; }
+  const double lme = log(S / K) + m;
+  cost = 0;
+  wt.assign(K, 0);
+  cq.assign(K, 0);
+  for (int j = 0; j < K; ++j) {
+    wt[j] = exp(l[j] - m) / S;
+    cost -= wt[j] * l[j];
+    cq[j] = wt[j];
+    if (est == ZS_IW_VIMCO) {
+      const double sub = (sumL - l[j]) / (K - 1);
+      double m2 = sub, S2 = 0;
+      for (int i = 0; i < K; ++i) if (i != j && l[i] > m2) m2 = l[i];
+      for (int i = 0; i < K; ++i) S2 += exp((i == j ? sub : l[i]) - m2);
+      const double signal = lme - (log(S2 / K) + m2);
+      cost -= lq[j] * signal;
+      cq[j] = wt[j] - signal;
+    }
+  }
+}
+
+static void test_iw_particle() {
+  srand(7);
+  for (int trial = 0; trial < 400; ++trial) {
+    const int K = 2 + rand() % 63;
+    const double spread = (trial % 3 == 0) ? 1.0 : (trial % 3 == 1 ? 5.0 : 30.0);
+    std::vector<double> l(K), lq(K);
+    std::vector<float> lf(K), lqf(K);
+    for (int j = 0; j < K; ++j) {
+      lf[j] = (float)(-550.0 + spread * ((rand() / (double)RAND_MAX) * 2 - 1) * 3);
+      lqf[j] = (float)(-50.0 + (rand() / (double)RAND_MAX));
+      if (trial % 5 == 4 && j == 0) lf[j] += 80.0f;                    // one particle dominates the row (S < 2 branch)
+      l[j] = lf[j];
+      lq[j] = lqf[j];
+    }
+    // row scalars as the kernels form them (zs_iw.hip:k_iw_reduce_wave), in fp32
+    zs::IwRow r;
+    r.m1 = -INFINITY;
+    r.jstar = 0;
+    for (int j = 0; j < K; ++j) if (lf[j] > r.m1) { r.m1 = lf[j]; r.jstar = j; }
+    r.m2 = -INFINITY;
+    for (int j = 0; j < K; ++j) if (j != r.jstar && lf[j] > r.m2) r.m2 = lf[j];
+    r.S = 0; r.S2 = 0; r.sumL = 0;
+    for (int j = 0; j < K; ++j) { r.S += expf(lf[j] - r.m1); r.sumL += lf[j]; if (j != r.jstar) r.S2 += expf(lf[j] - r.m2); }
+    r.logS = logf(r.S);
+    r.invK = 1.0f / K;
+    r.invKm1 = 1.0f / (K - 1);
+    for (int est = 0; est < 2; ++est) {
+      std::vector<double> wt, cq;
+      double cost;
+      iw_truth(l, lq, est, wt, cq, cost);
+      double got_cost = 0;
+      for (int j = 0; j < K; ++j) {
+        float w, ct, c;
+        zs::iw_particle(r, lf[j], lqf[j], j, est, w, ct, c);
+        got_cost += ct;
+        expect(close_rel(w, wt[j], 2e-5, 1e-7), "iw_particle weight", w, wt[j]);
+        expect(close_rel(c, cq[j], 2e-4, 2e-5), "iw_particle d cost / d logq", c, cq[j]);
+        expect(isfinite(w) && isfinite(ct) && isfinite(c), "iw_particle finite", c, 0);
+      }
+      expect(close_rel(got_cost, cost, 2e-5, 1e-3), "iw row cost", got_cost, cost);
+    }
+  }
+}
+
+int main() {
+  test_philox_kat();
+  test_uniform_and_normal();
+  test_normal_bernoulli_terms();
+  test_iw_particle();
+  if (n_fail) {
+    fprintf(stderr, "host math: %d of %ld checks FAILED\n", n_fail, n_checks);
+    return 1;
+  }
+  printf("host math ok: %ld checks\n", n_checks);
+  return 0;
+}

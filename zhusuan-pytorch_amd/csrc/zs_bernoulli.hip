@@ -9,18 +9,9 @@ using namespace zs;
 
 namespace {
 
-__device__ __forceinline__ float sigmoid_fast(float l) {  // torch.sigmoid: 1 / (1 + exp(-l)), bernoulli.py:50
-  return __builtin_amdgcn_rcpf(1.0f + exp_fast(-l));
-}
-
 __device__ __forceinline__ float bern_row_terms(const float4& pv, const float4& xv) {
   return bern_lp2_term(pv.x, xv.x) + bern_lp2_term(pv.y, xv.y) + bern_lp2_term(pv.z, xv.z) +
          bern_lp2_term(pv.w, xv.w);
-}
-
-// d/dp of x*log(p+e) + (1-x)*log((1-p)+e)
-__device__ __forceinline__ float bern_dp(float p, float x) {
-  return x * __builtin_amdgcn_rcpf(p + ZS_BERN_EPS) - (1.0f - x) * __builtin_amdgcn_rcpf((1.0f - p) + ZS_BERN_EPS);
 }
 
 // ------------------------------------------------------------------------------------

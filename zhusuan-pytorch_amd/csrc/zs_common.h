@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <string.h>
 
 #define ZS_WAVE 64
 #define ZS_LN2 0.69314718055994530942f
@@ -52,30 +53,88 @@ bool prof_begin_launch(int kid, hipEvent_t* start, hipEvent_t* stop);  // define
   } while (0)
 
 // ---------------------------------------------------------------- math
+// The per-element arithmetic of the kernels is __host__ __device__: tests/host_math/zs_host_math.hip compiles it for the
+// HOST (hipcc --cuda-host-only) under AddressSanitizer + UndefinedBehaviorSanitizer and checks it against double-precision
+// references (GPU sanitizers are not available on this pool).  ZS_ON_DEVICE selects the gfx950
+// instruction; the host branch is the same function by definition (log2f for v_log_f32, ...), used by that test only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZS_ON_DEVICE 1
+#else
+#define ZS_ON_DEVICE 0
+#include <math.h>
+#endif
+#define ZS_HD __host__ __device__ __forceinline__
+
 // v_log_f32 / v_exp_f32 are base-2 and 1-ulp; natural log/exp are one multiply away.
-__device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }
-__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float ln_fast(float x) { return log2_fast(x) * ZS_LN2; }
-__device__ __forceinline__ float exp_fast(float x) { return exp2_fast(x * 1.44269504088896340736f); }
+ZS_HD float log2_fast(float x) {
+#if ZS_ON_DEVICE
+  return __builtin_amdgcn_logf(x);
+#else
+  return log2f(x);
+#endif
+}
+ZS_HD float exp2_fast(float x) {
+#if ZS_ON_DEVICE
+  return __builtin_amdgcn_exp2f(x);
+#else
+  return exp2f(x);
+#endif
+}
+ZS_HD float rcp_fast(float x) {
+#if ZS_ON_DEVICE
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+ZS_HD float sqrt_fast(float x) {       // raw v_sqrt_f32 (1 ulp): the IEEE fix-up of sqrtf() costs ~20 instructions per root
+#if ZS_ON_DEVICE
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
+}
+ZS_HD float sin_rev(float x) {         // v_sin_f32 / v_cos_f32 take their argument in revolutions
+#if ZS_ON_DEVICE
+  return __builtin_amdgcn_sinf(x);
+#else
+  return (float)sin(6.283185307179586476925 * (double)(x - floorf(x)));
+#endif
+}
+ZS_HD float cos_rev(float x) {
+#if ZS_ON_DEVICE
+  return __builtin_amdgcn_cosf(x);
+#else
+  return (float)cos(6.283185307179586476925 * (double)(x - floorf(x)));
+#endif
+}
+ZS_HD float ln_fast(float x) { return log2_fast(x) * ZS_LN2; }
+ZS_HD float exp_fast(float x) { return exp2_fast(x * 1.44269504088896340736f); }
 
 // Normal log-density term for one element given log2(sigma) and prec = sigma^-2
 // (normal.py:121-124: c - logstd - 0.5 * precision * (x - mean)^2).
-__device__ __forceinline__ float normal_lp_term(float diff, float logstd, float prec) {
+ZS_HD float normal_lp_term(float diff, float logstd, float prec) {
   return (ZS_NEG_HALF_LOG_2PI - logstd) - 0.5f * prec * (diff * diff);
 }
 
 // Bernoulli term in log2 units (bernoulli.py:94); caller multiplies the row sum by ln 2.
-__device__ __forceinline__ float bern_lp2_term(float p, float x) {
+ZS_HD float bern_lp2_term(float p, float x) {
   float a = log2_fast(p + ZS_BERN_EPS);
   float b = log2_fast((1.0f - p) + ZS_BERN_EPS);
   return x * a + (1.0f - x) * b;
+}
+// torch.sigmoid: 1 / (1 + exp(-l)), bernoulli.py:50
+ZS_HD float sigmoid_fast(float l) { return rcp_fast(1.0f + exp_fast(-l)); }
+// d/dp of x*log(p+e) + (1-x)*log((1-p)+e)
+ZS_HD float bern_dp(float p, float x) {
+  return x * rcp_fast(p + ZS_BERN_EPS) - (1.0f - x) * rcp_fast((1.0f - p) + ZS_BERN_EPS);
 }
 
 // ---------------------------------------------------------------- index arithmetic
 // 64-bit integer division expands to ~100 VALU instructions on CDNA; row / tile indices almost always fit
 // 31 bits, where the 32-bit expansion is 4-5x shorter.  (At the config sizes a wave handles 1-3 rows, so
 // two 64-bit divisions per row were costing as much as the row's own arithmetic.)
-__device__ __forceinline__ void divmod(int64_t a, int64_t b, int64_t& q, int64_t& r) {
+ZS_HD void divmod(int64_t a, int64_t b, int64_t& q, int64_t& r) {
   if ((((uint64_t)a | (uint64_t)b) >> 31) == 0) {
     const uint32_t qq = (uint32_t)a / (uint32_t)b;
     q = (int64_t)qq;
@@ -85,7 +144,7 @@ __device__ __forceinline__ void divmod(int64_t a, int64_t b, int64_t& q, int64_t
     r = a - q * b;
   }
 }
-__device__ __forceinline__ int64_t mod_fast(int64_t a, int64_t b) {
+ZS_HD int64_t mod_fast(int64_t a, int64_t b) {
   int64_t q, r;
   divmod(a, b, q, r);
   return r;
@@ -124,10 +183,22 @@ struct Philox4 {
 // a ^ b ^ key in ONE VALU instruction: CDNA4's v_bitop3_b32 with the parity truth table 0x96 (gfx950 has no
 // v_xor3_b32, and the compiler emits two v_xor_b32 for the C expression: 38 of the 104 instructions of K1's inner loop
 // were xors).  `key` is a round key: uniform across the wavefront, so it stays in a scalar register.
-__device__ __forceinline__ uint32_t xor3_key(uint32_t a, uint32_t b, uint32_t key) {
+ZS_HD uint32_t xor3_key(uint32_t a, uint32_t b, uint32_t key) {
+#if ZS_ON_DEVICE
   uint32_t r;
   asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(key));
   return r;
+#else
+  return a ^ b ^ key;
+#endif
+}
+// a uniform value pinned to the scalar unit (no-op on the host)
+ZS_HD uint32_t uniform_u32(uint32_t v) {
+#if ZS_ON_DEVICE
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
 }
 
 // Rounds of the generator.  10 = Philox4x32-10, the curand / torch / Random123 default and what the oracle implements;
@@ -143,7 +214,7 @@ __device__ __forceinline__ uint32_t xor3_key(uint32_t a, uint32_t b, uint32_t ke
 // scalar-unit work, and the second round still has one uniform counter word.  Those two rounds are therefore written as
 // plain C (the compiler keeps uniform values in SGPRs: one v_mad_u64_u32 and three plain xors instead of two
 // multiplies and two three-input xors fed by v_mov copies); rounds 3..10 use the one-instruction three-input xor.
-__device__ __forceinline__ Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) {
+ZS_HD Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) {
   uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32);
   uint32_t c2 = (uint32_t)call, c3 = (uint32_t)(call >> 32);
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -154,10 +225,10 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t group, uint64_t call, 
     uint32_t n0, n2;
     // readfirstlane pins a uniform xor to the scalar unit (the optimiser otherwise re-associates it into two v_xor)
     if (r == 0) {                                  // uniform here: p1 (both halves), k0, c3, k1
-      n0 = __builtin_amdgcn_readfirstlane((uint32_t)(p1 >> 32) ^ k0) ^ c1;   // one v_xor with the lane's c1 = hi(group)
-      n2 = (uint32_t)(p0 >> 32) ^ __builtin_amdgcn_readfirstlane(c3 ^ k1);   // one v_xor
+      n0 = uniform_u32((uint32_t)(p1 >> 32) ^ k0) ^ c1;   // one v_xor with the lane's c1 = hi(group)
+      n2 = (uint32_t)(p0 >> 32) ^ uniform_u32(c3 ^ k1);   // one v_xor
     } else if (r == 1) {                           // uniform here: c1 (= lo(p1) of round 0), k0, k1
-      n0 = (uint32_t)(p1 >> 32) ^ __builtin_amdgcn_readfirstlane(c1 ^ k0);   // one v_xor
+      n0 = (uint32_t)(p1 >> 32) ^ uniform_u32(c1 ^ k0);   // one v_xor
       n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
     } else {
       n0 = xor3_key((uint32_t)(p1 >> 32), c1, k0);
@@ -171,40 +242,49 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t group, uint64_t call, 
   Philox4 o = {c0, c1, c2, c3};
   return o;
 }
-// 24-bit uniform strictly inside (0, 1): (m + 0.5) * 2^-24 with m = v >> 8.  One fma after the conversion; the result is
-// bit-identical to ((float)m + 0.5f) * 2^-24 (scaling by a power of two is exact).
-__device__ __forceinline__ float u01(uint32_t v) {
-  return __builtin_fmaf((float)(v >> 8), 5.9604644775390625e-08f, 2.98023223876953125e-08f);
+// Uniform STRICTLY inside (0, 1): (m + 0.5) * 2^-23 with m = v >> 9, i.e. the 2^23 midpoints 2^-24 ... 1 - 2^-24.  m + 0.5
+// needs 24 significant bits, so every value is exact in fp32 (shift, convert, one fma).  Round 1 used m = v >> 8 and
+// 2^-24: there m + 0.5 needs 25 bits, the top 256 words rounded up to exactly 1.0 and a Logistic draw log(u) - log(1 - u)
+// became +inf about once in 1.7e7 draws (found by the host-side sanitizer / reference test of this header,
+// tests/host_math/zs_host_math.hip).
+ZS_HD float u01(uint32_t v) {
+  return __builtin_fmaf((float)(v >> 9), 1.1920928955078125e-07f, 5.9604644775390625e-08f);
 }
 
 // Angle of a Box-Muller pair, in revolutions, from one Philox word: the word's upper 23 bits become the mantissa of a
 // float in [1, 2) -- ONE instruction, v_alignbit_b32 ({0x7F, w} >> 9 = 0x3F800000 | (w >> 9)) -- and v_sin_f32 /
 // v_cos_f32 take revolutions, so the integer part drops out: cos(2*pi*(1 + t)) = cos(2*pi*t), t = (w >> 9) * 2^-23.
 // (Shift, convert and scale would be three instructions per angle; the kernel is bound by VALU issue.)
-__device__ __forceinline__ float angle_rev(uint32_t w) {
+ZS_HD float angle_rev(uint32_t w) {
+#if ZS_ON_DEVICE
   return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, w, 9));
+#else
+  const uint32_t bits = 0x3F800000u | (w >> 9);
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+#endif
 }
 
 // Four standard normals for Philox group `group`: Box-Muller on (x, y) and (z, w) --
-//   radius from the 24-bit uniform u01(x) strictly inside (0, 1), angle 2*pi*t from the upper 23 bits of y.
+//   radius from the uniform u01(x) strictly inside (0, 1) (at most 5.77 sigma), angle 2*pi*t from the upper 23 bits of y.
 // (The logarithm is taken of the scaled uniform itself: log2(m + 0.5) - 24 would save nothing after the fma in u01 and
 // cancels catastrophically for u close to 1, i.e. for radii close to 0.)
-__device__ __forceinline__ float4 philox_normal4(uint64_t group, uint64_t call, uint64_t seed) {
+ZS_HD float4 philox_normal4(uint64_t group, uint64_t call, uint64_t seed) {
   Philox4 r = philox4x32_10(group, call, seed);
   const float u0 = u01(r.x), u2 = u01(r.z);
   const float a1 = angle_rev(r.y), a3 = angle_rev(r.w);
-  // raw v_sqrt_f32 (1 ulp): the IEEE fix-up sequence of sqrtf() costs ~20 extra instructions per root
-  const float ra = __builtin_amdgcn_sqrtf(-2.0f * ZS_LN2 * log2_fast(u0));
-  const float rb = __builtin_amdgcn_sqrtf(-2.0f * ZS_LN2 * log2_fast(u2));
+  const float ra = sqrt_fast(-2.0f * ZS_LN2 * log2_fast(u0));
+  const float rb = sqrt_fast(-2.0f * ZS_LN2 * log2_fast(u2));
   float4 n;
-  n.x = ra * __builtin_amdgcn_cosf(a1);
-  n.y = ra * __builtin_amdgcn_sinf(a1);
-  n.z = rb * __builtin_amdgcn_cosf(a3);
-  n.w = rb * __builtin_amdgcn_sinf(a3);
+  n.x = ra * cos_rev(a1);
+  n.y = ra * sin_rev(a1);
+  n.z = rb * cos_rev(a3);
+  n.w = rb * sin_rev(a3);
   return n;
 }
 
-__device__ __forceinline__ float f4_get(const float4& v, int i) {
+ZS_HD float f4_get(const float4& v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
