@@ -260,7 +260,7 @@ def _cmp(a, b, rtol=2e-5, atol=2e-5):
 
 NORMAL_SHAPES = [  # (K, R, D)
     (1, 1, 1), (1, 7, 1), (3, 5, 4), (5, 6, 40), (50, 16, 40), (2, 3, 700), (4, 1, 51), (3, 9, 7), (2, 130, 8),
-    (1, 1, 256), (2, 2, 260), (64, 3, 12), (9, 256, 260), (10, 1, 700),
+    (1, 1, 256), (2, 2, 260), (64, 3, 12), (9, 256, 260), (10, 1, 700), (3, 70, 60), (4, 33, 28), (17, 5, 100),
 ]
 
 

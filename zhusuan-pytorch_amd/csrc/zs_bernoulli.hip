@@ -415,7 +415,7 @@ inline int64_t pick_jc(int64_t J, int64_t xrows) {
   static const int jc_env = getenv("ZS_K3_JC") ? atoi(getenv("ZS_K3_JC")) : 0;     // experiments only
   if (jc_env > 0) return jc_env < J ? jc_env : J;
   const int64_t target = 256ll * 32 * 16;
-  for (int64_t jc = J; jc >= 1; --jc) {
+  for (int64_t jc = J < 4096 ? J : 4096; jc >= 1; --jc) {     // (bounded host loop; chunks beyond 4096 rows gain nothing)
     const int64_t chunks = (J + jc - 1) / jc;
     if ((chunks * jc - J) * 8 > J) continue;          // unequal last chunk: skip
     if (xrows * chunks >= target || jc <= 4) return jc;

@@ -1055,6 +1055,7 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
                          (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
                          (float4*)gsigma, K, M4, (int)(D / 4), ls);
   } else {
+    if ((M + 63) / 64 > 0x7fffffffll) return ZS_ENOTSUP;
     ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, k_normal_sample_bwd_serial, dim3((unsigned)((M + 63) / 64)), dim3(256), st, sigma, eps, seed,
                        offset, rng_state, gz, glp, gsk, gsr, gmu, gsigma, K, M, D, ls);
   }
