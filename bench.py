@@ -61,6 +61,9 @@ def parse_args(argv=None):
                          "is still running (zhusuan.dataparallel.OverlappedBuckets)")
     ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "rocblas"],
                     help="BLAS library PyTorch uses for the MLPs' fp32 GEMMs (outside the hot path)")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="leave PyTorch's default GEMM solution selection for the callers' fp32 nn.Linear stack (default: PyTorch "
+                         "TunableOp picks the fastest fp32 hipBLASLt / rocBLAS solution per GEMM shape during warm-up)")
     return ap.parse_args(argv)
 
 
@@ -101,6 +104,25 @@ def baseline_metric():
             return json.load(f)["metric"]
     except (OSError, ValueError, KeyError):
         return "ELBO-evals/sec (batch\u00d7K particles) VAE-MNIST K=50 @1/2/4/8 GPU"
+
+
+def gemm_tuning(on, tune=True):
+    """The callers' MLPs (outside the hot path, 72 % of the step) are fp32 GEMMs dispatched by PyTorch.  Its TunableOp
+    times the available fp32 hipBLASLt / rocBLAS solutions for each GEMM shape once (during the eager warm-up steps,
+    ~4 s in total for this workload) and uses the fastest from then on: same precision, same arithmetic, another tiling.
+    `--no-gemm-tuning` measures with PyTorch's default heuristic selection."""
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(bool(on))
+        tunable.tuning_enable(bool(on and tune))
+        if on:
+            tunable.set_max_tuning_duration(30)
+            import tempfile                  # TunableOp dumps its picks at exit: keep that file out of the repository
+            tunable.set_filename(os.path.join(tempfile.gettempdir(), "zs_bench_tunableop_%d.csv" % os.getpid()))
+        return bool(on)
+    except Exception as e:                                          # noqa: BLE001
+        sys.stderr.write("bench: TunableOp unavailable (%r); default GEMM selection\n" % (e,))
+        return False
 
 
 def collective_library(share_device):
@@ -276,9 +298,10 @@ def timed_trials(step, steps, world, dev, min_seconds=MIN_TIMED_SECONDS, max_tri
     return trials, last
 
 
-def run_single_gpu_config(name, dev, steps, warmup):
+def run_single_gpu_config(name, dev, steps, warmup, tuned=True):
     """A BASELINE config other than the headline one on this GPU: full training steps replayed from one hipGraph."""
     import zhusuan
+    gemm_tuning(tuned)
     torch.manual_seed(0)
     model, obs, evals, label = make_workload(name, dev)
     opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
@@ -293,13 +316,15 @@ def run_single_gpu_config(name, dev, steps, warmup):
         return loss.detach()
     with zhusuan.device_rng(rng):
         step = zhusuan.GraphedStep(compute, opt.step, rng=rng, warmup=max(3, min(warmup, 10)))
+        gemm_tuning(tuned, tune=False)       # every GEMM shape of the step has been seen: keep the picks, stop timing
         for _ in range(3):
             step()
         trials, last = timed_trials(step, steps, 1, dev, min_seconds=0.3)
     med = float(np.median(trials))
     assert np.isfinite(float(last))
     return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
-            "launch_mode": "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last)}
+            "launch_mode": "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
+            "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape)" if tuned else "PyTorch default"}
 
 
 def hbm_resident_kernels(klib, dev, launches=20):
@@ -424,6 +449,7 @@ def main():
 
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library("cublaslt" if args.blas == "hipblaslt" else "cublas")
+    tuned = gemm_tuning(not args.no_gemm_tuning)
     import zhusuan  # noqa: F401
     from zhusuan import _hip, dataparallel
 
@@ -525,6 +551,7 @@ def main():
                 step, mode = step_body, "eager"
         if hooks:
             mode = "eager, all-reduce overlapped with backward from autograd hooks (2 buckets)"
+        gemm_tuning(tuned, tune=False)       # the warm-up has seen every GEMM shape of the step: keep the picks, stop timing
         trials, last = timed_trials(step, args.steps, world, dev)
         elapsed = float(np.median(trials))
         final_loss = float(last)
@@ -643,7 +670,11 @@ def main():
                            world, "two flat buckets (decoder | encoder gradients + objective)" if (staged or hooks)
                            else "one flat bucket [gradients | objective]", nbytes),
                        "bernoulli_path": "logits (sigmoid fused)" if args.fused_logits else "probs (reference default)",
-                       "mlp_gemm_library": args.blas, "launch_mode": mode,
+                       "mlp_gemm_library": args.blas,
+                       "mlp_gemm_selection": ("PyTorch TunableOp: fastest fp32 hipBLASLt / rocBLAS solution per GEMM shape, picked during "
+                                              "warm-up (callers' nn.Linear stack, outside the hot path; extra_configs.c3_default_gemm "
+                                              "is the same step with PyTorch's default selection)") if tuned else "PyTorch default",
+                       "launch_mode": mode,
                        "timing": "median of %d trials of %d steps, each bracketed by synchronize + barrier, max over ranks"
                                  % (len(trials), args.steps)},
             "final_loss": final_loss,
@@ -676,9 +707,14 @@ def main():
             out["extra_configs"] = {}
             for name in ("c2", "c5", "c3_logits"):
                 try:
-                    out["extra_configs"][name] = run_single_gpu_config(name, dev, args.steps, args.warmup)
+                    out["extra_configs"][name] = run_single_gpu_config(name, dev, args.steps, args.warmup, tuned=tuned)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"][name] = {"error": repr(e)}
+            if tuned:       # the headline step once more with PyTorch's default GEMM selection (what round 1 measured)
+                try:
+                    out["extra_configs"]["c3_default_gemm"] = run_single_gpu_config("c3", dev, args.steps, args.warmup, tuned=False)
+                except Exception as e:                              # noqa: BLE001
+                    out["extra_configs"]["c3_default_gemm"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline("c3")
             if extras:
