@@ -327,10 +327,10 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True):
             "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape)" if tuned else "PyTorch default"}
 
 
-def hbm_resident_kernels(klib, dev, launches=20):
+def hbm_resident_kernels(klib, dev, launches=30):
     """The streaming kernels on working sets that cannot sit in the 256 MiB Infinity Cache (the config-size figures in
     `hip_kernels` can: 41 / 81 MB), in this same process: K3 forward / backward at N = 131 050 rows x 784 (420 / 831 MB),
-    K1 with in-kernel Philox at N = 4 194 300 rows x 40 (715 MB).  Median of `launches` back-to-back launches, HIP
+    K1 with in-kernel Philox at N = 4 194 300 rows x 40 (715 MB).  Median of `launches` (30) back-to-back launches, HIP
     events bound to each dispatch."""
     import ctypes
     from zhusuan import _hip
@@ -352,6 +352,15 @@ def hbm_resident_kernels(klib, dev, launches=20):
         out[entry] = {"rows": rows, "row_length": width, "algorithmic_bytes": nbytes, "median_us": med, "min_us": d[0],
                       "launches": len(d), "GBps": nbytes / med / 1e3, "frac_of_hbm_peak": nbytes / med / 1e3 / HBM_PEAK_GBS}
     K = PARTICLES
+    # K1 first: it is bound by VALU issue, i.e. by the shader clock, which sags after the long streaming launches below
+    B, D = 83886, Z_DIM
+    N, M = K * B, B * D
+    mu, sg = torch.randn(M, device=dev), torch.rand(M, device=dev) + 0.5
+    z, lp = torch.empty(K * M, device=dev), torch.empty(B * K, device=dev)
+    timed("zs_normal_sample_logprob_f32", 4 * N * D + 4 * N + 8 * M,
+          lambda: klib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, 2, None, P(z), P(lp), K, M, D, 1, K, 0, None, st),
+          N, D)
+    del mu, sg, z, lp
     B, X = 2621, X_DIM
     N = K * B
     p = torch.rand(N * X, device=dev) * 0.96 + 0.02
@@ -364,14 +373,7 @@ def hbm_resident_kernels(klib, dev, launches=20):
     timed("zs_bernoulli_logprob_bwd_f32", 8 * N * X + 4 * B * X + 4 * N,
           lambda: klib.call("zs_bernoulli_logprob_bwd_f32", P(p), P(x), B * X, P(glp), 1, K, P(gp), K, B, X, st), N, X)
     del p, gp, x
-    B, D = 83886, Z_DIM
-    N, M = K * B, B * D
-    mu, sg = torch.randn(M, device=dev), torch.rand(M, device=dev) + 0.5
-    z, lp = torch.empty(K * M, device=dev), torch.empty(B * K, device=dev)
-    timed("zs_normal_sample_logprob_f32", 4 * N * D + 4 * N + 8 * M,
-          lambda: klib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, 2, None, P(z), P(lp), K, M, D, 1, K, 0, None, st),
-          N, D)
-    del mu, sg, z, lp
+    del lp, glp
     torch.cuda.empty_cache()
     return out
 

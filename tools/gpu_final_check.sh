@@ -12,9 +12,23 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" 
 rm -f "$ROOT/gpurun_out/prof/bench_kernel_trace.csv"     # 8 MB of per-dispatch rows; the stats file is the summary
 cp "$ROOT/gpurun_out/prof/bench_kernel_stats.csv" "$ROOT/gpurun_out/${TAG}_bench_n1_kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$ROOT/gpurun_out/pmc_$c" -o pmc -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-extras > "$ROOT/gpurun_out/pmc_$c.log" 2>&1
+  # (--no-gemm-tuning: the counter passes are about the hot-path kernels; TunableOp's thousands of trial GEMMs would only bloat the CSVs)
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$ROOT/gpurun_out/pmc_$c" -o pmc -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-extras --no-gemm-tuning > "$ROOT/gpurun_out/pmc_$c.log" 2>&1
   echo "pmc $c rc=$?"
   rm -f "$ROOT/gpurun_out/pmc_$c/pmc_kernel_trace.csv"
 done
-cd "$ROOT" && python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE --out gpurun_out/${TAG}_pmc_traffic.json
-ls "$ROOT/gpurun_out/prof"
+cd "$ROOT" && python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE --out gpurun_out/${TAG}_pmc_traffic.json \
+  --command "python3 bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-extras --no-gemm-tuning"
+# keep the summaries small enough to travel back (gpurun merges at most 64 MiB): hot-path rows of the counter CSVs only
+python - <<PY
+import csv
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = "gpurun_out/pmc_%s/pmc_counter_collection.csv" % c
+    rows = list(csv.reader(open(f)))
+    ki = rows[0].index("Kernel_Name")
+    keep = [r for r in rows[1:] if "anonymous namespace)::k_" in r[ki]]
+    with open("gpurun_out/${TAG}_pmc_%s_counter_collection.csv" % c.lower(), "w", newline="") as fh:
+        w = csv.writer(fh); w.writerow(rows[0]); w.writerows(keep)
+PY
+rm -rf gpurun_out/prof gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+du -sh gpurun_out
