@@ -358,6 +358,25 @@ def test_cpu_tensor_without_gpu_library_fails_loudly():
         Bernoulli(probs=torch.full([4], 0.5)).log_prob(torch.ones(4))
 
 
+def test_non_reparameterised_normal_draws_one_epsilon_per_broadcast_element(dev):
+    """normal.py:102: the non-reparameterised draw is torch.normal(mean_rep, std_rep) -- one independent value per element of
+    the BROADCAST shape (the reparameterised draw has mean's shape and is shared along std-only axes, :104)."""
+    mean = torch.zeros(1, 3, device=dev)
+    std = torch.ones(2, 1, device=dev)
+    d = Normal(mean=mean, std=std, is_reparameterized=False)
+    z = d.sample(4)
+    assert tuple(z.shape) == (4, 2, 3) and not z.requires_grad
+    assert not torch.equal(z[:, 0], z[:, 1])                    # rows along the std-only axis are independent draws
+    eps = np.random.RandomState(5).standard_normal((4, 2, 3)).astype(np.float32)
+    with zs.inject_epsilon([eps]):                              # injected epsilon has the broadcast shape too
+        z2 = d.sample(4)
+    close(z2, eps, 1e-6, 1e-6)
+    close(d.log_prob(None), stats.norm.logpdf(eps), 1e-5, 1e-5)
+    dr = Normal(mean=mean, std=std)                             # reparameterised: shared along the std-only axis
+    zr = dr.sample(4)
+    close(zr[:, 0], zr[:, 1], 1e-6, 1e-6)
+
+
 # ------------------------------------------------------------------ device-resident RNG state (hipGraph-safe draws)
 def test_device_rng_state_drives_the_draws(dev):
     mu = torch.zeros([64, 8], device=dev)
