@@ -12,6 +12,8 @@
 //   * rows longer than a tile: one workgroup per row, register accumulation + block reduction;
 //   * D == 1 (no fold) with a contiguous result: terms go straight from registers to the result.
 #include "zs_common.h"
+#include "zs_sample_tile.h"
+#include <type_traits>
 #include "../../include/zs_hip.h"
 
 using namespace zs;
@@ -624,6 +626,27 @@ int logistic_sample(const T* loc, const T* scale, const T* u, uint64_t seed, uin
   if (!loc || !scale || !z) return ZS_EINVAL;
   const size_t A = sizeof(T) * 4;
   const bool vec = (M & 3) == 0 && al(loc, A) && al(scale, A) && al(u, A) && al(z, A);
+  if constexpr (std::is_same<T, float>::value) {
+    // in-kernel Philox, fp32, rows of up to 256 elements: the fused flat-plane kernel shared with Normal (zs_sample_tile.h)
+    if (!u && vec && (D & 3) == 0) {
+      const int D4 = (int)(D / 4);
+      const int64_t R = M / D;
+      const K1Tile g = k1_tile(K, R, D4, lp != nullptr);
+      if (g.ok) {
+        hipStream_t st = (hipStream_t)stream;
+        const bool nt = (double)K * (double)M * 4.0 > 268435456.0;   // z cannot stay in the Infinity Cache
+#define ZS_LAUNCH_LTILE(L, NTF)                                                                                          \
+  ZS_LAUNCH_SMEM(KID_LOGISTIC_SAMPLE, (k_sample_tile<D_LOGISTIC, L, NTF>), dim3(g.grid), dim3(g.threads), g.smem, st,     \
+                 (const float4*)loc, (const float4*)scale, seed, offset, rng_state, (float4*)z, lp, (uint32_t)K, R,      \
+                 (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, false, rng_used)
+        if (nt) { if (lp) ZS_LAUNCH_LTILE(true, true); else ZS_LAUNCH_LTILE(false, true); }
+        else    { if (lp) ZS_LAUNCH_LTILE(true, false); else ZS_LAUNCH_LTILE(false, false); }
+#undef ZS_LAUNCH_LTILE
+        ZS_CHECK_LAUNCH();
+        return 0;
+      }
+    }
+  }
   // D <= kTile: the tile kernel knows the index inside the [R*D] parameter plane (C_PLANE); the long-row kernel does not
   if (D <= kTile) {
     if (u) {

@@ -1,0 +1,232 @@
+// Fused sample + log-density kernel of the location-scale families (Normal: K1, Logistic: L1) and its launch geometry,
+// shared by zs_normal.hip and zs_locscale.hip.  See the comment on k_sample_tile.
+#pragma once
+#include <stdlib.h>
+
+#include "zs_common.h"
+
+#ifndef ZS_K1_EXPERIMENT
+#define ZS_K1_EXPERIMENT 0      // 1 / 2: timing experiments on k_sample_tile (never shipped)
+#endif
+
+namespace zs {
+
+enum { D_NORMAL = 0, D_LOGISTIC = 1 };
+typedef float zs_f4v __attribute__((ext_vector_type(4)));
+
+// round-to-nearest mul / add that the compiler may not contract into an FMA: the sample
+// z = mean + std * eps must round twice like the reference's separate mul and add
+// (normal.py:105) so that z is bit-identical for identical eps.
+__device__ __forceinline__ float mul_add_2round(float m, float s, float e) {
+#pragma clang fp contract(off)   // HIP's __fmul_rn/__fadd_rn are plain * and + and would still fuse
+  const float prod = s * e;
+  return m + prod;
+}
+
+// `sigma` operand given as log(sigma) (Normal(logstd=...), normal.py:56: std = exp(logstd)): the kernels form sigma
+// themselves instead of the caller launching an exp (and a multiply in backward).  Precise expf: it runs once per
+// parameter, not per particle.  d/d logstd = sigma * d/d sigma.
+__device__ __forceinline__ float sigma_of(float v, bool is_logstd) { return is_logstd ? expf(v) : v; }
+__device__ __forceinline__ float4 sigma_of(float4 v, bool is_logstd) {
+  if (is_logstd) { v.x = expf(v.x); v.y = expf(v.y); v.z = expf(v.z); v.w = expf(v.w); }
+  return v;
+}
+// resolved Philox ids of a draw, written once per launch for the backward call (which may run after the caller has
+// advanced the live rng_state)
+__device__ __forceinline__ void publish_rng(uint64_t* __restrict__ rng_used, uint64_t seed, uint64_t call) {
+  if (rng_used && blockIdx.x == 0 && threadIdx.x == 0) { rng_used[0] = seed; rng_used[1] = call; }
+}
+
+// ------------------------------------------------------------------------------------
+// Fused sample + log-density, flat-plane tiling (the kernel the benchmark shapes run; DIST = D_NORMAL: K1, D_LOGISTIC: L1,
+// location-scale families that differ only in how a standard draw and its density are formed): a workgroup of NW waves owns TB = 64*NW
+// CONSECUTIVE float4 groups of the [R, D4] parameter plane, with NW chosen on the host so that TB is a multiple of D4
+// (whole rows; D = 40 -> D4 = 10 -> 5 waves = 320 lanes = 32 rows).  Against the row-per-lane-group mapping above this
+// keeps all 64 lanes of every wave busy (10-lane groups fill only 60 of 64: the kernel is VALU-bound on the
+// generator, so idle lanes are lost throughput) and makes every z store of a wave one contiguous 1 KB segment.
+// The particle loop runs on scalar counters and a uniform base pointer per particle (lane offset in a 32-bit VGPR), so
+// per particle and lane the VALU work is the generator, the sample, the density and one 64-bit counter increment.
+// Row sums: each lane parks its partial per particle in LDS ([KB][TB+1], odd leading dimension: conflict-free both
+// ways); after KB particles the workgroup reads them back transposed, adds the D4 partials of a row and writes log q
+// coalesced along the particle axis of the K-fastest result.
+// In-kernel Philox only: with eps handed in (the parity path) the kernel is memory-bound and the row-per-lane-group
+// kernel above, which needs no workgroup barrier, is the faster one (69 % against 65 % of the roofline at 4.2 M rows).
+// ------------------------------------------------------------------------------------
+template <int DIST, bool HAS_LP, bool NT>
+__global__ __launch_bounds__(1024) void k_sample_tile(
+    const float4* __restrict__ mu, const float4* __restrict__ sigma,
+    uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float4* __restrict__ z, float* __restrict__ lp,
+    uint32_t K, int64_t R, uint32_t D4, uint32_t M4, uint32_t kchunk, uint32_t KB, uint32_t n_ptiles, uint32_t total,
+    int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used) {
+  extern __shared__ float zs_k1_stage[];
+  if (rs) { seed = rs[0]; call += rs[1]; }
+  publish_rng(rng_used, seed, call);
+  const uint32_t TB = blockDim.x, LDW = TB + 1, tid = threadIdx.x;
+  const uint32_t rows_in_tile = TB / D4;
+  for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {          // uniform: scalar registers throughout
+    const uint32_t kt = t / n_ptiles, pt = t - kt * n_ptiles;
+    const uint32_t m4 = pt * TB + tid;
+    const bool on = m4 < M4;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (on) {
+      m = mu[m4];
+      s = sigma_of(sigma[m4], ls);
+    }
+    // per-lane constants, reused for every particle of the chunk:
+    // Normal:   rowc = sum_j (c - log sigma_j)  (normal.py:121-124),  hp_j = 0.5 * exp(-2 log sigma_j)
+    // Logistic: rowc = -sum_j log scale_j       (logistic.py:81-82)
+    float rowc = 0.f, hp[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float l2 = log2_fast(sv[j]);
+        if (DIST == D_NORMAL) {
+          rowc += ZS_NEG_HALF_LOG_2PI - l2 * ZS_LN2;
+          hp[j] = 0.5f * exp2_fast(-2.0f * l2);
+        } else {
+          rowc -= l2 * ZS_LN2;
+        }
+      }
+    }
+    const uint32_t k0 = kt * kchunk;
+    const uint32_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
+    const int64_t rbase = (int64_t)pt * rows_in_tile;
+    for (uint32_t kb0 = k0; kb0 < k1; kb0 += KB) {
+      const uint32_t kb = (k1 - kb0 < KB) ? (k1 - kb0) : KB;
+      if (on) {
+        const uint64_t base = (uint64_t)kb0 * M4;                      // uniform
+        // uniform base pointer per particle (scalar registers) + this lane's 32-bit byte offset: the stores need no
+        // per-lane 64-bit address arithmetic (M4 < 2^28 is guaranteed by the host)
+        char* __restrict__ zk = reinterpret_cast<char*>(z + base);
+        const uint32_t lane_off = m4 * 16u;
+        const uint64_t step = (uint64_t)M4 * 16u;
+        uint64_t g = base + m4;                                        // Philox group of (particle kb0, this lane)
+        float* __restrict__ stp = zs_k1_stage + tid;
+        // one particle: sample, store, density partial.  `e` = the standard draw, `dens` = what the draw itself contributes
+        // to the log-density (Logistic: sum_j log u_j + log(1 - u_j); unused for Normal)
+        auto particle = [&](const float4& e, float dens) {
+          float4 zz;
+          zz.x = mul_add_2round(m.x, s.x, e.x);
+          zz.y = mul_add_2round(m.y, s.y, e.y);
+          zz.z = mul_add_2round(m.z, s.z, e.z);
+          zz.w = mul_add_2round(m.w, s.w, e.w);
+#if ZS_K1_EXPERIMENT == 1      // timing experiment: no z stores (generator + density only)
+          if (zz.x == 123.456f)
+#endif
+          {
+            // scalar base + 32-bit lane offset addressing, spelled out: the compiler keeps a 64-bit pointer per lane
+            // (one more VALU instruction per particle) for the C form of this store.
+            // The s_nop is the wait a store of more than 8 bytes needs before a VALU instruction may overwrite its
+            // data registers (the compiler's hazard recogniser does not look inside inline assembly; without it the
+            // next particle's arithmetic clobbers the sample on its way out).
+            const zs_f4v v = {zz.x, zz.y, zz.z, zz.w};
+            if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(lane_off), "v"(v), "s"(zk) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(lane_off), "v"(v), "s"(zk) : "memory");
+          }
+          if (HAS_LP) {
+            if (DIST == D_NORMAL) {
+              const float d0 = zz.x - m.x, d1 = zz.y - m.y, d2 = zz.z - m.z, d3 = zz.w - m.w;
+              *stp = rowc - (hp[0] * (d0 * d0) + hp[1] * (d1 * d1) + hp[2] * (d2 * d2) + hp[3] * (d3 * d3));
+            } else {
+              *stp = rowc + dens;
+            }
+            stp += LDW;
+          }
+          zk += step;
+        };
+        for (uint32_t kk = 0; kk < kb; ++kk) {
+#if ZS_K1_EXPERIMENT == 2      // timing experiment: no generator (store + density only)
+          particle(make_float4((float)(uint32_t)g, 1.f, 2.f, 3.f), 0.f);
+#else
+          if (DIST == D_NORMAL) {
+            particle(philox_normal4(g, call, seed), 0.f);
+          } else {
+            // Logistic draw (logistic.py:64-66): eps = log u - log(1 - u); its own log-density -eps - 2 softplus(-eps)
+            // is log u + log(1 - u): the two logarithms serve both
+            const Philox4 r = philox4x32_10(g, call, seed);
+            const float u0 = u01(r.x), u1 = u01(r.y), u2 = u01(r.z), u3 = u01(r.w);
+            const float a0 = ln_fast(u0), a1 = ln_fast(u1), a2 = ln_fast(u2), a3 = ln_fast(u3);
+            const float b0 = ln_fast(1.0f - u0), b1 = ln_fast(1.0f - u1), b2 = ln_fast(1.0f - u2), b3 = ln_fast(1.0f - u3);
+            particle(make_float4(a0 - b0, a1 - b1, a2 - b2, a3 - b3), ((a0 + b0) + (a1 + b1)) + ((a2 + b2) + (a3 + b3)));
+          }
+#endif
+          g += M4;
+        }
+      }
+      if (HAS_LP) {
+        __syncthreads();
+        const uint32_t nout = rows_in_tile * kb;
+        for (uint32_t o = tid; o < nout; o += TB) {
+          uint32_t q, kk;
+          if (kb == 16u) { q = o >> 4; kk = o & 15u; }       // the full batches: no integer division
+          else { q = o / kb; kk = o - q * kb; }
+          const float* __restrict__ src = zs_k1_stage + kk * LDW + q * D4;
+          float sum = 0.f;
+          for (uint32_t j = 0; j < D4; ++j) sum += src[j];
+          if (rbase + q < R) lp[(int64_t)(kb0 + kk) * sk + (rbase + q) * sr] = sum;
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// Launch geometry of k_sample_tile.
+struct K1Tile {
+  bool ok;
+  unsigned threads, grid, smem;
+  uint32_t kchunk, KB, n_ptiles, total;
+};
+inline int64_t gcd64(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+inline K1Tile k1_tile(int64_t K, int64_t R, int D4, bool want_lp) {   // (K1Tile: named after its first user)
+  K1Tile g = {};
+  // experiments: ZS_K1_TILE=0 disables the kernel, ZS_K1_KB / ZS_K1_ITEMS override the heuristics below
+  static const int enable = env_int("ZS_K1_TILE", 1), kb_env = env_int("ZS_K1_KB", 0), items_env = env_int("ZS_K1_ITEMS", 0);
+  if (!enable || D4 < 1 || D4 > 64) return g;
+  const int64_t M4 = R * (int64_t)D4;
+  if (M4 >= (1ll << 28) || K >= (1ll << 31)) return g;                 // lane offsets are 32-bit byte offsets
+  // workgroup = whole rows and whole waves: the smallest multiple of lcm(64, D4) lanes that is at least 256
+  const int64_t l = 64 / gcd64(64, D4) * D4;
+  int64_t TB = l * ((256 + l - 1) / l);
+  if (TB > 1024) TB = l;
+  if (TB > 1024) return g;                                             // e.g. D4 = 25: lcm = 1600 lanes
+  const int64_t n_ptiles = (M4 + TB - 1) / TB;
+  uint32_t KB = (uint32_t)(kb_env > 0 ? kb_env : 16);     // 16: the flush kernel's shift fast path; 20.5 KB of LDS at 320 lanes
+  // about two work items per resident workgroup slot: every item pays the parameter loads and eight logarithms /
+  // exponentials once, so chunks of particles should be long, while the hardware dispatcher needs spare items to even
+  // out the CUs (measured at the 1 M-row sweep point: 1 / 2 / 3 / 8 items per slot = 37.5 / 35.8 / 35.2 / 42.8 us;
+  // at 131 k rows, where 3 per slot means one particle per item: 8.9 / 9.5 / 12.4 us)
+  const int64_t resident = 256ll * (2048 / TB > 8 ? 8 : 2048 / TB);
+  const int64_t want = resident * (items_env > 0 ? items_env : 2);
+  int64_t k_tiles = (want + n_ptiles - 1) / n_ptiles;
+  if (k_tiles < 1) k_tiles = 1;
+  if (k_tiles > K) k_tiles = K;
+  int64_t kchunk = (K + k_tiles - 1) / k_tiles;
+  if (kchunk < 3) kchunk = K < 3 ? K : 3;        // an item of one or two particles is mostly prologue
+  k_tiles = (K + kchunk - 1) / kchunk;
+  const int64_t total = n_ptiles * k_tiles;
+  if (total >= (1ll << 31)) return g;
+  if (kchunk < KB) KB = (uint32_t)kchunk;
+  g.ok = true;
+  g.threads = (unsigned)TB;
+  g.smem = want_lp ? (unsigned)(KB * (TB + 1) * sizeof(float)) : 0u;
+  g.kchunk = (uint32_t)kchunk;
+  g.KB = KB;
+  g.n_ptiles = (uint32_t)n_ptiles;
+  g.total = (uint32_t)total;
+  // one work item per workgroup: the hardware dispatcher hands out items as slots free up, which balances the CUs to
+  // within one item (a fixed grid striding over the items leaves workgroups with floor/ceil(items / grid) of them --
+  // 2 vs 3 at the 1 M-row sweep point: 71 % efficiency).  The stride loop in the kernel only serves grids beyond the cap.
+  static const int grid_env = env_int("ZS_K1_GRID", 0);
+  const int64_t cap = grid_env > 0 ? grid_env : (1ll << 20);
+  g.grid = (unsigned)(total < cap ? total : cap);
+  return g;
+}
+
+
+}  // namespace zs
