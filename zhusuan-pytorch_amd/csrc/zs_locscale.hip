@@ -489,7 +489,9 @@ __global__ __launch_bounds__(256) void k_elem(F f, int64_t N) {
 }
 
 // L1 backward: workgroup = 64 groups of 4 parameters x 4 K-slices, slices combined through LDS.
-template <typename T, bool VEC>
+// SAME_ROW (D % 4 == 0): the four elements of a group share their row, so the incoming log-prob gradient is ONE unguarded
+// load per particle, issued together with the gz loads (four guarded gathers serialised the loop: 45 -> see DESIGN 4a).
+template <typename T, bool VEC, bool SAME_ROW>
 __global__ __launch_bounds__(256) void k_logistic_sample_bwd(const T* __restrict__ scale, const T* __restrict__ u, uint64_t seed,
                                                              uint64_t call, const uint64_t* __restrict__ rs,
                                                              const T* __restrict__ gz, const T* __restrict__ glp, int64_t gsk,
@@ -507,6 +509,8 @@ __global__ __launch_bounds__(256) void k_logistic_sample_bwd(const T* __restrict
     for (int j = 0; j < 4; ++j) r[j] = (m0 + j) / D;
     for (int64_t k = slice; k < K; k += 4) {
       const int64_t i0 = k * M + m0;
+      T grow = (T)0;
+      if (SAME_ROW && glp) grow = glp[k * gsk + r[0] * gsr];
       if (gz) {
         T gv[4], uu[4];
         ld4<T, VEC>(gz, i0, n, gv);
@@ -518,7 +522,10 @@ __global__ __launch_bounds__(256) void k_logistic_sample_bwd(const T* __restrict
           b[j] += gv[j] * eps;
         }
       }
-      if (glp) {
+      if (SAME_ROW) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gl[j] += grow;
+      } else if (glp) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (j < n) gl[j] += glp[k * gsk + r[j] * gsr];
@@ -677,12 +684,15 @@ int logistic_sample_bwd(const T* scale, const T* u, uint64_t seed, uint64_t offs
   const size_t A = sizeof(T) * 4;
   const bool vec = (M & 3) == 0 && al(scale, A) && al(u, A) && al(gz, A) && al(gloc, A) && al(gscale, A);
   const dim3 grid((unsigned)((M + 255) / 256));
-  if (vec)
-    ZS_LAUNCH(KID_LOGISTIC_SAMPLE_BWD, (k_logistic_sample_bwd<T, true>), grid, dim3(256), (hipStream_t)stream, scale, u, seed,
-              offset, rng_state, gz, glp, gsk, gsr, gloc, gscale, K, M, D);
+  if (vec && (D & 3) == 0)
+    ZS_LAUNCH(KID_LOGISTIC_SAMPLE_BWD, (k_logistic_sample_bwd<T, true, true>), grid, dim3(256), (hipStream_t)stream, scale, u,
+              seed, offset, rng_state, gz, glp, gsk, gsr, gloc, gscale, K, M, D);
+  else if (vec)
+    ZS_LAUNCH(KID_LOGISTIC_SAMPLE_BWD, (k_logistic_sample_bwd<T, true, false>), grid, dim3(256), (hipStream_t)stream, scale, u,
+              seed, offset, rng_state, gz, glp, gsk, gsr, gloc, gscale, K, M, D);
   else
-    ZS_LAUNCH(KID_LOGISTIC_SAMPLE_BWD, (k_logistic_sample_bwd<T, false>), grid, dim3(256), (hipStream_t)stream, scale, u, seed,
-              offset, rng_state, gz, glp, gsk, gsr, gloc, gscale, K, M, D);
+    ZS_LAUNCH(KID_LOGISTIC_SAMPLE_BWD, (k_logistic_sample_bwd<T, false, false>), grid, dim3(256), (hipStream_t)stream, scale, u,
+              seed, offset, rng_state, gz, glp, gsk, gsr, gloc, gscale, K, M, D);
   ZS_CHECK_LAUNCH();
   return 0;
 }
