@@ -441,10 +441,12 @@ def _iw_truth_f64(logp, logq, est):
         e = torch.exp(l - m1)
         S = e.sum(1, keepdim=True)
         cv = torch.log((S - e + torch.exp(sub - m1)) / K) + m1
-        for b in range(B):                      # the arg-max column needs the second maximum
-            j = int(idx[b, 0])
-            others = torch.cat([l[b, :j], l[b, j + 1:]])
-            cv[b, j] = torch.log((torch.exp(others - m2[b]).sum() + torch.exp(sub[b, j] - m2[b])) / K) + m2[b]
+        # the arg-max column needs the second maximum: sum over the OTHER particles relative to m2
+        rows, j = torch.arange(B), idx[:, 0]
+        mine = torch.zeros(B, K, dtype=torch.bool)
+        mine[rows, j] = True
+        s2 = torch.where(mine, torch.zeros_like(l), torch.exp(torch.where(mine, m2.expand(B, K), l) - m2)).sum(1)
+        cv[rows, j] = torch.log((s2 + torch.exp(sub[rows, j] - m2[:, 0])) / K) + m2[:, 0]
         signal = bound.unsqueeze(1) - cv
         cost = cost - (lq * signal).sum(1)
         cq = wt - signal
@@ -456,6 +458,19 @@ def _iw_truth_f64(logp, logq, est):
 @pytest.mark.parametrize("B,K", [(1, 1), (3, 2), (8, 5), (256, 50), (5, 64), (4, 65), (3, 200), (2, 1000), (1, 10000)])
 @pytest.mark.parametrize("spread", [1.0, 5.0, 30.0])
 def test_hip_iw_reduce(hip, orc, B, K, spread):
+    _check_iw_reduce(hip, orc, B, K, spread)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K", [(4100, 50), (4100, 64), (4100, 2), (4099, 17), (17000, 50), (17000, 7), (66000, 50),
+                                 (66001, 13), (66000, 64)])
+@pytest.mark.parametrize("spread", [1.0, 30.0])
+def test_hip_iw_reduce_lane_groups(hip, orc, B, K, spread):
+    """K <= 64 with thousands of datapoints runs the lane-group kernel (16 / 8 / 4 lanes per datapoint by B)."""
+    _check_iw_reduce(hip, orc, B, K, spread)
+
+
+def _check_iw_reduce(hip, orc, B, K, spread):
     rng = np.random.RandomState(B * 7 + K)
     logp = (-550 + spread * rng.standard_normal((B, K))).astype(np.float32)
     logq = (-50 + 0.3 * spread * rng.standard_normal((B, K))).astype(np.float32)

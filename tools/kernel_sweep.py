@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--max-rows", type=int, default=1 << 22)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--x-dim", type=int, default=784)
-    ap.add_argument("--only", default=None, help="only kernels whose name contains this substring")
+    ap.add_argument("--only", action="append", default=None, help="only kernels whose name contains this substring (repeatable)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _hip.lib()
@@ -38,7 +38,7 @@ def main():
     results = []
 
     def timed(name, entry, bytes_, fn, note=""):
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only):
             return
         for _ in range(3):
             fn()
@@ -102,7 +102,7 @@ def main():
         timed("U1 uniform sample (Philox)", "zs_uniform_sample_f32", 8 * N * D + 8 * M,
               lambda: lib.call("zs_uniform_sample_f32", P(mu), M, P(hi), M, None, 1, 2, None, P(z), P(gz), K * M, 1, st), tag)
         timed("U2 uniform logprob", "zs_uniform_logprob_f32", 4 * N * D + 4 * N + 8 * M,
-              lambda: lib.call("zs_uniform_logprob_f32", P(z), K * M, P(mu), M, P(hi), M, P(lp), K, B, D, 1, K, 0, st), tag)
+              lambda: lib.call("zs_uniform_logprob_f32", P(z), K * M, P(mu), M, P(hi), M, P(lp), K, B, D, 1, K, st), tag)
         del eps, gz, z, u, hi
         # ---------------- K4
         logp = torch.randn(B, K, device=dev) - 550

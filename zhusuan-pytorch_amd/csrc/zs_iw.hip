@@ -11,6 +11,7 @@
 //   j != argmax : max stays m1, sum = (S - e_j) + exp(sub_j - m1)      (S - e_j >= 1: no cancellation)
 //   j == argmax : max becomes m2 (second largest), sum = S2 + exp(sub_j - m2) with
 //                 S2 = sum_{i != j} exp(l_i - m2) accumulated separately (exact, no subtraction).
+#include <stdlib.h>
 #include "zs_common.h"
 #include "zs_iw_math.h"
 #include "../../include/zs_hip.h"
@@ -101,6 +102,148 @@ __global__ __launch_bounds__(256) void k_iw_reduce_wave(
     }
   }
   if (ext.mean_cost) {
+    if (lane == 0) wave_cost[threadIdx.x >> 6] = my_cost;
+    __syncthreads();
+    iw_finish_mean(ext, (wave_cost[0] + wave_cost[1]) + (wave_cost[2] + wave_cost[3]));
+  }
+}
+
+// ---- K <= 64, many datapoints: LPR (8 / 16) lanes per datapoint, lane q owns particles q, q + LPR, ... (NI of them, in
+// registers), 64 / LPR datapoints per wave.  The wave-per-datapoint kernel above spends most of its time in six 64-lane
+// butterflies per row (ds_bpermute) with 50 of 64 lanes holding a particle; here a reduction is 2-4 DPP instructions
+// (quad_perm, row_half_mirror, row_mirror: plain VALU, no LDS) after NI local steps, and every lane slot but
+// LPR * NI - K per row is a particle.  Needs B * LPR / 64 waves to fill the chip: the host picks LPR from B.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+#define ZS_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define ZS_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define ZS_DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i within 8
+#define ZS_DPP_MIRROR 0x140       // lane i <-> 15 - i within 16
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_f<ZS_DPP_XOR1>(v);
+  v += dpp_f<ZS_DPP_XOR2>(v);
+  if (LPR >= 8) v += dpp_f<ZS_DPP_HALF_MIRROR>(v);
+  if (LPR >= 16) v += dpp_f<ZS_DPP_MIRROR>(v);
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, dpp_f<ZS_DPP_XOR1>(v));
+  v = fmaxf(v, dpp_f<ZS_DPP_XOR2>(v));
+  if (LPR >= 8) v = fmaxf(v, dpp_f<ZS_DPP_HALF_MIRROR>(v));
+  if (LPR >= 16) v = fmaxf(v, dpp_f<ZS_DPP_MIRROR>(v));
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ int group_min(int v) {
+  int t;
+  t = dpp_i<ZS_DPP_XOR1>(v); v = t < v ? t : v;
+  t = dpp_i<ZS_DPP_XOR2>(v); v = t < v ? t : v;
+  if (LPR >= 8) { t = dpp_i<ZS_DPP_HALF_MIRROR>(v); v = t < v ? t : v; }
+  if (LPR >= 16) { t = dpp_i<ZS_DPP_MIRROR>(v); v = t < v ? t : v; }
+  return v;
+}
+
+template <int LPR, int NI>
+__global__ __launch_bounds__(256) void k_iw_reduce_group(
+    const float* __restrict__ logp, int64_t ld_p, const float* __restrict__ logq, int64_t ld_q,
+    int64_t B, int K, int estimator, float* __restrict__ cost_b, float* __restrict__ bound_b,
+    float* __restrict__ coef_p, float* __restrict__ coef_q, IwExt ext) {
+  __shared__ float wave_cost[4];
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int rw = lane / LPR, q = lane % LPR;
+  const int64_t items = (B + RPW - 1) / RPW;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float my_cost = 0.f;
+  for (int64_t it = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); it < items; it += nwaves) {
+    const int64_t b = it * RPW + rw;
+    const bool row_on = b < B;
+    const int64_t bc = row_on ? b : B - 1;                   // clamped: every lane loads and takes part in the reductions
+    float l[NI], lq[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = q + i * LPR, kc = k < K ? k : 0;
+      lq[i] = logq[bc * ld_q + kc];
+      l[i] = logp[bc * ld_p + kc];
+    }
+    if (ext.logp_b) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int k = q + i * LPR, kc = k < K ? k : 0;
+        l[i] += ext.logp_b[bc * ext.ld_b + kc];                // (a + b) - q, rounded like the reference's add
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const bool on = q + i * LPR < K;
+      l[i] = on ? l[i] - lq[i] : -INFINITY;
+      mx = fmaxf(mx, l[i]);
+    }
+    IwRow r;
+    r.m1 = group_max<LPR>(mx);
+    int jl = 0x7fffffff;
+#pragma unroll
+    for (int i = NI - 1; i >= 0; --i)
+      if (q + i * LPR < K && l[i] == r.m1) jl = q + i * LPR;    // lowest particle index holding the maximum
+    jl = group_min<LPR>(jl);
+    r.jstar = jl == 0x7fffffff ? 0 : jl;
+    float m2 = -INFINITY, sl = 0.f, s = 0.f, e[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = q + i * LPR;
+      const bool on = k < K;
+      if (k != r.jstar) m2 = fmaxf(m2, l[i]);
+      sl += on ? l[i] : 0.f;
+      e[i] = on ? expf(l[i] - r.m1) : 0.f;
+      s += e[i];
+    }
+    r.m2 = group_max<LPR>(m2);
+    r.sumL = group_sum<LPR>(sl);
+    r.S = group_sum<LPR>(s);
+    r.S2 = 0.f;
+    r.logS = 0.f;
+    if (estimator == ZS_IW_VIMCO && r.S < 2.0f) {             // the only rows whose arg-max particle reads S2 / logS
+      float s2 = 0.f;                                          // (uniform within the lane group: the DPP partners are active)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int k = q + i * LPR;
+        s2 += (k < K && k != r.jstar) ? expf(l[i] - r.m2) : 0.f;
+      }
+      r.S2 = group_sum<LPR>(s2);
+      r.logS = logf(r.S);
+    }
+    r.invK = 1.0f / (float)K;
+    r.invKm1 = K > 1 ? 1.0f / (float)(K - 1) : 0.f;
+    float ct = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = q + i * LPR;
+      if (k < K) {
+        float wt, c1, cq;
+        iw_particle_e(r, l[i], lq[i], e[i], k, estimator, wt, c1, cq);
+        ct += c1;
+        if (row_on) {
+          if (coef_p) coef_p[b * K + k] = -wt * ext.scale;
+          if (coef_q) coef_q[b * K + k] = cq * ext.scale;
+        }
+      }
+    }
+    const float cost = group_sum<LPR>(ct);
+    if (row_on && q == 0) {
+      my_cost += cost;
+      if (cost_b) cost_b[b] = cost;
+      if (bound_b) bound_b[b] = logf(r.S * r.invK) + r.m1;     // log(mean(exp(x - max))) + max, utils.py:18
+    }
+  }
+  if (ext.mean_cost) {
+    my_cost = wave_sum(my_cost);
     if (lane == 0) wave_cost[threadIdx.x >> 6] = my_cost;
     __syncthreads();
     iw_finish_mean(ext, (wave_cost[0] + wave_cost[1]) + (wave_cost[2] + wave_cost[3]));
@@ -233,6 +376,30 @@ static int iw_launch(int kid, const float* logp, int64_t ld_p, const float* logq
   if (B == 0) return 0;
   if (!logp || !logq) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  // K <= 64 and enough datapoints to fill the chip with fewer lanes per datapoint: the lane-group kernel
+  static const int lpr_env = [] { const char* v = getenv("ZS_K4_LPR"); return (v && *v) ? atoi(v) : -1; }();
+  // measured at K = 50 (tools/kernel_sweep.py, VIMCO): B = 20 971: wave kernel 14.3 us, 16 lanes 11.8, 8 lanes 11.1, 4 lanes
+  // 13.9; B = 83 886: 46.6 / 33.5 / 31.2 / 33.6 us (the precise exp / log1p / divisions of the particles set the pace from
+  // there); B = 2 621: launch floor either way
+  int lpr = K > 64 || B < 4096 ? 0 : (B < 16384 ? 16 : 8);
+  if (lpr_env >= 0 && K <= 64) lpr = lpr_env;
+  if (lpr == 8 || lpr == 16) {
+    const int rpw = 64 / lpr;
+    const unsigned grid = grid_for((B + rpw - 1) / rpw, 4);
+    if (ext.mean_cost && (!ext.partials || !ext.ticket || workspace_len < (int64_t)grid)) return ZS_EINVAL;
+    const int ni = (int)((K + lpr - 1) / lpr);
+#define ZS_IW_GROUP(L, N)                                                                                                    \
+  ZS_LAUNCH(kid, (k_iw_reduce_group<L, N>), dim3(grid), dim3(256), st, logp, ld_p, logq, ld_q, B, (int)K, estimator, cost_b, \
+            bound_b, coef_p, coef_q, ext)
+    if (lpr == 8) {
+      if (ni <= 2) ZS_IW_GROUP(8, 2); else if (ni <= 4) ZS_IW_GROUP(8, 4); else if (ni <= 7) ZS_IW_GROUP(8, 7); else ZS_IW_GROUP(8, 8);
+    } else {
+      if (ni <= 1) ZS_IW_GROUP(16, 1); else if (ni <= 2) ZS_IW_GROUP(16, 2); else ZS_IW_GROUP(16, 4);
+    }
+#undef ZS_IW_GROUP
+    ZS_CHECK_LAUNCH();
+    return 0;
+  }
   const unsigned grid = K <= 64 ? grid_for(B, 4) : grid_for(B, 1);
   if (ext.mean_cost && (!ext.partials || !ext.ticket || workspace_len < (int64_t)grid)) return ZS_EINVAL;
   if (K <= 64)

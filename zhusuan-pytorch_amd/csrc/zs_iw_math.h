@@ -18,9 +18,9 @@ struct IwRow {  // row-level scalars, uniform across the lanes that own the row
 // ~|log w|-sized numbers (the fp32 reference loses ~1e-5 absolute there).  For the arg-max particle,
 // when it dominates the row (S < 2), S - e_j would cancel instead: there the sum over the other
 // particles S2 (taken relative to the second maximum m2) is used directly.
-ZS_HD void iw_particle(const IwRow& r, float l, float lq, int j, int estimator,
-                                            float& wt, float& cost_term, float& cq) {
-  const float e = expf(l - r.m1);
+// `e` = exp(l - m1), which the callers' row sums already formed
+ZS_HD void iw_particle_e(const IwRow& r, float l, float lq, float e, int j, int estimator,
+                         float& wt, float& cost_term, float& cq) {
   wt = e / r.S;
   cost_term = -wt * l;
   cq = wt;
@@ -36,6 +36,10 @@ ZS_HD void iw_particle(const IwRow& r, float l, float lq, int j, int estimator,
     cost_term -= lq * signal;
     cq = wt - signal;
   }
+}
+ZS_HD void iw_particle(const IwRow& r, float l, float lq, int j, int estimator,
+                                            float& wt, float& cost_term, float& cq) {
+  iw_particle_e(r, l, lq, expf(l - r.m1), j, estimator, wt, cost_term, cq);
 }
 
 

@@ -645,7 +645,8 @@ int logistic_sample(const T* loc, const T* scale, const T* u, uint64_t seed, uin
 #define ZS_LAUNCH_LTILE(L, NTF)                                                                                          \
   ZS_LAUNCH_SMEM(KID_LOGISTIC_SAMPLE, (k_sample_tile<D_LOGISTIC, L, NTF>), dim3(g.grid), dim3(g.threads), g.smem, st,     \
                  (const float4*)loc, (const float4*)scale, seed, offset, rng_state, (float4*)z, lp, (uint32_t)K, R,      \
-                 (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, false, rng_used)
+                 (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, false, rng_used,     \
+                 (float4*)nullptr, false)
         if (nt) { if (lp) ZS_LAUNCH_LTILE(true, true); else ZS_LAUNCH_LTILE(false, true); }
         else    { if (lp) ZS_LAUNCH_LTILE(true, false); else ZS_LAUNCH_LTILE(false, false); }
 #undef ZS_LAUNCH_LTILE
@@ -736,6 +737,16 @@ int logistic_logprob(const T* x, int64_t Px, const T* loc, int64_t Pm, const T* 
   if (N % Px || N % Pm || N % Ps) return ZS_EINVAL;
   const size_t A = sizeof(T) * 4;
   const bool vec = per4(Px) && per4(Pm) && per4(Ps) && (Px == 1 || al(x, A)) && (Pm == 1 || al(loc, A)) && (Ps == 1 || al(scale, A));
+  if constexpr (sizeof(T) == 4) {
+    // parameters [R, D] shared by the K particles, rows of up to 256 elements: the K2 mapping (per-lane 1/scale and
+    // log scale formed once, value rows streamed past them)
+    if (vec && K > 1 && D % 4 == 0 && D / 4 <= 64 && Px == N && Pm == R * D && Ps == R * D) {
+      launch_logprob_krep<D_LOGISTIC>(KID_LOGISTIC_LOGPROB, (const float*)x, (const float*)loc, (const float*)scale, (float*)lp, K, R,
+                                      (int)(D / 4), sk, sr, false, (hipStream_t)stream);
+      ZS_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   ZS_DISPATCH_CLASSES(LogisticLogProbF, KID_LOGISTIC_LOGPROB, x, Px, loc, Pm, scale, Ps);
   ZS_CHECK_LAUNCH();
   return 0;
@@ -768,6 +779,31 @@ int uniform_sample(const T* low, int64_t Pl, const T* high, int64_t Ph, const T*
   const size_t A = sizeof(T) * 4;
   const bool vec = per4(Pl) && per4(Ph) && (Pl == 1 || al(low, A)) && (Ph == 1 || al(high, A)) && al(u, A) && al(out, A) &&
                    al(cache, A);
+  if constexpr (std::is_same<T, float>::value) {
+    // in-kernel Philox, bounds of one period shared by the K = N / P repetitions: the flat-plane kernel of Normal / Logistic
+    // (zs_sample_tile.h) with two store streams and no density (scalar loop control, one store instruction per output and
+    // particle, non-temporal beyond the Infinity Cache)
+    if (!u && vec && Pl == Ph && Pl >= 4 && (N & 3) == 0) {
+      const int64_t K = N / Pl;
+      const K1Tile g = k1_tile(K, Pl / 4, 1, false);
+      if (g.ok) {
+        hipStream_t st = (hipStream_t)stream;
+        const bool nt = (double)N * (cache ? 8.0 : 4.0) > 268435456.0;
+        if (nt)
+          ZS_LAUNCH_SMEM(KID_UNIFORM_SAMPLE, (k_sample_tile<D_UNIFORM, false, true>), dim3(g.grid), dim3(g.threads), 0, st,
+                         (const float4*)low, (const float4*)high, seed, offset, rng_state, (float4*)out, (float*)nullptr, (uint32_t)K,
+                         Pl / 4, 1u, (uint32_t)(Pl / 4), g.kchunk, g.KB, g.n_ptiles, g.total, (int64_t)0, (int64_t)0, false,
+                         (uint64_t*)nullptr, (float4*)cache, reparam != 0);
+        else
+          ZS_LAUNCH_SMEM(KID_UNIFORM_SAMPLE, (k_sample_tile<D_UNIFORM, false, false>), dim3(g.grid), dim3(g.threads), 0, st,
+                         (const float4*)low, (const float4*)high, seed, offset, rng_state, (float4*)out, (float*)nullptr, (uint32_t)K,
+                         Pl / 4, 1u, (uint32_t)(Pl / 4), g.kchunk, g.KB, g.n_ptiles, g.total, (int64_t)0, (int64_t)0, false,
+                         (uint64_t*)nullptr, (float4*)cache, reparam != 0);
+        ZS_CHECK_LAUNCH();
+        return 0;
+      }
+    }
+  }
   UniformSampleF<T> f = {low, Pl, high, Ph, u, seed, offset, rng_state, out, cache, reparam};
   launch_elem<T>(KID_UNIFORM_SAMPLE, f, vec, N, (hipStream_t)stream);
   ZS_CHECK_LAUNCH();
@@ -784,6 +820,14 @@ int uniform_logprob(const T* x, int64_t Px, const T* low, int64_t Pl, const T* h
   if (N % Px || N % Pl || N % Ph) return ZS_EINVAL;
   const size_t A = sizeof(T) * 4;
   const bool vec = per4(Px) && per4(Pl) && per4(Ph) && (Px == 1 || al(x, A)) && (Pl == 1 || al(low, A)) && (Ph == 1 || al(high, A));
+  if constexpr (sizeof(T) == 4) {
+    if (vec && K > 1 && D % 4 == 0 && D / 4 <= 64 && Px == N && Pl == R * D && Ph == R * D) {   // bounds shared by the particles
+      launch_logprob_krep<D_UNIFORM>(KID_UNIFORM_LOGPROB, (const float*)x, (const float*)low, (const float*)high, (float*)lp, K, R,
+                                     (int)(D / 4), sk, sr, false, (hipStream_t)stream);
+      ZS_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   ZS_DISPATCH_CLASSES(UniformLogProbF, KID_UNIFORM_LOGPROB, x, Px, low, Pl, high, Ph);
   ZS_CHECK_LAUNCH();
   return 0;

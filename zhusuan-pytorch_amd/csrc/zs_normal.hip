@@ -12,19 +12,6 @@ using namespace zs;
 
 namespace {
 
-struct RowMap {
-  int G;      // lanes per row
-  int rpw;    // rows per wave pass
-  int p2;     // next pow2 >= G
-};
-inline RowMap row_map(int64_t D4) {
-  RowMap m;
-  m.G = D4 >= 64 ? 64 : (int)D4;
-  m.rpw = 64 / m.G;
-  m.p2 = next_pow2(m.G);
-  return m;
-}
-
 // ------------------------------------------------------------------------------------
 // K1 forward, rows of up to 256 elements (D4 <= 64): a wave owns `rpw` parameter rows (G = D4 lanes
 // each) and walks a chunk of the K particles, so log(sigma) and sigma^-2 are computed once per lane and
@@ -496,76 +483,6 @@ __global__ __launch_bounds__(256) void k_normal_logprob_blockrow(
   }
 }
 
-// K2 forward, parameters [R, D] repeated over the K particles (IWAE prior / q of a given sample,
-// normal.py:112-116) and D4 <= 64: same tiling as the fused sampling kernel -- a wave owns `rpw` parameter
-// rows, computes log(sigma) and sigma^-2 once per lane and streams the K value rows past them; no
-// per-element index arithmetic.
-__global__ __launch_bounds__(256) void k_normal_logprob_krep(
-    const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
-    float* __restrict__ lp, int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t kchunk,
-    int64_t sk, int64_t sr, bool ls) {
-  const int lane = threadIdx.x & 63;
-  const int rw = lane / G, lig = lane - rw * G;
-  const bool lane_on = rw < rpw;
-  const int64_t M4 = R * (int64_t)D4;
-  const int64_t row_tiles = (R + rpw - 1) / rpw;
-  const int64_t k_tiles = (K + kchunk - 1) / kchunk;
-  const int64_t total = row_tiles * k_tiles;
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < total; t += nwaves) {
-    int64_t kt, rt;
-    divmod(t, row_tiles, kt, rt);
-    const int64_t r = rt * rpw + rw;
-    const bool on = lane_on && r < R;
-    const int64_t m4 = r * D4 + lig;
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (on) {
-      m = mu[m4];
-      s = sigma_of(sigma[m4], ls);
-    }
-    float rowc = 0.f, hp[4];
-    {
-      const float sv[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float l2 = log2_fast(sv[j]);
-        rowc += ZS_NEG_HALF_LOG_2PI - l2 * ZS_LN2;
-        hp[j] = 0.5f * exp2_fast(-2.0f * l2);
-      }
-    }
-    const int64_t k0 = kt * kchunk;
-    const int64_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
-    int64_t g = k0 * M4 + m4;
-    float* __restrict__ lpp = lp + (k0 * sk + r * sr);
-    int64_t k = k0;
-    for (; k + 1 < k1; k += 2, g += 2 * M4, lpp += 2 * sk) {   // two value rows in flight
-      float4 xa = m, xb = m;
-      if (on) {
-        xa = x[g];
-        xb = x[g + M4];
-      }
-      const float a0 = xa.x - m.x, a1 = xa.y - m.y, a2 = xa.z - m.z, a3 = xa.w - m.w;
-      const float b0 = xb.x - m.x, b1 = xb.y - m.y, b2 = xb.z - m.z, b3 = xb.w - m.w;
-      float acca = rowc - (hp[0] * (a0 * a0) + hp[1] * (a1 * a1) + hp[2] * (a2 * a2) + hp[3] * (a3 * a3));
-      float accb = rowc - (hp[0] * (b0 * b0) + hp[1] * (b1 * b1) + hp[2] * (b2 * b2) + hp[3] * (b3 * b3));
-      acca = group_sum_down(acca, lig, G, p2);
-      accb = group_sum_down(accb, lig, G, p2);
-      if (on && lig == 0) {
-        lpp[0] = acca;
-        lpp[sk] = accb;
-      }
-    }
-    for (; k < k1; ++k, g += M4, lpp += sk) {
-      float4 xa = m;
-      if (on) xa = x[g];
-      const float a0 = xa.x - m.x, a1 = xa.y - m.y, a2 = xa.z - m.z, a3 = xa.w - m.w;
-      float acca = rowc - (hp[0] * (a0 * a0) + hp[1] * (a1 * a1) + hp[2] * (a2 * a2) + hp[3] * (a3 * a3));
-      acca = group_sum_down(acca, lig, G, p2);
-      if (on && lig == 0) lpp[0] = acca;
-    }
-  }
-}
-
 // K2 forward, every operand either full-size or a scalar: rows with no index arithmetic at all.
 __global__ __launch_bounds__(256) void k_normal_logprob_full(
     const float4* __restrict__ x, int x_scalar, const float4* __restrict__ mu, int mu_scalar,
@@ -771,7 +688,8 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
 #define ZS_LAUNCH_TILE(L, T)                                                                                  \
   ZS_LAUNCH_SMEM(KID_NORMAL_SAMPLE, (k_sample_tile<D_NORMAL, L, T>), dim3(kt_.grid), dim3(kt_.threads), kt_.smem, st, \
                  m4, s4, seed, offset, rng_state, (float4*)z, lp, (uint32_t)K, R, (uint32_t)D4,                \
-                 (uint32_t)(R * D4), kt_.kchunk, kt_.KB, kt_.n_ptiles, kt_.total, sk, sr, ls, rng_used)
+                 (uint32_t)(R * D4), kt_.kchunk, kt_.KB, kt_.n_ptiles, kt_.total, sk, sr, ls, rng_used,    \
+                 (float4*)nullptr, false)
       if (nt) { if (lp) ZS_LAUNCH_TILE(true, true); else ZS_LAUNCH_TILE(false, true); }
       else    { if (lp) ZS_LAUNCH_TILE(true, false); else ZS_LAUNCH_TILE(false, false); }
 #undef ZS_LAUNCH_TILE
@@ -888,21 +806,7 @@ extern "C" int zs_normal_logprob_f32(const float* x, int64_t Px, const float* mu
     const int64_t tiles = (rows + rm.rpw - 1) / rm.rpw;
     const bool simple = (Px == N || Px == 1) && (Pm == N || Pm == 1) && (Ps == N || Ps == 1);
     if (K > 1 && D4 <= 64 && Px == N && Pm == R * D && Ps == R * D) {
-      const int64_t row_tiles = (R + rm.rpw - 1) / rm.rpw;
-      // One work item (row tile x chunk of particles) per wave, the grid sized to the items.  When every item fits on the
-      // chip at once (256 CUs x 32 wave slots) the particles are split only as far as needed to give every SIMD two
-      // waves -- one round, long chunks (1 M rows: 74 % with 50-particle chunks, 67 % with 25, 60 % with 5: every item pays
-      // the parameter loads and eight logarithms / exponentials); with more row tiles than slots, four items per tile so
-      // that the dispatcher can even out the rounds (4.2 M rows: 57 -> 60-62 %).
-      const int64_t slots = 256 * 32;
-      int64_t kt = row_tiles > slots ? 4 : (row_tiles >= 2048 ? 1 : slots / row_tiles);   // >= 2 waves per SIMD: do not split
-      if (kt < 1) kt = 1;
-      if (kt > K) kt = K;
-      int64_t kchunk = (K + kt - 1) / kt;
-      if (kchunk < 4) kchunk = K < 4 ? K : 4;
-      const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
-      ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_krep, dim3(grid_for(total, 4, 1u << 22)), dim3(256), st, (const float4*)x,
-                (const float4*)mu, (const float4*)sigma, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr, ls);
+      launch_logprob_krep<D_NORMAL>(KID_NORMAL_LOGPROB, x, mu, sigma, lp, K, R, D4, sk, sr, ls, st);
     } else if (simple) {
       ZS_LAUNCH(KID_NORMAL_LOGPROB, k_normal_logprob_full, dim3(grid_for(tiles, 4)), dim3(256), st, (const float4*)x,
                 (int)(Px == 1 && N != 1), (const float4*)mu, (int)(Pm == 1 && N != 1), (const float4*)sigma,

@@ -11,7 +11,7 @@
 
 namespace zs {
 
-enum { D_NORMAL = 0, D_LOGISTIC = 1 };
+enum { D_NORMAL = 0, D_LOGISTIC = 1, D_UNIFORM = 2 };
 typedef float zs_f4v __attribute__((ext_vector_type(4)));
 
 // round-to-nearest mul / add that the compiler may not contract into an FMA: the sample
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
     const float4* __restrict__ mu, const float4* __restrict__ sigma,
     uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float4* __restrict__ z, float* __restrict__ lp,
     uint32_t K, int64_t R, uint32_t D4, uint32_t M4, uint32_t kchunk, uint32_t KB, uint32_t n_ptiles, uint32_t total,
-    int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used) {
+    int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used, float4* __restrict__ z2, bool raw_draw) {
   extern __shared__ float zs_k1_stage[];
   if (rs) { seed = rs[0]; call += rs[1]; }
   publish_rng(rng_used, seed, call);
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
       m = mu[m4];
       s = sigma_of(sigma[m4], ls);
     }
+    if (DIST == D_UNIFORM) { s.x -= m.x; s.y -= m.y; s.z -= m.z; s.w -= m.w; }   // (low, high) -> (low, width)
     // per-lane constants, reused for every particle of the chunk:
     // Normal:   rowc = sum_j (c - log sigma_j)  (normal.py:121-124),  hp_j = 0.5 * exp(-2 log sigma_j)
     // Logistic: rowc = -sum_j log scale_j       (logistic.py:81-82)
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
       const float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (DIST == D_UNIFORM) continue;                 // U1 has no density output
         const float l2 = log2_fast(sv[j]);
         if (DIST == D_NORMAL) {
           rowc += ZS_NEG_HALF_LOG_2PI - l2 * ZS_LN2;
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
         // uniform base pointer per particle (scalar registers) + this lane's 32-bit byte offset: the stores need no
         // per-lane 64-bit address arithmetic (M4 < 2^28 is guaranteed by the host)
         char* __restrict__ zk = reinterpret_cast<char*>(z + base);
+        char* __restrict__ zk2 = reinterpret_cast<char*>(z2 + base);   // second output (Uniform: the cached draw)
         const uint32_t lane_off = m4 * 16u;
         const uint64_t step = (uint64_t)M4 * 16u;
         uint64_t g = base + m4;                                        // Philox group of (particle kb0, this lane)
@@ -135,12 +138,36 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
           }
           zk += step;
         };
+        // Uniform (uniform.py:63-70): cached value c = u (reparameterised) or low + u * width, sample = low + c * width
+        auto particle_uniform = [&](const float4& u) {
+          float4 c = u;
+          if (!raw_draw) {
+            c.x = mul_add_2round(m.x, u.x, s.x);
+            c.y = mul_add_2round(m.y, u.y, s.y);
+            c.z = mul_add_2round(m.z, u.z, s.z);
+            c.w = mul_add_2round(m.w, u.w, s.w);
+          }
+          const zs_f4v o = {mul_add_2round(m.x, c.x, s.x), mul_add_2round(m.y, c.y, s.y), mul_add_2round(m.z, c.z, s.z),
+                            mul_add_2round(m.w, c.w, s.w)};
+          const zs_f4v cv = {c.x, c.y, c.z, c.w};
+          if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(lane_off), "v"(o), "s"(zk) : "memory");
+          else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(lane_off), "v"(o), "s"(zk) : "memory");
+          if (z2) {
+            if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(lane_off), "v"(cv), "s"(zk2) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(lane_off), "v"(cv), "s"(zk2) : "memory");
+          }
+          zk += step;
+          zk2 += step;
+        };
         for (uint32_t kk = 0; kk < kb; ++kk) {
 #if ZS_K1_EXPERIMENT == 2      // timing experiment: no generator (store + density only)
           particle(make_float4((float)(uint32_t)g, 1.f, 2.f, 3.f), 0.f);
 #else
           if (DIST == D_NORMAL) {
             particle(philox_normal4(g, call, seed), 0.f);
+          } else if (DIST == D_UNIFORM) {
+            const Philox4 r = philox4x32_10(g, call, seed);
+            particle_uniform(make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w)));
           } else {
             // Logistic draw (logistic.py:64-66): eps = log u - log(1 - u); its own log-density -eps - 2 softplus(-eps)
             // is log u + log(1 - u): the two logarithms serve both
@@ -228,5 +255,143 @@ inline K1Tile k1_tile(int64_t K, int64_t R, int D4, bool want_lp) {   // (K1Tile
   return g;
 }
 
+// ------------------------------------------------------------------------------------
+// Log-density of GIVEN values, parameters [R, D] repeated over the K particles (IWAE prior / q of a given sample,
+// normal.py:112-116; logistic.py:81-82) and D4 <= 64: a wave owns `rpw` parameter rows, forms the per-lane constants
+// once (Normal: log sigma and 0.5 sigma^-2; Logistic: 1/scale and log scale) and streams the K value rows past them,
+// two rows in flight; no per-element index arithmetic.  DIST = D_NORMAL: K2, D_LOGISTIC: L2.
+// ------------------------------------------------------------------------------------
+struct RowMap {
+  int G;      // lanes per row
+  int rpw;    // rows per wave pass
+  int p2;     // next pow2 >= G
+};
+inline RowMap row_map(int64_t D4) {
+  RowMap m;
+  m.G = D4 >= 64 ? 64 : (int)D4;
+  m.rpw = 64 / m.G;
+  m.p2 = next_pow2(m.G);
+  return m;
+}
+
+// sum over the four elements of a lane of the value-dependent part of the (negated) log-density; c[j] per-lane constants
+// (Normal: 0.5 sigma^-2; Logistic: 1/scale; Uniform: the upper bound, `m` the lower)
+template <int DIST>
+__device__ __forceinline__ float krep_terms(const float4 xv, const float4 m, const float c[4]) {
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ms[4] = {m.x, m.y, m.z, m.w};
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float d = xs[j] - ms[j];
+    if (DIST == D_NORMAL) {
+      acc += c[j] * (d * d);                             // 0.5 (x - mu)^2 / sigma^2
+    } else if (DIST == D_LOGISTIC) {
+      // t + 2 softplus(-t) = |t| + 2 log1p(exp(-|t|))   (logistic.py:81-82; even in t)
+      const float at = __builtin_fabsf(d * c[j]);
+      const float e = exp2_fast(at * -1.44269504088896341f);
+      acc += at + 2.0f * ZS_LN2 * log2_fast(1.0f + e);
+    } else {
+      const bool inside = (ms[j] <= xs[j]) && (c[j] > xs[j]);   // torch Uniform.log_prob: lb * ub (uniform.py:78-81)
+      acc += inside ? 0.f : INFINITY;
+    }
+  }
+  return acc;
+}
+
+template <int DIST>
+__global__ __launch_bounds__(256) void k_logprob_krep(
+    const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
+    float* __restrict__ lp, int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t kchunk,
+    int64_t sk, int64_t sr, bool ls) {
+  const int lane = threadIdx.x & 63;
+  const int rw = lane / G, lig = lane - rw * G;
+  const bool lane_on = rw < rpw;
+  const int64_t M4 = R * (int64_t)D4;
+  const int64_t row_tiles = (R + rpw - 1) / rpw;
+  const int64_t k_tiles = (K + kchunk - 1) / kchunk;
+  const int64_t total = row_tiles * k_tiles;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < total; t += nwaves) {
+    int64_t kt, rt;
+    divmod(t, row_tiles, kt, rt);
+    const int64_t r = rt * rpw + rw;
+    const bool on = lane_on && r < R;
+    const int64_t m4 = r * D4 + lig;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (on) {
+      m = mu[m4];
+      s = sigma_of(sigma[m4], ls);
+    }
+    float rowc = 0.f, c[4];
+    {
+      const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (DIST == D_UNIFORM) {
+          const float mv = j == 0 ? m.x : (j == 1 ? m.y : (j == 2 ? m.z : m.w));
+          rowc -= logf(sv[j] - mv);                      // -log(high - low), once per item: precise
+          c[j] = sv[j];
+          continue;
+        }
+        const float l2 = log2_fast(sv[j]);
+        if (DIST == D_NORMAL) {
+          rowc += ZS_NEG_HALF_LOG_2PI - l2 * ZS_LN2;
+          c[j] = 0.5f * exp2_fast(-2.0f * l2);
+        } else {
+          rowc -= l2 * ZS_LN2;
+          c[j] = 1.0f / sv[j];
+        }
+      }
+    }
+    const int64_t k0 = kt * kchunk;
+    const int64_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
+    int64_t g = k0 * M4 + m4;
+    float* __restrict__ lpp = lp + (k0 * sk + r * sr);
+    int64_t k = k0;
+    for (; k + 1 < k1; k += 2, g += 2 * M4, lpp += 2 * sk) {   // two value rows in flight
+      float4 xa = m, xb = m;
+      if (on) {
+        xa = x[g];
+        xb = x[g + M4];
+      }
+      float acca = rowc - krep_terms<DIST>(xa, m, c);
+      float accb = rowc - krep_terms<DIST>(xb, m, c);
+      acca = group_sum_down(acca, lig, G, p2);
+      accb = group_sum_down(accb, lig, G, p2);
+      if (on && lig == 0) {
+        lpp[0] = acca;
+        lpp[sk] = accb;
+      }
+    }
+    for (; k < k1; ++k, g += M4, lpp += sk) {
+      float4 xa = m;
+      if (on) xa = x[g];
+      float acca = rowc - krep_terms<DIST>(xa, m, c);
+      acca = group_sum_down(acca, lig, G, p2);
+      if (on && lig == 0) lpp[0] = acca;
+    }
+  }
+}
+
+template <int DIST>
+inline void launch_logprob_krep(int kid, const float* x, const float* mu, const float* sigma, float* lp, int64_t K, int64_t R,
+                                int D4, int64_t sk, int64_t sr, bool ls, hipStream_t st) {
+  const RowMap rm = row_map(D4);
+  const int64_t row_tiles = (R + rm.rpw - 1) / rm.rpw;
+  // One work item (row tile x chunk of particles) per wave, the grid sized to the items.  When every item fits on the
+  // chip at once (256 CUs x 32 wave slots) the particles are split only as far as needed to give every SIMD two
+  // waves -- one round, long chunks (1 M rows: 74 % with 50-particle chunks, 67 % with 25, 60 % with 5: every item pays
+  // the parameter loads and eight logarithms / exponentials); with more row tiles than slots, four items per tile so
+  // that the dispatcher can even out the rounds (4.2 M rows: 57 -> 60-62 %).
+  const int64_t slots = 256 * 32;
+  int64_t kt = row_tiles > slots ? 4 : (row_tiles >= 2048 ? 1 : slots / row_tiles);   // >= 2 waves per SIMD: do not split
+  if (kt < 1) kt = 1;
+  if (kt > K) kt = K;
+  int64_t kchunk = (K + kt - 1) / kt;
+  if (kchunk < 4) kchunk = K < 4 ? K : 4;
+  const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
+  ZS_LAUNCH(kid, (k_logprob_krep<DIST>), dim3(grid_for(total, 4, 1u << 22)), dim3(256), st, (const float4*)x,
+            (const float4*)mu, (const float4*)sigma, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr, ls);
+}
 
 }  // namespace zs
