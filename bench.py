@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave PyTorch's default GEMM solution selection for the callers' fp32 nn.Linear stack (default: PyTorch "
                          "TunableOp picks the fastest fp32 hipBLASLt / rocBLAS solution per GEMM shape during warm-up)")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="update with torch.optim.Adam(fused=True, capturable=True) instead of zhusuan.optim.FlatAdam "
+                         "(the same update over flat buckets, one launch)")
     return ap.parse_args(argv)
 
 
@@ -298,13 +301,23 @@ def timed_trials(step, steps, world, dev, min_seconds=MIN_TIMED_SECONDS, max_tri
     return trials, last
 
 
-def run_single_gpu_config(name, dev, steps, warmup, tuned=True):
+def make_optimizer(model, torch_adam, groups=None):
+    """Adam, lr 1e-3 (the reference callers' optimizer, iwae.py:141): zhusuan.optim.FlatAdam -- the same update over flat
+    buckets, one launch per bucket -- or torch.optim.Adam(fused, capturable) with --torch-adam.  `groups`: parameter
+    lists that should be one bucket each (the stages of dataparallel.StagedBuckets)."""
+    if torch_adam:
+        return torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
+    import zhusuan
+    return zhusuan.optim.FlatAdam(groups if groups is not None else model.parameters(), lr=1e-3)
+
+
+def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False):
     """A BASELINE config other than the headline one on this GPU: full training steps replayed from one hipGraph."""
     import zhusuan
     gemm_tuning(tuned)
     torch.manual_seed(0)
     model, obs, evals, label = make_workload(name, dev)
-    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
+    opt = make_optimizer(model, torch_adam)
     rng = zhusuan.DeviceRNG(dev, seed=1)
 
     def compute():
@@ -324,7 +337,8 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True):
     assert np.isfinite(float(last))
     return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
             "launch_mode": "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
-            "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape)" if tuned else "PyTorch default"}
+            "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape)" if tuned else "PyTorch default",
+            "optimizer": "torch.optim.Adam(fused=True, capturable=True)" if torch_adam else "zhusuan.optim.FlatAdam"}
 
 
 def hbm_resident_kernels(klib, dev, launches=30):
@@ -458,7 +472,6 @@ def main():
     torch.manual_seed(0)
     model, obs, evals_per_step, _ = make_workload("c3", dev, seed_rank=rank, fused_logits=args.fused_logits)
     dataparallel.broadcast_parameters(model)
-    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
     rng = zhusuan.DeviceRNG(dev, seed=1000 + rank)          # per-rank Philox stream, state in device memory
 
     multi = world > 1 or args.force_collective_path
@@ -468,6 +481,9 @@ def main():
     obuckets = dataparallel.OverlappedBuckets(model, n_buckets=2) if hooks else None
     # backward reaches the decoder's (generator's) parameters first, then the encoder's: two stages, two buckets
     sbuckets = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()]) if staged else None
+    # one optimizer bucket per gradient bucket: the update reads the averaged gradients where the collective left them
+    opt = make_optimizer(model, args.torch_adam,
+                         groups=[list(model.generator.parameters()), list(model.variational.parameters())] if staged else None)
     held = {}
 
     def compute_part():
@@ -676,6 +692,9 @@ def main():
                        "mlp_gemm_selection": ("PyTorch TunableOp: fastest fp32 hipBLASLt / rocBLAS solution per GEMM shape, picked during "
                                               "warm-up (callers' nn.Linear stack, outside the hot path; extra_configs.c3_default_gemm "
                                               "is the same step with PyTorch's default selection)") if tuned else "PyTorch default",
+                       "optimizer": "torch.optim.Adam(lr=1e-3, fused=True, capturable=True)" if args.torch_adam else
+                                    "zhusuan.optim.FlatAdam(lr=1e-3): torch.optim.Adam's update over flat buckets, one launch per "
+                                    "bucket (extra_configs.c3_torch_adam: the same step with torch's multi-tensor Adam)",
                        "launch_mode": mode,
                        "timing": "median of %d trials of %d steps, each bracketed by synchronize + barrier, max over ranks"
                                  % (len(trials), args.steps)},
@@ -709,14 +728,22 @@ def main():
             out["extra_configs"] = {}
             for name in ("c2", "c5", "c3_logits"):
                 try:
-                    out["extra_configs"][name] = run_single_gpu_config(name, dev, args.steps, args.warmup, tuned=tuned)
+                    out["extra_configs"][name] = run_single_gpu_config(name, dev, args.steps, args.warmup, tuned=tuned,
+                                                                       torch_adam=args.torch_adam)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"][name] = {"error": repr(e)}
             if tuned:       # the headline step once more with PyTorch's default GEMM selection (what round 1 measured)
                 try:
-                    out["extra_configs"]["c3_default_gemm"] = run_single_gpu_config("c3", dev, args.steps, args.warmup, tuned=False)
+                    out["extra_configs"]["c3_default_gemm"] = run_single_gpu_config("c3", dev, args.steps, args.warmup, tuned=False,
+                                                                                    torch_adam=True)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"]["c3_default_gemm"] = {"error": repr(e)}
+            if not args.torch_adam:     # the headline step with torch's multi-tensor Adam
+                try:
+                    out["extra_configs"]["c3_torch_adam"] = run_single_gpu_config("c3", dev, args.steps, args.warmup, tuned=tuned,
+                                                                                  torch_adam=True)
+                except Exception as e:                              # noqa: BLE001
+                    out["extra_configs"]["c3_torch_adam"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline("c3")
             if extras:

@@ -47,8 +47,9 @@ ORACLE_SO = os.environ.get("ZS_ORACLE_LIBRARY") or os.path.join(ROOT, "oracle", 
 def build_oracle_lib():
     if os.environ.get("ZS_ORACLE_LIBRARY"):
         return ORACLE_SO
-    src = os.path.join(ROOT, "oracle", "zs_oracle_c.c")
-    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("zs_oracle_c.c", "zs_oracle_impl.inc")] + \
+           [os.path.join(ROOT, "include", "zs_hip.h")]
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return ORACLE_SO
 

@@ -72,6 +72,16 @@ def test_bench_line_single_rank():
         cb = rec["extra_configs"][name]["cpu_baseline"]
         assert cb["value"] > 0 and cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0
     assert cpu["one_thread"]["cores"] == 1 and cpu["one_thread"]["value"] > 0
+    # the update: one launch over the flat bucket by default, torch's multi-tensor Adam beside it
+    assert "FlatAdam" in rec["config"]["optimizer"] and "torch.optim.Adam" in rec["extra_configs"]["c3_torch_adam"]["optimizer"]
+    assert rec["extra_configs"]["c3_torch_adam"]["value"] > 1e5
+    assert abs(rec["extra_configs"]["c3_torch_adam"]["final_loss"] - rec["final_loss"]) < 0.05 * abs(rec["final_loss"])
+
+
+@pytest.mark.gpu
+def test_bench_line_with_torch_adam():
+    rec = _run_bench("--no-cpu-baseline", "--no-extras", "--torch-adam")
+    assert rec["value"] > 1e5 and rec["config"]["optimizer"].startswith("torch.optim.Adam")
 
 
 @pytest.mark.gpu

@@ -27,14 +27,14 @@ def declared_symbols():
 
 def test_header_symbols_exported_by_both_libraries():
     names = declared_symbols()
-    assert len(names) == 52 and set(_hip.PROTOTYPES) <= set(names)
+    assert len(names) == 54 and set(_hip.PROTOTYPES) <= set(names)
     hip = ctypes.CDLL(_hip.LIB_PATH)           # loads without a GPU; no compute call is made here
     orc = ctypes.CDLL(build_oracle_lib())
     for n in names:
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 8
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 9
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 
@@ -742,3 +742,93 @@ def test_hip_scalar_objective(hip, orc, hip64, orc64):
         a64, _ = _scalar_objective(hip64, vecs, coefs)
         exact64 = sum(c * v.sum() for c, v in zip(coefs, vecs))
         assert abs(a64 - exact64) <= 1e-12 * max(1.0, abs(exact64))
+
+
+# ------------------------------------------------------------------ A1: Adam update of up to 32 tensors, one launch
+def _adam_run(raw, sizes, steps, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, gs=1.0, missing=(), misalign=False, seed=0):
+    """`steps` launches over tensors of `sizes` elements (`missing`: tensors without a gradient; `misalign`: every tensor
+    4 bytes off a 16-byte boundary).  Returns (params concatenated, exp_avg, exp_avg_sq)."""
+    rng = np.random.RandomState(seed + int(sum(sizes)))
+    n = int(sum(sizes))
+    starts = (ctypes.c_int64 * (len(sizes) + 1))(*[int(x) for x in np.concatenate([[0], np.cumsum(sizes)])])
+
+    def tensor(a):
+        return raw.t(np.concatenate([[0.0], a]))[1:] if misalign else raw.t(a)
+    ps = [tensor(rng.standard_normal(k)) for k in sizes]
+    m, v = raw.t(np.zeros(n)), raw.t(np.zeros(n))
+    step = torch.zeros(1, dtype=torch.int64, device=raw.dev)
+    ticket = torch.zeros(1, dtype=torch.int32, device=raw.dev)
+    pptr = (ctypes.c_void_p * len(sizes))(*[p.data_ptr() for p in ps])
+    for s in range(steps):
+        scale = 10.0 ** rng.uniform(-4, 1)
+        gs_ = [tensor(rng.standard_normal(k) * scale) for k in sizes]
+        gptr = (ctypes.c_void_p * len(sizes))(*[None if i in missing else g.data_ptr() for i, g in enumerate(gs_)])
+        raw.call("zs_adam_step_f32", pptr, gptr, starts, len(sizes), m, v, step, ticket, n, lr, b1, b2, eps, gs)
+    assert int(step.item()) == steps and int(ticket.item()) == 0
+    return torch.cat(ps).cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()
+
+
+def test_c_oracle_adam_is_torch_adam(orc, orc64):
+    """The oracle's A1 against torch.optim.Adam itself (defaults; the callers' optimizer: vae_mnist.py:104, iwae.py:141,
+    bnn_vi.py:135), same gradients, 7 steps, three tensors of which one never receives a gradient."""
+    for raw, dt, tol in ((orc, torch.float32, 3e-6), (orc64, torch.float64, 1e-13)):
+        rng = np.random.RandomState(3)
+        sizes = [1001, 40, 7]
+        ws = [torch.nn.Parameter(torch.tensor(rng.standard_normal(k), dtype=dt)) for k in sizes]
+        opt = torch.optim.Adam(ws, lr=2e-3)
+        ps = [raw.t(w.detach().numpy().copy()) for w in ws]
+        n = sum(sizes)
+        m, v = raw.t(np.zeros(n)), raw.t(np.zeros(n))
+        step, ticket = torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int32)
+        starts = (ctypes.c_int64 * 4)(0, 1001, 1041, 1048)
+        pptr = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in ps])
+        for s in range(7):
+            gs = [rng.standard_normal(k) * (10.0 ** rng.uniform(-4, 1)) for k in sizes]
+            for w, g in zip(ws[:2], gs[:2]):
+                w.grad = torch.tensor(g, dtype=dt)
+            opt.step()
+            gt = [raw.t(g) for g in gs]
+            gptr = (ctypes.c_void_p * 3)(gt[0].data_ptr(), gt[1].data_ptr(), None)
+            raw.call("zs_adam_step_f32", pptr, gptr, starts, 3, m, v, step, ticket, n, 2e-3, 0.9, 0.999, 1e-8, 1.0)
+            for p, w in zip(ps, ws):
+                np.testing.assert_allclose(p.numpy(), w.detach().numpy(), rtol=tol, atol=tol * 1e-2)
+        assert int(step.item()) == 7
+    p = orc.t(np.zeros(8))
+    one = (ctypes.c_void_p * 1)(p.data_ptr())
+    two = (ctypes.c_void_p * 2)(p.data_ptr(), p.data_ptr())
+    ok = (ctypes.c_int64 * 2)(0, 8)
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.call("zs_adam_step_f32", one, one, ok, 1, p, p, step, ticket, 8, 1e-3, 1.0, 0.999, 1e-8, 1.0)      # beta1 = 1
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.call("zs_adam_step_f32", one, one, ok, 1, p, p, None, ticket, 8, 1e-3, 0.9, 0.999, 1e-8, 1.0)     # no step counter
+    with pytest.raises(RuntimeError, match="code -1"):                                                          # does not end at n
+        orc.call("zs_adam_step_f32", two, two, (ctypes.c_int64 * 3)(0, 4, 7), 2, p, p, step, ticket, 8, 1e-3, 0.9, 0.999, 1e-8, 1.0)
+    many = (ctypes.c_void_p * 33)(*([p.data_ptr()] * 33))
+    with pytest.raises(RuntimeError, match="code -2"):                     # more than ZS_ADAM_MAX_TENSORS
+        orc.call("zs_adam_step_f32", many, many, (ctypes.c_int64 * 34)(*range(34)), 33, orc.t(np.zeros(33)), orc.t(np.zeros(33)),
+                 step, ticket, 33, 1e-3, 0.9, 0.999, 1e-8, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,missing,misalign", [
+    ([1], (), False), ([3], (), False), ([4], (), False), ([1000], (), False), ([4099], (), False), ([4096], (), True),
+    ([1 << 20], (), False), ([1346864], (), False),                                   # the VAE / IWAE parameter count, flat
+    ([392000, 500, 250000, 500, 20000, 40, 20000, 40, 20000, 500, 250000, 500, 392000, 784], (), False),   # ... as its tensors
+    ([700, 700, 51, 51, 1], (), False),                                               # the BNN's
+    ([12, 500, 3, 40], (2,), False), ([400, 4096, 64], (0,), True), (list(range(1, 33)), (5, 31), False)])
+def test_hip_adam(hip, orc, sizes, missing, misalign):
+    """HIP A1 against the C oracle: 16-byte and element-wise paths, tensors that straddle thread groups, missing gradients,
+    the step counter and the ticket after several launches (the last workgroup publishes the count)."""
+    for gs in (1.0, 0.125):
+        a = _adam_run(hip, sizes, 4, gs=gs, missing=missing, misalign=misalign)
+        b = _adam_run(orc, sizes, 4, gs=gs, missing=missing, misalign=misalign)
+        for x, y, name in zip(a, b, ("param", "exp_avg", "exp_avg_sq")):
+            # (the first moment is a sum of gradients of either sign: absolute tolerance at the tensor's scale)
+            np.testing.assert_allclose(x, y, rtol=2e-6, atol=3e-7 * np.abs(y).max(), err_msg=name)
+
+
+@pytest.mark.gpu
+def test_hip_adam_f64(hip64, orc64):
+    a, b = _adam_run(hip64, [777, 12, 5], 4), _adam_run(orc64, [777, 12, 5], 4)
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x, y, rtol=1e-13, atol=1e-15 * np.abs(y).max())

@@ -111,6 +111,20 @@ def main():
         cp, cq = torch.empty(B, K, device=dev), torch.empty(B, K, device=dev)
         timed("K4 iw reduce (vimco)", "zs_iw_reduce_f32", 16 * N + 8 * B,
               lambda: lib.call("zs_iw_reduce_f32", P(logp), K, P(logq), K, B, K, 1, P(cost), P(bound), P(cp), P(cq), st), tag)
+        # ---------------- A1: Adam (first size: the parameter tensors of the VAE / IWAE models; then one flat tensor)
+        sizes = [392000, 500, 250000, 500, 20000, 40, 20000, 40, 20000, 500, 250000, 500, 392000, 784] if N == 12800 else [N * D]
+        n_par = sum(sizes)
+        a_p, a_g = [torch.randn(k, device=dev) for k in sizes], [torch.randn(k, device=dev) for k in sizes]
+        a_m, a_v = torch.zeros(n_par, device=dev), torch.zeros(n_par, device=dev)
+        a_step = torch.zeros(1, dtype=torch.int64, device=dev)
+        a_ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        a_pp = (ctypes.c_void_p * len(sizes))(*[t.data_ptr() for t in a_p])
+        a_gp = (ctypes.c_void_p * len(sizes))(*[t.data_ptr() for t in a_g])
+        a_st = (ctypes.c_int64 * (len(sizes) + 1))(*([sum(sizes[:i]) for i in range(len(sizes))] + [n_par]))
+        timed("A1 adam step", "zs_adam_step_f32", 28 * n_par,
+              lambda: lib.call("zs_adam_step_f32", a_pp, a_gp, a_st, len(sizes), P(a_m), P(a_v), P(a_step), P(a_ticket), n_par, 1e-3,
+                               0.9, 0.999, 1e-8, 1.0, st), "n=%d in %d tensors" % (n_par, len(sizes)))
+        del a_p, a_g, a_m, a_v
         # ---------------- K3: X = 784 (--x-dim: experiments on the row length)
         X = args.x_dim
         if N * X * 4 * 2 > 200e9:

@@ -1,0 +1,177 @@
+// A1: Adam update of up to 32 parameter tensors in one launch (include/zs_hip.h).
+//
+// The callers' optimizer is torch.optim.Adam(model.parameters(), lr) with its defaults (reference examples
+// variational_autoencoder/vae_mnist.py:104, iwae.py:141, bayesian_neural_nets/bnn_vi.py:135).  PyTorch's fused
+// multi-tensor Adam splits the tensors into 64 K-element chunks, one workgroup each: the 1.35 M parameters of the VAE / IWAE
+// models are 21 workgroups on a 256-CU chip (43 us per step).  Here the tensors form ONE flat index space
+// [starts[s], starts[s+1]) -- parameters and gradients are read where they live through a pointer table passed by value
+// (the gradients of a data-parallel bucket are consecutive slices of one buffer, zhusuan/dataparallel.py; a single
+// process's are one tensor per parameter), both moments are flat --, a thread owns four consecutive elements and finds
+// their tensor by bisection, and the 1/world factor of the gradient mean is folded into the read.  HBM-bound: 28 bytes per
+// parameter.
+//
+// The step count is device state (the call is hipGraph-capturable): every workgroup reads it first; the last workgroup
+// to finish -- found with a ticket, as in zs_iw.hip -- writes the incremented value back, so no workgroup can see the
+// new count early.
+#include <stdlib.h>
+#include "zs_common.h"
+#include "../../include/zs_hip.h"
+
+using namespace zs;
+
+namespace {
+
+template <typename T>
+struct alignas(16) Vec4 { T v[4]; };
+
+template <typename T>
+struct Tensors {
+  T* param[ZS_ADAM_MAX_TENSORS];
+  const T* grad[ZS_ADAM_MAX_TENSORS];          // NULL: no gradient this step (read as zero)
+  int64_t start[ZS_ADAM_MAX_TENSORS + 1];      // start[n_tensors] = n
+  int n_tensors;
+};
+template <typename T>
+__device__ __forceinline__ int tensor_of(const Tensors<T>& ts, int64_t i) {
+  int lo = 0, hi = ts.n_tensors - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (ts.start[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __restrict__ m, T* __restrict__ v,
+                                                    int64_t* __restrict__ step, unsigned* __restrict__ ticket, int64_t n, double lr,
+                                                    double beta1, double beta2, double eps, double grad_scale) {
+  // bias corrections, once per workgroup, the two powers on two waves; beta^t by squaring (<= 62 double multiplies)
+  __shared__ T consts[2];   // lr / bc1, 1 / sqrt(bc2)
+  if (threadIdx.x == 0 || threadIdx.x == 64) {
+    int64_t t = step[0] + 1;
+    double b = threadIdx.x == 0 ? beta1 : beta2, pw = 1.0;
+    for (; t > 0; t >>= 1, b *= b)
+      if (t & 1) pw *= b;
+    if (threadIdx.x == 0) consts[0] = (T)(lr / (1.0 - pw));
+    else consts[1] = (T)(1.0 / sqrt(1.0 - pw));
+  }
+  __syncthreads();
+  const T step_size = consts[0], inv_sqrt_bc2 = consts[1];
+  const T b1w = (T)(1.0 - beta1), b2 = (T)beta2, b2w = (T)(1.0 - beta2), e = (T)eps, gs = (T)grad_scale;
+  const int64_t groups = (n + 3) >> 2;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = g << 2;
+    const int cnt = n - i0 < 4 ? (int)(n - i0) : 4;
+    T pp[4], gg[4], mm[4], vv[4];
+    T* pdst[4];
+    if (VEC) {
+      // every tensor starts at a multiple of 4 and is 16-byte aligned (checked on the host): one tensor per group
+      const int s = tensor_of(ts, i0);
+      const int64_t off = i0 - ts.start[s];
+      pdst[0] = ts.param[s] + off;
+      const Vec4<T> a = *reinterpret_cast<const Vec4<T>*>(pdst[0]), c = *reinterpret_cast<const Vec4<T>*>(m + i0),
+                    d = *reinterpret_cast<const Vec4<T>*>(v + i0);
+      Vec4<T> b = {{(T)0, (T)0, (T)0, (T)0}};
+      if (ts.grad[s]) b = *reinterpret_cast<const Vec4<T>*>(ts.grad[s] + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { pp[j] = a.v[j]; gg[j] = b.v[j]; mm[j] = c.v[j]; vv[j] = d.v[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t i = i0 + (j < cnt ? j : 0);   // clamped: unconditional loads
+        const int s = tensor_of(ts, i);
+        const int64_t off = i - ts.start[s];
+        pdst[j] = ts.param[s] + off;
+        pp[j] = *pdst[j]; mm[j] = m[i]; vv[j] = v[i];
+        gg[j] = ts.grad[s] ? ts.grad[s][off] : (T)0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const T gr = gs * gg[j];
+      mm[j] = mm[j] + b1w * (gr - mm[j]);                      // exp_avg.lerp_(grad, 1 - beta1)
+      vv[j] = b2 * vv[j] + b2w * (gr * gr);                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const T denom = sqrt(vv[j]) * inv_sqrt_bc2 + e;          // sqrt(v) / sqrt(bc2) + eps
+      pp[j] = pp[j] - step_size * (mm[j] / denom);             // param.addcdiv_(exp_avg, denom, -lr / bc1)
+    }
+    if (VEC) {
+      Vec4<T> a, c, d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a.v[j] = pp[j]; c.v[j] = mm[j]; d.v[j] = vv[j]; }
+      *reinterpret_cast<Vec4<T>*>(pdst[0]) = a;
+      *reinterpret_cast<Vec4<T>*>(m + i0) = c;
+      *reinterpret_cast<Vec4<T>*>(v + i0) = d;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < cnt) { *pdst[j] = pp[j]; m[i0 + j] = mm[j]; v[i0 + j] = vv[j]; }
+    }
+  }
+  // Every workgroup has read step[0] -- the value has come back and gone into `consts` -- before it takes its ticket, and
+  // the last one to take a ticket publishes the new count.  Relaxed atomics on purpose: an agent-scope release here is an
+  // L2 write-back per workgroup (the XCDs' L2s are not coherent with each other): 56 instead of 20 us for a 1 315-workgroup
+  // launch over the VAE / IWAE parameters; nothing but the ticket itself is communicated between workgroups.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      step[0] = step[0] + 1;
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <typename T>
+int adam_step(T* const* param_ptrs, const T* const* grad_ptrs, const int64_t* starts, int n_tensors, T* m, T* v, int64_t* step,
+              uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, void* stream) {
+  if (n < 0 || !(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return ZS_EINVAL;
+  if (n_tensors < 1 || !param_ptrs || !grad_ptrs || !starts) return ZS_EINVAL;
+  if (n_tensors > ZS_ADAM_MAX_TENSORS) return ZS_ENOTSUP;
+  if (n == 0) return 0;
+  if (!m || !v || !step || !ticket) return ZS_EINVAL;
+  if (starts[0] != 0 || starts[n_tensors] != n) return ZS_EINVAL;
+  const size_t A = sizeof(T) * 4;
+  bool vec = (n & 3) == 0 && !(((uintptr_t)m | (uintptr_t)v) & (A - 1));
+  Tensors<T> ts;
+  memset(&ts, 0, sizeof(ts));
+  ts.n_tensors = n_tensors;
+  for (int i = 0; i < n_tensors; ++i) {
+    if (starts[i + 1] <= starts[i] || !param_ptrs[i]) return ZS_EINVAL;       // non-empty, ascending
+    ts.param[i] = param_ptrs[i];
+    ts.grad[i] = grad_ptrs[i];
+    ts.start[i] = starts[i];
+    vec = vec && (starts[i] & 3) == 0 && !(((uintptr_t)param_ptrs[i] | (uintptr_t)grad_ptrs[i]) & (A - 1));
+  }
+  ts.start[n_tensors] = n;
+  // few, fat workgroups: every workgroup ends with an atomic on the one ticket word, and same-address atomics retire at
+  // 6-10 ns each.  Measured for the 1.35 M parameters of the VAE / IWAE models (37.7 MB, one flat tensor): 1 315 workgroups
+  // of 256 threads 19.3 us, 512 x 256: 11.1, 512 x 1024: 8.6, 256 x 1024 (one per CU): 7.6-7.9 us = 60 % of the HBM
+  // roofline; 5.2 M parameters: 80 %; 168 M parameters: 1024 x 1024 73 % against 67 % with 256.
+  static const int grid_env = getenv("ZS_ADAM_GRID") ? atoi(getenv("ZS_ADAM_GRID")) : 0;      // experiments only
+  static const int block_env = getenv("ZS_ADAM_BLOCK") ? atoi(getenv("ZS_ADAM_BLOCK")) : 0;
+  const unsigned block = block_env > 0 ? (unsigned)block_env : 1024u;
+  const unsigned grid = grid_for((n + 3) / 4, (int)block, grid_env > 0 ? (unsigned)grid_env : (n > (int64_t(1) << 24) ? 1024u : 256u));
+  if (vec)
+    ZS_LAUNCH(KID_ADAM, (k_adam_step<T, true>), dim3(grid), dim3(block), (hipStream_t)stream, ts, m, v, step, (unsigned*)ticket, n,
+              lr, beta1, beta2, eps, grad_scale);
+  else
+    ZS_LAUNCH(KID_ADAM, (k_adam_step<T, false>), dim3(grid), dim3(block), (hipStream_t)stream, ts, m, v, step, (unsigned*)ticket, n,
+              lr, beta1, beta2, eps, grad_scale);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int zs_adam_step_f32(float* const* param_ptrs, const float* const* grad_ptrs, const int64_t* starts, int n_tensors,
+                                float* exp_avg, float* exp_avg_sq, int64_t* step, uint32_t* ticket, int64_t n, double lr,
+                                double beta1, double beta2, double eps, double grad_scale, void* stream) {
+  return adam_step<float>(param_ptrs, grad_ptrs, starts, n_tensors, exp_avg, exp_avg_sq, step, ticket, n, lr, beta1, beta2, eps,
+                          grad_scale, stream);
+}
+extern "C" int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors,
+                                double* exp_avg, double* exp_avg_sq, int64_t* step, uint32_t* ticket, int64_t n, double lr,
+                                double beta1, double beta2, double eps, double grad_scale, void* stream) {
+  return adam_step<double>(param_ptrs, grad_ptrs, starts, n_tensors, exp_avg, exp_avg_sq, step, ticket, n, lr, beta1, beta2, eps,
+                           grad_scale, stream);
+}

@@ -16,3 +16,4 @@ from . import framework
 from .utils import *
 from ._rng import inject_epsilon, DeviceRNG, device_rng, reference_rng
 from .graph import GraphedStep, GraphedStages
+from . import optim

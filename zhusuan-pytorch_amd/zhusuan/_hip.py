@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments); default: the in-tree library
 LIB_PATH = os.environ.get("ZS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -51,7 +51,11 @@ PROTOTYPES = {
     "zs_iw_objective_f32": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _i64, _p, _p],
     # scalar ELBO epilogue: six (rows, n, coef) slots, out, coef_out, stream
     "zs_scalar_objective_f32": [_p, _i64, ctypes.c_double] * 6 + [_p, _p, _p],
+    # Adam update: param_ptrs, grad_ptrs, starts (host arrays), n_tensors, exp_avg, exp_avg_sq, step, ticket, n, lr, beta1,
+    # beta2, eps, grad_scale, stream
+    "zs_adam_step_f32": [_p, _p, _p, _int, _p, _p, _p, _p, _i64] + [ctypes.c_double] * 5 + [_p],
 }
+ADAM_MAX_TENSORS = 32      # ZS_ADAM_MAX_TENSORS of include/zs_hip.h
 
 
 # every compute entry point exists as name_f32 and name_f64 with the same argument list

@@ -41,6 +41,8 @@ def _optimizer_state_tensors(optimizer):
     out = []
     if optimizer is None:
         return out
+    if hasattr(optimizer, 'state_tensors'):          # zhusuan.optim.FlatAdam: flat moments and device step counts
+        return list(optimizer.state_tensors())
     for group in optimizer.param_groups:
         for p in group['params']:
             st = optimizer.state.get(p, None)
@@ -70,7 +72,7 @@ class GraphedStep(object):
         self._compute, self._opt_step, self._exchange, self._rng = compute, optimizer_step, exchange, rng
         self.graphs = []
         if optimizer is None and optimizer_step is not None and hasattr(optimizer_step, '__self__') and \
-                isinstance(optimizer_step.__self__, torch.optim.Optimizer):
+                hasattr(optimizer_step.__self__, 'param_groups'):
             optimizer = optimizer_step.__self__
         params = list(parameters) if parameters is not None else (
             [p for g in optimizer.param_groups for p in g['params']] if optimizer is not None else [])
