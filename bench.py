@@ -532,8 +532,12 @@ def main():
         sbuckets.backward_stage(held["loss"], 1)
 
     def stage_update():
-        sbuckets.scale()
-        opt.step()
+        if args.torch_adam:
+            sbuckets.scale()
+            opt.step()
+        else:                              # the 1/world rides along in the update's gradient read: no pass over the buckets
+            sbuckets.scale(gradients=False)
+            opt.step(grad_scale=sbuckets.grad_scale())
 
     klib = _hip.lib()
     mode = "eager"

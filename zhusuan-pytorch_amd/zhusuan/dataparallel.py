@@ -217,7 +217,8 @@ class StagedBuckets(object):
         b.launch(0)                                                # 2 (eager)  asynchronous all-reduce of bucket 0
         b.backward_stage(loss, 1)                                  # 3 (graph)  encoder backward, bucket 1 packed
         b.launch(1); b.wait()                                      # 4 (eager)
-        b.scale(); optimizer.step()                                # 5 (graph)  1/world, update
+        b.scale(); optimizer.step()                                # 5 (graph)  1/world, update  (or b.scale(gradients=False);
+                                                                   #            FlatAdam.step(grad_scale=b.grad_scale()): one pass less)
         global_loss = b.loss()
 
     The objective rides in bucket 0 (the first to leave).  Every ``p.grad`` ends up aliasing its slice of a bucket."""
@@ -275,13 +276,26 @@ class StagedBuckets(object):
                 st["handle"].wait()
                 st["handle"] = None
 
-    def scale(self):
+    def scale(self, gradients=True):
+        """1/world.  ``gradients=False``: the optimizer applies the factor itself while it reads the gradients
+        (``zhusuan.optim.FlatAdam.step(grad_scale=buckets.grad_scale())``) -- no pass over the buckets; only the objective's
+        slot is scaled, when ``loss()`` reads it."""
         w = self._world()
+        self._loss_factor = 1.0
         if w > 1:
-            torch._foreach_mul_([st["flat"] for st in self.stages], 1.0 / w)
+            if gradients:
+                torch._foreach_mul_([st["flat"] for st in self.stages], 1.0 / w)
+            else:
+                self._loss_factor = 1.0 / w
+
+    def grad_scale(self):
+        """The factor that turns the all-reduced SUM into the mean (1 with a single rank)."""
+        return 1.0 / self._world()
 
     def loss(self):
-        return self.stages[0]["flat"][self.stages[0]["n"]]
+        v = self.stages[0]["flat"][self.stages[0]["n"]]
+        f = getattr(self, "_loss_factor", 1.0)
+        return v if f == 1.0 else v * f
 
     def nbytes(self):
         return sum(st["flat"].numel() * st["flat"].element_size() for st in self.stages)
