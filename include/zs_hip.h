@@ -254,6 +254,14 @@ int zs_logistic_logprob_bwd_f32(const float* x, int64_t Px, const float* loc, in
                                 float* gx, float* gloc, float* gscale,
                                 int64_t K, int64_t R, int64_t D, void* stream);
 
+/* Backward of L2 reduced over the K axis for parameters of period R*D (loc, scale of shape [R, D] repeated K times: a
+ * Logistic latent under a non-reparameterised / importance-weighted estimator, logistic.py:73-77).  x has full size
+ * [K, R, D].   gloc[r, d] = sum_k ...,  gscale[r, d] = sum_k ...;  gx (full size) optional. */
+int zs_logistic_logprob_bwd_ksum_f32(const float* x, const float* loc, const float* scale,
+                                     const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
+                                     float* gx, float* gloc, float* gscale,
+                                     int64_t K, int64_t R, int64_t D, void* stream);
+
 /* ---------------------------------------------------------------------------
  * U1  Uniform sample (zhusuan/distributions/uniform.py:51-70).  N elements, low / high periodic.
  *   reparam != 0:  cache = u,                       out = u * (high - low) + low      (uniform.py:66-70)
@@ -366,6 +374,7 @@ int zs_logistic_sample_logprob_f64(const double* loc, const double* scale, const
 int zs_logistic_sample_logprob_bwd_f64(const double* scale, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, const double* gz, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gloc, double* gscale, int64_t K, int64_t M, int64_t D, void* stream);
 int zs_logistic_logprob_f64(const double* x, int64_t Px, const double* loc, int64_t Pm, const double* scale, int64_t Ps, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
 int zs_logistic_logprob_bwd_f64(const double* x, int64_t Px, const double* loc, int64_t Pm, const double* scale, int64_t Ps, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gloc, double* gscale, int64_t K, int64_t R, int64_t D, void* stream);
+int zs_logistic_logprob_bwd_ksum_f64(const double* x, const double* loc, const double* scale, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gloc, double* gscale, int64_t K, int64_t R, int64_t D, void* stream);
 int zs_uniform_sample_f64(const double* low, int64_t Pl, const double* high, int64_t Ph, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* out, double* cache, int64_t N, int reparam, void* stream);
 int zs_uniform_logprob_f64(const double* x, int64_t Px, const double* low, int64_t Pl, const double* high, int64_t Ph, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
 int zs_philox_uniform_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);

@@ -138,6 +138,19 @@ class Raw2(Raw):
                   self.t(glp), R, 1, outs[0], outs[1], outs[2], K, R, D)
         return {n: o.cpu().numpy() for n, o in zip(("gx", "gloc", "gscale"), outs) if o is not None}
 
+    def logistic_lp_bwd_ksum(self, x, loc, scale, glp, K, R, D, want_gx=True, kfast=False):
+        """glp [K, R] (or its K-fastest transpose with kfast): strides as the caller's objective leaves them."""
+        gx = self.empty(K * R * D) if want_gx else None
+        gloc, gscale = self.empty(R * D), self.empty(R * D)
+        g = np.ascontiguousarray(glp.reshape(K, R).T) if kfast else glp
+        sk, sr = (1, K) if kfast else (R, 1)
+        self.call("zs_logistic_logprob_bwd_ksum_f32", self.t(x), self.t(loc), self.t(scale), self.t(g), sk, sr, gx, gloc, gscale,
+                  K, R, D)
+        out = dict(gloc=gloc.cpu().numpy(), gscale=gscale.cpu().numpy())
+        if want_gx:
+            out["gx"] = gx.cpu().numpy()
+        return out
+
     def uniform_sample(self, low, high, u, N, reparam, seed=0, off=0, rs=None, want_cache=True):
         out, cache = self.empty(N), self.empty(N)
         self.call("zs_uniform_sample_f32", self.t(low), low.size, self.t(high), high.size, self.t(u), seed, off, rs, out,
@@ -570,3 +583,51 @@ def test_logistic_graph_capture_draws_fresh_numbers():
         torch.cuda.synchronize()
         assert not torch.equal(z1, z) and not torch.equal(g1, scale.grad)
         close(lp, stats.logistic.logpdf(z.detach().cpu().numpy()).sum(-1), 1e-5, 2e-5)
+
+
+# ------------------------------------------------------------------ L2 backward reduced over the K particles
+def _ksum_case(K, R, D, seed=0):
+    rng = np.random.RandomState(seed + K * 100 + R * 10 + D)
+    M = R * D
+    x = (3 * rng.standard_normal(K * M)).astype(np.float32)
+    loc = rng.standard_normal(M).astype(np.float32)
+    sc = np.exp(0.3 * rng.standard_normal(M)).astype(np.float32)
+    glp = rng.standard_normal(K * R).astype(np.float32)
+    return x, loc, sc, glp
+
+
+def test_c_oracle_logistic_bwd_ksum_is_the_folded_elementwise_backward(orc, orc64):
+    """The K-summed backward equals the element-wise partials (pinned above against the reference's autograd) folded over
+    the K repetitions of the parameters; gx is the same tensor."""
+    for raw, tol in ((orc, 2e-6), (orc64, 1e-13)):
+        for (K, R, D) in [(5, 3, 4), (2, 1, 1), (7, 2, 6), (1, 4, 3)]:
+            x, loc, sc, glp = _ksum_case(K, R, D)
+            M = R * D
+            full = raw.logistic_lp_bwd(x, np.tile(loc, K), np.tile(sc, K), glp, K, R, D)
+            for kfast in (False, True):
+                got = raw.logistic_lp_bwd_ksum(x, loc, sc, glp, K, R, D, kfast=kfast)
+                np.testing.assert_allclose(got["gx"], full["gx"], rtol=tol, atol=tol)
+                np.testing.assert_allclose(got["gloc"], full["gloc"].reshape(K, M).sum(0), rtol=10 * tol, atol=10 * tol)
+                np.testing.assert_allclose(got["gscale"], full["gscale"].reshape(K, M).sum(0), rtol=10 * tol, atol=10 * tol)
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.call("zs_logistic_logprob_bwd_ksum_f32", None, orc.t(loc), orc.t(sc), orc.t(glp), 1, 1, None, orc.empty(1), orc.empty(1), 1, 1, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,D", [(50, 256, 40), (5, 3, 4), (2, 1, 1), (7, 2, 6), (3, 5, 2500), (50, 64, 8), (1, 4, 3), (13, 300, 44)])
+def test_hip_logistic_bwd_ksum(hip, orc, K, R, D):
+    x, loc, sc, glp = _ksum_case(K, R, D)
+    for kfast in (False, True):
+        for want_gx in (True, False):
+            a = hip.logistic_lp_bwd_ksum(x, loc, sc, glp, K, R, D, want_gx, kfast)
+            b = orc.logistic_lp_bwd_ksum(x, loc, sc, glp, K, R, D, want_gx, kfast)
+            _cmp(a, b, 2e-4, 2e-5 * np.sqrt(K))
+
+
+@pytest.mark.gpu
+def test_hip_logistic_bwd_ksum_f64(hip64, orc64):
+    for (K, R, D) in [(5, 3, 4), (4, 7, 51)]:
+        x, loc, sc, glp = _ksum_case(K, R, D)
+        a = hip64.logistic_lp_bwd_ksum(x.astype(np.float64), loc.astype(np.float64), sc.astype(np.float64), glp.astype(np.float64), K, R, D)
+        b = orc64.logistic_lp_bwd_ksum(x.astype(np.float64), loc.astype(np.float64), sc.astype(np.float64), glp.astype(np.float64), K, R, D)
+        _cmp(a, b, 1e-11, 1e-12)

@@ -769,6 +769,50 @@ int logistic_logprob_bwd(const T* x, int64_t Px, const T* loc, int64_t Pm, const
   return 0;
 }
 
+// L2 backward reduced over the K particles, parameters [R, D] repeated over them: the float32 form is the kernel shared
+// with Normal (zs_sample_tile.h); float64 (untuned, like every fp64 twin): a thread per parameter element.
+template <typename T>
+__global__ __launch_bounds__(256) void k_logistic_logprob_bwd_ksum_serial(
+    const T* __restrict__ x, const T* __restrict__ loc, const T* __restrict__ scale, const T* __restrict__ glp, int64_t gsk,
+    int64_t gsr, T* __restrict__ gx, T* __restrict__ gloc, T* __restrict__ gscale, int64_t K, int64_t M, int64_t D) {
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = m / D;
+    const T a = loc[m], b = scale[m];
+    T sl = (T)0, ss = (T)0;
+    for (int64_t k = 0; k < K; ++k) {
+      const T g = glp[k * gsk + r * gsr];
+      const T t = (x[k * M + m] - a) / b;
+      const T e = t_exp(-t_abs(t));
+      T h = ((T)1 - e) / ((T)1 + e);            // tanh(|t|/2)
+      h = t < (T)0 ? -h : h;
+      const T gh = g * h / b;
+      sl += gh;
+      ss += g * (h * t - (T)1) / b;
+      if (gx) gx[k * M + m] = -gh;
+    }
+    if (gloc) gloc[m] = sl;
+    if (gscale) gscale[m] = ss;
+  }
+}
+
+template <typename T>
+int logistic_logprob_bwd_ksum(const T* x, const T* loc, const T* scale, const T* glp, int64_t gsk, int64_t gsr, T* gx, T* gloc,
+                              T* gscale, int64_t K, int64_t R, int64_t D, void* stream) {
+  if (K < 1 || R < 0 || D < 1) return ZS_EINVAL;
+  const int64_t M = R * D;
+  if (M == 0) return 0;
+  if (!x || !loc || !scale || !glp) return ZS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if constexpr (std::is_same<T, float>::value) {
+    launch_logprob_bwd_ksum<D_LOGISTIC>(KID_LOGISTIC_LOGPROB_BWD, x, loc, scale, glp, gsk, gsr, gx, gloc, gscale, K, R, D, false, st);
+  } else {
+    ZS_LAUNCH(KID_LOGISTIC_LOGPROB_BWD, (k_logistic_logprob_bwd_ksum_serial<T>), dim3(grid_for(M, 256)), dim3(256), st, x, loc, scale,
+              glp, gsk, gsr, gx, gloc, gscale, K, M, D);
+  }
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T>
 int uniform_sample(const T* low, int64_t Pl, const T* high, int64_t Ph, const T* u, uint64_t seed, uint64_t offset,
                    const uint64_t* rng_state, T* out, T* cache, int64_t N, int reparam, void* stream) {
@@ -866,6 +910,11 @@ int philox_uniform(T* out, int64_t N, uint64_t seed, uint64_t offset, const uint
                                               const T* glp, int64_t gsk, int64_t gsr, T* gx, T* gloc, T* gscale, int64_t K,        \
                                               int64_t R, int64_t D, void* stream) {                                                \
     return logistic_logprob_bwd<T>(x, Px, loc, Pm, scale, Ps, glp, gsk, gsr, gx, gloc, gscale, K, R, D, stream);                   \
+  }                                                                                                                                \
+  extern "C" int zs_logistic_logprob_bwd_ksum##SFX(const T* x, const T* loc, const T* scale, const T* glp, int64_t gsk,             \
+                                                   int64_t gsr, T* gx, T* gloc, T* gscale, int64_t K, int64_t R, int64_t D,          \
+                                                   void* stream) {                                                                   \
+    return logistic_logprob_bwd_ksum<T>(x, loc, scale, glp, gsk, gsr, gx, gloc, gscale, K, R, D, stream);                            \
   }                                                                                                                                \
   extern "C" int zs_uniform_sample##SFX(const T* low, int64_t Pl, const T* high, int64_t Ph, const T* u, uint64_t seed,            \
                                         uint64_t offset, const uint64_t* rng_state, T* out, T* cache, int64_t N, int reparam,      \

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "zs_logistic_sample_logprob_bwd_f32": [_p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p],
     "zs_logistic_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_logistic_logprob_bwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
+    "zs_logistic_logprob_bwd_ksum_f32": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _p],
     "zs_uniform_sample_f32": [_p, _i64, _p, _i64, _p, _u64, _u64, _p, _p, _p, _i64, _int, _p],
     "zs_uniform_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_philox_uniform_f32": [_p, _i64, _u64, _u64, _p, _p],

@@ -545,6 +545,13 @@ class LogisticLogProb(torch.autograd.Function):
         if N == 0 or not any(need):
             return (None,) * 7
         glp, gsk, gsr = _kr_view(glp, K, R)
+        if K > 1 and Px == N and Pm == Ps == R * D:
+            # parameters [R, D] repeated over the K particles: reduce over K inside the kernel
+            gx = torch.empty_like(x) if need[0] else None
+            gloc, gscale = torch.empty_like(loc), torch.empty_like(scale)
+            _hip.lib().call("zs_logistic_logprob_bwd_ksum" + _sfx(x), _hip.ptr(x), _hip.ptr(loc), _hip.ptr(scale), _hip.ptr(glp),
+                            gsk, gsr, _hip.ptr(gx), _hip.ptr(gloc), _hip.ptr(gscale), K, R, D, _hip.stream_for(x))
+            return (gx, gloc if need[1] else None, gscale if need[2] else None, None, None, None, None)
         outs = [torch.empty(N, dtype=x.dtype, device=x.device) if n else None for n in need]
         _hip.lib().call("zs_logistic_logprob_bwd" + _sfx(x), _hip.ptr(x), Px, _hip.ptr(loc), Pm, _hip.ptr(scale), Ps,
                         _hip.ptr(glp), gsk, gsr, _hip.ptr(outs[0]), _hip.ptr(outs[1]), _hip.ptr(outs[2]), K, R, D,
