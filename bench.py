@@ -46,7 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--fused-logits", action="store_true",
-                    help="decoder hands logits to Bernoulli(logits=...): sigmoid fused into the log-prob kernel")
+                    help="the decoder hands logits to Bernoulli(logits=...): its final sigmoid is formed inside the log-prob "
+                         "kernel instead of a separate pass over [K, B, 784] (extra_configs.c3_logits in the default run; the "
+                         "default keeps the nn.Sigmoid pass and Bernoulli(probs=...) of the reference's example)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs and the HBM-resident kernel figures")
     ap.add_argument("--force-collective-path", action="store_true",
@@ -167,11 +169,13 @@ def make_workload(name, dev, seed_rank=0, fused_logits=False):
     from examples import iwae, vae_mnist, bnn_vi
     rs = np.random.RandomState(1234 + seed_rank)
     bits = lambda B: torch.tensor((rs.uniform(size=(B, X_DIM)) < 0.5).astype(np.float32), device=dev)
-    if name in ("c3", "c3_logits"):
+    if name in ("c3", "c3_logits", "c3_probs"):
+        fused = name == "c3_logits" or (fused_logits and name != "c3_probs")
         model = iwae.build(n_samples=PARTICLES, estimator="vimco", x_dim=X_DIM, z_dim=Z_DIM, hidden=HIDDEN, device=dev,
-                           fused_logits=fused_logits or name == "c3_logits")
+                           fused_logits=fused)
         return model, {"x": bits(BATCH_PER_GPU)}, BATCH_PER_GPU * PARTICLES, \
-            "IWAE-MNIST VIMCO, batch=256, K=50" + (", Bernoulli from logits (sigmoid fused)" if name == "c3_logits" else "")
+            "IWAE-MNIST VIMCO, batch=256, K=50, " + ("Bernoulli from logits (the decoder's sigmoid inside the log-prob kernel)"
+                                                      if fused else "Bernoulli from probabilities (nn.Sigmoid pass, as the reference's example)")
     if name == "c2":
         return vae_mnist.build(512, device=dev), {"x": bits(512)}, 512, "VAE-MNIST SGVB, batch=512, K=1 (BASELINE configs[1])"
     if name == "c5":
@@ -311,12 +315,12 @@ def make_optimizer(model, torch_adam, groups=None):
     return zhusuan.optim.FlatAdam(groups if groups is not None else model.parameters(), lr=1e-3)
 
 
-def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False):
+def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False):
     """A BASELINE config other than the headline one on this GPU: full training steps replayed from one hipGraph."""
     import zhusuan
     gemm_tuning(tuned)
     torch.manual_seed(0)
-    model, obs, evals, label = make_workload(name, dev)
+    model, obs, evals, label = make_workload(name, dev, fused_logits=fused_logits)
     opt = make_optimizer(model, torch_adam)
     rng = zhusuan.DeviceRNG(dev, seed=1)
 
@@ -386,6 +390,11 @@ def hbm_resident_kernels(klib, dev, launches=30):
           lambda: klib.call("zs_bernoulli_logprob_f32", P(p), P(x), B * X, P(lp), K, B, X, 1, K, st), N, X)
     timed("zs_bernoulli_logprob_bwd_f32", 8 * N * X + 4 * B * X + 4 * N,
           lambda: klib.call("zs_bernoulli_logprob_bwd_f32", P(p), P(x), B * X, P(glp), 1, K, P(gp), K, B, X, st), N, X)
+    p.mul_(8.0).sub_(4.0)                      # the same buffer as logits
+    timed("zs_bernoulli_logits_logprob_f32", 4 * N * X + 4 * B * X + 4 * N,
+          lambda: klib.call("zs_bernoulli_logits_logprob_f32", P(p), P(x), B * X, P(lp), None, K, B, X, 1, K, st), N, X)
+    timed("zs_bernoulli_logits_logprob_bwd_f32", 8 * N * X + 4 * B * X + 4 * N,
+          lambda: klib.call("zs_bernoulli_logits_logprob_bwd_f32", P(p), P(x), B * X, P(glp), 1, K, P(gp), K, B, X, st), N, X)
     del p, gp, x
     del lp, glp
     torch.cuda.empty_cache()
@@ -393,7 +402,11 @@ def hbm_resident_kernels(klib, dev, launches=30):
 
 
 # kernel-name fragment -> C-ABI entry point (most specific first); logits forms carry <true, ...> as first template argument
+# (the kernels shared by the location-scale families live in namespace zs: first template argument 0 = Normal, 1 = Logistic)
 _KERNEL_ENTRY = [("k_bern_logprob_bwd", "zs_bernoulli%s_logprob_bwd_f32"), ("k_bern_logprob", "zs_bernoulli%s_logprob_f32"),
+                 ("k_sample_tile<0", "zs_normal_sample_logprob_f32"), ("k_sample_tile<1", "zs_logistic_sample_logprob_f32"),
+                 ("k_logprob_bwd_ksum<0", "zs_normal_logprob_bwd_ksum_f32"), ("k_logprob_krep<0", "zs_normal_logprob_f32"),
+                 ("k_adam_step", "zs_adam_step_f32"),
                  ("k_normal_sample_bwd", "zs_normal_sample_logprob_bwd_f32"), ("k_normal_sample", "zs_normal_sample_logprob_f32"),
                  ("k_normal_logprob_bwd_ksum", "zs_normal_logprob_bwd_ksum_f32"), ("k_normal_logprob_bwd", "zs_normal_logprob_bwd_f32"),
                  ("k_normal_logprob", "zs_normal_logprob_f32"), ("k_iw_reduce", "zs_iw_reduce_f32"), ("k_lme", "zs_log_mean_exp_f32")]
@@ -623,6 +636,7 @@ def main():
             "zs_normal_logprob_bwd_ksum_f32": 4 * N * D + 4 * N + 16 * B * D,
             "zs_iw_reduce_f32": 16 * N + 8 * B,
             "zs_iw_objective_f32": 20 * N + 4 * B + 4,                            # read a, b, q; write [2,B,K] coefficients, bounds, mean
+            "zs_adam_step_f32": 28 * sum(p.numel() for p in model.parameters()),  # read p, g, m, v; write p, m, v
         }
         # the IW kernels serve two entry points; the tracer sees kernel names only
         if "zs_iw_reduce_f32" in dev_times and klib.prof_query("zs_iw_objective_f32")["count"] and \
@@ -691,7 +705,10 @@ def main():
                        "parallelism": "dp%d (minibatch shards; %s, %d bytes per step)" % (
                            world, "two flat buckets (decoder | encoder gradients + objective)" if (staged or hooks)
                            else "one flat bucket [gradients | objective]", nbytes),
-                       "bernoulli_path": "logits (sigmoid fused)" if args.fused_logits else "probs (reference default)",
+                       "bernoulli_path": "logits: the decoder's final sigmoid is formed inside the Bernoulli log-prob kernel"
+                                         if args.fused_logits else
+                                         "probs (nn.Sigmoid pass, as the reference's example is written; extra_configs.c3_logits: the "
+                                         "same step with the sigmoid inside the Bernoulli log-prob kernel)",
                        "mlp_gemm_library": args.blas,
                        "mlp_gemm_selection": ("PyTorch TunableOp: fastest fp32 hipBLASLt / rocBLAS solution per GEMM shape, picked during "
                                               "warm-up (callers' nn.Linear stack, outside the hot path; extra_configs.c3_default_gemm "
@@ -730,7 +747,7 @@ def main():
             del model, opt, bucket
             torch.cuda.empty_cache()
             out["extra_configs"] = {}
-            for name in ("c2", "c5", "c3_logits"):
+            for name in ("c2", "c5", "c3_probs" if args.fused_logits else "c3_logits"):
                 try:
                     out["extra_configs"][name] = run_single_gpu_config(name, dev, args.steps, args.warmup, tuned=tuned,
                                                                        torch_adam=args.torch_adam)
@@ -738,14 +755,14 @@ def main():
                     out["extra_configs"][name] = {"error": repr(e)}
             if tuned:       # the headline step once more with PyTorch's default GEMM selection (what round 1 measured)
                 try:
-                    out["extra_configs"]["c3_default_gemm"] = run_single_gpu_config("c3", dev, args.steps, args.warmup, tuned=False,
-                                                                                    torch_adam=True)
+                    out["extra_configs"]["c3_default_gemm"] = run_single_gpu_config("c3_probs", dev, args.steps, args.warmup,
+                                                                                    tuned=False, torch_adam=True)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"]["c3_default_gemm"] = {"error": repr(e)}
             if not args.torch_adam:     # the headline step with torch's multi-tensor Adam
                 try:
                     out["extra_configs"]["c3_torch_adam"] = run_single_gpu_config("c3", dev, args.steps, args.warmup, tuned=tuned,
-                                                                                  torch_adam=True)
+                                                                                  torch_adam=True, fused_logits=args.fused_logits)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"]["c3_torch_adam"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
@@ -755,8 +772,9 @@ def main():
                     if "error" not in out["extra_configs"].get(name, {"error": 1}):
                         out["extra_configs"][name]["cpu_baseline"] = cpu_baseline(name, budget_s=b1, one_thread_budget_s=b2,
                                                                                   max_steps=2000)
-                if "error" not in out["extra_configs"].get("c3_logits", {"error": 1}):
-                    out["extra_configs"]["c3_logits"]["cpu_baseline"] = "same workload as the headline line: see cpu_baseline"
+                for name in ("c3_logits", "c3_probs"):
+                    if "error" not in out["extra_configs"].get(name, {"error": 1}):
+                        out["extra_configs"][name]["cpu_baseline"] = "same workload as the headline line: see cpu_baseline"
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

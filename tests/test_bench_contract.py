@@ -62,7 +62,8 @@ def test_bench_line_single_rank():
     assert roof["traffic_source"] is None or roof["traffic_source"]["measured_in_this_run"] is False
     # the same kernels on working sets beyond the Infinity Cache, measured in this run
     hb = rec["hbm_resident"]
-    for k in ("zs_bernoulli_logprob_f32", "zs_bernoulli_logprob_bwd_f32", "zs_normal_sample_logprob_f32"):
+    for k in ("zs_bernoulli_logprob_f32", "zs_bernoulli_logprob_bwd_f32", "zs_bernoulli_logits_logprob_f32",
+              "zs_bernoulli_logits_logprob_bwd_f32", "zs_normal_sample_logprob_f32"):
         assert hb[k]["algorithmic_bytes"] > 256 * 2 ** 20 and 0.2 < hb[k]["frac_of_hbm_peak"] < 1.0
     assert 0.2 < roof["hbm_resident"]["frac"] < 1.0
     # the other single-GPU configs, each with its CPU baselines (calibrated thread count and one thread)
@@ -74,6 +75,7 @@ def test_bench_line_single_rank():
         assert cb["value"] > 0 and cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0
     assert cpu["one_thread"]["cores"] == 1 and cpu["one_thread"]["value"] > 0
     # the update: one launch over the flat bucket by default, torch's multi-tensor Adam beside it
+    assert rec["config"]["bernoulli_path"].startswith("probs") and roof["kernel"] == "zs_bernoulli_logprob_bwd_f32"
     assert "FlatAdam" in rec["config"]["optimizer"] and "torch.optim.Adam" in rec["extra_configs"]["c3_torch_adam"]["optimizer"]
     assert rec["extra_configs"]["c3_torch_adam"]["value"] > 1e5
     assert np.isfinite(rec["extra_configs"]["c3_torch_adam"]["final_loss"]) and np.isfinite(rec["final_loss"])
@@ -81,8 +83,10 @@ def test_bench_line_single_rank():
 
 @pytest.mark.gpu
 def test_bench_line_with_torch_adam():
+    """The step with torch's optimizer (as round 1 ran it)."""
     rec = _run_bench("--no-cpu-baseline", "--no-extras", "--torch-adam")
     assert rec["value"] > 1e5 and rec["config"]["optimizer"].startswith("torch.optim.Adam")
+    assert rec["config"]["bernoulli_path"].startswith("probs") and rec["roofline"]["kernel"] == "zs_bernoulli_logprob_bwd_f32"
 
 
 @pytest.mark.gpu

@@ -744,6 +744,14 @@ def test_hip_scalar_objective(hip, orc, hip64, orc64):
         assert abs(a64 - exact64) <= 1e-12 * max(1.0, abs(exact64))
 
 
+@pytest.mark.gpu
+def test_every_entry_point_has_a_timing_id(hip):
+    """bench.py asks the library for the recorded launches of every compute entry point: each name must resolve."""
+    for name in _hip.PROTOTYPES:
+        assert hip.k.cdll.zs_prof_kernel_id(name.encode()) >= 0, name
+        assert hip.k.prof_query(name)["count"] >= 0
+
+
 # ------------------------------------------------------------------ A1: Adam update of up to 32 tensors, one launch
 def _adam_run(raw, sizes, steps, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, gs=1.0, missing=(), misalign=False, seed=0):
     """`steps` launches over tensors of `sizes` elements (`missing`: tensors without a gradient; `misalign`: every tensor

@@ -26,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = "gpurun_out/pmc_%s/pmc_counter_collection.csv" % c
     rows = list(csv.reader(open(f)))
     ki = rows[0].index("Kernel_Name")
-    keep = [r for r in rows[1:] if "anonymous namespace)::k_" in r[ki]]
+    keep = [r for r in rows[1:] if "anonymous namespace)::k_" in r[ki] or "zs::k_" in r[ki]]
     with open("gpurun_out/${TAG}_pmc_%s_counter_collection.csv" % c.lower(), "w", newline="") as fh:
         w = csv.writer(fh); w.writerow(rows[0]); w.writerows(keep)
 PY

@@ -98,7 +98,7 @@ def main():
               lambda: lib.call("zs_logistic_logprob_f32", P(z), K * M, P(mu), M, P(sg), M, P(lp), K, B, D, 1, K, st), tag)
         timed("L1 bwd (Philox)", "zs_logistic_sample_logprob_bwd_f32", 4 * N * D + 4 * N + 12 * M,
               lambda: lib.call("zs_logistic_sample_logprob_bwd_f32", P(sg), None, 1, 2, None, P(gz), P(glp), 1, K, P(gmu), P(gsg), K, M, D, st), tag)
-        timed("L2 bwd ksum (non-reparam)", "zs_logistic_logprob_bwd_f32", 4 * N * D + 4 * N + 16 * M,
+        timed("L2 bwd ksum (non-reparam)", "zs_logistic_logprob_bwd_ksum_f32", 4 * N * D + 4 * N + 16 * M,
               lambda: lib.call("zs_logistic_logprob_bwd_ksum_f32", P(z), P(mu), P(sg), P(glp), 1, K, None, P(gmu), P(gsg), K, B, D, st), tag)
         hi = mu + sg
         timed("U1 uniform sample (Philox)", "zs_uniform_sample_f32", 8 * N * D + 8 * M,

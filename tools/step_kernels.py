@@ -42,12 +42,20 @@ def main():
     ap.add_argument("--config", default="C5", choices=["C2", "C3", "C3-logits", "C5"])
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--external", action="store_true", help="an outside tracer counts; just run the steps")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused, capturable) instead of zhusuan.optim.FlatAdam")
+    ap.add_argument("--tuned-gemm", action="store_true", help="PyTorch TunableOp picks the callers' GEMM solutions, as bench.py does")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model, obs, evals = make(args.config, dev)
-    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
+    if args.tuned_gemm:
+        import tempfile
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(True)
+        torch.cuda.tunable.set_filename(os.path.join(tempfile.mkdtemp(), "tunableop.csv"))
+    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True) if args.torch_adam else \
+        zhusuan.optim.FlatAdam(model.parameters(), lr=1e-3)
     rng = zhusuan.DeviceRNG(dev, seed=1)
 
     def step():
@@ -67,6 +75,8 @@ def main():
         for _ in range(5):
             step()
         torch.cuda.synchronize()
+        if args.tuned_gemm:
+            torch.cuda.tunable.tuning_enable(False)
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             for _ in range(args.steps):

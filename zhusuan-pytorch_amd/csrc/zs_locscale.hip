@@ -804,9 +804,9 @@ int logistic_logprob_bwd_ksum(const T* x, const T* loc, const T* scale, const T*
   if (!x || !loc || !scale || !glp) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if constexpr (std::is_same<T, float>::value) {
-    launch_logprob_bwd_ksum<D_LOGISTIC>(KID_LOGISTIC_LOGPROB_BWD, x, loc, scale, glp, gsk, gsr, gx, gloc, gscale, K, R, D, false, st);
+    launch_logprob_bwd_ksum<D_LOGISTIC>(KID_LOGISTIC_LOGPROB_BWD_KSUM, x, loc, scale, glp, gsk, gsr, gx, gloc, gscale, K, R, D, false, st);
   } else {
-    ZS_LAUNCH(KID_LOGISTIC_LOGPROB_BWD, (k_logistic_logprob_bwd_ksum_serial<T>), dim3(grid_for(M, 256)), dim3(256), st, x, loc, scale,
+    ZS_LAUNCH(KID_LOGISTIC_LOGPROB_BWD_KSUM, (k_logistic_logprob_bwd_ksum_serial<T>), dim3(grid_for(M, 256)), dim3(256), st, x, loc, scale,
               glp, gsk, gsr, gx, gloc, gscale, K, M, D);
   }
   ZS_CHECK_LAUNCH();
