@@ -5,12 +5,8 @@ ROOT=$(pwd)
 TAG=${1:-r02}
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4
-python bench.py --steps 200 --warmup 20 > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/bench_n1.err; echo "bench rc=$?"
+timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -16
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -o bench -- python3 "$ROOT/bench.py" --steps 200 --warmup 20 --no-cpu-baseline --no-extras > "$ROOT/gpurun_out/bench_prof.json" 2> "$ROOT/gpurun_out/bench_prof.err"; echo "rocprof rc=$?"
-rm -f "$ROOT/gpurun_out/prof/bench_kernel_trace.csv"     # 8 MB of per-dispatch rows; the stats file is the summary
-cp "$ROOT/gpurun_out/prof/bench_kernel_stats.csv" "$ROOT/gpurun_out/${TAG}_bench_n1_kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
   # (--no-gemm-tuning: the counter passes are about the hot-path kernels; TunableOp's thousands of trial GEMMs would only bloat the CSVs)
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$ROOT/gpurun_out/pmc_$c" -o pmc -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-extras --no-gemm-tuning > "$ROOT/gpurun_out/pmc_$c.log" 2>&1
@@ -19,6 +15,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd "$ROOT" && python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE --out gpurun_out/${TAG}_pmc_traffic.json \
   --command "python3 bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-extras --no-gemm-tuning"
+cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json      # the bench line below quotes it (roofline.traffic)
+python bench.py --steps 200 --warmup 20 > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/bench_n1.err; echo "bench rc=$?"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -o bench -- python3 "$ROOT/bench.py" --steps 200 --warmup 20 --no-cpu-baseline --no-extras > "$ROOT/gpurun_out/bench_prof.json" 2> "$ROOT/gpurun_out/bench_prof.err"; echo "rocprof rc=$?"
+rm -f "$ROOT/gpurun_out/prof/bench_kernel_trace.csv"     # 8 MB of per-dispatch rows; the stats file is the summary
+cp "$ROOT/gpurun_out/prof/bench_kernel_stats.csv" "$ROOT/gpurun_out/${TAG}_bench_n1_kernel_stats.csv"
+cd "$ROOT"
 # keep the summaries small enough to travel back (gpurun merges at most 64 MiB): hot-path rows of the counter CSVs only
 python - <<PY
 import csv
