@@ -12,7 +12,7 @@ for kind in ("iwae", "vae", "bnn"):
         model, obs = vae_mnist.build(512, device=dev), {"x": (torch.rand(512, 784, device=dev) < 0.5).float()}
     else:
         model, obs = bnn_vi.build(n_particles=10, device=dev), {"x": torch.randn(512, 13, device=dev), "y": torch.randn(512, device=dev)}
-    opt = torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
+    opt = zhusuan.optim.FlatAdam(model.parameters(), lr=1e-3)
     rng = zhusuan.DeviceRNG(dev, seed=1)
     def compute():
         rng.begin_step()
@@ -28,4 +28,6 @@ for kind in ("iwae", "vae", "bnn"):
     with zhusuan.device_rng(rng):
         for i in range(300): compute(); opt.step()
     torch.cuda.synchronize()
+    steps_seen = [int(b.step.item()) for b in opt.buckets]
+    print(kind, "adam step counters", steps_seen, "tickets", [int(b.ticket.item()) for b in opt.buckets])
     print(kind, "loss %.2f -> %.2f" % (l0, float(last)), "ms/step %.4f" % (1e3 * dt / 5000), "mem delta %d B" % (torch.cuda.memory_allocated() - m0), "finite", bool(torch.isfinite(last)))
