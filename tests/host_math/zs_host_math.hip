@@ -12,6 +12,7 @@
 
 #include "../../zhusuan-pytorch_amd/csrc/zs_common.h"
 #include "../../zhusuan-pytorch_amd/csrc/zs_iw_math.h"
+#include "../../zhusuan-pytorch_amd/csrc/zs_locscale_math.h"
 
 static long n_checks = 0;
 static int n_fail = 0;
@@ -102,6 +103,41 @@ static void test_normal_bernoulli_terms() {
     }
 }
 
+// Logistic / Uniform element math of the shared kernels (zs_locscale_math.h) against float64 restatements of
+// logistic.py:64-66,81-82 and uniform.py:78-81
+static void test_logistic_uniform_terms() {
+  const float scales[] = {1e-3f, 0.05f, 1.0f, 7.0f, 1e3f};
+  const float diffs[] = {0.0f, 1e-6f, -1e-6f, 0.3f, -0.3f, 2.5f, -40.0f, 1e4f, -1e6f};
+  for (float sc : scales)
+    for (float d : diffs) {
+      const float inv = 1.0f / sc;
+      const double t = (double)d * (double)inv;
+      const double sp = (t < 0 ? -t : 0.0) + log1p(exp(-fabs(t)));             // softplus(-t)
+      const double want = t + 2.0 * sp;                                        // -(log-density) - log(scale)
+      const float got = zs::logistic_neg_lp_term(d, inv);
+      expect(close_rel(got, want, 4e-6, 4e-6) && isfinite(got), "logistic_neg_lp_term", got, want);
+      float gx = 0, a = 0.25f, b = -0.5f;
+      const float g = 1.7f;
+      zs::logistic_ksum_elem(g, d, inv, gx, a, b);
+      const double h = tanh(0.5 * t);
+      const double wgx = -(double)g * h * inv, wb = (double)g * (h * t - 1.0) * inv;
+      expect(close_rel(gx, wgx, 1e-5, 1e-6 * fabs((double)g * inv)), "logistic_ksum_elem gx", gx, wgx);
+      expect(close_rel(a - 0.25f, -wgx, 1e-5, 1e-6 * fabs((double)g * inv) + 1e-7), "logistic_ksum_elem d loc", a - 0.25f, -wgx);
+      expect(close_rel(b + 0.5f, wb, 1e-5, 1e-5 * fabs((double)g * inv) * (1.0 + fabs(t))) && isfinite(b), "logistic_ksum_elem d scale", b + 0.5f, wb);
+    }
+  const uint32_t words[] = {0u, 1u, 511u, 512u, 0x7fffffffu, 0x80000000u, 0xfffffdffu, 0xfffffe00u, 0xffffffffu, 0x12345678u};
+  for (uint32_t w : words) {
+    const float u = zs::u01(w);
+    float eps, dens;
+    zs::logistic_draw(u, eps, dens);
+    const double lu = log((double)u), l1 = log1p(-(double)u);
+    expect(isfinite(eps) && isfinite(dens) && close_rel(eps, lu - l1, 1e-5, 2e-6) && close_rel(dens, lu + l1, 1e-5, 2e-6),
+           "logistic_draw", eps, lu - l1);
+  }
+  expect(zs::uniform_inside(0.0f, 0.0f, 1.0f) && !zs::uniform_inside(1.0f, 0.0f, 1.0f) && !zs::uniform_inside(-1e-30f, 0.0f, 1.0f) &&
+         !zs::uniform_inside(NAN, 0.0f, 1.0f), "uniform_inside: [low, high)", 0, 0);
+}
+
 // float64 restatement of importance_weighted_objective.py:16-25,123-132,152-191 for one row
 static void iw_truth(const std::vector<double>& l, const std::vector<double>& lq, int est, std::vector<double>& wt,
                      std::vector<double>& cq, double& cost) {
@@ -178,6 +214,7 @@ int main() {
   test_uniform_and_normal();
   test_normal_bernoulli_terms();
   test_iw_particle();
+  test_logistic_uniform_terms();
   if (n_fail) {
     fprintf(stderr, "host math: %d of %ld checks FAILED\n", n_fail, n_checks);
     return 1;

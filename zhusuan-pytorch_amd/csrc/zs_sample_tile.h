@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "zs_common.h"
+#include "zs_locscale_math.h"
 
 #ifndef ZS_K1_EXPERIMENT
 #define ZS_K1_EXPERIMENT 0      // 1 / 2: timing experiments on k_sample_tile (never shipped)
@@ -172,10 +173,13 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
             // Logistic draw (logistic.py:64-66): eps = log u - log(1 - u); its own log-density -eps - 2 softplus(-eps)
             // is log u + log(1 - u): the two logarithms serve both
             const Philox4 r = philox4x32_10(g, call, seed);
-            const float u0 = u01(r.x), u1 = u01(r.y), u2 = u01(r.z), u3 = u01(r.w);
-            const float a0 = ln_fast(u0), a1 = ln_fast(u1), a2 = ln_fast(u2), a3 = ln_fast(u3);
-            const float b0 = ln_fast(1.0f - u0), b1 = ln_fast(1.0f - u1), b2 = ln_fast(1.0f - u2), b3 = ln_fast(1.0f - u3);
-            particle(make_float4(a0 - b0, a1 - b1, a2 - b2, a3 - b3), ((a0 + b0) + (a1 + b1)) + ((a2 + b2) + (a3 + b3)));
+            float4 e;
+            float d0, d1, d2, d3;
+            logistic_draw(u01(r.x), e.x, d0);
+            logistic_draw(u01(r.y), e.y, d1);
+            logistic_draw(u01(r.z), e.z, d2);
+            logistic_draw(u01(r.w), e.w, d3);
+            particle(e, (d0 + d1) + (d2 + d3));
           }
 #endif
           g += M4;
@@ -286,13 +290,9 @@ __device__ __forceinline__ float krep_terms(const float4 xv, const float4 m, con
     if (DIST == D_NORMAL) {
       acc += c[j] * (d * d);                             // 0.5 (x - mu)^2 / sigma^2
     } else if (DIST == D_LOGISTIC) {
-      // t + 2 softplus(-t) = |t| + 2 log1p(exp(-|t|))   (logistic.py:81-82; even in t)
-      const float at = __builtin_fabsf(d * c[j]);
-      const float e = exp2_fast(at * -1.44269504088896341f);
-      acc += at + 2.0f * ZS_LN2 * log2_fast(1.0f + e);
+      acc += logistic_neg_lp_term(d, c[j]);
     } else {
-      const bool inside = (ms[j] <= xs[j]) && (c[j] > xs[j]);   // torch Uniform.log_prob: lb * ub (uniform.py:78-81)
-      acc += inside ? 0.f : INFINITY;
+      acc += uniform_inside(xs[j], ms[j], c[j]) ? 0.f : INFINITY;
     }
   }
   return acc;
@@ -410,14 +410,7 @@ __device__ __forceinline__ void ksum_elem(float g, float xv, float mv, float c, 
     a += t;
     b += g * (c * diff * diff - 1.0f) * inv;
   } else {                           // inv = 1/scale
-    const float u = diff * inv;
-    const float e = exp2_fast(__builtin_fabsf(u) * -1.44269504088896341f);
-    float h = (1.0f - e) * rcp_fast(1.0f + e);           // tanh(|u| / 2)
-    h = u < 0.f ? -h : h;
-    const float gh = g * h * inv;
-    gx = -gh;
-    a += gh;
-    b += g * (h * u - 1.0f) * inv;
+    logistic_ksum_elem(g, diff, inv, gx, a, b);
   }
 }
 
