@@ -32,7 +32,7 @@ def test_c_oracle_under_asan_and_ubsan():
 
 def test_kernel_arithmetic_on_the_host_under_asan_and_ubsan(tmp_path):
     """The HIP sources' per-element helpers (Philox4x32-10, the uniform and Box-Muller conversions, the Normal / Bernoulli
-    density terms and derivatives, the VIMCO per-particle arithmetic, the index helpers) built for the HOST with
+    / Logistic / Uniform density terms and derivatives, the VIMCO per-particle arithmetic, the index helpers) built for the HOST with
     `hipcc --cuda-host-only -fsanitize=address,undefined` and run: Random123 known answers, double-precision references,
     edge values.  (This harness found round 1's uniform reaching exactly 1.0 -- an infinite Logistic draw once in 1.7e7.)"""
     import shutil
