@@ -203,7 +203,9 @@ def test_training_reduces_loss(dev):
                                       ("examples.iwae", ["--batch", "16", "--particles", "8", "--steps", "60"]),
                                       ("examples.iwae", ["--batch", "16", "--particles", "8", "--steps", "60", "--estimator", "sgvb",
                                                          "--fused-logits"]),
-                                      ("examples.bnn_vi", ["--steps", "60"])])
+                                      ("examples.bnn_vi", ["--steps", "60"]),
+                                      ("examples.vae_mnist", ["--batch", "32", "--steps", "60", "--flat-adam"]),
+                                      ("examples.bnn_vi", ["--steps", "60", "--flat-adam"])])
 def test_example_scripts_run(mod, args):
     """The counterparts of the reference's example scripts run as programs on the GPU (synthetic data)."""
     import subprocess

@@ -100,10 +100,16 @@ def main():
     ap.add_argument('--batch', type=int, default=114)
     ap.add_argument('--particles', type=int, default=512)
     ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--flat-adam', action='store_true',
+                    help="zhusuan.optim.FlatAdam: torch.optim.Adam's update as one kernel launch")
     args = ap.parse_args()
     device = torch.device('cuda')
     model = build(n_particles=args.particles, device=device)
-    opt = torch.optim.Adam(model.parameters(), 1e-3)
+    if args.flat_adam:
+        import zhusuan
+        opt = zhusuan.optim.FlatAdam(model.parameters(), lr=1e-3)
+    else:
+        opt = torch.optim.Adam(model.parameters(), 1e-3)          # as the reference's example
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(args.batch, 13, generator=g).to(device)
     y = torch.randn(args.batch, generator=g).to(device)

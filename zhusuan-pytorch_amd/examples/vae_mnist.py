@@ -76,10 +76,16 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--flat-adam', action='store_true',
+                    help="zhusuan.optim.FlatAdam: torch.optim.Adam's update as one kernel launch")
     args = ap.parse_args()
     device = torch.device('cuda')
     model = build(args.batch, device=device)
-    opt = torch.optim.Adam(model.parameters(), args.lr)
+    if args.flat_adam:
+        import zhusuan
+        opt = zhusuan.optim.FlatAdam(model.parameters(), lr=args.lr)
+    else:
+        opt = torch.optim.Adam(model.parameters(), args.lr)          # as the reference's example
     g = torch.Generator().manual_seed(1234)
     x_all = (torch.rand(args.batch * 32, 784, generator=g) < 0.5).float().to(device)
     t0 = time.time()
