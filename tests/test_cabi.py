@@ -285,6 +285,11 @@ def test_hip_normal_sample_and_backward(hip, orc, K, R, D, kfast):
     np.testing.assert_allclose(a["z"], b["z"], rtol=0, atol=2e-5 * float(sd.max()) * 6)
     _cmp(hip.normal_sample_bwd(sd, None, gz, glp, K, D, 77, 5), orc.normal_sample_bwd(sd, None, gz, glp, K, D, 77, 5),
          2e-4, 2e-4 * np.sqrt(K))
+    # every combination of the optional gradients (each is its own kernel instantiation)
+    _cmp(hip.normal_sample_bwd(sd, None, gz, None, K, D, 77, 5), orc.normal_sample_bwd(sd, None, gz, None, K, D, 77, 5),
+         2e-4, 2e-4 * np.sqrt(K))
+    _cmp(hip.normal_sample_bwd(sd, eps, gz, None, K, D), orc.normal_sample_bwd(sd, eps, gz, None, K, D), 1e-4, 1e-4)
+    _cmp(hip.normal_sample_bwd(sd, None, None, glp, K, D, 77, 5), orc.normal_sample_bwd(sd, None, None, glp, K, D, 77, 5), 1e-4, 1e-4)
 
 
 @pytest.mark.gpu

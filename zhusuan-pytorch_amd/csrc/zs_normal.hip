@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_normal_logprob_waverow(
 // K1 backward (reparameterised): thread tile = 64 parameter float4 groups x 4 K-slices,
 // K-slice partials combined through LDS.
 // ------------------------------------------------------------------------------------
-template <bool HAS_EPS>
+template <bool HAS_EPS, bool HAS_GZ, bool HAS_GLP>
 __global__ __launch_bounds__(256) void k_normal_sample_bwd(
     const float4* __restrict__ sigma, const float4* __restrict__ eps, uint64_t seed, uint64_t call,
     const uint64_t* __restrict__ rs, const float4* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
@@ -301,19 +301,33 @@ __global__ __launch_bounds__(256) void k_normal_sample_bwd(
   const bool on = m4 < M4;
   float4 am = make_float4(0.f, 0.f, 0.f, 0.f), as = am;
   float gl = 0.f;
-  if (on) {
+  if (on && slice < K) {
     const int64_t r = (int64_t)((uint64_t)m4 >> 31 ? m4 / D4 : (int64_t)((uint32_t)m4 / (uint32_t)D4));
+    // rolling prefetch: the loads of particle k + 4 are in flight while the draw of particle k is regenerated (which
+    // operands exist is compiled in: a branch between two loads would make the second wait for the first)
+    float4 gn = make_float4(0.f, 0.f, 0.f, 0.f), en = gn;
+    float gln = 0.f;
+    {
+      const int64_t g0 = (int64_t)slice * M4 + m4;
+      if (HAS_GZ) gn = gz[g0];
+      if (HAS_GZ && HAS_EPS) en = eps[g0];
+      if (HAS_GLP) gln = glp[(int64_t)slice * gsk + r * gsr];
+    }
     for (int64_t k = slice; k < K; k += 4) {
       const int64_t g = k * M4 + m4;
-      if (gz) {
-        const float4 gv = gz[g];
-        float4 e;
-        if (HAS_EPS) e = eps[g];
-        else e = philox_normal4((uint64_t)g, call, seed);
+      const float4 gv = gn;
+      float4 e = en;
+      gl += gln;
+      const int64_t kn = k + 4 < K ? k + 4 : k;            // last iteration: a harmless re-read
+      const int64_t gnx = kn * M4 + m4;
+      if (HAS_GZ) gn = gz[gnx];
+      if (HAS_GZ && HAS_EPS) en = eps[gnx];
+      if (HAS_GLP) gln = glp[kn * gsk + r * gsr];
+      if (HAS_GZ) {
+        if (!HAS_EPS) e = philox_normal4((uint64_t)g, call, seed);
         am.x += gv.x; am.y += gv.y; am.z += gv.z; am.w += gv.w;
         as.x += gv.x * e.x; as.y += gv.y * e.y; as.z += gv.z * e.z; as.w += gv.w * e.w;
       }
-      if (glp) gl += glp[k * gsk + r * gsr];
     }
   }
   red_a[slice][lane] = am;
@@ -688,14 +702,17 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
   if (vec) {
     const int64_t M4 = M / 4;
     const unsigned grid = (unsigned)((M4 + 63) / 64);
-    if (eps)
-      ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<true>), dim3(grid), dim3(256), st, (const float4*)sigma,
-                         (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
-                         (float4*)gsigma, K, M4, (int)(D / 4), ls);
-    else
-      ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<false>), dim3(grid), dim3(256), st, (const float4*)sigma,
-                         (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu,
-                         (float4*)gsigma, K, M4, (int)(D / 4), ls);
+#define ZS_LAUNCH_K1_BWD(E, G, L)                                                                                             \
+  ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<E, G, L>), dim3(grid), dim3(256), st, (const float4*)sigma,             \
+            (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu, (float4*)gsigma, K, M4, \
+            (int)(D / 4), ls)
+    if (gz) {
+      if (eps) { if (glp) ZS_LAUNCH_K1_BWD(true, true, true); else ZS_LAUNCH_K1_BWD(true, true, false); }
+      else     { if (glp) ZS_LAUNCH_K1_BWD(false, true, true); else ZS_LAUNCH_K1_BWD(false, true, false); }
+    } else {
+      if (glp) ZS_LAUNCH_K1_BWD(false, false, true); else ZS_LAUNCH_K1_BWD(false, false, false);
+    }
+#undef ZS_LAUNCH_K1_BWD
   } else {
     if ((M + 63) / 64 > 0x7fffffffll) return ZS_ENOTSUP;
     ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, k_normal_sample_bwd_serial, dim3((unsigned)((M + 63) / 64)), dim3(256), st, sigma, eps, seed,
