@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--max-rows", type=int, default=1 << 22)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--x-dim", type=int, default=784)
+    ap.add_argument("--batches", type=int, nargs="*", default=None, help="batch sizes B (rows N = 50 B) instead of the default ladder")
     ap.add_argument("--only", action="append", default=None, help="only kernels whose name contains this substring (repeatable)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -61,7 +62,7 @@ def main():
             name, note, bytes_ / 1e6, rec["avg_us"], rec["min_us"], med, rec["GBps"], 100 * rec["frac_of_8TBps"],
             100 * rec["median_frac_of_8TBps"]), flush=True)
 
-    Bs = [256, 2621, 20971, 83886]          # N = K*B ~ 12800 (C3), 2^17, 2^20, 2^22
+    Bs = args.batches or [256, 2621, 20971, 83886]          # N = K*B ~ 12800 (C3), 2^17, 2^20, 2^22
     for B in Bs:
         N = K * B
         if N > args.max_rows:

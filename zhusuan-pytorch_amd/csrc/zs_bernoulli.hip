@@ -14,6 +14,20 @@ __device__ __forceinline__ float bern_row_terms(const float4& pv, const float4& 
          bern_lp2_term(pv.w, xv.w);
 }
 
+typedef float zs_f4v __attribute__((ext_vector_type(4)));
+
+// The streamed operand read with the non-temporal hint.  Forward (read-only stream): pays at every size of the
+// shared-observation kernel.  Backward (a read and a write stream): only far beyond the 256 MB Infinity Cache (6.6 GB of p:
+// 63 -> 67 % of the roofline; 0.8-3.2 GB: 72 -> 65 %), so the host asks for it above 4 GB.
+template <bool NTL>
+__device__ __forceinline__ float4 ld_stream(const float4* __restrict__ q) {
+  if (NTL) {
+    const zs_f4v v = __builtin_nontemporal_load(reinterpret_cast<const zs_f4v*>(q));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *q;
+}
+
 // ------------------------------------------------------------------------------------
 // K3 forward.  One wave handles `rpw` rows per pass with G lanes per row; for long rows
 // (D4 > 64, e.g. 784 pixels = 196 float4) G = 64 and the four chunk loads of a lane are issued
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_longrow(
 // streams JC particle rows past it (U of them in flight), which halves the load instructions per byte
 // of p.  Measured: 6.1-6.3 TB/s at 321 MB and 5.8 TB/s at 2.6 GB, against 5.4 / 4.7 TB/s for one
 // wave per row.
-template <bool LOGITS, bool WRITE_P, int U>
+template <bool LOGITS, bool WRITE_P, int U, bool NTL>
 __global__ __launch_bounds__(256) void k_bern_logprob_xreuse(
     const float4* __restrict__ p, const float4* __restrict__ x, int64_t xrows, int64_t J, int64_t JC,
     float* __restrict__ lp, float4* __restrict__ probs_out, int64_t R, int D4, int64_t sk, int64_t sr) {
@@ -161,7 +175,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_xreuse(
         const float4* __restrict__ prow = p + ((j + v) * xrows + r0) * D4;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (live[v] && ok[u]) pv[v][u] = prow[lane + 64 * u];
+          if (live[v] && ok[u]) pv[v][u] = ld_stream<NTL>(prow + lane + 64 * u);
       }
 #pragma unroll
       for (int v = 0; v < U; ++v) {
@@ -218,7 +232,6 @@ __global__ __launch_bounds__(256) void k_bern_logprob_serial(
 // K3 backward: gp = glp[k, r] * (x/(p+e) - (1-x)/((1-p)+e))   [* p*(1-p) for logits]
 // same row mapping as the forward; reads p and x, writes gp, 16 B per lane.
 // ------------------------------------------------------------------------------------
-typedef float zs_f4v __attribute__((ext_vector_type(4)));
 
 template <bool LOGITS, bool NT>
 __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
 // K3 backward for big problems with a shared observation (same tiling as k_bern_logprob_xreuse): the wave keeps
 // x[b, :] in registers, streams JC particle rows of p past it and writes the gradient rows, non-temporally when
 // the tensor cannot stay in the Infinity Cache.
-template <bool LOGITS, bool NT, int U>
+template <bool LOGITS, bool NT, int U, bool NTL>
 __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
     const float4* __restrict__ p, const float4* __restrict__ x, int64_t xrows, int64_t J, int64_t JC,
     const float* __restrict__ glp, int64_t gsk, int64_t gsr, float4* __restrict__ gp, int64_t R, int D4) {
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
       gn = glp[k * gsk + r * gsr];
       const float4* __restrict__ prow = p + row * D4;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) nx[u] = prow[col[u]];
+      for (int u = 0; u < 4; ++u) nx[u] = ld_stream<NTL>(prow + col[u]);
     }
     for (int64_t j = j0; j < j1; ++j) {
       float4 pv[4];
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
         gn = glp[k * gsk + r * gsr];
         const float4* __restrict__ prow = p + rown * D4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) nx[u] = prow[col[u]];
+        for (int u = 0; u < 4; ++u) nx[u] = ld_stream<NTL>(prow + col[u]);
       }
       float4* __restrict__ grow = gp + row * D4;
 #pragma unroll
@@ -449,13 +462,22 @@ int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* pro
         const int64_t JC = pick_jc(J, xrows);
         const int64_t items = xrows * ((J + JC - 1) / JC);
         const unsigned grid = grid_for_items(items);
+        // p is read once: non-temporal loads leave L2 to the observation rows that ARE re-used.  Measured (probs form) from
+        // 160 MB to 13.4 GB of p: 69 -> 74, 67 -> 74, 69 -> 73, 67 -> 72, 65 -> 74, 68 -> 82 % of the roofline; the logits form
+        // gains 0-6 points.  (The backward, which also writes a stream, only gains beyond 4 GB: see launch_bwd.)
+        static const int ntl_env = getenv("ZS_K3_NTLOAD") ? atoi(getenv("ZS_K3_NTLOAD")) : -1;     // experiments only
+        const bool ntl = ntl_env >= 0 ? ntl_env != 0 : true;
+#define ZS_LAUNCH_FWD_X(W, UU, L)                                                                                          \
+  ZS_LAUNCH(kid, (k_bern_logprob_xreuse<LOGITS, W, UU, L>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, \
+            xrows, J, JC, lp, po, R, D4, sk, sr)
         if (rows >= 400000) {
-          if (probs_out) ZS_LAUNCH(kid, (k_bern_logprob_xreuse<LOGITS, true, 2>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, lp, po, R, D4, sk, sr);
-          else ZS_LAUNCH(kid, (k_bern_logprob_xreuse<LOGITS, false, 2>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, lp, po, R, D4, sk, sr);
+          if (ntl) { if (probs_out) ZS_LAUNCH_FWD_X(true, 2, true); else ZS_LAUNCH_FWD_X(false, 2, true); }
+          else     { if (probs_out) ZS_LAUNCH_FWD_X(true, 2, false); else ZS_LAUNCH_FWD_X(false, 2, false); }
         } else {
-          if (probs_out) ZS_LAUNCH(kid, (k_bern_logprob_xreuse<LOGITS, true, 1>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, lp, po, R, D4, sk, sr);
-          else ZS_LAUNCH(kid, (k_bern_logprob_xreuse<LOGITS, false, 1>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, J, JC, lp, po, R, D4, sk, sr);
+          if (ntl) { if (probs_out) ZS_LAUNCH_FWD_X(true, 1, true); else ZS_LAUNCH_FWD_X(false, 1, true); }
+          else     { if (probs_out) ZS_LAUNCH_FWD_X(true, 1, false); else ZS_LAUNCH_FWD_X(false, 1, false); }
         }
+#undef ZS_LAUNCH_FWD_X
       } else {
         const unsigned grid = grid_for(rows, 4);
         if (probs_out) ZS_LAUNCH(kid, (k_bern_logprob_longrow<LOGITS, true>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, lp, po, rows, R, D4, sk, sr);
@@ -505,11 +527,14 @@ int launch_bwd(const float* p, const float* x, int64_t Px, const float* glp, int
       const unsigned grid = grid_for_items(xrows * ((J + JC - 1) / JC));
       static const int u_env = getenv("ZS_K3_BWD_U") ? atoi(getenv("ZS_K3_BWD_U")) : 0;     // experiments only
       const bool two = u_env ? u_env == 2 : rows >= 400000;
-#define ZS_LAUNCH_BWD_X(T, UU)                                                                                         \
-  ZS_LAUNCH(kid, (k_bern_logprob_bwd_xreuse<LOGITS, T, UU>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, \
+      static const int ntl_env = getenv("ZS_K3_NTLOAD") ? atoi(getenv("ZS_K3_NTLOAD")) : -1;     // experiments only
+      const bool ntl = ntl_env >= 0 ? ntl_env != 0 : (double)N * 4.0 > 4294967296.0;
+#define ZS_LAUNCH_BWD_X(T, UU, L)                                                                                      \
+  ZS_LAUNCH(kid, (k_bern_logprob_bwd_xreuse<LOGITS, T, UU, L>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, \
             xrows, J, JC, glp, gsk, gsr, (float4*)gp, R, D4)
-      if (nt) { if (two) ZS_LAUNCH_BWD_X(true, 2); else ZS_LAUNCH_BWD_X(true, 1); }
-      else    { if (two) ZS_LAUNCH_BWD_X(false, 2); else ZS_LAUNCH_BWD_X(false, 1); }
+      if (ntl)     { if (two) ZS_LAUNCH_BWD_X(true, 2, true); else ZS_LAUNCH_BWD_X(true, 1, true); }
+      else if (nt) { if (two) ZS_LAUNCH_BWD_X(true, 2, false); else ZS_LAUNCH_BWD_X(true, 1, false); }
+      else         { if (two) ZS_LAUNCH_BWD_X(false, 2, false); else ZS_LAUNCH_BWD_X(false, 1, false); }
 #undef ZS_LAUNCH_BWD_X
     } else if (nt) {
       ZS_LAUNCH(kid, (k_bern_logprob_bwd_rows<LOGITS, true>), dim3(grid_for(tiles, 4, (unsigned)cap_env)), dim3(256), st,
