@@ -228,17 +228,41 @@ inline K1Tile k1_tile(int64_t K, int64_t R, int D4, bool want_lp) {   // (K1Tile
   if (TB > 1024) return g;                                             // e.g. D4 = 25: lcm = 1600 lanes
   const int64_t n_ptiles = (M4 + TB - 1) / TB;
   uint32_t KB = (uint32_t)(kb_env > 0 ? kb_env : 16);     // 16: the flush kernel's shift fast path; 20.5 KB of LDS at 320 lanes
-  // about two work items per resident workgroup slot: every item pays the parameter loads and eight logarithms /
-  // exponentials once, so chunks of particles should be long, while the hardware dispatcher needs spare items to even
-  // out the CUs (measured at the 1 M-row sweep point: 1 / 2 / 3 / 8 items per slot = 37.5 / 35.8 / 35.2 / 42.8 us;
-  // at 131 k rows, where 3 per slot means one particle per item: 8.9 / 9.5 / 12.4 us)
+  // every item pays the parameter loads and eight logarithms / exponentials once, so chunks of particles should be long, while
+  // the hardware dispatcher needs spare items to even out the CUs (measured at the 1 M-row sweep point: 1 / 2 / 3 / 8 items per
+  // slot = 37.5 / 35.8 / 35.2 / 42.8 us; at 131 k rows, where 3 per slot means one particle per item: 8.9 / 9.5 / 12.4 us)
   const int64_t resident = 256ll * (2048 / TB > 8 ? 8 : 2048 / TB);
-  const int64_t want = resident * (items_env > 0 ? items_env : 2);
-  int64_t k_tiles = (want + n_ptiles - 1) / n_ptiles;
-  if (k_tiles < 1) k_tiles = 1;
-  if (k_tiles > K) k_tiles = K;
-  int64_t kchunk = (K + k_tiles - 1) / k_tiles;
-  if (kchunk < 3) kchunk = K < 3 ? K : 3;        // an item of one or two particles is mostly prologue
+  int64_t k_tiles, kchunk;
+  if (items_env > 0 || !want_lp) {
+    // fixed rule, about two items per slot: the experiments' override, and the store-only Uniform sampler (no density, hardly
+    // any prologue: the scored split below cost it 7-12 points at 0.25 M and 1 M rows)
+    const int64_t want = resident * (items_env > 0 ? items_env : 2);
+    k_tiles = (want + n_ptiles - 1) / n_ptiles;
+    if (k_tiles < 1) k_tiles = 1;
+    if (k_tiles > K) k_tiles = K;
+    kchunk = (K + k_tiles - 1) / k_tiles;
+    if (kchunk < 3) kchunk = K < 3 ? K : 3;
+  } else {
+    // Split of the particle axis: the hardware hands items to workgroup slots as they free up, so a launch takes about
+    // ceil(items / slots) item-times, and every item pays a prologue worth ~0.7 particles.  Pick the split with the best
+    // (fill of the last round) x (particles per item / (particles per item + 0.7)); an item of one or two particles is
+    // mostly prologue.  (Against "two items per slot", one process, Normal / Logistic: 0.25 M rows 38.7 -> 41.9 / 38 -> 40.5 %,
+    // 0.5 M rows 49.2 -> 51.4 / 47.6 -> 50 %, 1 M rows 59.8 -> 61-62.5 %, 2 M rows and beyond unchanged.)
+    double best = -1.0;
+    k_tiles = 1;
+    kchunk = K;
+    for (int64_t kt = 1; kt <= K && kt <= 256; ++kt) {
+      int64_t kc = (K + kt - 1) / kt;
+      if (kc < 3) kc = K < 3 ? K : 3;
+      const int64_t kt2 = (K + kc - 1) / kc;
+      const int64_t items = n_ptiles * kt2;
+      const int64_t rounds = (items + resident - 1) / resident;
+      const double fill = (double)items / (double)(rounds * resident);
+      const double score = fill * (double)kc / ((double)kc + 0.7);
+      if (score > best + 1e-9) { best = score; k_tiles = kt2; kchunk = kc; }
+      if (kc <= 3) break;
+    }
+  }
   k_tiles = (K + kchunk - 1) / kchunk;
   const int64_t total = n_ptiles * k_tiles;
   if (total >= (1ll << 31)) return g;
