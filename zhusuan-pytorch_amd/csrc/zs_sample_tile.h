@@ -438,13 +438,13 @@ __device__ __forceinline__ void ksum_elem(float g, float xv, float mv, float c, 
   }
 }
 
-template <int DIST>
-__global__ __launch_bounds__(256) void k_logprob_bwd_ksum(
+template <int DIST, int NS>
+__global__ __launch_bounds__(64 * NS) void k_logprob_bwd_ksum(
     const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
     const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float4* __restrict__ gx, float4* __restrict__ gmu, float4* __restrict__ gsigma,
     int64_t K, int64_t M4, int D4, bool ls) {
-  __shared__ float4 red[2][4][64];
+  __shared__ float4 red[2][NS][64];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int64_t m4 = (int64_t)blockIdx.x * 64 + lane;
   const bool on = m4 < M4;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_logprob_bwd_ksum(
       inv[j] = (DIST == D_NORMAL && ls) ? 1.0f : 1.0f / sv[j];     // d/d logstd = sigma * d/d sigma
     }
     float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t k = slice; k < K; k += 4) {       // (unrolling by 4 was measured: 76 -> 67 % at 1 M rows, registers)
+    for (int64_t k = slice; k < K; k += NS) {      // (unrolling by 4 was measured: 76 -> 67 % at 1 M rows, registers)
       const int64_t i4 = k * M4 + m4;
       const float g = glp[k * gsk + r * gsr];
       const float4 xv = x[i4];
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void k_logprob_bwd_ksum(
   if (slice == 0 && on) {
     float4 a = red[0][0][lane], b = red[1][0][lane];
 #pragma unroll
-    for (int s = 1; s < 4; ++s) {
+    for (int s = 1; s < NS; ++s) {
       const float4 a2 = red[0][s][lane], b2 = red[1][s][lane];
       a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
       b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
@@ -523,9 +523,16 @@ inline void launch_logprob_bwd_ksum(int kid, const float* x, const float* mu, co
                    (!gmu || aligned16(gmu)) && (!gsigma || aligned16(gsigma));
   if (vec) {
     const int64_t M4 = M / 4;
-    ZS_LAUNCH(kid, (k_logprob_bwd_ksum<DIST>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), st, (const float4*)x,
-              (const float4*)mu, (const float4*)sigma, glp, gsk, gsr, (float4*)gx, (float4*)gmu, (float4*)gsigma, K, M4,
-              (int)(D / 4), ls);
+    // K-slices per workgroup: 4, or 16 when the parameter plane gives fewer than 256 workgroups (the config shapes: 40
+    // workgroups whose waves each walked 13 particles one after the other -- 7.5 us for 2.3 MB)
+    if ((M4 + 63) / 64 < 256 && K >= 16)
+      ZS_LAUNCH(kid, (k_logprob_bwd_ksum<DIST, 16>), dim3((unsigned)((M4 + 63) / 64)), dim3(1024), st, (const float4*)x,
+                (const float4*)mu, (const float4*)sigma, glp, gsk, gsr, (float4*)gx, (float4*)gmu, (float4*)gsigma, K, M4,
+                (int)(D / 4), ls);
+    else
+      ZS_LAUNCH(kid, (k_logprob_bwd_ksum<DIST, 4>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), st, (const float4*)x,
+                (const float4*)mu, (const float4*)sigma, glp, gsk, gsr, (float4*)gx, (float4*)gmu, (float4*)gsigma, K, M4,
+                (int)(D / 4), ls);
   } else {
     ZS_LAUNCH(kid, (k_logprob_bwd_ksum_serial<DIST>), dim3(grid_for(M, 256)), dim3(256), st, x, mu, sigma, glp, gsk, gsr, gx, gmu,
               gsigma, K, M, D, ls);
