@@ -412,7 +412,11 @@ inline void launch_logprob_krep(int kid, const float* x, const float* mu, const 
   if (kt < 1) kt = 1;
   if (kt > K) kt = K;
   int64_t kchunk = (K + kt - 1) / kt;
-  if (kchunk < 4) kchunk = K < 4 ? K : 4;
+  // chunks of at least 4 particles (two loop rounds of two rows in flight) -- 2 when even that leaves most wave slots empty
+  // (the config shapes: the second round of cold-cache loads is what the kernel then waits for)
+  static const int kmin_env = env_int("ZS_K2_KMIN", 0);     // experiments only
+  const int64_t kmin = kmin_env > 0 ? kmin_env : (row_tiles * ((K + 3) / 4) * 4 < slots ? 2 : 4);
+  if (kchunk < kmin) kchunk = K < kmin ? K : kmin;
   const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
   ZS_LAUNCH(kid, (k_logprob_krep<DIST>), dim3(grid_for(total, 4, 1u << 22)), dim3(256), st, (const float4*)x,
             (const float4*)mu, (const float4*)sigma, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr, ls);
