@@ -70,9 +70,13 @@ __global__ __launch_bounds__(256) void k_iw_reduce_wave(
   for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < B; b += nwaves) {
     float lq = 0.f, l = -INFINITY;
     if (on) {
+      // three loads issued together (a branch in front of the optional third would make it wait for the first two: one
+      // more cold-cache round trip inside the step); without a second term the first is simply read twice
+      const float* __restrict__ second = ext.logp_b ? ext.logp_b + b * ext.ld_b : logp + b * ld_p;
       lq = logq[b * ld_q + lane];
       float lp = logp[b * ld_p + lane];
-      if (ext.logp_b) lp += ext.logp_b[b * ext.ld_b + lane];     // (a + b) - q, rounded like the reference's add
+      const float lb = second[lane];
+      if (ext.logp_b) lp += lb;                                   // (a + b) - q, rounded like the reference's add
       l = lp - lq;
     }
     IwRow r;
