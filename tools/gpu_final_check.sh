@@ -1,5 +1,5 @@
-# Round-end GPU verification: build + smoke, the gpu test-suite, the bench line, its rocprofv3 kernel-trace summary and the
-# PMC traffic passes.  Run through gpurun from the repository root:  gpurun --timeout 2400 -- 'bash tools/gpu_final_check.sh r02'
+# Round-end GPU verification: build + smoke, the gpu test-suite, the PMC traffic passes (first: the bench line quotes them), the
+# bench line and its rocprofv3 kernel-trace summary.  Run through gpurun from the repository root:  gpurun --timeout 2400 -- 'bash tools/gpu_final_check.sh r02'
 cd "$(dirname "$0")/.." || exit 1
 ROOT=$(pwd)
 TAG=${1:-r02}
