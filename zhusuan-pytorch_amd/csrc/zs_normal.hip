@@ -287,14 +287,14 @@ __global__ __launch_bounds__(256) void k_normal_logprob_waverow(
 // K1 backward (reparameterised): thread tile = 64 parameter float4 groups x 4 K-slices,
 // K-slice partials combined through LDS.
 // ------------------------------------------------------------------------------------
-template <bool HAS_EPS, bool HAS_GZ, bool HAS_GLP>
-__global__ __launch_bounds__(256) void k_normal_sample_bwd(
+template <bool HAS_EPS, bool HAS_GZ, bool HAS_GLP, int NS>
+__global__ __launch_bounds__(64 * NS) void k_normal_sample_bwd(
     const float4* __restrict__ sigma, const float4* __restrict__ eps, uint64_t seed, uint64_t call,
     const uint64_t* __restrict__ rs, const float4* __restrict__ gz, const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float4* __restrict__ gmu, float4* __restrict__ gsigma, int64_t K, int64_t M4, int D4, bool ls) {
-  __shared__ float4 red_a[4][64];
-  __shared__ float4 red_b[4][64];
-  __shared__ float red_g[4][64];
+  __shared__ float4 red_a[NS][64];
+  __shared__ float4 red_b[NS][64];
+  __shared__ float red_g[NS][64];
   if (rs) { seed = rs[0]; call += rs[1]; }
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int64_t m4 = (int64_t)blockIdx.x * 64 + lane;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_normal_sample_bwd(
   float gl = 0.f;
   if (on && slice < K) {
     const int64_t r = (int64_t)((uint64_t)m4 >> 31 ? m4 / D4 : (int64_t)((uint32_t)m4 / (uint32_t)D4));
-    // rolling prefetch: the loads of particle k + 4 are in flight while the draw of particle k is regenerated (which
+    // rolling prefetch: the loads of particle k + NS are in flight while the draw of particle k is regenerated (which
     // operands exist is compiled in: a branch between two loads would make the second wait for the first)
     float4 gn = make_float4(0.f, 0.f, 0.f, 0.f), en = gn;
     float gln = 0.f;
@@ -313,12 +313,12 @@ __global__ __launch_bounds__(256) void k_normal_sample_bwd(
       if (HAS_GZ && HAS_EPS) en = eps[g0];
       if (HAS_GLP) gln = glp[(int64_t)slice * gsk + r * gsr];
     }
-    for (int64_t k = slice; k < K; k += 4) {
+    for (int64_t k = slice; k < K; k += NS) {
       const int64_t g = k * M4 + m4;
       const float4 gv = gn;
       float4 e = en;
       gl += gln;
-      const int64_t kn = k + 4 < K ? k + 4 : k;            // last iteration: a harmless re-read
+      const int64_t kn = k + NS < K ? k + NS : k;          // last iteration: a harmless re-read
       const int64_t gnx = kn * M4 + m4;
       if (HAS_GZ) gn = gz[gnx];
       if (HAS_GZ && HAS_EPS) en = eps[gnx];
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_normal_sample_bwd(
     float4 a = red_a[0][lane], b = red_b[0][lane];
     float g = red_g[0][lane];
 #pragma unroll
-    for (int s = 1; s < 4; ++s) {
+    for (int s = 1; s < NS; ++s) {
       const float4 a2 = red_a[s][lane], b2 = red_b[s][lane];
       a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
       b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
@@ -702,10 +702,21 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
   if (vec) {
     const int64_t M4 = M / 4;
     const unsigned grid = (unsigned)((M4 + 63) / 64);
+    // K-slices per workgroup: 4, or 16 when the parameter plane gives fewer than 256 workgroups and there are particles to
+    // share out (the config shapes inside a training step: fewer dependent rounds of cold-cache loads per wave)
+    static const int wide_env = env_int("ZS_K1_BWD_WIDE", -1);     // experiments only
+    const bool wide = wide_env >= 0 ? wide_env != 0 : (grid < 256 && K >= 16);
 #define ZS_LAUNCH_K1_BWD(E, G, L)                                                                                             \
-  ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<E, G, L>), dim3(grid), dim3(256), st, (const float4*)sigma,             \
-            (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu, (float4*)gsigma, K, M4, \
-            (int)(D / 4), ls)
+  do {                                                                                                                        \
+    if (wide)                                                                                                                 \
+      ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<E, G, L, 16>), dim3(grid), dim3(1024), st, (const float4*)sigma,  \
+                (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu, (float4*)gsigma, \
+                K, M4, (int)(D / 4), ls);                                                                                     \
+    else                                                                                                                      \
+      ZS_LAUNCH(KID_NORMAL_SAMPLE_BWD, (k_normal_sample_bwd<E, G, L, 4>), dim3(grid), dim3(256), st, (const float4*)sigma,    \
+                (const float4*)eps, seed, offset, rng_state, (const float4*)gz, glp, gsk, gsr, (float4*)gmu, (float4*)gsigma, \
+                K, M4, (int)(D / 4), ls);                                                                                     \
+  } while (0)
     if (gz) {
       if (eps) { if (glp) ZS_LAUNCH_K1_BWD(true, true, true); else ZS_LAUNCH_K1_BWD(true, true, false); }
       else     { if (glp) ZS_LAUNCH_K1_BWD(false, true, true); else ZS_LAUNCH_K1_BWD(false, true, false); }
