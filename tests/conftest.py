@@ -12,10 +12,6 @@ for p in (ROOT, PKG_ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-# the package's host-library test hook (zhusuan/_hip.py) only opens for this token; nothing else sets it
-os.environ["ZS_TESTS_HOST_LIBRARY_TOKEN"] = "tests/conftest.py:host-library"
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -33,12 +29,15 @@ def golden():
 # Kernel back-ends for product-level tests.
 #   "hip"  : the real thing -- zhusuan package + libzs_hip.so on cuda:0 (marked gpu).
 #   "host" : the SAME package code with the plain-C oracle (oracle/zs_oracle_c.c, identical C ABI,
-#            host pointers) injected through the package's test hook, so the host logic (shapes,
-#            reductions, autograd wiring, ctypes marshalling) is covered on a CPU-only machine.
+#            host pointers) patched in by tests/host_backend.py (the package has no such routing), so
+#            the host logic (shapes, reductions, autograd wiring, ctypes marshalling) is covered on a
+#            CPU-only machine.
 # ---------------------------------------------------------------------------------------------
 import subprocess
 
 import torch
+
+import host_backend
 
 # ZS_ORACLE_LIBRARY: an alternative build of the C oracle (tests/test_sanitizers.py points it at the ASan + UBSan build)
 ORACLE_SO = os.environ.get("ZS_ORACLE_LIBRARY") or os.path.join(ROOT, "oracle", "_build", "libzs_oracle.so")
@@ -69,12 +68,12 @@ def host_kernel_library():
 def dev(request):
     from zhusuan import _hip
     if request.param == "host":
-        _hip._install_host_library_for_tests(host_kernel_library())
+        host_backend.install(host_kernel_library())
         try:
             yield torch.device("cpu")
         finally:
-            _hip._install_host_library_for_tests(None)
+            host_backend.uninstall()
     else:
-        _hip._install_host_library_for_tests(None)
+        host_backend.uninstall()
         assert torch.cuda.is_available(), "gpu-marked test needs a GPU"
         yield torch.device("cuda:0")

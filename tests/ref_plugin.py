@@ -16,4 +16,5 @@ def pytest_configure(config):
     assert zhusuan.__file__.startswith(os.path.join(ROOT, "zhusuan-pytorch_amd")), zhusuan.__file__
     from zhusuan import _hip
     import conftest
-    _hip._install_host_library_for_tests(conftest.host_kernel_library())
+    import host_backend
+    host_backend.install(conftest.host_kernel_library())

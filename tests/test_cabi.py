@@ -616,17 +616,25 @@ def test_hip_f64_entry_points(hip64, orc64):
     np.testing.assert_allclose(hip64.philox(1001, 1, 2), orc64.philox(1001, 1, 2), rtol=0, atol=3e-5)
 
 
-def test_host_library_hook_is_refused_outside_pytest():
-    """The test hook that lets CPU tensors reach a kernel library must not be usable by product code: without the
-    token that tests/conftest.py puts in the environment it refuses -- even when pytest happens to be imported."""
+def test_package_has_no_host_routing():
+    """The product package holds no code that routes kernel calls anywhere but libzs_hip.so: the host back-end of this
+    test-suite is a set of monkeypatches that live in tests/host_backend.py.  A fresh interpreter that imports the
+    package (nothing from tests/) refuses CPU tensors, and the package's sources mention neither the oracle nor a hook."""
     import subprocess
     import sys as _sys
-    code = ("import sys, pytest; sys.path.insert(0, %r); from zhusuan import _hip\n"
-            "try:\n    _hip._install_host_library_for_tests(object())\n    print('INSTALLED')\n"
-            "except RuntimeError as e:\n    print('REFUSED', e)\n") % os.path.join(ROOT, "zhusuan-pytorch_amd")
-    env = {k: v for k, v in os.environ.items() if k != "ZS_TESTS_HOST_LIBRARY_TOKEN"}
-    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
-    assert "REFUSED" in r.stdout and "no CPU execution path" in r.stdout, r.stdout + r.stderr
+    pkg = os.path.join(ROOT, "zhusuan-pytorch_amd")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch, zhusuan\nfrom zhusuan import _hip\nfrom zhusuan.distributions import Normal\n"
+            "assert not hasattr(_hip, '_install_host_library_for_tests') and not hasattr(_hip, '_HOST_LIB')\n"
+            "try:\n    Normal(mean=torch.zeros(4), std=torch.ones(4)).sample()\n    print('COMPUTED')\n"
+            "except RuntimeError as e:\n    print('REFUSED', e)\n") % pkg
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in r.stdout and "no CPU path" in r.stdout, r.stdout + r.stderr
+    for dirpath, _, files in os.walk(os.path.join(pkg, "zhusuan")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower() and "host_library" not in src.lower(), os.path.join(dirpath, f)
 
 
 # ------------------------------------------------------------------ K4b: the whole IW objective in one launch

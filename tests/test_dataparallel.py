@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT, host_kernel_library
 import helpers as H
+import host_backend
 
 B, K, HID = 16, 5, 32
 
@@ -38,7 +39,7 @@ def _run_shard(rank, world, estimator):
     import zhusuan as zs
     from zhusuan import _hip, dataparallel
     from examples import iwae
-    _hip._install_host_library_for_tests(host_kernel_library())
+    host_backend.install(host_kernel_library())
     dev = torch.device("cpu")
     model = iwae.build(n_samples=K, estimator=estimator, hidden=HID, device=dev)
     if rank == 0:
@@ -67,7 +68,7 @@ def _run_shard_overlapped(rank, world, estimator, n_buckets):
     import zhusuan as zs
     from zhusuan import _hip, dataparallel
     from examples import iwae
-    _hip._install_host_library_for_tests(host_kernel_library())
+    host_backend.install(host_kernel_library())
     dev = torch.device("cpu")
     model = iwae.build(n_samples=K, estimator=estimator, hidden=HID, device=dev)
     H.load_params_into(model, 4242 if rank == 0 else 9999)
@@ -97,7 +98,7 @@ def _run_shard_staged(rank, world, estimator):
     import zhusuan as zs
     from zhusuan import _hip, dataparallel
     from examples import iwae
-    _hip._install_host_library_for_tests(host_kernel_library())
+    host_backend.install(host_kernel_library())
     model = iwae.build(n_samples=K, estimator=estimator, hidden=HID, device=torch.device("cpu"))
     H.load_params_into(model, 4242 if rank == 0 else 9999)
     dataparallel.broadcast_parameters(model, src=0)
@@ -128,7 +129,7 @@ def _run_shard_staged_update(rank, world, estimator, steps=3):
     import zhusuan as zs
     from zhusuan import _hip, dataparallel
     from examples import iwae
-    _hip._install_host_library_for_tests(host_kernel_library())
+    host_backend.install(host_kernel_library())
     model = iwae.build(n_samples=K, estimator=estimator, hidden=HID, device=torch.device("cpu"))
     H.load_params_into(model, 4242 if rank == 0 else 9999)
     dataparallel.broadcast_parameters(model, src=0)
@@ -236,7 +237,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path, estimator):
     # single process, full minibatch
     loss, flat, _ = _run_shard(0, 1, estimator)
     from zhusuan import _hip
-    _hip._install_host_library_for_tests(None)
+    host_backend.uninstall()
     assert abs(r0["loss"] - loss) <= 2e-6 * abs(loss)
     np.testing.assert_allclose(r0["flat"].numpy(), flat.numpy(), rtol=2e-4, atol=2e-6)
 
@@ -276,7 +277,7 @@ def test_overlapped_buckets_two_ranks_match_the_single_bucket(tmp_path):
     assert o0["loss"] == o1["loss"] and torch.equal(o0["flat"], o1["flat"])
     loss, flat, _ = _run_shard(0, 1, "vimco")                      # single process, full minibatch
     from zhusuan import _hip
-    _hip._install_host_library_for_tests(None)
+    host_backend.uninstall()
     assert abs(o0["loss"] - loss) <= 2e-6 * abs(loss)
     np.testing.assert_allclose(o0["flat"].numpy(), flat.numpy(), rtol=2e-4, atol=2e-6)
 
@@ -365,7 +366,7 @@ def test_staged_buckets_two_ranks_match_the_single_bucket(tmp_path, estimator):
     assert s0["loss"] == s1["loss"] and torch.equal(s0["flat"], s1["flat"])
     loss, flat, _ = _run_shard(0, 1, estimator)                    # single process, full minibatch, one bucket
     from zhusuan import _hip
-    _hip._install_host_library_for_tests(None)
+    host_backend.uninstall()
     assert abs(s0["loss"] - loss) <= 2e-6 * abs(loss)
     np.testing.assert_allclose(s0["flat"].numpy(), flat.numpy(), rtol=2e-4, atol=2e-6)
 
@@ -382,7 +383,7 @@ def test_staged_update_with_flat_adam_matches_full_batch_adam(tmp_path):
         assert torch.equal(a, b)
     losses, params = _run_shard_staged_update(0, 1, "vimco")
     from zhusuan import _hip
-    _hip._install_host_library_for_tests(None)
+    host_backend.uninstall()
     np.testing.assert_allclose(u0["losses"], losses, rtol=5e-6)
     for a, b in zip(u0["params"], params):
         # Adam normalises every gradient by its own magnitude: where a gradient is ~0 the shard-sum's rounding decides the

@@ -11,6 +11,7 @@ import torch
 
 from conftest import load_golden
 import helpers as H
+import host_backend
 import zhusuan as zs
 from examples import vae_mnist, iwae, bnn_vi
 
@@ -183,7 +184,7 @@ def test_training_reduces_loss(dev):
     """A few Adam steps on the Philox path: the surrogate goes down and stays finite."""
     torch.manual_seed(0)
     from zhusuan import _rng
-    _rng.manual_seed_host(0)
+    host_backend.manual_seed(0)
     model = iwae.build(n_samples=8, estimator="vimco", hidden=64, device=dev)
     opt = torch.optim.Adam(model.parameters(), 1e-3)
     x = (torch.rand(32, 784, generator=torch.Generator().manual_seed(1)) < 0.5).float().to(dev)

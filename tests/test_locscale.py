@@ -12,6 +12,7 @@ import torch
 from scipy import stats
 
 from conftest import load_golden, host_kernel_library
+import host_backend
 from oracle import zs_oracle as O
 from test_cabi import Raw
 from zhusuan import _hip
@@ -537,7 +538,7 @@ def test_logistic_uniform_nodes_in_a_bayesian_net(dev):
 
 def test_logistic_uniform_draw_statistics(dev):
     torch.manual_seed(3)
-    zs._rng.manual_seed_host(3)
+    host_backend.manual_seed(3)
     d = Logistic(torch.zeros(4000, 8), torch.full((4000, 8), 2.0), device=dev)
     z = d.sample(4).double()
     assert abs(float(z.mean())) < 0.05 and abs(float(z.var()) - (2.0 * np.pi) ** 2 / 3) < 0.3

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+import host_backend
 import zhusuan
 from zhusuan import dataparallel
 from zhusuan.optim import FlatAdam
@@ -137,7 +138,7 @@ def test_flat_adam_argument_errors(dev):
 def test_flat_adam_refuses_cpu_parameters_without_the_library():
     """No CPU path: parameters that are not on the GPU are refused (outside the tests' host-library hook)."""
     from zhusuan import _hip
-    _hip._install_host_library_for_tests(None)
+    host_backend.uninstall()
     with pytest.raises(RuntimeError, match="MI355X build"):
         FlatAdam(_model(torch.device("cpu")).parameters())
 

@@ -135,33 +135,14 @@ class KernelLibrary(object):
 
 
 _LIB = None          # the HIP library (lazy)
-_HOST_LIB = None     # test hook: a host-pointer implementation of the same ABI (tests/ only)
 
 
 def lib():
     """The HIP kernel library; raises loudly when it has not been built."""
     global _LIB
-    if _HOST_LIB is not None:
-        return _HOST_LIB
     if _LIB is None:
         _LIB = KernelLibrary(LIB_PATH)
     return _LIB
-
-
-HOST_LIBRARY_TOKEN_ENV = "ZS_TESTS_HOST_LIBRARY_TOKEN"
-HOST_LIBRARY_TOKEN = "tests/conftest.py:host-library"
-
-
-def _install_host_library_for_tests(klib):
-    """TESTS ONLY: route kernel calls on CPU tensors to ``klib`` (the C oracle built from
-    oracle/zs_oracle_c.c) so host logic can be exercised without a GPU.  Never called by the package, and
-    refused unless the environment carries the token that only tests/conftest.py sets (worker processes of
-    the multi-rank tests inherit it): the product has no CPU path."""
-    global _HOST_LIB
-    if klib is not None and os.environ.get(HOST_LIBRARY_TOKEN_ENV) != HOST_LIBRARY_TOKEN:
-        raise RuntimeError("zhusuan: _install_host_library_for_tests is a test hook (tests/conftest.py only); "
-                           "the MI355X build has no CPU execution path")
-    _HOST_LIB = klib
 
 
 def require_device(*tensors):
@@ -169,10 +150,6 @@ def require_device(*tensors):
     dev = None
     for t in tensors:
         if t is None:
-            continue
-        if _HOST_LIB is not None:
-            if t.device.type != "cpu":
-                raise RuntimeError("zhusuan test hook: host library installed but tensor is on %s" % t.device)
             continue
         if t.device.type != "cuda":
             raise RuntimeError(
@@ -187,9 +164,9 @@ def require_device(*tensors):
 
 
 def default_device():
-    """Where parameters given as Python numbers / lists are placed when no device is named:
-    the current HIP device (the host, only while the tests' host library is installed)."""
-    if _HOST_LIB is not None or not torch.cuda.is_available():
+    """Where parameters given as Python numbers / lists are placed when no device is named: the current HIP device
+    (the host when there is none -- the first kernel call then raises in require_device)."""
+    if not torch.cuda.is_available():
         return torch.device("cpu")
     return torch.device("cuda", torch.cuda.current_device())
 

@@ -30,7 +30,6 @@ import contextlib
 import torch
 
 _queue = None
-_host_state = {"seed": 0, "call": 0}
 
 
 @contextlib.contextmanager
@@ -97,12 +96,6 @@ def pop_injected(shape, device, dtype=torch.float32, kind="normal"):
     return e.to(device).contiguous()
 
 
-def manual_seed_host(seed):
-    """Seed of the host-side (test hook) stream; device streams follow torch.manual_seed."""
-    _host_state["seed"] = int(seed)
-    _host_state["call"] = 0
-
-
 class DeviceRNG(object):
     """Philox (seed, base offset) kept in DEVICE memory, so that sampling kernels captured in a hipGraph
     draw fresh numbers on every replay: kernels read the state themselves (``rng_state`` argument of the
@@ -151,21 +144,20 @@ def device_rng(rng):
 def next_call(device):
     """(seed, call id, device state tensor or None) for one draw on `device`."""
     if _device_rng is not None:
-        if _device_rng.device != device and not (_device_rng.device.type == device.type == "cpu"):
+        if _device_rng.device != device:
             raise RuntimeError("DeviceRNG lives on %s, draw requested on %s" % (_device_rng.device, device))
         return 0, _device_rng.next_delta(), _device_rng.state
-    s, c = _next_call_host_state(device)
+    s, c = _seed_and_call(device)
     return s, c, None
 
 
-def _next_call_host_state(device):
-    if device.type == "cuda":
-        idx = device.index if device.index is not None else torch.cuda.current_device()
-        gen = torch.cuda.default_generators[idx]
-        seed = gen.initial_seed()
-        off = gen.get_offset()
-        gen.set_offset(off + 4)
-        return seed & 0xFFFFFFFFFFFFFFFF, off // 4
-    c = _host_state["call"]
-    _host_state["call"] = c + 1
-    return _host_state["seed"] & 0xFFFFFFFFFFFFFFFF, c
+def _seed_and_call(device):
+    """(seed, call id) of the next draw from torch's generator of a HIP device: every draw consumes 4 of its offset."""
+    if device.type != "cuda":
+        raise RuntimeError("zhusuan (MI355X build): draws are made by HIP kernels and device '%s' has none (no CPU path)" % device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    seed = gen.initial_seed()
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    return seed & 0xFFFFFFFFFFFFFFFF, off // 4
