@@ -957,7 +957,69 @@ def gen_reference_tests():
     save("g_reference_tests", **out)
 
 
+def gen_error_conventions():
+    """Where the reference RAISES (and what) on unusual layouts -- the build must raise the same exception type there and
+    agree on the value everywhere else (SURVEY.md section 8b "error conventions"):
+      * ImportanceWeightedObjective.sgvb / .vimco on 1-D / 2-D / 3-D log-weights with every axis
+        (importance_weighted_objective.py:123-132,152-191: VIMCO only works for 1-D and [K, B] with axis=0);
+      * log_prob of a value with 0, 1, 2 or 3 more leading axes than the parameters for the four hand-written families
+        (normal.py:112-116, bernoulli.py:88-90, logistic.py:73-77, uniform.py:73-77: the parameters are repeated
+        x.shape[0] times, which only lines up for ONE extra axis or equal leading sizes)."""
+    from zhusuan.distributions import Logistic, Uniform
+    rng = np.random.RandomState(77)
+    out = {}
+    names, outcomes = [], []
+
+    def record(name, fn):
+        try:
+            v = fn()
+            outcomes.append("ok")
+            out[name + "_value"] = v
+        except Exception as e:                       # noqa: BLE001  (the TYPE is the datum)
+            outcomes.append(type(e).__name__)
+        names.append(name)
+
+    i = 0
+    for shape in [(7,), (3, 5), (4, 4), (4, 3, 5)]:
+        logp = (-20.0 + 2.0 * rng.standard_normal(shape)).astype(F32)
+        logq = (-5.0 + rng.standard_normal(shape)).astype(F32)
+        for axis in range(-len(shape) - 1, len(shape) + 1):
+            for est in ["sgvb", "vimco"]:
+                for reduce_mean in [True, False]:
+                    name = "iw%03d" % i
+                    out[name + "_logp"], out[name + "_logq"] = logp, logq
+                    out[name + "_axis"], out[name + "_reduce_mean"] = np.array(axis), np.array(reduce_mean)
+                    out[name + "_est"] = np.array(est)
+                    record(name, lambda: getattr(_iw(est, axis), est)(t(logp), t(logq), reduce_mean))
+                    i += 1
+    out["n_iw"] = np.array(i)
+    par_a = (0.3 * rng.standard_normal((3, 4))).astype(F32)
+    par_b = rng.uniform(0.5, 1.5, size=(3, 4)).astype(F32)
+    fams = {
+        "normal": lambda: Normal(mean=t(par_a), std=t(par_b)),
+        "bernoulli": lambda: Bernoulli(probs=t(par_b / 2.0)),
+        "logistic": lambda: Logistic(loc=t(par_a), scale=t(par_b)),
+        "uniform": lambda: Uniform(low=t(par_a - 3.0), high=t(par_b + 3.0)),
+    }
+    out["par_a"], out["par_b"] = par_a, par_b
+    j = 0
+    for fam in ["normal", "bernoulli", "logistic", "uniform"]:
+        for xs in [(3, 4), (4,), (1, 4), (2, 3, 4), (2, 1, 4), (5, 2, 3, 4), (5, 5, 3, 4), (1, 2, 3, 4), (2, 1, 3, 4),
+                   (6, 5, 2, 3, 4), (2, 2, 2, 3, 4)]:
+            x = rng.uniform(0.0, 1.0, size=xs).astype(F32)
+            if fam == "bernoulli":
+                x = (x < 0.5).astype(F32)
+            name = "lp%03d" % j
+            out[name + "_x"], out[name + "_family"] = x, np.array(fam)
+            record(name, lambda: fams[fam]().log_prob(t(x)))
+            j += 1
+    out["n_lp"] = np.array(j)
+    out["names"], out["outcomes"] = np.array(names), np.array(outcomes)
+    save("g_error_conventions", **out)
+
+
 if __name__ == "__main__":
+    gen_error_conventions()
     gen_normal()
     gen_bernoulli()
     gen_stochastic_tensor()

@@ -5,7 +5,7 @@ import torch
 from .base import Distribution
 from .utils import assert_same_log_float_dtype
 from .. import _hip, _ops, _rng
-from .._shapes import broadcast_shapes
+from .._shapes import value_shape
 
 __all__ = ['Bernoulli']
 
@@ -92,7 +92,7 @@ class Bernoulli(Distribution):
             raise RuntimeError("Bernoulli.log_prob(None) needs a cached sample: call sample() first")
         par = self._param()
         x = torch.as_tensor(x, dtype=self._dtype).to(par.device)
-        full = tuple(broadcast_shapes(x.shape, par.shape))
+        full = value_shape(x.shape, par.dim(), par.shape)
         if n_fold > len(full):
             raise ValueError("cannot sum %d trailing axes of a result of shape %s" % (n_fold, full))
         p_full = par if tuple(par.shape) == full else par.expand(full)

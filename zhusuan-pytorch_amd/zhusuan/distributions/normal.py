@@ -5,7 +5,7 @@ import torch
 from .base import Distribution
 from .utils import assert_same_log_float_dtype, check_broadcast
 from .. import _hip, _ops, _rng
-from .._shapes import broadcast_shapes
+from .._shapes import broadcast_shapes, value_shape
 
 __all__ = ['Normal']
 
@@ -137,7 +137,7 @@ class Normal(Distribution):
         if self._fused is not None and self._fused[0] is x and self._fused[2] == n_fold:
             return self._fused[1]
         x = torch.as_tensor(x, dtype=self._dtype).to(self._mean.device)
-        full = tuple(broadcast_shapes(x.shape, self._batch_shape()))
+        full = value_shape(x.shape, self._mean.dim(), self._mean.shape, self._scale_operand().shape)
         if n_fold > len(full):
             raise ValueError("cannot sum %d trailing axes of a result of shape %s" % (n_fold, full))
         px, Px = _ops.periodic_operand(x, full)

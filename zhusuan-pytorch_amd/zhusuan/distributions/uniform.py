@@ -5,7 +5,7 @@ import torch
 from .base import Distribution
 from .utils import assert_same_log_float_dtype, check_broadcast
 from .. import _hip, _ops, _rng
-from .._shapes import broadcast_shapes
+from .._shapes import broadcast_shapes, value_shape
 
 __all__ = ['Uniform']
 
@@ -109,7 +109,11 @@ class Uniform(Distribution):
             raise RuntimeError("Uniform.log_prob(None) needs a cached sample: call sample() first")
         x = torch.as_tensor(x, dtype=self._dtype).to(self._low.device)
         self._check_args()
-        full = tuple(broadcast_shapes(x.shape, self._batch_shape()))
+        try:
+            full = value_shape(x.shape, self._low.dim(), self._low.shape, self._high.shape)
+        except RuntimeError as e:
+            # torch.distributions.Uniform(_low, _high).log_prob validates the value's shape first (uniform.py:82)
+            raise ValueError("Value is not broadcastable with batch_shape+event_shape: %s" % e)
         if n_fold > len(full):
             raise ValueError("cannot sum %d trailing axes of a result of shape %s" % (n_fold, full))
         if _validating(x.device) and not bool((torch.ge(x, self._low) & torch.le(x, self._high)).all()):

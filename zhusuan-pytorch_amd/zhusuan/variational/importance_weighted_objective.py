@@ -75,16 +75,39 @@ class ImportanceWeightedObjective(nn.Module):
             return self._objective(terms_p[0], None, logqz, reduce_mean)
         return self._objective(head, terms_p[-1], logqz, reduce_mean)
 
-    def _rows(self, tensors):
+    def _rows(self, tensors, vimco=False):
         """The given log-joint tensors as K-fastest [B, K] matrices plus K and the shape of the non-particle axes.
         Tensors produced by the log-prob kernels already have this layout, so no copy happens."""
         tensors = [torch.as_tensor(t) for t in tensors]
         dev = tensors[0].device
         tensors = [t if t.device == dev else t.to(dev) for t in tensors]
         shape = broadcast_shapes(*[tuple(t.shape) for t in tensors])
-        if len(shape) == 0:
+        nd = len(shape)
+        if nd == 0:
             raise ValueError(_ERR_VIMCO)
-        axis = self._axis % len(shape)
+        if not -nd <= self._axis < nd:
+            if vimco:
+                raise ValueError(_ERR_VIMCO)       # _shape[self._axis] fails inside the reference's size check (:154-162)
+            raise IndexError("Dimension out of range (expected to be in range of [%d, %d], but got %d)"
+                             % (-nd, nd - 1, self._axis))
+        if vimco:
+            if shape[self._axis] < 2:
+                raise ValueError(_ERR_VIMCO)
+            # The reference's VIMCO (:164-186) works for a 1-D log_w and for a 2-D one whose particle axis is 0; every
+            # other layout fails there, and fails here with the same exception type: a negative axis in F.one_hot (:173),
+            # three or more axes in torch.transpose(x, *perm) (:183), [B, K] with axis=1 in the broadcast of :186 (its
+            # permutation is the identity, so the diagonal terms no longer line up; for a SQUARE log_w the reference
+            # returns a meaningless number instead of raising -- refused here as well).
+            if self._axis < 0:
+                raise RuntimeError("Class values must be non-negative.")
+            if nd >= 3:
+                raise TypeError("transpose() received an invalid combination of arguments - got (Tensor, %s), but expected "
+                                "(Tensor input, int dim0, int dim1): VIMCO supports a 1-D or [K, B] log-weight tensor "
+                                "(importance_weighted_objective.py:176-183)" % ", ".join(["Tensor"] * nd))
+            if nd == 2 and self._axis != 0:
+                raise RuntimeError("The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton "
+                                   "dimension 2: VIMCO needs the particle axis first (axis=0)" % (shape[1], shape[0]))
+        axis = self._axis % nd
         K = shape[axis]
         rest = tuple(s for i, s in enumerate(shape) if i != axis)
 
@@ -96,8 +119,8 @@ class ImportanceWeightedObjective(nn.Module):
     def _objective(self, logp_a, logp_b, logqz, reduce_mean, estimator=None):
         vimco = (estimator or self.estimator) == 'vimco'
         try:
-            mats, K, rest = self._rows([logp_a, logqz] if logp_b is None else [logp_a, logp_b, logqz])
-        except (IndexError, ZeroDivisionError):
+            mats, K, rest = self._rows([logp_a, logqz] if logp_b is None else [logp_a, logp_b, logqz], vimco)
+        except ZeroDivisionError:
             raise ValueError(_ERR_VIMCO)
         if vimco and K < 2:
             raise ValueError(_ERR_VIMCO)
