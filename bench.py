@@ -66,6 +66,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave PyTorch's default GEMM solution selection for the callers' fp32 nn.Linear stack (default: PyTorch "
                          "TunableOp picks the fastest fp32 hipBLASLt / rocBLAS solution per GEMM shape during warm-up)")
+    ap.add_argument("--allow-experiments", action="store_true",
+                    help="run although ZS_* experiment variables are set (ZS_HIP_LIBRARY: another build of the kernel library; "
+                         "ZS_K*: dispatch knobs of a -DZS_EXPERIMENTS build) or the loaded library is an experiments build; the "
+                         "line then says so (`env_overrides`, `library`).  Without the flag such a run is refused (exit code 2)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="update with torch.optim.Adam(fused=True, capturable=True) instead of zhusuan.optim.FlatAdam "
                          "(the same update over flat buckets, one launch)")
@@ -91,6 +95,26 @@ def launch_ranks(n_ranks, argv):
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
+# ZS_* variables that are this script's own test hooks (reported, never refused); every other ZS_* variable is an experiment
+_BENCH_OWN_ENV = ("ZS_BENCH_SHARE_DEVICE", "ZS_BENCH_NO_TRACER")
+
+
+def env_overrides():
+    """Every ZS_* variable set in this process's environment: the line records them all."""
+    return dict((k, v) for k, v in sorted(os.environ.items()) if k.startswith("ZS_"))
+
+
+def refuse_experiments(args):
+    """A number measured with a swapped library or dispatch knobs must not pass for the shipped configuration."""
+    bad = [k for k in env_overrides() if k not in _BENCH_OWN_ENV]
+    if bad and not args.allow_experiments:
+        sys.stderr.write("bench: refusing to run with experiment variables set (%s); unset them or pass --allow-experiments "
+                         "(the JSON line then records them)\n" % ", ".join(bad))
+        raise SystemExit(2)
+
+
+if __name__ == "__main__":
+    refuse_experiments(parse_args())
 if __name__ == "__main__" and "RANK" not in os.environ:
     _a = parse_args()
     if _a.gpus > 1:
@@ -137,6 +161,18 @@ def collective_library(share_device):
         return "RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())
     except Exception:                                               # noqa: BLE001
         return "RCCL (version unavailable)"
+
+
+def library_record(klib):
+    """Which kernel library produced the numbers: path, content hash, ABI and the library's own build description."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(klib.path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return {"path": os.path.relpath(klib.path, ROOT) if klib.path.startswith(ROOT) else klib.path, "sha256": h.hexdigest(),
+            "abi": klib.cdll.zs_abi_version(), "build": klib.build_info(),
+            "default_path": os.environ.get("ZS_HIP_LIBRARY") is None}
 
 
 def pmc_traffic(entry, fused_logits, abi_version):
@@ -265,7 +301,9 @@ def cpu_baseline(name="c3", budget_s=8.0, one_thread_budget_s=5.0, max_steps=40)
     n, dt = timed(budget_s)
     rec = {"value": evals * n / dt, "unit": "ELBO-evals/s", "cores": torch.get_num_threads(), "kind": "port",
            "ms_per_step": 1e3 * dt / n, "host_cpus_available": avail,
-           "sample": "%d full training steps (fwd+bwd+Adam) of the same workload, torch-CPU fp32 oracle, %.1f s" % (n, dt)}
+           "sample": "%d full training steps (fwd+bwd+Adam) of the same workload, torch-CPU fp32 oracle, %.1f s" % (n, dt),
+           "includes": "objective forward + backward + torch.optim.Adam update, like the GPU step it stands beside (the CPU table "
+                       "of SURVEY.md section 6 / BASELINE.md times forward + backward only: no optimizer)"}
     torch.set_num_threads(1)
     n1, dt1 = timed(one_thread_budget_s)
     rec["one_thread"] = {"value": evals * n1 / dt1, "unit": "ELBO-evals/s", "cores": 1, "ms_per_step": 1e3 * dt1 / n1,
@@ -553,6 +591,8 @@ def main():
             opt.step(grad_scale=sbuckets.grad_scale())
 
     klib = _hip.lib()
+    if "experiments" in klib.build_info() and not args.allow_experiments:
+        raise SystemExit("bench: %s is an experiments build (%s); pass --allow-experiments" % (klib.path, klib.build_info()))
     mode = "eager"
     with zhusuan.device_rng(rng):
         step = step_body
@@ -720,6 +760,7 @@ def main():
                        "timing": "median of %d trials of %d steps, each bracketed by synchronize + barrier, max over ranks"
                                  % (len(trials), args.steps)},
             "final_loss": final_loss,
+            "library": library_record(klib), "env_overrides": env_overrides(),
             **({"test_mode": "ranks share GPU 0 and reduce over gloo (ZS_BENCH_SHARE_DEVICE): control-flow test, NOT a measurement"}
                if share_device else {}),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

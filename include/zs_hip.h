@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 9
+#define ZS_ABI_VERSION 10
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -43,6 +43,11 @@ extern "C" {
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION). */
 int zs_abi_version(void);
+
+/* One line describing the loaded library: target, ABI version and whether it was built with the experiment knobs
+ * (`make EXTRA=-DZS_EXPERIMENTS`: dispatch overrides read from ZS_* environment variables).  The default build never
+ * reads the environment; bench.py refuses an experiments build unless told otherwise and records this string. */
+const char* zs_build_info(void);
 
 /* Human-readable text for a return code of any function below. */
 const char* zs_error_string(int code);
@@ -330,22 +335,26 @@ int zs_scalar_objective_f32(const float* r0, int64_t n0, double c0, const float*
  * torch.optim.Adam(model.parameters(), lr) with its defaults (reference examples variational_autoencoder/vae_mnist.py:104,
  * iwae.py:141, bayesian_neural_nets/bnn_vi.py:135: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad); this is
  * that update.  The tensors form one flat index space: tensor s covers [starts[s], starts[s+1]) and is read / written at
- * param_ptrs[s], its gradient read at grad_ptrs[s] (NULL: no gradient this step, read as zero; the gradients of a
- * data-parallel bucket are consecutive slices of one buffer, zhusuan/dataparallel.py); both moments are flat [n].
+ * param_ptrs[s], its gradient read at grad_ptrs[s]; both moments are flat [n].  A tensor whose gradient pointer is NULL
+ * has no gradient this step and is LEFT ALONE, exactly like a parameter with `grad is None` in torch.optim.Adam: its
+ * values, its moments and its step count do not change.  (The gradients of a data-parallel bucket are consecutive slices
+ * of one buffer, zhusuan/dataparallel.py: never NULL.)
  * param_ptrs, grad_ptrs (n_tensors device pointers each) and starts (n_tensors + 1 values, starts[0] = 0,
- * starts[n_tensors] = n, strictly ascending) are HOST arrays, copied into the kernel arguments.
- *   t = step[0] + 1
+ * starts[n_tensors] = n, strictly ascending) are HOST arrays, copied into the kernel arguments.  Per tensor s:
+ *   t = steps[s] + 1
  *   g = grad_scale * grad[i]                      (grad_scale: the 1/world of the gradient mean, folded into the read)
  *   m[i] += (1 - beta1) * (g - m[i]);   v[i] = beta2 * v[i] + (1 - beta2) * g * g
  *   param[i] -= lr / (1 - beta1^t) * m[i] / (sqrt(v[i]) / sqrt(1 - beta2^t) + eps)
- *   step[0] = t
- * step (int64, 1 element) is DEVICE state, so the call is hipGraph-capturable; ticket is a zero-initialised device word
- * owned by the caller (one per call that may run concurrently), handed back at zero.  More than ZS_ADAM_MAX_TENSORS
- * tensors: ZS_ENOTSUP (call once per 32). */
+ *   steps[s] = t
+ * steps (int64, n_tensors elements) is DEVICE state, so the call is hipGraph-capturable; hyper (optional) is a DEVICE
+ * array of four doubles {lr, beta1, beta2, eps} that, when given, replaces the by-value arguments -- a captured launch then
+ * follows learning-rate changes written into it between replays; ticket is a zero-initialised device word owned by the
+ * caller (one per call that may run concurrently), handed back at zero.  More than ZS_ADAM_MAX_TENSORS tensors:
+ * ZS_ENOTSUP (call once per 32). */
 #define ZS_ADAM_MAX_TENSORS 32
 int zs_adam_step_f32(float* const* param_ptrs, const float* const* grad_ptrs, const int64_t* starts, int n_tensors,
-                     float* exp_avg, float* exp_avg_sq, int64_t* step, uint32_t* ticket, int64_t n, double lr,
-                     double beta1, double beta2, double eps, double grad_scale, void* stream);
+                     float* exp_avg, float* exp_avg_sq, int64_t* steps, uint32_t* ticket, int64_t n, double lr,
+                     double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream);
 
 
 
@@ -380,7 +389,7 @@ int zs_uniform_logprob_f64(const double* x, int64_t Px, const double* low, int64
 int zs_philox_uniform_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 int zs_reinforce_f64(const double* logp, const double* logq, const double* baseline, int64_t Pb, int64_t n, int variance_reduction, int do_mean, double decay, float* moving_mean, int32_t* local_step, double* signal, double* cost, double* resid, void* stream);
 int zs_scalar_objective_f64(const double* r0, int64_t n0, double c0, const double* r1, int64_t n1, double c1, const double* r2, int64_t n2, double c2, const double* r3, int64_t n3, double c3, const double* r4, int64_t n4, double c4, const double* r5, int64_t n5, double c5, double* out, double* coef_out, void* stream);
-int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors, double* exp_avg, double* exp_avg_sq, int64_t* step, uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, void* stream);
+int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors, double* exp_avg, double* exp_avg_sq, int64_t* steps, uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Per-kernel timing for the benchmark harness (no reference counterpart).

@@ -60,6 +60,7 @@ static void philox_normal4(uint64_t group, uint64_t call, uint64_t seed, float n
   n[3] = (float)(rb * sin(two_pi * t3));
 }
 int zs_abi_version(void) { return ZS_ABI_VERSION; }
+const char* zs_build_info(void) { return "libzs_oracle: plain-C CPU restatement (test infrastructure, host pointers)"; }
 const char* zs_error_string(int code) {
   if (code == 0) return "success";
   if (code == ZS_EINVAL) return "zs(oracle): invalid argument";

@@ -28,6 +28,28 @@ def test_entry_points_exist():
     assert 'json.load(f)["metric"]' in src and "BASELINE.json" in src     # the line carries BASELINE.json's metric verbatim
 
 
+def test_bench_refuses_experiment_variables():
+    """A run with a swapped kernel library or dispatch knobs must not pass for the shipped configuration: exit code 2
+    before anything touches a GPU, unless --allow-experiments (the line then records them under env_overrides)."""
+    for var in ("ZS_K3_JC", "ZS_HIP_LIBRARY", "ZS_ADAM_GRID"):
+        env = dict(os.environ, **{var: "1"})
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "--allow-experiments" in r.stderr and var in r.stderr, (r.returncode, r.stderr[-500:])
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"library": library_record(klib)' in src and '"env_overrides": env_overrides()' in src
+
+
+def test_shipped_library_reads_no_environment():
+    """The release build of libzs_hip.so has no getenv: its dispatch depends on call arguments only."""
+    import ctypes
+    from zhusuan import _hip
+    k = _hip.KernelLibrary(_hip.LIB_PATH)
+    assert "release (no environment knobs)" in k.build_info()
+    out = subprocess.run(["nm", "-D", "--undefined-only", _hip.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in out, "libzs_hip.so imports getenv: built with -DZS_EXPERIMENTS?"
+
+
 def _run_bench(*extra):
     env = dict(os.environ)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -58,6 +80,9 @@ def test_bench_line_single_rank():
     assert rec["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     # a 6-step trial is ~7 ms: the timed region is repeated until it covers at least half a second, median reported
     assert rec["trials"] >= 3 and rec["timed_seconds_total"] >= 0.45
+    lib = rec["library"]
+    assert lib["abi"] == 10 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
+    assert lib["path"].endswith("lib/libzs_hip.so") and rec["env_overrides"] == {}
     assert rec["trial_ms_per_step"]["min"] <= rec["ms_per_step"] <= rec["trial_ms_per_step"]["max"]
     assert roof["traffic_source"] is None or roof["traffic_source"]["measured_in_this_run"] is False
     # the same kernels on working sets beyond the Infinity Cache, measured in this run

@@ -27,14 +27,15 @@ def declared_symbols():
 
 def test_header_symbols_exported_by_both_libraries():
     names = declared_symbols()
-    assert len(names) == 56 and set(_hip.PROTOTYPES) <= set(names)
+    assert len(names) == 57 and set(_hip.PROTOTYPES) <= set(names)
     hip = ctypes.CDLL(_hip.LIB_PATH)           # loads without a GPU; no compute call is made here
     orc = ctypes.CDLL(build_oracle_lib())
     for n in names:
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 9
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 10
+    assert "release (no environment knobs)" in k.build_info() and "ABI 10" in k.build_info()
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 
@@ -199,10 +200,14 @@ def test_c_oracle_normal_golden(orc):
     g = load_golden("g_normal_sample")
     for c in range(int(g["n_cases"])):
         p = "c%03d_" % c
-        if int(g[p + "g"]) == 0:
-            continue
         K = max(int(g[p + "K"]), 1)
         mu, sd, eps = g[p + "mu"], g[p + "sd"], g[p + "eps"]
+        if mu.shape != sd.shape:        # the kernels take same-shape operands; other broadcasts are expanded by the caller
+            full = np.broadcast_shapes(mu.shape, sd.shape)
+            eps = np.broadcast_to(eps.reshape((K,) + (1,) * (len(full) - mu.ndim) + mu.shape) if eps.ndim > mu.ndim else
+                                  eps.reshape((1,) * (len(full) - mu.ndim) + mu.shape), ((K,) if eps.ndim > mu.ndim else ()) + full)
+            mu, sd = np.ascontiguousarray(np.broadcast_to(mu, full)), np.ascontiguousarray(np.broadcast_to(sd, full))
+            eps = np.ascontiguousarray(eps)
         D = int(np.prod(mu.shape[mu.ndim - int(g[p + "g"]):]))
         out = orc.normal_sample(mu.ravel(), sd.ravel(), eps.ravel(), K, D)
         assert np.array_equal(out["z"].reshape(g[p + "z"].shape), g[p + "z"])
@@ -777,21 +782,28 @@ def _adam_run(raw, sizes, steps, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, gs=1.0, mi
         return raw.t(np.concatenate([[0.0], a]))[1:] if misalign else raw.t(a)
     ps = [tensor(rng.standard_normal(k)) for k in sizes]
     m, v = raw.t(np.zeros(n)), raw.t(np.zeros(n))
-    step = torch.zeros(1, dtype=torch.int64, device=raw.dev)
+    step = torch.zeros(len(sizes), dtype=torch.int64, device=raw.dev)
     ticket = torch.zeros(1, dtype=torch.int32, device=raw.dev)
     pptr = (ctypes.c_void_p * len(sizes))(*[p.data_ptr() for p in ps])
+    hyper = torch.tensor([lr, b1, b2, eps], dtype=torch.float64, device=raw.dev)
     for s in range(steps):
         scale = 10.0 ** rng.uniform(-4, 1)
         gs_ = [tensor(rng.standard_normal(k) * scale) for k in sizes]
-        gptr = (ctypes.c_void_p * len(sizes))(*[None if i in missing else g.data_ptr() for i, g in enumerate(gs_)])
-        raw.call("zs_adam_step_f32", pptr, gptr, starts, len(sizes), m, v, step, ticket, n, lr, b1, b2, eps, gs)
-    assert int(step.item()) == steps and int(ticket.item()) == 0
+        # `missing` tensors have no gradient on the ODD steps only: their moments are non-zero when they are skipped
+        gptr = (ctypes.c_void_p * len(sizes))(*[None if (i in missing and s % 2 == 1) else g.data_ptr() for i, g in enumerate(gs_)])
+        if s % 3 == 2:     # hyper-parameters from device memory (the by-value ones are then ignored)
+            raw.call("zs_adam_step_f32", pptr, gptr, starts, len(sizes), m, v, step, ticket, n, 7.0, 0.1, 0.2, 3.0, gs, hyper)
+        else:
+            raw.call("zs_adam_step_f32", pptr, gptr, starts, len(sizes), m, v, step, ticket, n, lr, b1, b2, eps, gs, None)
+    want = [steps - (steps // 2 if i in missing else 0) for i in range(len(sizes))]
+    assert step.cpu().tolist() == want and int(ticket.item()) == 0
     return torch.cat(ps).cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()
 
 
 def test_c_oracle_adam_is_torch_adam(orc, orc64):
     """The oracle's A1 against torch.optim.Adam itself (defaults; the callers' optimizer: vae_mnist.py:104, iwae.py:141,
-    bnn_vi.py:135), same gradients, 7 steps, three tensors of which one never receives a gradient."""
+    bnn_vi.py:135), same gradients, 7 steps, three tensors: one never receives a gradient, one misses it on steps 2 and 5
+    (``grad is None``: torch leaves such a parameter, its moments and its step count alone -- with non-zero moments)."""
     for raw, dt, tol in ((orc, torch.float32, 3e-6), (orc64, torch.float64, 1e-13)):
         rng = np.random.RandomState(3)
         sizes = [1001, 40, 7]
@@ -800,34 +812,36 @@ def test_c_oracle_adam_is_torch_adam(orc, orc64):
         ps = [raw.t(w.detach().numpy().copy()) for w in ws]
         n = sum(sizes)
         m, v = raw.t(np.zeros(n)), raw.t(np.zeros(n))
-        step, ticket = torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int32)
+        step, ticket = torch.zeros(3, dtype=torch.int64), torch.zeros(1, dtype=torch.int32)
         starts = (ctypes.c_int64 * 4)(0, 1001, 1041, 1048)
         pptr = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in ps])
         for s in range(7):
             gs = [rng.standard_normal(k) * (10.0 ** rng.uniform(-4, 1)) for k in sizes]
-            for w, g in zip(ws[:2], gs[:2]):
-                w.grad = torch.tensor(g, dtype=dt)
+            skip1 = s in (2, 5)
+            ws[0].grad = torch.tensor(gs[0], dtype=dt)
+            ws[1].grad = None if skip1 else torch.tensor(gs[1], dtype=dt)
             opt.step()
             gt = [raw.t(g) for g in gs]
-            gptr = (ctypes.c_void_p * 3)(gt[0].data_ptr(), gt[1].data_ptr(), None)
-            raw.call("zs_adam_step_f32", pptr, gptr, starts, 3, m, v, step, ticket, n, 2e-3, 0.9, 0.999, 1e-8, 1.0)
+            gptr = (ctypes.c_void_p * 3)(gt[0].data_ptr(), None if skip1 else gt[1].data_ptr(), None)
+            raw.call("zs_adam_step_f32", pptr, gptr, starts, 3, m, v, step, ticket, n, 2e-3, 0.9, 0.999, 1e-8, 1.0, None)
             for p, w in zip(ps, ws):
                 np.testing.assert_allclose(p.numpy(), w.detach().numpy(), rtol=tol, atol=tol * 1e-2)
-        assert int(step.item()) == 7
+        assert step.tolist() == [7, 5, 0]
+        assert [int(opt.state[w]["step"]) if w in opt.state and opt.state[w] else 0 for w in ws] == [7, 5, 0]
     p = orc.t(np.zeros(8))
     one = (ctypes.c_void_p * 1)(p.data_ptr())
     two = (ctypes.c_void_p * 2)(p.data_ptr(), p.data_ptr())
     ok = (ctypes.c_int64 * 2)(0, 8)
     with pytest.raises(RuntimeError, match="code -1"):
-        orc.call("zs_adam_step_f32", one, one, ok, 1, p, p, step, ticket, 8, 1e-3, 1.0, 0.999, 1e-8, 1.0)      # beta1 = 1
+        orc.call("zs_adam_step_f32", one, one, ok, 1, p, p, step, ticket, 8, 1e-3, 1.0, 0.999, 1e-8, 1.0, None)      # beta1 = 1
     with pytest.raises(RuntimeError, match="code -1"):
-        orc.call("zs_adam_step_f32", one, one, ok, 1, p, p, None, ticket, 8, 1e-3, 0.9, 0.999, 1e-8, 1.0)     # no step counter
+        orc.call("zs_adam_step_f32", one, one, ok, 1, p, p, None, ticket, 8, 1e-3, 0.9, 0.999, 1e-8, 1.0, None)     # no step counter
     with pytest.raises(RuntimeError, match="code -1"):                                                          # does not end at n
-        orc.call("zs_adam_step_f32", two, two, (ctypes.c_int64 * 3)(0, 4, 7), 2, p, p, step, ticket, 8, 1e-3, 0.9, 0.999, 1e-8, 1.0)
+        orc.call("zs_adam_step_f32", two, two, (ctypes.c_int64 * 3)(0, 4, 7), 2, p, p, step, ticket, 8, 1e-3, 0.9, 0.999, 1e-8, 1.0, None)
     many = (ctypes.c_void_p * 33)(*([p.data_ptr()] * 33))
     with pytest.raises(RuntimeError, match="code -2"):                     # more than ZS_ADAM_MAX_TENSORS
         orc.call("zs_adam_step_f32", many, many, (ctypes.c_int64 * 34)(*range(34)), 33, orc.t(np.zeros(33)), orc.t(np.zeros(33)),
-                 step, ticket, 33, 1e-3, 0.9, 0.999, 1e-8, 1.0)
+                 step, ticket, 33, 1e-3, 0.9, 0.999, 1e-8, 1.0, None)
 
 
 @pytest.mark.gpu

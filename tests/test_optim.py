@@ -44,7 +44,7 @@ def test_flat_adam_equals_torch_adam(dev, dtype, tol):
     _train(b, opt, x, 8)
     for p, q in zip(a.parameters(), b.parameters()):
         np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=tol, atol=tol * 1e-1)
-    assert int(opt.buckets[0].step.item()) == 8
+    assert opt.buckets[0].step.tolist() == [8] * len(list(b.parameters()))
     assert where == [p.data_ptr() for p in b.parameters()], "parameters are updated where they live"
 
 
@@ -106,16 +106,64 @@ def test_flat_adam_many_parameters_take_several_launches(dev):
         np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
-def test_flat_adam_missing_gradient_counts_as_zero(dev):
-    m = _model(dev, seed=3)
-    frozen_before = copy.deepcopy(m[4].weight.detach())
-    opt = FlatAdam(m.parameters(), lr=1e-2)
+def test_flat_adam_leaves_parameters_without_a_gradient_alone(dev):
+    """torch.optim.Adam skips a parameter whose ``grad is None``: no moment decay, no movement, its own step count does
+    not advance.  Alternating training of two parameter subsets (non-zero moments when a tensor is skipped) must therefore
+    equal torch.optim.Adam exactly, step for step."""
+    a, b = _model(dev, seed=3), _model(dev, seed=3)
+    ref, opt = torch.optim.Adam(a.parameters(), lr=1e-2), FlatAdam(b.parameters(), lr=1e-2)
     x = torch.randn(4, 7, device=dev)
-    opt.zero_grad()
-    (m[2](torch.relu(m[0](x))) ** 2).sum().backward()      # the last layer receives no gradient
-    opt.step()
-    assert torch.equal(m[4].weight.detach(), frozen_before)
-    assert not torch.equal(m[0].weight.detach(), _model(dev, seed=3)[0].weight.detach())
+    for it in range(6):
+        for m, o in ((a, ref), (b, opt)):
+            o.zero_grad(set_to_none=True)
+            if it % 2 == 0:
+                _loss(m, x).backward()                                # every parameter
+            else:
+                (m[2](torch.relu(m[0](x))) ** 2).sum().backward()     # the last layer receives no gradient
+            o.step()
+        for p, q in zip(a.parameters(), b.parameters()):
+            np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=5e-6, atol=5e-7)
+    assert opt.buckets[0].step.tolist() == [6, 6, 6, 6, 3, 3]
+    assert [int(ref.state[p]["step"]) for p in a.parameters()] == [6, 6, 6, 6, 3, 3]
+
+
+def test_flat_adam_param_groups_schedulers_and_checkpoints(dev):
+    """param_groups is persistent (the `for g in opt.param_groups: g['lr'] = ...` idiom and torch's schedulers act on the
+    update), state_dict / load_state_dict resume a run exactly."""
+    a, b = _model(dev, seed=6), _model(dev, seed=6)
+    x = torch.randn(5, 7, device=dev)
+    ref, opt = torch.optim.Adam(a.parameters(), lr=1e-2), FlatAdam(b.parameters(), lr=1e-2)
+    assert opt.param_groups is opt.param_groups and opt.param_groups[0]["lr"] == 1e-2
+    sa = torch.optim.lr_scheduler.StepLR(ref, step_size=2, gamma=0.5)
+    for it in range(5):
+        _train(a, ref, x, 1)
+        sa.step()
+        _train(b, opt, x, 1)
+        if it % 2 == 1:
+            for g in opt.param_groups:
+                g["lr"] = g["lr"] * 0.5
+    assert opt.param_groups[0]["lr"] == ref.param_groups[0]["lr"] == opt.lr
+    for p, q in zip(a.parameters(), b.parameters()):
+        np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=5e-6, atol=5e-7)
+    # checkpoint, continue, and resume a copy from the checkpoint: same parameters
+    ck = opt.state_dict()
+    params_at_ck = [q.detach().clone() for q in b.parameters()]
+    _train(b, opt, x, 3)
+    c = _model(dev, seed=6)
+    with torch.no_grad():
+        for q, v in zip(c.parameters(), params_at_ck):
+            q.copy_(v)
+    opt_c = FlatAdam(c.parameters(), lr=123.0)
+    opt_c.load_state_dict(ck)
+    assert opt_c.lr == opt.lr and opt_c.buckets[0].step.tolist() == [5] * 6
+    _train(c, opt_c, x, 3)
+    for p, q in zip(b.parameters(), c.parameters()):
+        assert torch.equal(p.detach(), q.detach())
+    with pytest.raises(ValueError, match="another parameter layout"):
+        FlatAdam([torch.nn.Parameter(torch.zeros(3, device=dev))]).load_state_dict(ck)
+    with pytest.raises(ValueError, match="invalid hyper-parameters"):
+        opt.lr = -1.0
+        opt.step()
 
 
 def test_flat_adam_argument_errors(dev):
@@ -161,10 +209,38 @@ def test_flat_adam_in_a_graphed_step():
         return loss.detach()
 
     step = zhusuan.GraphedStep(compute, eb.step, warmup=3, restore=True)
-    assert int(eb.buckets[0].step.item()) == 0
+    assert eb.buckets[0].step.tolist() == [0] * 6
     for _ in range(6):
         step()
     torch.cuda.synchronize()
-    assert int(eb.buckets[0].step.item()) == 6
+    assert eb.buckets[0].step.tolist() == [6] * 6
+    for p, q in zip(a.parameters(), b.parameters()):
+        np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_graphed_flat_adam_follows_learning_rate_changes():
+    """lr / betas / eps are read from device memory by the captured launch: changing param_groups between replays acts."""
+    dev = torch.device("cuda:0")
+    a, b = _model(dev, seed=8), _model(dev, seed=8)
+    x = torch.randn(16, 7, device=dev)
+    ea, eb = FlatAdam(a.parameters(), lr=2e-3), FlatAdam(b.parameters(), lr=2e-3)
+
+    def compute():
+        for p in b.parameters():
+            p.grad = None
+        loss = _loss(b, x)
+        loss.backward()
+        return loss.detach()
+
+    step = zhusuan.GraphedStep(compute, eb.step, warmup=3, restore=True)
+    for it in range(6):
+        if it == 3:
+            ea.lr = 5e-4
+            for g in eb.param_groups:
+                g["lr"] = 5e-4
+        _train(a, ea, x, 1)
+        step()
+    torch.cuda.synchronize()
     for p, q in zip(a.parameters(), b.parameters()):
         np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)

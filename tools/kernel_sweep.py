@@ -119,14 +119,14 @@ def main():
         n_par = sum(sizes)
         a_p, a_g = [torch.randn(k, device=dev) for k in sizes], [torch.randn(k, device=dev) for k in sizes]
         a_m, a_v = torch.zeros(n_par, device=dev), torch.zeros(n_par, device=dev)
-        a_step = torch.zeros(1, dtype=torch.int64, device=dev)
+        a_step = torch.zeros(len(sizes), dtype=torch.int64, device=dev)
         a_ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         a_pp = (ctypes.c_void_p * len(sizes))(*[t.data_ptr() for t in a_p])
         a_gp = (ctypes.c_void_p * len(sizes))(*[t.data_ptr() for t in a_g])
         a_st = (ctypes.c_int64 * (len(sizes) + 1))(*([sum(sizes[:i]) for i in range(len(sizes))] + [n_par]))
         timed("A1 adam step", "zs_adam_step_f32", 28 * n_par,
               lambda: lib.call("zs_adam_step_f32", a_pp, a_gp, a_st, len(sizes), P(a_m), P(a_v), P(a_step), P(a_ticket), n_par, 1e-3,
-                               0.9, 0.999, 1e-8, 1.0, st), "n=%d in %d tensors" % (n_par, len(sizes)))
+                               0.9, 0.999, 1e-8, 1.0, None, st), "n=%d in %d tensors" % (n_par, len(sizes)))
         del a_p, a_g, a_m, a_v
         # ---------------- K3: X = 784 (--x-dim: experiments on the row length)
         X = args.x_dim

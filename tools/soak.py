@@ -28,6 +28,6 @@ for kind in ("iwae", "vae", "bnn"):
     with zhusuan.device_rng(rng):
         for i in range(300): compute(); opt.step()
     torch.cuda.synchronize()
-    steps_seen = [int(b.step.item()) for b in opt.buckets]
+    steps_seen = [b.step.tolist() for b in opt.buckets]
     print(kind, "adam step counters", steps_seen, "tickets", [int(b.ticket.item()) for b in opt.buckets])
     print(kind, "loss %.2f -> %.2f" % (l0, float(last)), "ms/step %.4f" % (1e3 * dt / 5000), "mem delta %d B" % (torch.cuda.memory_allocated() - m0), "finite", bool(torch.isfinite(last)))

@@ -43,38 +43,46 @@ __device__ __forceinline__ int tensor_of(const Tensors<T>& ts, int64_t i) {
 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __restrict__ m, T* __restrict__ v,
-                                                    int64_t* __restrict__ step, unsigned* __restrict__ ticket, int64_t n, double lr,
-                                                    double beta1, double beta2, double eps, double grad_scale) {
-  // bias corrections, once per workgroup, the two powers on two waves; beta^t by squaring (<= 62 double multiplies)
-  __shared__ T consts[2];   // lr / bc1, 1 / sqrt(bc2)
-  if (threadIdx.x == 0 || threadIdx.x == 64) {
-    int64_t t = step[0] + 1;
-    double b = threadIdx.x == 0 ? beta1 : beta2, pw = 1.0;
+                                                    int64_t* __restrict__ steps, unsigned* __restrict__ ticket, int64_t n, double lr,
+                                                    double beta1, double beta2, double eps, double grad_scale,
+                                                    const double* __restrict__ hyper) {
+  // Per-TENSOR step counts (torch.optim.Adam keeps one per parameter and leaves a parameter without a gradient alone:
+  // no moment decay, no movement, no step).  Bias corrections once per workgroup: thread 2s forms lr / (1 - beta1^t_s),
+  // thread 2s + 1 forms 1 / sqrt(1 - beta2^t_s); beta^t by squaring (<= 62 double multiplies).  A workgroup has at least
+  // 64 threads = 2 * ZS_ADAM_MAX_TENSORS (checked on the host).
+  __shared__ T c_step[ZS_ADAM_MAX_TENSORS], c_isq[ZS_ADAM_MAX_TENSORS];
+  if (hyper) { lr = hyper[0]; beta1 = hyper[1]; beta2 = hyper[2]; eps = hyper[3]; }     // device-resident: graph replays see updates
+  if ((int)threadIdx.x < 2 * ts.n_tensors) {
+    const int s = threadIdx.x >> 1;
+    int64_t t = steps[s] + 1;
+    double b = (threadIdx.x & 1) ? beta2 : beta1, pw = 1.0;
     for (; t > 0; t >>= 1, b *= b)
       if (t & 1) pw *= b;
-    if (threadIdx.x == 0) consts[0] = (T)(lr / (1.0 - pw));
-    else consts[1] = (T)(1.0 / sqrt(1.0 - pw));
+    if (threadIdx.x & 1) c_isq[s] = (T)(1.0 / sqrt(1.0 - pw));
+    else c_step[s] = (T)(lr / (1.0 - pw));
   }
   __syncthreads();
-  const T step_size = consts[0], inv_sqrt_bc2 = consts[1];
   const T b1w = (T)(1.0 - beta1), b2 = (T)beta2, b2w = (T)(1.0 - beta2), e = (T)eps, gs = (T)grad_scale;
   const int64_t groups = (n + 3) >> 2;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i0 = g << 2;
     const int cnt = n - i0 < 4 ? (int)(n - i0) : 4;
-    T pp[4], gg[4], mm[4], vv[4];
+    T pp[4], gg[4], mm[4], vv[4], ss[4], iq[4];
+    bool live[4];
     T* pdst[4];
     if (VEC) {
       // every tensor starts at a multiple of 4 and is 16-byte aligned (checked on the host): one tensor per group
       const int s = tensor_of(ts, i0);
+      if (!ts.grad[s]) continue;                       // no gradient this step: the tensor is left alone
       const int64_t off = i0 - ts.start[s];
       pdst[0] = ts.param[s] + off;
       const Vec4<T> a = *reinterpret_cast<const Vec4<T>*>(pdst[0]), c = *reinterpret_cast<const Vec4<T>*>(m + i0),
-                    d = *reinterpret_cast<const Vec4<T>*>(v + i0);
-      Vec4<T> b = {{(T)0, (T)0, (T)0, (T)0}};
-      if (ts.grad[s]) b = *reinterpret_cast<const Vec4<T>*>(ts.grad[s] + off);
+                    d = *reinterpret_cast<const Vec4<T>*>(v + i0), b = *reinterpret_cast<const Vec4<T>*>(ts.grad[s] + off);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { pp[j] = a.v[j]; gg[j] = b.v[j]; mm[j] = c.v[j]; vv[j] = d.v[j]; }
+      for (int j = 0; j < 4; ++j) {
+        pp[j] = a.v[j]; gg[j] = b.v[j]; mm[j] = c.v[j]; vv[j] = d.v[j];
+        ss[j] = c_step[s]; iq[j] = c_isq[s]; live[j] = true;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -83,7 +91,9 @@ __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __re
         const int64_t off = i - ts.start[s];
         pdst[j] = ts.param[s] + off;
         pp[j] = *pdst[j]; mm[j] = m[i]; vv[j] = v[i];
+        live[j] = j < cnt && ts.grad[s] != nullptr;
         gg[j] = ts.grad[s] ? ts.grad[s][off] : (T)0;
+        ss[j] = c_step[s]; iq[j] = c_isq[s];
       }
     }
 #pragma unroll
@@ -91,8 +101,8 @@ __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __re
       const T gr = gs * gg[j];
       mm[j] = mm[j] + b1w * (gr - mm[j]);                      // exp_avg.lerp_(grad, 1 - beta1)
       vv[j] = b2 * vv[j] + b2w * (gr * gr);                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-      const T denom = sqrt(vv[j]) * inv_sqrt_bc2 + e;          // sqrt(v) / sqrt(bc2) + eps
-      pp[j] = pp[j] - step_size * (mm[j] / denom);             // param.addcdiv_(exp_avg, denom, -lr / bc1)
+      const T denom = sqrt(vv[j]) * iq[j] + e;                 // sqrt(v) / sqrt(bc2) + eps
+      pp[j] = pp[j] - ss[j] * (mm[j] / denom);                 // param.addcdiv_(exp_avg, denom, -lr / bc1)
     }
     if (VEC) {
       Vec4<T> a, c, d;
@@ -104,26 +114,31 @@ __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __re
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < cnt) { *pdst[j] = pp[j]; m[i0 + j] = mm[j]; v[i0 + j] = vv[j]; }
+        if (live[j]) { *pdst[j] = pp[j]; m[i0 + j] = mm[j]; v[i0 + j] = vv[j]; }
     }
   }
-  // Every workgroup has read step[0] -- the value has come back and gone into `consts` -- before it takes its ticket, and
-  // the last one to take a ticket publishes the new count.  Relaxed atomics on purpose: an agent-scope release here is an
-  // L2 write-back per workgroup (the XCDs' L2s are not coherent with each other): 56 instead of 20 us for a 1 315-workgroup
-  // launch over the VAE / IWAE parameters; nothing but the ticket itself is communicated between workgroups.
+  // Every workgroup has read the step counts -- the values have come back and gone into LDS -- before it takes its
+  // ticket, and the last one to take a ticket publishes the new counts.  Relaxed atomics on purpose: an agent-scope
+  // release here is an L2 write-back per workgroup (the XCDs' L2s are not coherent with each other): 56 instead of 20 us
+  // for a 1 315-workgroup launch over the VAE / IWAE parameters; nothing but the ticket itself is communicated between
+  // workgroups.
   __syncthreads();
+  __shared__ unsigned last;
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {
-      step[0] = step[0] + 1;
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    last = (t == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last) {
+    if ((int)threadIdx.x < ts.n_tensors && ts.grad[threadIdx.x]) steps[threadIdx.x] += 1;
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 template <typename T>
 int adam_step(T* const* param_ptrs, const T* const* grad_ptrs, const int64_t* starts, int n_tensors, T* m, T* v, int64_t* step,
-              uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, void* stream) {
+              uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale,
+              const double* hyper, void* stream) {
   if (n < 0 || !(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return ZS_EINVAL;
   if (n_tensors < 1 || !param_ptrs || !grad_ptrs || !starts) return ZS_EINVAL;
   if (n_tensors > ZS_ADAM_MAX_TENSORS) return ZS_ENOTSUP;
@@ -147,16 +162,16 @@ int adam_step(T* const* param_ptrs, const T* const* grad_ptrs, const int64_t* st
   // 6-10 ns each.  Measured for the 1.35 M parameters of the VAE / IWAE models (37.7 MB, one flat tensor): 1 315 workgroups
   // of 256 threads 19.3 us, 512 x 256: 11.1, 512 x 1024: 8.6, 256 x 1024 (one per CU): 7.6-7.9 us = 60 % of the HBM
   // roofline; 5.2 M parameters: 80 %; 168 M parameters: 1024 x 1024 73 % against 67 % with 256.
-  static const int grid_env = getenv("ZS_ADAM_GRID") ? atoi(getenv("ZS_ADAM_GRID")) : 0;      // experiments only
-  static const int block_env = getenv("ZS_ADAM_BLOCK") ? atoi(getenv("ZS_ADAM_BLOCK")) : 0;
-  const unsigned block = block_env > 0 ? (unsigned)block_env : 1024u;
+  static const int grid_env = env_knob("ZS_ADAM_GRID", 0);      // experiments only (zs_common.h)
+  static const int block_env = env_knob("ZS_ADAM_BLOCK", 0);
+  const unsigned block = block_env >= 64 ? (unsigned)block_env : 1024u;      // >= 2 * ZS_ADAM_MAX_TENSORS threads (bias corrections)
   const unsigned grid = grid_for((n + 3) / 4, (int)block, grid_env > 0 ? (unsigned)grid_env : (n > (int64_t(1) << 24) ? 1024u : 256u));
   if (vec)
     ZS_LAUNCH(KID_ADAM, (k_adam_step<T, true>), dim3(grid), dim3(block), (hipStream_t)stream, ts, m, v, step, (unsigned*)ticket, n,
-              lr, beta1, beta2, eps, grad_scale);
+              lr, beta1, beta2, eps, grad_scale, hyper);
   else
     ZS_LAUNCH(KID_ADAM, (k_adam_step<T, false>), dim3(grid), dim3(block), (hipStream_t)stream, ts, m, v, step, (unsigned*)ticket, n,
-              lr, beta1, beta2, eps, grad_scale);
+              lr, beta1, beta2, eps, grad_scale, hyper);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -165,13 +180,13 @@ int adam_step(T* const* param_ptrs, const T* const* grad_ptrs, const int64_t* st
 
 extern "C" int zs_adam_step_f32(float* const* param_ptrs, const float* const* grad_ptrs, const int64_t* starts, int n_tensors,
                                 float* exp_avg, float* exp_avg_sq, int64_t* step, uint32_t* ticket, int64_t n, double lr,
-                                double beta1, double beta2, double eps, double grad_scale, void* stream) {
+                                double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream) {
   return adam_step<float>(param_ptrs, grad_ptrs, starts, n_tensors, exp_avg, exp_avg_sq, step, ticket, n, lr, beta1, beta2, eps,
-                          grad_scale, stream);
+                          grad_scale, hyper, stream);
 }
 extern "C" int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors,
                                 double* exp_avg, double* exp_avg_sq, int64_t* step, uint32_t* ticket, int64_t n, double lr,
-                                double beta1, double beta2, double eps, double grad_scale, void* stream) {
+                                double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream) {
   return adam_step<double>(param_ptrs, grad_ptrs, starts, n_tensors, exp_avg, exp_avg_sq, step, ticket, n, lr, beta1, beta2, eps,
-                           grad_scale, stream);
+                           grad_scale, hyper, stream);
 }

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_bern_sample(const float* __restrict__ p
 // chunk that still gives every resident wave slot (256 CUs x 32) about sixteen items, divides J with little waste
 // (equal items), and is at least 4 rows so that the observation row in registers is amortised.
 inline int64_t pick_jc(int64_t J, int64_t xrows) {
-  static const int jc_env = getenv("ZS_K3_JC") ? atoi(getenv("ZS_K3_JC")) : 0;     // experiments only
+  static const int jc_env = env_knob("ZS_K3_JC", 0);     // experiments only
   if (jc_env > 0) return jc_env < J ? jc_env : J;
   const int64_t target = 256ll * 32 * 16;
   for (int64_t jc = J < 4096 ? J : 4096; jc >= 1; --jc) {     // (bounded host loop; chunks beyond 4096 rows gain nothing)
@@ -465,7 +465,7 @@ int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* pro
         // p is read once: non-temporal loads leave L2 to the observation rows that ARE re-used.  Measured (probs form) from
         // 160 MB to 13.4 GB of p: 69 -> 74, 67 -> 74, 69 -> 73, 67 -> 72, 65 -> 74, 68 -> 82 % of the roofline; the logits form
         // gains 0-6 points.  (The backward, which also writes a stream, only gains beyond 4 GB: see launch_bwd.)
-        static const int ntl_env = getenv("ZS_K3_NTLOAD") ? atoi(getenv("ZS_K3_NTLOAD")) : -1;     // experiments only
+        static const int ntl_env = env_knob("ZS_K3_NTLOAD", -1);     // experiments only
         const bool ntl = ntl_env >= 0 ? ntl_env != 0 : true;
 #define ZS_LAUNCH_FWD_X(W, UU, L)                                                                                          \
   ZS_LAUNCH(kid, (k_bern_logprob_xreuse<LOGITS, W, UU, L>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, \
@@ -518,16 +518,16 @@ int launch_bwd(const float* p, const float* x, int64_t Px, const float* glp, int
     const int kid = LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD;
     const int64_t rows = K * R, xrows = Px / D;
     const int64_t J = rows / xrows;
-    static const int nt_env = getenv("ZS_K3_NT") ? atoi(getenv("ZS_K3_NT")) : -1;     // experiments only
+    static const int nt_env = env_knob("ZS_K3_NT", -1);     // experiments only
     const bool nt = nt_env >= 0 ? nt_env != 0 : (double)N * 4.0 > 268435456.0;
-    static const int xr_env = getenv("ZS_K3_XREUSE") ? atoi(getenv("ZS_K3_XREUSE")) : 1;     // experiments only
-    static const int cap_env = getenv("ZS_K3_GRIDCAP") ? atoi(getenv("ZS_K3_GRIDCAP")) : 4096;
+    static const int xr_env = env_knob("ZS_K3_XREUSE", 1);     // experiments only
+    static const int cap_env = env_knob("ZS_K3_GRIDCAP", 4096);
     if (xr_env && D4 >= 64 && D4 <= 256 && J >= 2 && rows > 32768) {
       const int64_t JC = pick_jc(J, xrows);
       const unsigned grid = grid_for_items(xrows * ((J + JC - 1) / JC));
-      static const int u_env = getenv("ZS_K3_BWD_U") ? atoi(getenv("ZS_K3_BWD_U")) : 0;     // experiments only
+      static const int u_env = env_knob("ZS_K3_BWD_U", 0);     // experiments only
       const bool two = u_env ? u_env == 2 : rows >= 400000;
-      static const int ntl_env = getenv("ZS_K3_NTLOAD") ? atoi(getenv("ZS_K3_NTLOAD")) : -1;     // experiments only
+      static const int ntl_env = env_knob("ZS_K3_NTLOAD", -1);     // experiments only
       const bool ntl = ntl_env >= 0 ? ntl_env != 0 : (double)N * 4.0 > 4294967296.0;
 #define ZS_LAUNCH_BWD_X(T, UU, L)                                                                                      \
   ZS_LAUNCH(kid, (k_bern_logprob_bwd_xreuse<LOGITS, T, UU, L>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, \

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define ZS_WAVE 64
@@ -18,6 +19,21 @@
   } while (0)
 
 namespace zs {
+
+// ---------------------------------------------------------------- experiment knobs
+// The SHIPPED library never reads the environment: dispatch depends on the arguments of a call and on nothing else.  The
+// ZS_* knobs that kernel experiments use (tools/) exist only in a library built with
+// `make EXTRA=-DZS_EXPERIMENTS`; zs_build_info() of a loaded library says which kind it is, and bench.py records it.
+#ifdef ZS_EXPERIMENTS
+inline int env_knob(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+#define ZS_BUILD_KIND "experiments (reads ZS_* environment knobs)"
+#else
+constexpr int env_knob(const char*, int dflt) { return dflt; }
+#define ZS_BUILD_KIND "release (no environment knobs)"
+#endif
 
 // ---------------------------------------------------------------- launch + optional per-kernel timing
 // One id per C-ABI entry point.  When profiling is enabled (zs_prof_enable) a launch goes through
@@ -214,6 +230,14 @@ ZS_HD uint32_t uniform_u32(uint32_t v) {
 // scalar-unit work, and the second round still has one uniform counter word.  Those two rounds are therefore written as
 // plain C (the compiler keeps uniform values in SGPRs: one v_mad_u64_u32 and three plain xors instead of two
 // multiplies and two three-input xors fed by v_mov copies); rounds 3..10 use the one-instruction three-input xor.
+//
+// CONTRACT: `call` and `seed` must be WAVE-UNIFORM (the same value on all 64 lanes; every caller passes launch-wide
+// constants or values read from the 2-word rng_state); only `group` may differ between lanes.  The readfirstlane pins
+// below would otherwise take lane 0's value for the whole wave -- on the GPU only: the host build and the C oracle have
+// no such instruction, so a per-lane `call` / `seed` would pass every CPU test and still draw wrong numbers on the
+// device.  On the GPU every entry point that draws is compared with the oracle (tests/test_cabi.py::test_hip_rng,
+// ::test_hip_normal_sample_and_backward, ::test_hip_device_rng_state; tests/test_locscale.py::test_hip_logistic_sample_and_backward,
+// ::test_hip_uniform_sample).
 ZS_HD Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) {
   uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32);
   uint32_t c2 = (uint32_t)call, c3 = (uint32_t)(call >> 32);

@@ -381,7 +381,7 @@ static int iw_launch(int kid, const float* logp, int64_t ld_p, const float* logq
   if (!logp || !logq) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   // K <= 64 and enough datapoints to fill the chip with fewer lanes per datapoint: the lane-group kernel
-  static const int lpr_env = [] { const char* v = getenv("ZS_K4_LPR"); return (v && *v) ? atoi(v) : -1; }();
+  static const int lpr_env = env_knob("ZS_K4_LPR", -1);      // experiments only (zs_common.h)
   // measured at K = 50 (tools/kernel_sweep.py, VIMCO): B = 20 971: wave kernel 14.3 us, 16 lanes 11.8, 8 lanes 11.1, 4 lanes
   // 13.9; B = 83 886: 46.6 / 33.5 / 31.2 / 33.6 us (the precise exp / log1p / divisions of the particles set the pace from
   // there); B = 2 621: launch floor either way
@@ -600,7 +600,10 @@ extern "C" int64_t zs_prof_durations(int kernel_id, double* out_ms, int64_t capa
   return n;
 }
 
+#define ZS_STR_(x) #x
+#define ZS_STR(x) ZS_STR_(x)
 extern "C" int zs_abi_version(void) { return ZS_ABI_VERSION; }
+extern "C" const char* zs_build_info(void) { return "libzs_hip gfx950 ABI " ZS_STR(ZS_ABI_VERSION) ", " ZS_BUILD_KIND; }
 
 extern "C" const char* zs_error_string(int code) {
   if (code == 0) return "success";

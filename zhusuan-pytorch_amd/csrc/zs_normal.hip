@@ -617,7 +617,7 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
     const float4 *m4 = (const float4*)mu, *s4 = (const float4*)sigma, *e4 = (const float4*)eps;
     const K1Tile kt_ = eps ? K1Tile() : k1_tile(K, R, D4, lp != nullptr);
     if (kt_.ok) {
-      static const int nt_env = env_int("ZS_K1_NT", -1);
+      static const int nt_env = env_knob("ZS_K1_NT", -1);
       const bool nt = nt_env >= 0 ? nt_env != 0 : (double)K * (double)M * 4.0 > 268435456.0;   // z cannot stay in the Infinity Cache
 #define ZS_LAUNCH_TILE(L, T)                                                                                  \
   ZS_LAUNCH_SMEM(KID_NORMAL_SAMPLE, (k_sample_tile<D_NORMAL, L, T>), dim3(kt_.grid), dim3(kt_.threads), kt_.smem, st, \
@@ -641,7 +641,7 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
 #define ZS_LAUNCH_SMALL(E, L, T)                                                                          \
   ZS_LAUNCH(KID_NORMAL_SAMPLE, (k_normal_sample_smallrow<E, L, T>), dim3(grid), dim3(256), st, m4, s4, e4, \
             seed, offset, rng_state, (float4*)z, lp, K, R, D4, rm.G, rm.rpw, kchunk, sk, sr, ls, rng_used)
-      static const int nt_env2 = env_int("ZS_K1_NT", -1);
+      static const int nt_env2 = env_knob("ZS_K1_NT", -1);
       const bool nt = nt_env2 >= 0 ? nt_env2 != 0 : (double)K * (double)M * 4.0 > 268435456.0;   // z cannot stay in the Infinity Cache
       if (nt) {
         if (eps) { if (lp) ZS_LAUNCH_SMALL(true, true, true); else ZS_LAUNCH_SMALL(true, false, true); }
@@ -704,7 +704,7 @@ extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float*
     const unsigned grid = (unsigned)((M4 + 63) / 64);
     // K-slices per workgroup: 4, or 16 when the parameter plane gives fewer than 256 workgroups and there are particles to
     // share out (the config shapes inside a training step: fewer dependent rounds of cold-cache loads per wave)
-    static const int wide_env = env_int("ZS_K1_BWD_WIDE", -1);     // experiments only
+    static const int wide_env = env_knob("ZS_K1_BWD_WIDE", -1);     // experiments only
     const bool wide = wide_env >= 0 ? wide_env != 0 : (grid < 256 && K >= 16);
 #define ZS_LAUNCH_K1_BWD(E, G, L)                                                                                             \
   do {                                                                                                                        \

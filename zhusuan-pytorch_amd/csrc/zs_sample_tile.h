@@ -210,14 +210,10 @@ struct K1Tile {
   uint32_t kchunk, KB, n_ptiles, total;
 };
 inline int64_t gcd64(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
-inline int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 inline K1Tile k1_tile(int64_t K, int64_t R, int D4, bool want_lp) {   // (K1Tile: named after its first user)
   K1Tile g = {};
   // experiments: ZS_K1_TILE=0 disables the kernel, ZS_K1_KB / ZS_K1_ITEMS override the heuristics below
-  static const int enable = env_int("ZS_K1_TILE", 1), kb_env = env_int("ZS_K1_KB", 0), items_env = env_int("ZS_K1_ITEMS", 0);
+  static const int enable = env_knob("ZS_K1_TILE", 1), kb_env = env_knob("ZS_K1_KB", 0), items_env = env_knob("ZS_K1_ITEMS", 0);
   if (!enable || D4 < 1 || D4 > 64) return g;
   const int64_t M4 = R * (int64_t)D4;
   if (M4 >= (1ll << 28) || K >= (1ll << 31)) return g;                 // lane offsets are 32-bit byte offsets
@@ -277,7 +273,7 @@ inline K1Tile k1_tile(int64_t K, int64_t R, int D4, bool want_lp) {   // (K1Tile
   // one work item per workgroup: the hardware dispatcher hands out items as slots free up, which balances the CUs to
   // within one item (a fixed grid striding over the items leaves workgroups with floor/ceil(items / grid) of them --
   // 2 vs 3 at the 1 M-row sweep point: 71 % efficiency).  The stride loop in the kernel only serves grids beyond the cap.
-  static const int grid_env = env_int("ZS_K1_GRID", 0);
+  static const int grid_env = env_knob("ZS_K1_GRID", 0);
   const int64_t cap = grid_env > 0 ? grid_env : (1ll << 20);
   g.grid = (unsigned)(total < cap ? total : cap);
   return g;
@@ -414,7 +410,7 @@ inline void launch_logprob_krep(int kid, const float* x, const float* mu, const 
   int64_t kchunk = (K + kt - 1) / kt;
   // chunks of at least 4 particles (two loop rounds of two rows in flight) -- 2 when even that leaves most wave slots empty
   // (the config shapes: the second round of cold-cache loads is what the kernel then waits for)
-  static const int kmin_env = env_int("ZS_K2_KMIN", 0);     // experiments only
+  static const int kmin_env = env_knob("ZS_K2_KMIN", 0);     // experiments only
   const int64_t kmin = kmin_env > 0 ? kmin_env : (row_tiles * ((K + 3) / 4) * 4 < slots ? 2 : 4);
   if (kchunk < kmin) kchunk = K < kmin ? K : kmin;
   const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);

@@ -13,9 +13,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments); default: the in-tree library
+# The in-tree library.  ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments: tools/); bench.py
+# records which file was loaded (path, sha256, zs_build_info) and refuses an override unless --allow-experiments is given.
 LIB_PATH = os.environ.get("ZS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -52,9 +53,9 @@ PROTOTYPES = {
     "zs_iw_objective_f32": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _i64, _p, _p],
     # scalar ELBO epilogue: six (rows, n, coef) slots, out, coef_out, stream
     "zs_scalar_objective_f32": [_p, _i64, ctypes.c_double] * 6 + [_p, _p, _p],
-    # Adam update: param_ptrs, grad_ptrs, starts (host arrays), n_tensors, exp_avg, exp_avg_sq, step, ticket, n, lr, beta1,
-    # beta2, eps, grad_scale, stream
-    "zs_adam_step_f32": [_p, _p, _p, _int, _p, _p, _p, _p, _i64] + [ctypes.c_double] * 5 + [_p],
+    # Adam update: param_ptrs, grad_ptrs, starts (host arrays), n_tensors, exp_avg, exp_avg_sq, steps, ticket, n, lr, beta1,
+    # beta2, eps, grad_scale, hyper (device, optional), stream
+    "zs_adam_step_f32": [_p, _p, _p, _int, _p, _p, _p, _p, _i64] + [ctypes.c_double] * 5 + [_p, _p],
 }
 ADAM_MAX_TENSORS = 32      # ZS_ADAM_MAX_TENSORS of include/zs_hip.h
 
@@ -78,6 +79,8 @@ class KernelLibrary(object):
         self.cdll.zs_abi_version.argtypes = []
         self.cdll.zs_error_string.restype = ctypes.c_char_p
         self.cdll.zs_error_string.argtypes = [_int]
+        self.cdll.zs_build_info.restype = ctypes.c_char_p
+        self.cdll.zs_build_info.argtypes = []
         got = self.cdll.zs_abi_version()
         if got != ABI_VERSION:
             raise RuntimeError("zhusuan: %s has ABI version %d, expected %d" % (path, got, ABI_VERSION))
@@ -93,6 +96,10 @@ class KernelLibrary(object):
         self.cdll.zs_prof_kernel_id.argtypes = [ctypes.c_char_p]
         self.cdll.zs_prof_query.restype = _int
         self.cdll.zs_prof_query.argtypes = [_int] + [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.POINTER(_i64)]
+
+    def build_info(self):
+        """The library's own one-line description (target, ABI, release / experiments build)."""
+        return self.cdll.zs_build_info().decode()
 
     def prof_durations(self, entry_point):
         """Durations (ms, launch order) of the launches recorded for `entry_point`."""

@@ -237,6 +237,8 @@ class StagedBuckets(object):
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             self.stages.append({"params": params, "flat": flat, "views": views, "n": n, "handle": None})
+        self._loss_factor = 1.0
+        self._holds_sum = False          # the buckets hold the all-reduced SUM and the 1/world was left to the optimizer
         seen = set()
         for st in self.stages:
             for p in st["params"]:
@@ -249,6 +251,7 @@ class StagedBuckets(object):
         return dist.get_world_size(self.group) if active else 1
 
     def zero(self):
+        self._holds_sum = False
         for st in self.stages:
             st["handle"] = None
             for p in st["params"]:
@@ -259,6 +262,12 @@ class StagedBuckets(object):
         bucket i.  All but the last stage keep the autograd graph alive for the stages that follow."""
         st = self.stages[i]
         last = i == len(self.stages) - 1
+        if self._holds_sum and any(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                                   for p, v in zip(st["params"], st["views"])):
+            # after scale(gradients=False) every p.grad aliases the all-reduced SUM of the last step: accumulating this
+            # step's gradients onto it would feed world-times-too-large stale values into the next all-reduce
+            raise RuntimeError("zhusuan.dataparallel.StagedBuckets: the buckets hold last step's all-reduced SUM "
+                               "(scale(gradients=False)); call zero() before the next backward")
         torch.autograd.backward(loss, inputs=st["params"], retain_graph=not last)
         _fill_flat(st["flat"], st["params"], st["views"], [loss] if i == 0 else [])
         for p, v in zip(st["params"], st["views"]):
@@ -279,14 +288,25 @@ class StagedBuckets(object):
     def scale(self, gradients=True):
         """1/world.  ``gradients=False``: the optimizer applies the factor itself while it reads the gradients
         (``zhusuan.optim.FlatAdam.step(grad_scale=buckets.grad_scale())``) -- no pass over the buckets; only the objective's
-        slot is scaled, when ``loss()`` reads it."""
+        slot is scaled, when ``loss()`` reads it.  In that mode every ``p.grad`` keeps aliasing the all-reduced SUM (world
+        times the mean): anything else that reads ``p.grad`` afterwards (clipping, logging, another optimizer) must use
+        ``mean_gradients()``, and the next backward needs ``zero()`` first (checked).  (``_loss_factor`` depends only on the
+        world size, so setting it from inside a captured stage is the same on every replay.)"""
         w = self._world()
         self._loss_factor = 1.0
         if w > 1:
             if gradients:
                 torch._foreach_mul_([st["flat"] for st in self.stages], 1.0 / w)
+                self._holds_sum = False
             else:
                 self._loss_factor = 1.0 / w
+                self._holds_sum = True
+
+    def mean_gradients(self):
+        """[(parameter, mean gradient)] whatever the scaling mode: the bucket views themselves after ``scale()``, scaled
+        copies after ``scale(gradients=False)``."""
+        f = self.grad_scale() if self._holds_sum else 1.0
+        return [(p, v if f == 1.0 else v * f) for st in self.stages for p, v in zip(st["params"], st["views"])]
 
     def grad_scale(self):
         """The factor that turns the all-reduced SUM into the mean (1 with a single rank)."""
@@ -294,7 +314,7 @@ class StagedBuckets(object):
 
     def loss(self):
         v = self.stages[0]["flat"][self.stages[0]["n"]]
-        f = getattr(self, "_loss_factor", 1.0)
+        f = self._loss_factor
         return v if f == 1.0 else v * f
 
     def nbytes(self):

@@ -74,6 +74,7 @@ class GraphedStep(object):
         if optimizer is None and optimizer_step is not None and hasattr(optimizer_step, '__self__') and \
                 hasattr(optimizer_step.__self__, 'param_groups'):
             optimizer = optimizer_step.__self__
+        self._optimizer = optimizer
         params = list(parameters) if parameters is not None else (
             [p for g in optimizer.param_groups for p in g['params']] if optimizer is not None else [])
         saved_params = saved_state = saved_rng = None
@@ -137,6 +138,9 @@ class GraphedStep(object):
 
     def __call__(self):
         """Replay the recorded step; returns the (static) loss tensor of this step."""
+        sync = getattr(self._optimizer, 'sync_hyperparameters', None)
+        if sync is not None:
+            sync()              # zhusuan.optim.FlatAdam: upload lr / betas / eps if the caller changed them (a 4-float compare)
         if self._exchange is None:
             self.graphs[0].replay()
             return self._static_loss
@@ -163,9 +167,12 @@ class GraphedStages(object):
     launched eagerly it is an ordinary stream-ordered operation).  All graphs share one memory pool: later stages read
     what earlier ones produced (the autograd graph of the forward pass lives across the stage boundary, so the first
     backward stage must keep it: ``retain_graph=True``).  Warm-up, capture stream and thread-local capture mode as for
-    ``GraphedStep``.  The value returned by the FIRST graph stage is the step's (static) loss tensor."""
+    ``GraphedStep``; so is ``restore`` (with ``optimizer`` / ``parameters``): the warm-up passes are real training steps,
+    and with ``restore=True`` parameters, optimizer state and the RNG state are put back after the last capture, so that
+    constructing the object has no side effect on training.  The value returned by the FIRST graph stage is the step's
+    (static) loss tensor."""
 
-    def __init__(self, stages, rng=None, warmup=3):
+    def __init__(self, stages, rng=None, warmup=3, restore=False, optimizer=None, parameters=None):
         if not torch.cuda.is_available():
             raise RuntimeError("zhusuan.GraphedStages needs a HIP device: the MI355X build has no CPU path")
         kinds = [k for k, _ in stages]
@@ -175,6 +182,16 @@ class GraphedStages(object):
         self._rng = rng
         self._plan = []
         self._static_loss = None
+        self._optimizer = optimizer
+        params = list(parameters) if parameters is not None else (
+            [p for g in optimizer.param_groups for p in g['params']] if optimizer is not None else [])
+        if restore and not params:
+            raise ValueError("GraphedStages(restore=True) needs `optimizer` or `parameters` to know what to put back")
+        saved_params = saved_state = saved_rng = None
+        if restore:
+            saved_params = [p.detach().clone() for p in params]
+            saved_state = dict((key, t.detach().clone()) for key, t in _optimizer_state_tensors(optimizer))
+            saved_rng = (rng.state.clone(), rng._delta) if rng is not None else None
 
         def eager_pass():
             first = None
@@ -207,6 +224,19 @@ class GraphedStages(object):
                 self._plan.append(g)
                 torch.cuda.synchronize()
         self.graphs = [g for g in self._plan if isinstance(g, torch.cuda.CUDAGraph)]
+        if restore:
+            with torch.no_grad():
+                for p, sp in zip(params, saved_params):
+                    p.copy_(sp)
+                for key, t in _optimizer_state_tensors(optimizer):
+                    if key in saved_state:
+                        t.copy_(saved_state[key])
+                    else:
+                        t.zero_()
+                if saved_rng is not None:
+                    rng.state.copy_(saved_rng[0])
+                    rng._delta = saved_rng[1]
+            torch.cuda.synchronize()
 
     def _rng_scope(self):
         if self._rng is not None:
@@ -215,6 +245,9 @@ class GraphedStages(object):
         return contextlib.nullcontext()
 
     def __call__(self):
+        sync = getattr(self._optimizer, 'sync_hyperparameters', None)
+        if sync is not None:
+            sync()
         for item in self._plan:
             if isinstance(item, torch.cuda.CUDAGraph):
                 item.replay()
