@@ -360,6 +360,99 @@ int zs_adam_step_f32(float* const* param_ptrs, const float* const* grad_ptrs, co
 
 
 /* ---------------------------------------------------------------------------
+ * LJ1  The scalar log-joint objective in ONE launch (forward) and ONE launch (backward).
+ * For objectives whose nodes all reduce to scalars (the VAE and BNN callers) the reference evaluates one log-prob per
+ * node in a Python loop -- ELBO.log_joint, zhusuan/variational/elbo.py:58-79, over StochasticTensor.log_prob,
+ * zhusuan/framework/stochastic_tensor.py:160-181 (dist.log_prob, mean / sum over the reduce dims, multiplier) -- and
+ * combines them in ELBO.sgvb (elbo.py:155-161).  Every such node contributes  coef_t * sum_i logprob_t(i)  with
+ * coef_t = -+ multiplier / prod(sizes of the mean axes); this call evaluates ALL terms and their weighted sum:
+ *     out[0] = sum_t coef_t * sum_{i < n_t} term_t(i)
+ *   ZS_LJ_ROWS              term(i) = x[i]                      values that exist already (the log q rows K1 produced)
+ *   ZS_LJ_NORMAL            term(i) = -0.5*log(2*pi) - log(b) - 0.5*exp(-2*log(b))*(x - a)^2      (normal.py:109-126)
+ *   ZS_LJ_NORMAL_LOGSTD     the same with b = exp(given b)                                         (normal.py:56)
+ *   ZS_LJ_BERNOULLI         term(i) = x*log(a + 1e-8) + (1 - x)*log((1 - a) + 1e-8)                (bernoulli.py:84-95)
+ *   ZS_LJ_BERNOULLI_LOGITS  the same with a = sigmoid(given a)                                     (bernoulli.py:50)
+ * Operands are periodic (x[i % px], a[i % pa], b[i % pb]; every period divides n).  `terms` is a HOST array, copied
+ * into the kernel arguments.  Sums are accumulated per thread in the operands' precision over <= 16 elements, from there
+ * on in double, and combined in a fixed order (per-workgroup partials in `workspace`, the last workgroup -- found with
+ * `ticket`, a zero-initialised device word handed back at zero -- adds them by index): deterministic.
+ * workspace: >= ZS_LJ_WORKSPACE doubles.
+ *
+ * Backward (zs_logjoint_scalar_bwd): with g = gout[0] (DEVICE scalar: the incoming gradient of out) every requested
+ * gradient in one launch --  gx / ga / gb (px / pa / pb elements; NULL = not wanted) = g * coef * d term / d operand, summed
+ * over the repeats of a periodic operand (in index order: deterministic).  For ZS_LJ_NORMAL_LOGSTD gb is d/d log std;
+ * for the Bernoulli families gx (the observation) is not provided (ZS_ENOTSUP); ZS_LJ_ROWS terms have no outputs here:
+ * their gradient is the scalar gcoef[t] = g * coef_t, written for every term (gcoef: n_terms values, optional).
+ * -------------------------------------------------------------------------*/
+#define ZS_LJ_MAX_TERMS 8
+#define ZS_LJ_WORKSPACE 8192
+#define ZS_LJ_ROWS 0
+#define ZS_LJ_NORMAL 1
+#define ZS_LJ_NORMAL_LOGSTD 2
+#define ZS_LJ_BERNOULLI 3
+#define ZS_LJ_BERNOULLI_LOGITS 4
+typedef struct zs_lj_term {
+  int32_t family;            /* ZS_LJ_* */
+  int32_t reserved;
+  int64_t n;                 /* elements of the term's full (broadcast) problem */
+  const void* x; int64_t px; /* value; ZS_LJ_ROWS: the values to add up */
+  const void* a; int64_t pa; /* mean / probs / logits (unused by ZS_LJ_ROWS) */
+  const void* b; int64_t pb; /* std or log std (Normal families only) */
+  double coef;
+  void* gx; void* ga; void* gb;   /* backward only */
+} zs_lj_term;
+int zs_logjoint_scalar_f32(const zs_lj_term* terms, int n_terms, float* out, double* workspace, int64_t workspace_len,
+                           uint32_t* ticket, void* stream);
+int zs_logjoint_scalar_bwd_f32(const zs_lj_term* terms, int n_terms, const float* gout, float* gcoef, double* workspace,
+                               int64_t workspace_len, uint32_t* ticket, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * MS1  K1 for SEVERAL Normal nodes in one launch: the variational net of a model with more than one latent node (the
+ * BNN's weight matrices, bnn_vi.py:83-93) draws them one after the other in the reference (ELBO.forward re-reads every
+ * node's .tensor, elbo.py:122); here all of them are one launch forward and one backward.  Per term exactly
+ * zs_normal_sample_logprob / _bwd (same formulas, same Philox stream: term t draws with call id  base + terms[t].offset,
+ * group = flat index / 4), meant for the launch-bound small shapes (a wavefront per row; use K1 for a single large node).
+ * `terms` is a HOST array.  rng_state / rng_used: as for K1, shared by all terms ({seed, base}).
+ * Backward: gz / glp (either may be NULL) -> gmu, gsigma per term (reparameterised nodes: normal.py:104-105).
+ * -------------------------------------------------------------------------*/
+#define ZS_MS_MAX_TERMS 8
+typedef struct zs_ms_term {
+  const void* mu; const void* sigma; const void* eps;  /* [M], [M], [K, M] or NULL (in-kernel Philox) */
+  void* z; void* lp;                                   /* [K, M]; row results (NULL: sample only) */
+  int64_t K, M, D, lp_stride_k, lp_stride_r;
+  uint64_t offset;                                     /* call id of this node's draw, relative to the base */
+  int32_t sigma_is_logstd;
+  int32_t reserved;
+  const void* gz; const void* glp;                     /* backward only */
+  int64_t glp_stride_k, glp_stride_r;
+  void* gmu; void* gsigma;
+} zs_ms_term;
+int zs_normal_sample_logprob_multi_f32(const zs_ms_term* terms, int n_terms, uint64_t seed, const uint64_t* rng_state,
+                                       uint64_t* rng_used, void* stream);
+int zs_normal_sample_logprob_multi_bwd_f32(const zs_ms_term* terms, int n_terms, uint64_t seed, const uint64_t* rng_state,
+                                           void* stream);
+
+/* ---------------------------------------------------------------------------
+ * PL1  The particle-batched dense layer of the BNN caller (reference
+ * examples/bayesian_neural_nets/bnn_vi.py:27-48): every particle k has its own weight matrix w[k] = [n_out, n_in + 1]
+ * whose last column is the bias.  The reference repeats w over the batch (a 115 MB copy at config 5), appends a column
+ * of ones to h, multiplies, divides by sqrt(n_in + 1) and applies ReLU -- five whole-tensor ops; this is one kernel:
+ *     out[k, b, o] = act( ( sum_{i < n_in} h[k, b, i] * w[k, o, i]  +  w[k, o, n_in] ) / sqrt(n_in + 1) )
+ * h is [K, B, n_in] (h_stride_k = B * n_in) or shared by the particles, [B, n_in] (h_stride_k = 0: the first layer's
+ * input x, which the reference repeats K times, bnn_vi.py:27).  relu != 0: act = max(., 0), else identity.
+ * n_in <= 255, n_out <= 256 (a particle's weights are staged in LDS); larger layers: ZS_ENOTSUP (use a batched GEMM).
+ * Backward, one launch:  gpre = gout * (out > 0) [relu],
+ *     gh[k, b, i] = sum_o gpre[k, b, o] * w[k, o, i] / sqrt(n_in + 1)          (optional; [K, B, n_in] also when h is shared:
+ *                                                                                the caller sums over k if it needs d/dx)
+ *     gw[k, o, i] = sum_b gpre[k, b, o] * h[k, b, i] / sqrt(n_in + 1),   gw[k, o, n_in] = sum_b gpre[k, b, o] / sqrt(n_in + 1)
+ * -------------------------------------------------------------------------*/
+int zs_particle_linear_f32(const float* h, int64_t h_stride_k, const float* w, float* out,
+                           int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, void* stream);
+int zs_particle_linear_bwd_f32(const float* h, int64_t h_stride_k, const float* w, const float* out, const float* gout,
+                               float* gh, float* gw, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu,
+                               void* stream);
+
+/* ---------------------------------------------------------------------------
  * float64 twins.  The reference accepts float64 parameters for Normal / Bernoulli
  * (zhusuan/distributions/utils.py:5,57-64); every entry point above exists with the suffix _f64,
  * identical argument meaning, double* instead of float*.  They are plain (untuned) kernels: none of the
@@ -389,6 +482,12 @@ int zs_uniform_logprob_f64(const double* x, int64_t Px, const double* low, int64
 int zs_philox_uniform_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 int zs_reinforce_f64(const double* logp, const double* logq, const double* baseline, int64_t Pb, int64_t n, int variance_reduction, int do_mean, double decay, float* moving_mean, int32_t* local_step, double* signal, double* cost, double* resid, void* stream);
 int zs_scalar_objective_f64(const double* r0, int64_t n0, double c0, const double* r1, int64_t n1, double c1, const double* r2, int64_t n2, double c2, const double* r3, int64_t n3, double c3, const double* r4, int64_t n4, double c4, const double* r5, int64_t n5, double c5, double* out, double* coef_out, void* stream);
+int zs_logjoint_scalar_f64(const zs_lj_term* terms, int n_terms, double* out, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
+int zs_logjoint_scalar_bwd_f64(const zs_lj_term* terms, int n_terms, const double* gout, double* gcoef, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
+int zs_normal_sample_logprob_multi_f64(const zs_ms_term* terms, int n_terms, uint64_t seed, const uint64_t* rng_state, uint64_t* rng_used, void* stream);
+int zs_normal_sample_logprob_multi_bwd_f64(const zs_ms_term* terms, int n_terms, uint64_t seed, const uint64_t* rng_state, void* stream);
+int zs_particle_linear_f64(const double* h, int64_t h_stride_k, const double* w, double* out, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, void* stream);
+int zs_particle_linear_bwd_f64(const double* h, int64_t h_stride_k, const double* w, const double* out, const double* gout, double* gh, double* gw, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, void* stream);
 int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors, double* exp_avg, double* exp_avg_sq, int64_t* steps, uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------

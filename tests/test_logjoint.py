@@ -1,0 +1,517 @@
+"""The one-launch pieces for the launch-bound configurations (include/zs_hip.h: LJ1 scalar log-joint objective, MS1 fused
+sampling of several Normal nodes, PL1 particle-batched dense layer).
+
+not gpu : the C oracle against float64 truths computed with torch on the same inputs (and, for PL1, against the
+          reference caller's own op sequence: repeat + cat + matmul + div + relu);
+gpu     : libzs_hip.so against the C oracle through raw ABI calls -- every family, full / scalar / periodic operands,
+          aligned and unaligned, empty and ragged, up to 2^20 elements, float32 and float64.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import host_kernel_library
+from zhusuan import _hip
+
+LJ = _hip
+
+
+class Raw(object):
+    def __init__(self, klib, device, dtype=torch.float32):
+        self.k, self.dev, self.dtype = klib, torch.device(device), dtype
+        self.sfx = "_f32" if dtype == torch.float32 else "_f64"
+
+    def t(self, a):
+        if a is None:
+            return None
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=self.dtype).to(self.dev)
+
+    def stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream) if self.dev.type == "cuda" else None
+
+    def sync(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    # ---- LJ1.  terms: list of dicts(family, x, a, b, coef, n, want=(gx, ga, gb))
+    def _table(self, terms, grads=None):
+        tab = (_hip.LJTerm * len(terms))()
+        keep = []
+        for i, tm in enumerate(terms):
+            e = tab[i]
+            e.family, e.n, e.coef = tm["family"], tm["n"], tm["coef"]
+            for name, pname in (("x", "px"), ("a", "pa"), ("b", "pb")):
+                v = tm.get(name)
+                if v is not None:
+                    tv = self.t(v)
+                    if tm.get("misalign"):
+                        tv = torch.cat([tv.new_zeros(1), tv.reshape(-1)])[1:]
+                    keep.append(tv)
+                    setattr(e, name, tv.data_ptr())
+                    setattr(e, pname, tv.numel())
+                else:
+                    setattr(e, pname, 1)
+            if grads is not None:
+                for j, (name, pname) in enumerate((("gx", "px"), ("ga", "pa"), ("gb", "pb"))):
+                    if tm.get("want", (False,) * 3)[j]:
+                        gt = torch.full((getattr(e, pname) + 1,), float("nan"), dtype=self.dtype, device=self.dev)[1:] \
+                            if tm.get("misalign") else torch.full((getattr(e, pname),), float("nan"), dtype=self.dtype, device=self.dev)
+                        grads[(i, j)] = gt
+                        setattr(e, name, gt.data_ptr())
+        return tab, keep
+
+    def lj_fwd(self, terms):
+        tab, keep = self._table(terms)
+        out = torch.full((1,), float("nan"), dtype=self.dtype, device=self.dev)
+        ws = torch.zeros(_hip.LJ_WORKSPACE, dtype=torch.float64, device=self.dev)
+        ticket = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        for _ in range(2):          # twice: the ticket must have been handed back at zero
+            self.k.call("zs_logjoint_scalar" + self.sfx, ctypes.byref(tab), len(terms), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                        _hip.ptr(ticket), self.stream())
+        self.sync()
+        assert int(ticket.item()) == 0
+        return float(out.item())
+
+    def lj_bwd(self, terms, g):
+        grads = {}
+        tab, keep = self._table(terms, grads)
+        gout = self.t(np.array([g]))
+        gcoef = torch.full((len(terms),), float("nan"), dtype=self.dtype, device=self.dev)
+        ws = torch.zeros(_hip.LJ_WORKSPACE, dtype=torch.float64, device=self.dev)
+        ticket = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        for _ in range(2):
+            self.k.call("zs_logjoint_scalar_bwd" + self.sfx, ctypes.byref(tab), len(terms), _hip.ptr(gout), _hip.ptr(gcoef),
+                        _hip.ptr(ws), ws.numel(), _hip.ptr(ticket), self.stream())
+        self.sync()
+        assert int(ticket.item()) == 0
+        return dict((k, v.cpu().numpy()) for k, v in grads.items()), gcoef.cpu().numpy()
+
+    # ---- MS1
+    def ms(self, nodes, seed=0, rs=None, want_used=False):
+        """nodes: list of dicts(mu, sigma, eps|None, K, D, offset, ls, kfast)."""
+        tab = (_hip.MSTerm * len(nodes))()
+        keep, outs = [], []
+        for i, nd in enumerate(nodes):
+            mu, sg, eps = self.t(nd["mu"]), self.t(nd["sigma"]), self.t(nd.get("eps"))
+            K, D, M = nd["K"], nd["D"], nd["mu"].size
+            R = M // D
+            z = torch.full((K, M), float("nan"), dtype=self.dtype, device=self.dev)
+            kfast = nd.get("kfast", False)
+            lp = torch.full((R, K) if kfast else (K, R), float("nan"), dtype=self.dtype, device=self.dev)
+            e = tab[i]
+            e.mu, e.sigma, e.eps = mu.data_ptr(), sg.data_ptr(), (eps.data_ptr() if eps is not None else None)
+            e.z, e.lp = z.data_ptr(), lp.data_ptr()
+            e.K, e.M, e.D = K, M, D
+            e.lp_stride_k, e.lp_stride_r = (1, K) if kfast else (R, 1)
+            e.offset, e.sigma_is_logstd = nd.get("offset", 0), nd.get("ls", 0)
+            keep += [mu, sg, eps]
+            outs.append((z, lp, kfast))
+        used = torch.zeros(2, dtype=torch.int64, device=self.dev) if want_used else None
+        self.k.call("zs_normal_sample_logprob_multi" + self.sfx, ctypes.byref(tab), len(nodes), seed, _hip.ptr(rs), _hip.ptr(used),
+                    self.stream())
+        self.sync()
+        res = [(z.cpu().numpy(), (lp.t() if kf else lp).cpu().numpy()) for z, lp, kf in outs]
+        return (res, used.cpu().numpy()) if want_used else res
+
+    def ms_bwd(self, nodes, seed=0, rs=None):
+        tab = (_hip.MSTerm * len(nodes))()
+        keep, outs = [], []
+        for i, nd in enumerate(nodes):
+            sg, eps = self.t(nd["sigma"]), self.t(nd.get("eps"))
+            gz, glp = self.t(nd.get("gz")), self.t(nd.get("glp"))
+            K, D, M = nd["K"], nd["D"], nd["sigma"].size
+            R = M // D
+            gmu = torch.full((M,), float("nan"), dtype=self.dtype, device=self.dev)
+            gs = torch.full((M,), float("nan"), dtype=self.dtype, device=self.dev)
+            e = tab[i]
+            e.sigma, e.eps = sg.data_ptr(), (eps.data_ptr() if eps is not None else None)
+            e.K, e.M, e.D = K, M, D
+            e.offset, e.sigma_is_logstd = nd.get("offset", 0), nd.get("ls", 0)
+            e.gz = gz.data_ptr() if gz is not None else None
+            e.glp = glp.data_ptr() if glp is not None else None
+            e.glp_stride_k, e.glp_stride_r = R, 1
+            e.gmu, e.gsigma = gmu.data_ptr(), gs.data_ptr()
+            keep += [sg, eps, gz, glp]
+            outs.append((gmu, gs))
+        self.k.call("zs_normal_sample_logprob_multi_bwd" + self.sfx, ctypes.byref(tab), len(nodes), seed, _hip.ptr(rs), self.stream())
+        self.sync()
+        return [(a.cpu().numpy(), b.cpu().numpy()) for a, b in outs]
+
+    # ---- single-node K1 (to compare MS1 with)
+    def k1(self, mu, sigma, eps, K, D, seed, off, ls=0):
+        M = mu.size
+        R = M // D
+        z = torch.full((K, M), float("nan"), dtype=self.dtype, device=self.dev)
+        lp = torch.full((K, R), float("nan"), dtype=self.dtype, device=self.dev)
+        mu, sigma, eps = self.t(mu), self.t(sigma), self.t(eps)          # (named: they must outlive the call)
+        self.k.call("zs_normal_sample_logprob" + self.sfx, _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(eps), seed, off,
+                    None, _hip.ptr(z), _hip.ptr(lp), K, M, D, R, 1, ls, None, self.stream())
+        self.sync()
+        return z.cpu().numpy(), lp.cpu().numpy()
+
+    # ---- PL1
+    def pl(self, h, w, relu):
+        K, n_out, n_in1 = w.shape
+        shared = h.ndim == 2
+        B = h.shape[-2]
+        out = torch.full((K, B, n_out), float("nan"), dtype=self.dtype, device=self.dev)
+        h, w = self.t(h), self.t(w)
+        self.k.call("zs_particle_linear" + self.sfx, _hip.ptr(h), 0 if shared else B * (n_in1 - 1), _hip.ptr(w),
+                    _hip.ptr(out), K, B, n_in1 - 1, n_out, int(relu), self.stream())
+        self.sync()
+        return out.cpu().numpy()
+
+    def pl_bwd(self, h, w, out, gout, relu, want_gh=True):
+        K, n_out, n_in1 = w.shape
+        shared = h.ndim == 2
+        B = h.shape[-2]
+        gh = torch.full((K, B, n_in1 - 1), float("nan"), dtype=self.dtype, device=self.dev)
+        gw = torch.full((K, n_out, n_in1), float("nan"), dtype=self.dtype, device=self.dev)
+        h, w, out, gout = self.t(h), self.t(w), self.t(out), self.t(gout)
+        self.k.call("zs_particle_linear_bwd" + self.sfx, _hip.ptr(h), 0 if shared else B * (n_in1 - 1), _hip.ptr(w),
+                    _hip.ptr(out), _hip.ptr(gout), _hip.ptr(gh) if want_gh else None, _hip.ptr(gw), K, B, n_in1 - 1,
+                    n_out, int(relu), self.stream())
+        self.sync()
+        return (gh.cpu().numpy() if want_gh else None), gw.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Raw(host_kernel_library(), "cpu")
+
+
+@pytest.fixture(scope="module")
+def orc64():
+    return Raw(host_kernel_library(), "cpu", torch.float64)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return Raw(_hip.KernelLibrary(_hip.LIB_PATH), "cuda:0")
+
+
+@pytest.fixture(scope="module")
+def hip64():
+    return Raw(_hip.KernelLibrary(_hip.LIB_PATH), "cuda:0", torch.float64)
+
+
+# ------------------------------------------------------------------------------------------------ LJ1 inputs
+def _operand(rng, kind, n, period, lo=None):
+    """Values of one operand with `period` elements (a divisor of n)."""
+    if kind == "value":
+        return rng.standard_normal(period)
+    if kind == "mean":
+        return 0.3 * rng.standard_normal(period)
+    if kind == "std":
+        return rng.uniform(0.5, 1.5, size=period)
+    if kind == "logstd":
+        return rng.uniform(-0.7, 0.4, size=period)
+    if kind == "probs":
+        v = rng.uniform(0.02, 0.98, size=period)
+        v[:3] = [0.0, 1.0, 1e-9][:min(3, period)]                       # the +1e-8 edges (bernoulli.py:94)
+        return v
+    if kind == "logits":
+        return 3.0 * rng.standard_normal(period)
+    if kind == "bits":
+        return (rng.uniform(size=period) < 0.5).astype(np.float64)
+    raise ValueError(kind)
+
+
+def _term(rng, family, n, periods=(None, None, None), coef=1.0, want=(False, False, False), misalign=False):
+    px, pa, pb = [n if p is None else p for p in periods]
+    tm = {"family": family, "n": n, "coef": coef, "want": want, "misalign": misalign}
+    if family == LJ.LJ_ROWS:
+        tm["x"] = 5.0 * rng.standard_normal(n)
+    elif family in (LJ.LJ_NORMAL, LJ.LJ_NORMAL_LOGSTD):
+        tm["x"], tm["a"] = _operand(rng, "value", n, px), _operand(rng, "mean", n, pa)
+        tm["b"] = _operand(rng, "logstd" if family == LJ.LJ_NORMAL_LOGSTD else "std", n, pb)
+    else:
+        tm["x"] = _operand(rng, "bits", n, px)
+        tm["a"] = _operand(rng, "logits" if family == LJ.LJ_BERNOULLI_LOGITS else "probs", n, pa)
+    return tm
+
+
+def _truth(terms, g=None):
+    """float64 torch evaluation of the objective and (with g) of every requested gradient."""
+    total = torch.zeros((), dtype=torch.float64)
+    leaves = {}
+    for i, tm in enumerate(terms):
+        n = tm["n"]
+
+        def full(name, j):
+            v = tm.get(name)
+            if v is None:
+                return None
+            t = torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=bool(tm["want"][j]))
+            if tm["want"][j]:
+                leaves[(i, j)] = t
+            return t.repeat(n // t.numel()) if t.numel() != n else t
+        x, a, b = full("x", 0), full("a", 1), full("b", 2)
+        fam = tm["family"]
+        if n == 0:
+            continue
+        if fam == LJ.LJ_ROWS:
+            s = x.sum()
+        elif fam in (LJ.LJ_NORMAL, LJ.LJ_NORMAL_LOGSTD):
+            sd = torch.exp(b) if fam == LJ.LJ_NORMAL_LOGSTD else b
+            s = torch.distributions.Normal(a, sd).log_prob(x).sum()
+        else:
+            p = torch.sigmoid(a) if fam == LJ.LJ_BERNOULLI_LOGITS else a
+            s = (x * torch.log(p + 1e-8) + (1 - x) * torch.log(1 - p + 1e-8)).sum()
+        total = total + tm["coef"] * s
+    grads = {}
+    if g is not None and leaves:
+        keys = list(leaves.keys())
+        gs = torch.autograd.grad(total * g, [leaves[k] for k in keys], allow_unused=True)
+        grads = dict((k, (v.numpy() if v is not None else np.zeros(leaves[k].shape))) for k, v in zip(keys, gs))
+    return float(total), grads
+
+
+def _cases(rng, small=False):
+    """Lists of terms covering families x operand classes (full / scalar / periodic) x alignment x sizes."""
+    big = 4099 if small else (1 << 20) + 3
+    N, NL, B, BL, R = LJ.LJ_NORMAL, LJ.LJ_NORMAL_LOGSTD, LJ.LJ_BERNOULLI, LJ.LJ_BERNOULLI_LOGITS, LJ.LJ_ROWS
+    all3, a_only = (True, True, True), (False, True, False)
+    cases = [
+        # the VAE objective's shape: prior on z, Bernoulli likelihood, the sampler's rows
+        [_term(rng, N, 16 * 40, coef=-1 / 16., want=(True, False, False)), _term(rng, B, 16 * 784, coef=-1 / 16., want=a_only),
+         _term(rng, R, 16, coef=1 / 16.)],
+        # the BNN objective's shape: two weight priors (parameters of period 700 / 51), the likelihood with a scalar log std
+        [_term(rng, N, 10 * 700, (None, 700, 700), coef=-0.1, want=(True, False, False)),
+         _term(rng, N, 10 * 51, (None, 51, 51), coef=-0.1, want=(True, False, False)),
+         _term(rng, NL, 10 * 64, (64, None, 1), coef=-456. / 640, want=(False, True, True)),
+         _term(rng, R, 10, coef=0.1), _term(rng, R, 10, coef=0.1)],
+        # every operand periodic with a gradient (fold jobs), unaligned bases, a 1-element term, an empty term
+        [_term(rng, N, 6 * 35, (35, 7 * 5, 5), coef=0.7, want=all3, misalign=True), _term(rng, NL, 12 * 8, (8, 96, 4), coef=-1.3, want=all3),
+         _term(rng, BL, 9 * 20, (20, 60, None), coef=2.0, want=a_only), _term(rng, N, 1, coef=3.0, want=all3),
+         _term(rng, B, 0, coef=1.0), _term(rng, R, 0, coef=1.0)],
+        # scalars everywhere
+        [_term(rng, N, 1000, (None, 1, 1), coef=1e-3, want=all3), _term(rng, NL, 777, (1, None, 1), coef=-2e-3, want=all3),
+         _term(rng, B, 333, (None, 1, None), coef=0.5, want=a_only)],
+        # ragged / large: more than one workgroup per term, a tail that is not a multiple of 4
+        [_term(rng, N, big, coef=1.0 / big, want=all3), _term(rng, BL, big - 1, coef=-1.0 / big, want=a_only, misalign=True),
+         _term(rng, R, big // 3, coef=1e-3)],
+        # eight terms (the table's capacity)
+        [_term(rng, f, 50 + 7 * i, coef=(-1.0) ** i * 0.25, want=(f in (N, NL), f != R, f in (N, NL)))
+         for i, f in enumerate([N, NL, B, BL, R, N, B, R])],
+    ]
+    return cases
+
+
+def _compare_bwd(got, truth, terms, rtol, atol_scale):
+    for key, ref in truth.items():
+        a = got[key]
+        scale = max(np.abs(ref).max(), 1e-30)
+        np.testing.assert_allclose(a, ref, rtol=rtol, atol=atol_scale * scale, err_msg="term %d operand %d" % key)
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle vs float64 truth
+def test_c_oracle_logjoint_against_float64_truth(orc, orc64):
+    rng = np.random.RandomState(11)
+    for terms in _cases(rng, small=True):
+        ref, gref = _truth(terms, g=0.75)
+        mag = sum(abs(tm["coef"]) * max(tm["n"], 1) for tm in terms)
+        assert abs(orc64.lj_fwd(terms) - ref) <= 1e-12 * mag
+        assert abs(orc.lj_fwd(terms) - ref) <= 3e-7 * mag
+        g64, c64 = orc64.lj_bwd(terms, 0.75)
+        _compare_bwd(g64, gref, terms, 1e-10, 1e-12)
+        np.testing.assert_allclose(c64, [0.75 * tm["coef"] for tm in terms], rtol=1e-14)
+        g32, c32 = orc.lj_bwd(terms, 0.75)
+        _compare_bwd(g32, gref, terms, 2e-4, 2e-6)
+        np.testing.assert_allclose(c32, [0.75 * tm["coef"] for tm in terms], rtol=1e-6)
+
+
+def test_c_oracle_logjoint_rejects_bad_tables(orc):
+    rng = np.random.RandomState(1)
+    with pytest.raises(RuntimeError, match="code -2"):
+        orc.lj_fwd([_term(rng, LJ.LJ_ROWS, 4) for _ in range(9)])                # more than ZS_LJ_MAX_TERMS
+    bad = _term(rng, LJ.LJ_NORMAL, 12, (None, 5, None))                           # period does not divide n
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.lj_fwd([bad])
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.lj_fwd([dict(_term(rng, LJ.LJ_NORMAL, 8), family=7)])
+    with pytest.raises(RuntimeError, match="code -2"):                             # d/d observation of a Bernoulli term
+        orc.lj_bwd([_term(rng, LJ.LJ_BERNOULLI, 8, want=(True, False, False))], 1.0)
+
+
+def test_c_oracle_multi_sampler_is_k1_per_node(orc, orc64):
+    """MS1 == K1 node by node (the oracle delegates: checked against explicit calls), with given eps and with Philox draws
+    whose call ids are base + offset."""
+    rng = np.random.RandomState(5)
+    for raw in (orc, orc64):
+        nodes = []
+        for (K, R, D, ls, given) in [(10, 1, 700, 1, False), (10, 1, 51, 1, False), (3, 8, 5, 0, True), (1, 4, 4, 0, False)]:
+            M = R * D
+            nd = {"mu": rng.standard_normal(M), "sigma": rng.uniform(-0.5, 0.3, M) if ls else rng.uniform(0.5, 1.5, M),
+                  "K": K, "D": D, "ls": ls, "offset": len(nodes) + 3, "kfast": bool(len(nodes) % 2)}
+            if given:
+                nd["eps"] = rng.standard_normal(K * M)
+            nodes.append(nd)
+        st = torch.tensor([77, 1000], dtype=torch.int64)
+        res, used = raw.ms(nodes, seed=123456, rs=st, want_used=True)
+        assert used.tolist() == [77, 1000]
+        for nd, (z, lp) in zip(nodes, res):
+            z1, lp1 = raw.k1(nd["mu"], nd["sigma"], nd.get("eps"), nd["K"], nd["D"], 77, 1000 + nd["offset"], nd["ls"])
+            assert np.array_equal(z, z1) and np.array_equal(lp, lp1)
+        for nd in nodes:
+            nd["gz"] = rng.standard_normal(nd["K"] * nd["mu"].size)
+            nd["glp"] = rng.standard_normal(nd["K"] * (nd["mu"].size // nd["D"]))
+        out = raw.ms_bwd(nodes, seed=1, rs=st)
+        for nd, (gmu, gs) in zip(nodes, out):
+            K, M, D = nd["K"], nd["mu"].size, nd["D"]
+            eps = nd.get("eps")
+            if eps is None:
+                # regenerate the draw: z = mu + sigma * eps
+                (z, _), = raw.ms([dict(nd, gz=None, glp=None)], rs=st)
+                sg = np.exp(nd["sigma"]) if nd["ls"] else nd["sigma"]
+                eps = ((z.reshape(K, M) - nd["mu"]) / sg).reshape(-1)
+            gz, glp = nd["gz"].reshape(K, M), nd["glp"].reshape(K, M // D)
+            sg = np.exp(nd["sigma"]) if nd["ls"] else nd["sigma"]
+            b = (gz * np.asarray(eps).reshape(K, M)).sum(0)
+            gl = np.repeat(glp.sum(0), D)
+            tol = 1e-9 if raw.dtype == torch.float64 else 2e-4
+            np.testing.assert_allclose(gmu, gz.sum(0), rtol=tol, atol=tol)
+            np.testing.assert_allclose(gs, b * sg - gl if nd["ls"] else b - gl / sg, rtol=tol, atol=tol * 10)
+
+
+def _pl_reference(h, w, relu):
+    """The reference caller's own op sequence (examples/bayesian_neural_nets/bnn_vi.py:36-48) in float64 torch."""
+    K, n_out, n_in1 = w.shape
+    ht = torch.tensor(h, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    hh = ht.repeat([K, 1, 1]) if ht.dim() == 2 else ht                       # x.repeat([n_particles, 1, 1])
+    B = hh.shape[1]
+    wr = torch.unsqueeze(wt, 1).repeat([1, B, 1, 1])
+    hh = torch.cat((hh, torch.ones([*hh.shape[:-1], 1], dtype=torch.float64)), -1)
+    hh = torch.unsqueeze(hh, -1)
+    p = torch.sqrt(torch.as_tensor(hh.shape[2], dtype=torch.float64))
+    out = torch.squeeze(torch.matmul(wr, hh) / p, -1)
+    if relu:
+        out = torch.nn.ReLU()(out)
+    return ht, wt, out
+
+
+PL_SHAPES = [  # (K, B, n_in, n_out, shared, relu)
+    (10, 512, 13, 50, True, True), (10, 512, 50, 1, False, False),       # the layers of BASELINE config 5, per GPU
+    (4, 16, 13, 50, True, True), (4, 16, 50, 1, False, False),           # the small golden's
+    (1, 1, 1, 1, False, True), (3, 65, 7, 5, False, True), (2, 130, 100, 50, True, False), (5, 63, 31, 33, False, True),
+    (2, 3, 255, 4, False, False), (2, 70, 3, 200, True, True), (7, 0, 4, 4, False, True)]
+
+
+def test_c_oracle_particle_linear_is_the_reference_layer(orc, orc64):
+    rng = np.random.RandomState(9)
+    for (K, B, n_in, n_out, shared, relu) in PL_SHAPES:
+        h = rng.standard_normal((B, n_in) if shared else (K, B, n_in))
+        w = rng.standard_normal((K, n_out, n_in + 1))
+        ht, wt, ref = _pl_reference(h, w, relu)
+        gout = rng.standard_normal((K, B, n_out))
+        for raw, tol in ((orc64, 1e-12), (orc, 2e-5)):
+            out = raw.pl(h, w, relu)
+            np.testing.assert_allclose(out, ref.detach().numpy(), rtol=tol, atol=tol)
+            if B == 0:
+                continue
+            gh_ref, gw_ref = torch.autograd.grad(ref, [ht, wt], torch.tensor(gout), retain_graph=True)
+            gh, gw = raw.pl_bwd(h, w, ref.detach().numpy(), gout, relu)
+            np.testing.assert_allclose(gw, gw_ref.numpy(), rtol=tol * 10, atol=tol * 10 * max(np.abs(gw_ref.numpy()).max(), 1))
+            gh_full = gh.sum(0) if shared else gh
+            np.testing.assert_allclose(gh_full, gh_ref.numpy(), rtol=tol * 10, atol=tol * 10 * max(np.abs(gh_ref.numpy()).max(), 1))
+    with pytest.raises(RuntimeError, match="code -2"):
+        orc.pl(np.zeros((1, 2, 300)), np.zeros((1, 2, 301)), False)               # n_in > 255
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.k.call("zs_particle_linear_f32", None, 5, None, None, 1, 2, 3, 4, 0, None)      # h_stride_k neither 0 nor B * n_in
+
+
+# ------------------------------------------------------------------------------------------------ GPU: HIP vs the C oracle
+@pytest.mark.gpu
+def test_hip_logjoint(hip, orc, hip64, orc64):
+    rng = np.random.RandomState(21)
+    for terms in _cases(rng):
+        mag = sum(abs(tm["coef"]) * max(tm["n"], 1) for tm in terms)
+        ref, gref = _truth(terms, g=-1.25)
+        a, b = hip.lj_fwd(terms), orc.lj_fwd(terms)
+        assert abs(a - b) <= 2e-7 * mag and abs(a - ref) <= 3e-7 * mag, (a, b, ref)
+        assert hip.lj_fwd(terms) == a                                           # deterministic: fixed combination order
+        ga, ca = hip.lj_bwd(terms, -1.25)
+        gb, cb = orc.lj_bwd(terms, -1.25)
+        assert ga.keys() == gb.keys() == gref.keys()
+        _compare_bwd(ga, gref, terms, 3e-4, 3e-6)
+        for key in ga:
+            scale = max(np.abs(gb[key]).max(), 1e-30)
+            np.testing.assert_allclose(ga[key], gb[key], rtol=3e-4, atol=3e-6 * scale, err_msg=str(key))
+        np.testing.assert_allclose(ca, cb, rtol=1e-6)
+        ga2, _ = hip.lj_bwd(terms, -1.25)
+        assert all(np.array_equal(ga[k], ga2[k]) for k in ga)                   # periodic / scalar sums are deterministic too
+    for terms in _cases(np.random.RandomState(22), small=True):
+        mag = sum(abs(tm["coef"]) * max(tm["n"], 1) for tm in terms)
+        assert abs(hip64.lj_fwd(terms) - orc64.lj_fwd(terms)) <= 1e-13 * mag
+        ga, _ = hip64.lj_bwd(terms, 0.5)
+        gb, _ = orc64.lj_bwd(terms, 0.5)
+        for key in ga:
+            np.testing.assert_allclose(ga[key], gb[key], rtol=1e-11, atol=1e-12 * max(np.abs(gb[key]).max(), 1e-30))
+    with pytest.raises(RuntimeError, match="code -2"):
+        hip.lj_fwd([_term(rng, LJ.LJ_ROWS, 4) for _ in range(9)])
+    with pytest.raises(RuntimeError, match="code -1"):
+        hip.lj_fwd([_term(rng, LJ.LJ_NORMAL, 12, (None, 5, None))])
+    with pytest.raises(RuntimeError, match="code -2"):
+        hip.lj_bwd([_term(rng, LJ.LJ_BERNOULLI, 8, want=(True, False, False))], 1.0)
+    assert hip.lj_fwd([_term(rng, LJ.LJ_ROWS, 0)]) == 0.0                       # all terms empty
+
+
+@pytest.mark.gpu
+def test_hip_multi_sampler(hip, orc, hip64, orc64):
+    rng = np.random.RandomState(31)
+    for h, o, tol in ((hip, orc, 2e-5), (hip64, orc64, 1e-12)):
+        for trial in range(3):
+            nodes = []
+            for (K, R, D, ls, given) in [(10, 1, 700, 1, False), (10, 1, 51, 1, False), (3, 8, 5, 0, True), (1, 4, 4, 0, False),
+                                         (50, 16, 40, 0, False), (2, 3, 1, 0, False), (4, 0, 3, 0, False)][trial:trial + 5]:
+                M = R * D
+                nd = {"mu": rng.standard_normal(M), "sigma": rng.uniform(-0.5, 0.3, M) if ls else rng.uniform(0.5, 1.5, M),
+                      "K": K, "D": D, "ls": ls, "offset": 5 * len(nodes) + trial, "kfast": bool(len(nodes) % 2)}
+                if given:
+                    nd["eps"] = rng.standard_normal(K * M)
+                nodes.append(nd)
+            st_h = torch.tensor([99, 12345], dtype=torch.int64, device=h.dev)
+            st_o = torch.tensor([99, 12345], dtype=torch.int64)
+            (ra, ua), (rb, ub) = h.ms(nodes, rs=st_h, want_used=True), o.ms(nodes, rs=st_o, want_used=True)
+            assert ua.tolist() == ub.tolist() == [99, 12345]
+            for nd, (za, la), (zb, lb) in zip(nodes, ra, rb):
+                if nd.get("eps") is not None:
+                    assert np.array_equal(za, zb)                               # z = mu + sigma * eps rounds like the reference
+                else:
+                    np.testing.assert_allclose(za, zb, rtol=0, atol=2e-5)       # device sin / cos / log vs libm
+                np.testing.assert_allclose(la, lb, rtol=2e-5 if tol > 1e-9 else 1e-6, atol=2e-4 if tol > 1e-9 else 1e-4)
+                # ... and MS1 == K1 on the device itself, bit for bit (same stream definition, same arithmetic)
+                if nd["mu"].size:
+                    z1, _ = h.k1(nd["mu"], nd["sigma"], nd.get("eps"), nd["K"], nd["D"], 99, 12345 + nd["offset"], nd["ls"])
+                    assert np.array_equal(za, z1)
+            for nd in nodes:
+                nd["gz"] = rng.standard_normal(nd["K"] * nd["mu"].size)
+                nd["glp"] = rng.standard_normal(nd["K"] * (nd["mu"].size // nd["D"]))
+            for (ga, sa), (gb, sb), nd in zip(h.ms_bwd(nodes, rs=st_h), o.ms_bwd(nodes, rs=st_o), nodes):
+                np.testing.assert_allclose(ga, gb, rtol=1e-5, atol=1e-5)
+                np.testing.assert_allclose(sa, sb, rtol=2e-4, atol=2e-4 * max(np.abs(sb).max(), 1) if sb.size else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,B,n_in,n_out,shared,relu", PL_SHAPES)
+def test_hip_particle_linear(hip, orc, hip64, orc64, K, B, n_in, n_out, shared, relu):
+    rng = np.random.RandomState(K * 1000 + B + n_in)
+    h = rng.standard_normal((B, n_in) if shared else (K, B, n_in))
+    w = rng.standard_normal((K, n_out, n_in + 1))
+    gout = rng.standard_normal((K, B, n_out))
+    for a, b, tol in ((hip, orc, 3e-5), (hip64, orc64, 1e-12)):
+        if a is hip64 and n_out * (n_in + 2) > 7000:
+            continue                                                            # the double twin has half the LDS budget
+        oa, ob = a.pl(h, w, relu), b.pl(h, w, relu)
+        np.testing.assert_allclose(oa, ob, rtol=tol, atol=tol)
+        for want_gh in (True, False):
+            gha, gwa = a.pl_bwd(h, w, ob, gout, relu, want_gh)
+            ghb, gwb = b.pl_bwd(h, w, ob, gout, relu, want_gh)
+            np.testing.assert_allclose(gwa, gwb, rtol=tol * 10, atol=tol * 10 * max(np.abs(gwb).max(), 1) if gwb.size else 0)
+            if want_gh and B:
+                np.testing.assert_allclose(gha, ghb, rtol=tol * 10, atol=tol * 10 * max(np.abs(ghb).max(), 1))
+    with pytest.raises(RuntimeError, match="code -2"):
+        hip.pl(np.zeros((1, 2, 300)), np.zeros((1, 2, 301)), False)

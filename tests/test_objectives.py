@@ -433,8 +433,10 @@ def test_torch_distribution_pass_through_families(dev):
 
 
 def test_scalar_sgvb_fast_path_is_taken_and_equals_the_unfused_objective(dev):
-    """VAE-shaped nets: every node reduces to a scalar, so ELBO.forward goes through ONE zs_scalar_objective launch;
-    its value and gradients must equal log_joint + sgvb evaluated node by node on the same draws."""
+    """VAE-shaped nets: every node reduces to a scalar, so ELBO.forward evaluates ALL log-probs and the objective in ONE
+    launch (LJ1, zs_logjoint_scalar: log p(x|z) as a Bernoulli term, log p(z) as a Normal term, log q(z|x) as the rows the
+    sampling kernel already produced); its value and gradients must equal log_joint + sgvb evaluated node by node (one
+    log-prob kernel per node, the reference's op sequence) on the same draws."""
     from zhusuan import _ops
     from examples import vae_mnist
     torch.manual_seed(0)
@@ -442,19 +444,35 @@ def test_scalar_sgvb_fast_path_is_taken_and_equals_the_unfused_objective(dev):
     x = (torch.rand(16, 784, device=dev) < 0.5).float()
     eps = [np.random.RandomState(i).standard_normal((16, 40)).astype(np.float32) for i in range(4)]
     calls = []
-    orig = _ops.ScalarObjective.apply
+    from zhusuan import _hip
+    orig = _ops.LogJointScalar.apply
+    lib_calls = []
+    klib = _hip.lib()
+    orig_call = klib.call
 
-    def spy(*a, **k):
-        calls.append(len(a) - 1)
-        return orig(*a, **k)
-    _ops.ScalarObjective.apply = spy
+    def spy(spec, *tensors):
+        calls.append([t[0] for t in spec])
+        return orig(spec, *tensors)
+
+    def call_spy(name, *a):
+        lib_calls.append(name)
+        return orig_call(name, *a)
+    _ops.LogJointScalar.apply = spy
+    klib.call = call_spy
     try:
         with zs.inject_epsilon(eps[:2]):
             loss = model({"x": x})
+        n_fwd = len(lib_calls)
+        grads = torch.autograd.grad(loss, list(model.parameters()))
     finally:
-        _ops.ScalarObjective.apply = orig
-    assert calls == [3]                                        # log p(x|z), log p(z), log q(z|x) in one launch
-    grads = torch.autograd.grad(loss, list(model.parameters()))
+        _ops.LogJointScalar.apply = orig
+        klib.call = orig_call
+    # generator nodes first (z: Normal term, x: Bernoulli term), then the variational node's ready-made rows
+    assert calls == [[_hip.LJ_NORMAL, _hip.LJ_BERNOULLI, _hip.LJ_ROWS]]
+    # the whole objective: two draws (the reference's discarded one and the used one) + ONE objective launch forward,
+    # ONE objective launch + the sampler's backward
+    assert lib_calls[:n_fwd] == ["zs_normal_sample_logprob_f32"] * 2 + ["zs_logjoint_scalar_f32"]
+    assert lib_calls[n_fwd:] == ["zs_logjoint_scalar_bwd_f32", "zs_normal_sample_logprob_bwd_f32"]
     # the same objective, node by node (the reference's op sequence)
     with zs.inject_epsilon(eps[:2]):
         model.variational({"x": x})
@@ -468,8 +486,8 @@ def test_scalar_sgvb_fast_path_is_taken_and_equals_the_unfused_objective(dev):
     for a, b in zip(grads, grads2):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6)
     # a node that keeps its batch axis switches the fast path off
-    plan = model.generator.nodes["x"]._scalar_term(rows=False)
-    assert plan is not None and abs(plan[1] - 1.0 / 16) < 1e-12
+    plan = model.generator.nodes["x"]._scalar_coef()
+    assert plan is not None and abs(plan[0] - 1.0 / 16) < 1e-12 and plan[1] == 1
 
 
 def test_subclass_hooks_are_honoured_by_the_fused_paths(dev):

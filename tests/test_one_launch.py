@@ -1,0 +1,243 @@
+"""Product-level behaviour of the one-launch paths (LJ1 / MS1 / PL1) and of ``zhusuan.skip_discarded_draws``: what is
+launched, and that the fused evaluation equals the node-by-node one (the reference's op sequence) on the same draws.
+Runs on the host back-end (package logic over the C oracle) and, marked gpu, on the HIP library."""
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import zhusuan as zs
+from zhusuan import _hip, _ops
+from zhusuan.framework.bn import BayesianNet
+from zhusuan.framework.stochastic_tensor import LazyDraw
+from zhusuan.variational.elbo import ELBO
+from zhusuan.variational.importance_weighted_objective import ImportanceWeightedObjective
+from examples import bnn_vi, vae_mnist, iwae
+
+
+@contextlib.contextmanager
+def launches():
+    """Names of the kernel-library entry points called inside the block, in order."""
+    klib = _hip.lib()
+    orig, names = klib.call, []
+
+    def spy(name, *a):
+        names.append(name[:-4])
+        return orig(name, *a)
+    klib.call = spy
+    try:
+        yield names
+    finally:
+        klib.call = orig
+
+
+def _bnn(dev, layer, B=16, K=4):
+    model = bnn_vi.build(n_particles=K, device=dev, layer=layer)
+    wm, wl, yl = H.bnn_params(B, K, device=dev)
+    with torch.no_grad():
+        for p, v in zip(list(model.variational.w_means) + list(model.variational.w_logstds) + [model.generator.y_logstd],
+                        wm + wl + [yl]):
+            p.copy_(v)
+    x, y, eps = H.bnn_data(B, K)
+    return model, {"x": torch.tensor(x, device=dev), "y": torch.tensor(y, device=dev)}, eps
+
+
+def _grads(model, loss):
+    return [g.detach().cpu().numpy() for g in torch.autograd.grad(loss, list(model.parameters()))]
+
+
+def test_bnn_step_is_five_kernels_each_way_and_equals_the_reference_op_sequence(dev):
+    """BNN-VI (examples/bayesian_neural_nets/bnn_vi.py): with the fused layer the forward of the objective is
+    [the two discarded draws] + ONE sampling launch for both weight matrices + one launch per layer + ONE launch for all five
+    log-probs and the objective; backward mirrors it.  Value and gradients equal the reference's op sequence (repeat + cat +
+    matmul + div + relu, one log-prob kernel per node) on the same epsilons."""
+    model, obs, eps = _bnn(dev, "fused")
+    with launches() as names, zs.inject_epsilon(eps):
+        loss = model(obs)
+        n_fwd = len(names)
+        g = _grads(model, loss)
+    assert names[:n_fwd] == ["zs_normal_sample_logprob"] * 2 + ["zs_normal_sample_logprob_multi"] + ["zs_particle_linear"] * 2 + \
+        ["zs_logjoint_scalar"]
+    assert names[n_fwd:] == ["zs_logjoint_scalar_bwd"] + ["zs_particle_linear_bwd"] * 2 + ["zs_normal_sample_logprob_multi_bwd"]
+    rmse = float(model.generator.cache["rmse"])
+    ref_model, _, _ = _bnn(dev, "materialize")
+    with zs.inject_epsilon(eps):
+        ref_loss = ref_model(obs)
+    g_ref = _grads(ref_model, ref_loss)
+    np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=3e-6)
+    np.testing.assert_allclose(rmse, float(ref_model.generator.cache["rmse"]), rtol=1e-5)
+    for a, b in zip(g, g_ref):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5 * max(np.abs(b).max(), 1e-3))
+    # ... and the batched-GEMM formulation of round 2
+    bmm_model, _, _ = _bnn(dev, "bmm")
+    with zs.inject_epsilon(eps):
+        bmm_loss = bmm_model(obs)
+    np.testing.assert_allclose(float(loss.detach()), float(bmm_loss.detach()), rtol=3e-6)
+
+
+def test_skip_discarded_draws_draws_each_latent_once(dev):
+    """Inside zhusuan.skip_discarded_draws() the draw that the reference throws away (the node factory's, bn.py:158 /
+    elbo.py:122) is not executed: one sampling launch per step instead of three for the BNN, one instead of two for the
+    VAE / IWAE; the objective sees exactly the second-draw epsilons, so its value is the default path's."""
+    model, obs, eps = _bnn(dev, "fused")
+    with zs.inject_epsilon(eps):
+        ref = float(model(obs).detach())
+    with zs.skip_discarded_draws(), launches() as names, zs.inject_epsilon(eps[2:]):      # only the USED draws are consumed
+        loss = model(obs)
+    assert names == ["zs_normal_sample_logprob_multi"] + ["zs_particle_linear"] * 2 + ["zs_logjoint_scalar"]
+    assert float(loss.detach()) == ref
+    # VAE: sample + objective = 2 launches forward, objective + sampler backward
+    vae = vae_mnist.build(16, hidden=32, device=dev)
+    x, e1, e2 = H.vae_data(16)
+    xb = torch.tensor(x, device=dev)
+    with zs.inject_epsilon([e1, e2]):
+        ref = float(vae({"x": xb}).detach())
+    with zs.skip_discarded_draws(), launches() as names, zs.inject_epsilon([e2]):
+        loss = vae({"x": xb})
+        loss.backward()
+    assert names == ["zs_normal_sample_logprob", "zs_logjoint_scalar", "zs_logjoint_scalar_bwd", "zs_normal_sample_logprob_bwd"]
+    assert float(loss.detach()) == ref
+    # IWAE / VIMCO
+    m = iwae.build(n_samples=5, estimator="vimco", hidden=32, device=dev)
+    x, e1, e2 = H.iwae_data(8, 5)
+    xb = torch.tensor(x, device=dev)
+    with zs.inject_epsilon([e1, e2]):
+        ref = float(m({"x": xb}).detach())
+    with zs.skip_discarded_draws(), launches() as names, zs.inject_epsilon([e2]):
+        loss = m({"x": xb})
+    assert names.count("zs_normal_sample_logprob") == 1 and float(loss.detach()) == ref
+    # outside the context nothing changes: two draws again
+    with launches() as names, zs.inject_epsilon([e1, e2]):
+        m({"x": xb})
+    assert names.count("zs_normal_sample_logprob") == 2
+
+
+class _Hierarchical(BayesianNet):
+    """q(z1) q(z2 | z1): the net's own code READS the value its first node factory returned."""
+
+    def __init__(self):
+        super().__init__()
+        self.mu = torch.nn.Parameter(torch.zeros(6, 3))
+        self.seen = None
+
+    def forward(self, observed):
+        self.observe(observed)
+        z1 = self.normal("z1", mean=self.mu, std=torch.ones_like(self.mu.detach()), reduce_mean_dims=[0], reduce_sum_dims=[1])
+        self.seen = z1
+        m2 = torch.tanh(z1) * 0.5 + z1[:, :1] - (1.0 - z1).mean()           # torch function, indexing, reflected arithmetic, method
+        self.normal("z2", mean=m2, std=torch.ones_like(self.mu.detach()), reduce_mean_dims=[0], reduce_sum_dims=[1])
+        return self
+
+
+class _Gen(BayesianNet):
+    def __init__(self):
+        super().__init__()
+        self.s = torch.nn.Parameter(torch.ones(1))
+
+    def forward(self, observed):
+        self.observe(observed)
+        z1 = self.normal("z1", mean=torch.zeros(6, 3, device=self.s.device), std=torch.ones(6, 3, device=self.s.device),
+                         reduce_mean_dims=[0], reduce_sum_dims=[1])
+        z2 = self.normal("z2", mean=z1 * self.s, std=torch.ones(6, 3, device=self.s.device), reduce_mean_dims=[0], reduce_sum_dims=[1])
+        self.normal("x", mean=z2, std=torch.ones(6, 3, device=self.s.device), reduce_mean_dims=[0], reduce_sum_dims=[1])
+        return self
+
+
+def test_a_net_that_reads_its_first_draw_still_gets_it(dev):
+    """Default (switch off): the factory returns a tensor, as in the reference.  Switch on: it returns a LazyDraw that
+    samples the moment the net's code touches it -- the value the reference's factory would have returned -- so a
+    hierarchical variational net computes the same numbers either way."""
+    rng = np.random.RandomState(3)
+    eps = [rng.standard_normal((6, 3)).astype(np.float32) for _ in range(4)]       # z1#1, z2#1, z1#2, z2#2
+    x = torch.tensor(rng.standard_normal((6, 3)).astype(np.float32), device=dev)
+    model = ELBO(_Gen(), _Hierarchical()).to(dev)
+    with zs.inject_epsilon(eps):
+        ref = model({"x": x})
+    assert isinstance(model.variational.seen, torch.Tensor)
+    g_ref = _grads(model, ref)
+    with zs.skip_discarded_draws(), launches() as names, zs.inject_epsilon(eps[:3]):
+        loss = model({"x": x})
+    assert isinstance(model.variational.seen, LazyDraw) and "drawn" in repr(model.variational.seen)
+    # z1 was touched (drawn inside the net: eps[0]), z2 was not (its discarded draw is skipped), then the objective re-read
+    # z1 (eps[1]) and z2 (eps[2]): three draws.  The default path makes the same three plus z2's discarded one (any epsilon)
+    assert names.count("zs_normal_sample_logprob") == 1 and names.count("zs_normal_sample_logprob_multi") == 1   # (re-read: one launch)
+    with zs.inject_epsilon([eps[0], eps[3], eps[1], eps[2]]):
+        same = model({"x": x})
+    np.testing.assert_allclose(float(loss.detach()), float(same.detach()), rtol=1e-6)
+    g = _grads(model, loss)
+    assert all(np.isfinite(a).all() for a in g) and len(g) == len(g_ref)
+
+
+def test_multi_sampler_draws_what_the_node_by_node_loop_draws(dev):
+    """MS1 consumes the same Philox call ids as the per-node loop: the BNN's two weight matrices come out identical
+    whether they are drawn by one launch or by two (same seed), and so does the objective."""
+    import host_backend
+    from zhusuan.variational import elbo as elbo_mod
+    model, obs, _ = _bnn(dev, "fused")
+
+    def run(batched):
+        if dev.type == "cuda":
+            torch.manual_seed(5)
+        else:
+            host_backend.manual_seed(5)
+        limit = elbo_mod._MULTI_DRAW_MAX_ELEMENTS
+        elbo_mod._MULTI_DRAW_MAX_ELEMENTS = limit if batched else 0
+        try:
+            with launches() as names:
+                loss = model(obs)
+        finally:
+            elbo_mod._MULTI_DRAW_MAX_ELEMENTS = limit
+        return names, float(loss.detach()), [model.variational.nodes[n].dist.sample_cache.detach().cpu().numpy() for n in ("w0", "w1")]
+    n1, l1, w1 = run(True)
+    n2, l2, w2 = run(False)
+    assert n1.count("zs_normal_sample_logprob_multi") == 1 and n2.count("zs_normal_sample_logprob_multi") == 0
+    assert n2.count("zs_normal_sample_logprob") == 4
+    assert all(np.array_equal(a, b) for a, b in zip(w1, w2))
+    np.testing.assert_allclose(l1, l2, rtol=2e-6)
+
+
+def test_objective_with_more_nodes_than_the_table_falls_back(dev):
+    """Nine scalar nodes do not fit LJ1's table of eight: the objective takes the node-by-node path (same value)."""
+    class Many(BayesianNet):
+        def __init__(self, n):
+            super().__init__()
+            self.n = n
+            self.p = torch.nn.Parameter(torch.zeros(4))
+
+        def forward(self, observed):
+            self.observe(observed)
+            for i in range(self.n):
+                self.normal("z%d" % i, mean=self.p + i, std=torch.ones(4, device=self.p.device), reduce_sum_dims=[0])
+            return self
+    rng = np.random.RandomState(0)
+    eps = [rng.standard_normal(4).astype(np.float32) for _ in range(10)]
+    for n, fused in ((3, True), (5, False)):
+        m = ELBO(Many(n), Many(n)).to(dev)
+        with launches() as names, zs.inject_epsilon(eps[:2 * n]):
+            loss = m({})
+        assert ("zs_logjoint_scalar" in names) == fused
+        # -(sum_p log p(z) - sum_q log q(z)) with identical p and q at the same z: exactly zero either way
+        assert abs(float(loss.detach())) < 1e-5
+
+
+def test_particle_linear_layer_against_torch(dev):
+    rng = np.random.RandomState(8)
+    for (K, B, n_in, n_out, shared, relu) in [(4, 16, 13, 50, True, True), (4, 16, 50, 1, False, False), (3, 70, 300, 5, False, True)]:
+        h = torch.tensor(rng.standard_normal((B, n_in) if shared else (K, B, n_in)).astype(np.float32), device=dev, requires_grad=True)
+        w = torch.tensor(rng.standard_normal((K, n_out, n_in + 1)).astype(np.float32), device=dev, requires_grad=True)
+        with launches() as names:
+            out = zs.particle_linear(h, w, relu=relu)
+            gh, gw = torch.autograd.grad((out * torch.linspace(-1, 1, out.numel(), device=dev).view_as(out)).sum(), [h, w])
+        assert (names == ["zs_particle_linear", "zs_particle_linear_bwd"]) == (n_in <= 255)     # larger layers: torch's batched GEMM
+        hd, wd = h.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
+        hh = hd.unsqueeze(0).expand(K, B, n_in) if shared else hd
+        ref = (torch.bmm(hh, wd[:, :, :n_in].transpose(1, 2)) + wd[:, :, n_in].unsqueeze(1)) / np.sqrt(n_in + 1)
+        ref = torch.relu(ref) if relu else ref
+        rh, rw = torch.autograd.grad((ref * torch.linspace(-1, 1, ref.numel(), dtype=torch.float64).view_as(ref)).sum(), [hd, wd])
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(gh.cpu().numpy(), rh.numpy(), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(gw.cpu().numpy(), rw.numpy(), rtol=2e-4, atol=2e-4 * max(float(rw.abs().max()), 1))
+    with pytest.raises(RuntimeError, match="does not match"):
+        zs.particle_linear(torch.zeros(2, 3, 4, device=dev), torch.zeros(2, 5, 7, device=dev))

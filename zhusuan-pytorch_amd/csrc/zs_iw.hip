@@ -510,7 +510,9 @@ const char* const kKernelNames[zs::KID_COUNT] = {
     "zs_logistic_sample_logprob_f32", "zs_logistic_sample_logprob_bwd_f32", "zs_logistic_logprob_f32",
     "zs_logistic_logprob_bwd_f32", "zs_uniform_sample_f32", "zs_uniform_logprob_f32", "zs_philox_uniform_f32",
     "zs_reinforce_f32", "zs_iw_objective_f32", "zs_scalar_objective_f32", "zs_adam_step_f32",
-    "zs_logistic_logprob_bwd_ksum_f32"};
+    "zs_logistic_logprob_bwd_ksum_f32", "zs_logjoint_scalar_f32", "zs_logjoint_scalar_bwd_f32",
+    "zs_normal_sample_logprob_multi_f32", "zs_normal_sample_logprob_multi_bwd_f32", "zs_particle_linear_f32",
+    "zs_particle_linear_bwd_f32"};
 void prof_clear(ProfState& s) {
   for (int k = 0; k < zs::KID_COUNT; ++k) {
     for (auto& p : s.ev[k]) {

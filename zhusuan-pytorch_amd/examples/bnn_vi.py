@@ -2,9 +2,10 @@
 
 Counterpart of the reference caller examples/bayesian_neural_nets/bnn_vi.py:16-99: a prior node and a
 variational node per weight matrix (``group_ndims=2``, K particles, ``reduce_mean_dims=[0]``), a Normal
-likelihood with ``multiplier`` = training-set size.  The particle-batched layer is evaluated with a
-batched GEMM (h [K, B, n_in+1] x w^T [K, n_in+1, n_out]) instead of materialising the reference's
-``w.repeat([1, B, 1, 1])`` copy (bnn_vi.py:39-44); ``materialize=True`` reproduces that op sequence.
+likelihood with ``multiplier`` = training-set size.  The particle-batched layer -- in the reference
+``w.repeat([1, B, 1, 1])``, a column of ones appended to h, ``matmul``, ``/ sqrt(n_in + 1)``, ReLU (bnn_vi.py:36-48) --
+is ONE kernel each way (``zhusuan.particle_linear``, PL1 of include/zs_hip.h); ``layer='bmm'`` is round 2's batched-GEMM
+formulation (cat + bmm + div + relu), ``layer='materialize'`` reproduces the reference's op sequence.
 """
 import argparse
 import math
@@ -12,17 +13,20 @@ import time
 
 import torch
 
+import zhusuan
 from zhusuan.framework.bn import BayesianNet
 from zhusuan.variational.elbo import ELBO
 
 
 class Net(BayesianNet):
-    def __init__(self, layer_sizes, n_particles, multiplier=456, materialize=False):
+    def __init__(self, layer_sizes, n_particles, multiplier=456, materialize=False, layer=None):
         super().__init__()
         self.layer_sizes = layer_sizes
         self.n_particles = n_particles
         self.multiplier = multiplier
-        self.materialize = materialize
+        self.layer = layer or ('materialize' if materialize else 'fused')
+        if self.layer not in ('fused', 'bmm', 'materialize'):
+            raise ValueError("layer: 'fused', 'bmm' or 'materialize'")
         self.y_logstd = torch.nn.Parameter(torch.zeros([1], dtype=torch.float32))
         self._priors = None
         self._ones = {}
@@ -38,27 +42,29 @@ class Net(BayesianNet):
         self.observe(observed)
         x = self.observed['x']
         K = self.n_particles
-        h = x.unsqueeze(0).expand(K, *x.shape)
+        h = x if self.layer == 'fused' else x.unsqueeze(0).expand(K, *x.shape)      # (the reference repeats x K times, :27)
         batch_size = x.shape[0]
         priors = self._prior_params()
         n_layers = len(self.layer_sizes) - 1
         for i in range(n_layers):
             w = self.normal(name='w' + str(i), mean=priors[i][0], std=priors[i][1], group_ndims=2,
                             n_samples=K, reduce_mean_dims=[0])
+            last = i == n_layers - 1
+            if self.layer == 'fused':
+                h = zhusuan.particle_linear(h, w, relu=not last)
+                continue
             key = (tuple(h.shape[:-1]), h.device, h.dtype)
             ones = self._ones.get(key)       # the bias column is a constant: built once, not once per layer and step
             if ones is None:
                 ones = self._ones[key] = torch.ones([*h.shape[:-1], 1], device=h.device, dtype=h.dtype)
-            # (folding the bias column and 1/sqrt(n) into one baddbmm was tried: its strided operands make torch copy and
-            #  pick slower batched-GEMM kernels -- 0.147 -> 0.180 ms per step at B=512, K=10)
             h = torch.cat((h, ones), -1)
             scale = math.sqrt(h.shape[2])      # host scalar: no H2D copy inside a captured step (bnn_vi.py:42)
-            if self.materialize:
+            if self.layer == 'materialize':
                 wr = torch.unsqueeze(w, 1).repeat([1, batch_size, 1, 1])
                 h = torch.squeeze(torch.matmul(wr, torch.unsqueeze(h, -1)), -1) / scale
             else:
                 h = torch.bmm(h, w.transpose(1, 2)) / scale
-            if i < n_layers - 1:
+            if not last:
                 h = torch.relu(h)
         y_mean = torch.squeeze(h, 2)
         y = self.observed['y']
@@ -89,8 +95,8 @@ class Variational(BayesianNet):
         return self
 
 
-def build(layer_sizes=(13, 50, 1), n_particles=10, multiplier=456, device='cuda', materialize=False):
-    net = Net(list(layer_sizes), n_particles, multiplier, materialize)
+def build(layer_sizes=(13, 50, 1), n_particles=10, multiplier=456, device='cuda', materialize=False, layer=None):
+    net = Net(list(layer_sizes), n_particles, multiplier, materialize, layer)
     variational = Variational(list(layer_sizes), n_particles)
     return ELBO(net, variational).to(device)
 

@@ -16,4 +16,6 @@ from . import framework
 from .utils import *
 from ._rng import inject_epsilon, DeviceRNG, device_rng, reference_rng
 from .graph import GraphedStep, GraphedStages
+from .framework.stochastic_tensor import skip_discarded_draws
+from .layers import particle_linear
 from . import optim

@@ -59,6 +59,39 @@ PROTOTYPES = {
 }
 ADAM_MAX_TENSORS = 32      # ZS_ADAM_MAX_TENSORS of include/zs_hip.h
 
+# LJ1 / MS1: host-side tables copied into the kernel arguments (struct zs_lj_term / zs_ms_term of include/zs_hip.h)
+LJ_MAX_TERMS, LJ_WORKSPACE = 8, 8192
+LJ_ROWS, LJ_NORMAL, LJ_NORMAL_LOGSTD, LJ_BERNOULLI, LJ_BERNOULLI_LOGITS = 0, 1, 2, 3, 4
+MS_MAX_TERMS = 8
+
+
+class LJTerm(ctypes.Structure):
+    _fields_ = [("family", ctypes.c_int32), ("reserved", ctypes.c_int32), ("n", _i64),
+                ("x", _p), ("px", _i64), ("a", _p), ("pa", _i64), ("b", _p), ("pb", _i64),
+                ("coef", ctypes.c_double), ("gx", _p), ("ga", _p), ("gb", _p)]
+
+
+class MSTerm(ctypes.Structure):
+    _fields_ = [("mu", _p), ("sigma", _p), ("eps", _p), ("z", _p), ("lp", _p),
+                ("K", _i64), ("M", _i64), ("D", _i64), ("lp_stride_k", _i64), ("lp_stride_r", _i64),
+                ("offset", _u64), ("sigma_is_logstd", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("gz", _p), ("glp", _p), ("glp_stride_k", _i64), ("glp_stride_r", _i64), ("gmu", _p), ("gsigma", _p)]
+
+
+PROTOTYPES.update({
+    # terms (host table), n_terms, out, workspace, workspace_len, ticket, stream
+    "zs_logjoint_scalar_f32": [_p, _int, _p, _p, _i64, _p, _p],
+    # terms, n_terms, gout (device scalar), gcoef, workspace, workspace_len, ticket, stream
+    "zs_logjoint_scalar_bwd_f32": [_p, _int, _p, _p, _p, _i64, _p, _p],
+    # terms, n_terms, seed, rng_state, rng_used, stream
+    "zs_normal_sample_logprob_multi_f32": [_p, _int, _u64, _p, _p, _p],
+    "zs_normal_sample_logprob_multi_bwd_f32": [_p, _int, _u64, _p, _p],
+    # h, h_stride_k, w, out, K, B, n_in, n_out, relu, stream
+    "zs_particle_linear_f32": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
+    # h, h_stride_k, w, out, gout, gh, gw, K, B, n_in, n_out, relu, stream
+    "zs_particle_linear_bwd_f32": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
+})
+
 
 # every compute entry point exists as name_f32 and name_f64 with the same argument list
 PROTOTYPES.update({name[:-4] + "_f64": args for name, args in list(PROTOTYPES.items())})

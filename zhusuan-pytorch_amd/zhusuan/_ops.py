@@ -5,6 +5,7 @@ stream.  Row results use the K-fastest layout when ``kfast`` is set: the buffer 
 user-visible tensor is its transposed view ``[K, *rest]``, so shapes equal the reference's while the
 K particles of a datapoint stay contiguous for the importance-weight reduction.
 """
+import ctypes
 import math
 
 import torch
@@ -724,3 +725,224 @@ def periodic_operand(t, full_shape):
     if shp == full_shape[len(full_shape) - len(shp):]:
         return t.contiguous(), t.numel()
     return t.expand(full_shape).contiguous(), N
+
+
+# ------------------------------------------------------------------------------------------------
+# One-launch pieces for the launch-bound shapes (include/zs_hip.h: LJ1, MS1, PL1)
+# ------------------------------------------------------------------------------------------------
+_LJ_WORKSPACE = {}     # (device, stream) -> (double [ZS_LJ_WORKSPACE], ticket int32 [1])
+
+
+def _lj_workspace(device):
+    """Scratch of LJ1's deterministic sums, one per (device, stream) -- same rules as ``_iw_workspace``."""
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (str(device), stream)
+    ws = _LJ_WORKSPACE.get(key)
+    if ws is None:
+        ws = (torch.zeros(_hip.LJ_WORKSPACE, dtype=torch.float64, device=device), torch.zeros(1, dtype=torch.int32, device=device))
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _LJ_WORKSPACE[key] = ws
+    return ws
+
+
+class LogJointScalar(torch.autograd.Function):
+    """LJ1: ``sum_t coef_t * sum_i logprob_t(i)`` over up to 8 terms in ONE launch, its whole backward in one more.
+
+    ``spec`` is a tuple of ``(family, coef, n, px, pa, pb)`` per term (``_hip.LJ_*`` families; periods in elements of the
+    term's full problem of ``n`` elements); ``tensors`` holds ``(x, a, b)`` per term (``None`` where a family has no such
+    operand), each contiguous with exactly its period's number of elements.  Replaces the per-node loop of ELBO.log_joint
+    (zhusuan/variational/elbo.py:58-79) over StochasticTensor.log_prob (zhusuan/framework/stochastic_tensor.py:160-181)
+    plus ELBO.sgvb's scalar arithmetic (elbo.py:155-161) for objectives whose nodes all reduce to scalars."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        nt = len(spec)
+        if not (1 <= nt <= _hip.LJ_MAX_TERMS) or len(tensors) != 3 * nt:
+            raise ValueError("LogJointScalar takes 1..%d terms with three operands each" % _hip.LJ_MAX_TERMS)
+        _hip.require_device(*tensors)
+        sfx = _sfx(*tensors)
+        first = next(t for t in tensors if t is not None)
+        dt, dev = first.dtype, first.device
+        terms = (_hip.LJTerm * nt)()
+        for i, (fam, coef, n, px, pa, pb) in enumerate(spec):
+            x, a, b = tensors[3 * i:3 * i + 3]
+            for t, P in ((x, px), (a, pa), (b, pb)):
+                if t is not None and (not t.is_contiguous() or t.numel() != P):
+                    raise ValueError("LogJointScalar: operand of %d elements given with period %d" % (t.numel(), P))
+            tm = terms[i]
+            tm.family, tm.n, tm.coef = int(fam), int(n), float(coef)
+            tm.x, tm.px = (x.data_ptr() if x is not None else None), int(px)
+            tm.a, tm.pa = (a.data_ptr() if a is not None else None), int(pa)
+            tm.b, tm.pb = (b.data_ptr() if b is not None else None), int(pb)
+        out = torch.empty((), dtype=dt, device=dev)
+        ws, ticket = _lj_workspace(dev)
+        _hip.lib().call("zs_logjoint_scalar" + sfx, ctypes.byref(terms), nt, _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                        _hip.ptr(ticket), _hip.stream_for(first))
+        ctx.spec = tuple(spec)
+        ctx.save_for_backward(*[t for t in tensors if t is not None])
+        ctx.present = [t is not None for t in tensors]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, nt = ctx.spec, len(ctx.spec)
+        saved = list(ctx.saved_tensors)
+        tensors = [saved.pop(0) if p else None for p in ctx.present]
+        first = next(t for t in tensors if t is not None)
+        dt, dev = first.dtype, first.device
+        sfx = _sfx(first)
+        need = ctx.needs_input_grad[1:]
+        terms = (_hip.LJTerm * nt)()
+        grads = [None] * (3 * nt)
+        for i, (fam, coef, n, px, pa, pb) in enumerate(spec):
+            x, a, b = tensors[3 * i:3 * i + 3]
+            tm = terms[i]
+            tm.family, tm.n, tm.coef = int(fam), int(n), float(coef)
+            tm.x, tm.px = (x.data_ptr() if x is not None else None), int(px)
+            tm.a, tm.pa = (a.data_ptr() if a is not None else None), int(pa)
+            tm.b, tm.pb = (b.data_ptr() if b is not None else None), int(pb)
+            if fam == _hip.LJ_ROWS:
+                continue
+            if need[3 * i] and fam in (_hip.LJ_BERNOULLI, _hip.LJ_BERNOULLI_LOGITS):
+                raise NotImplementedError("zhusuan (MI355X build): gradient w.r.t. the Bernoulli observation is not built")
+            for j, name in enumerate(("gx", "ga", "gb")):
+                t = tensors[3 * i + j]
+                if t is not None and need[3 * i + j]:
+                    grads[3 * i + j] = torch.empty_like(t)
+                    setattr(tm, name, grads[3 * i + j].data_ptr())
+        gcoef = torch.empty(nt, dtype=dt, device=dev)
+        g = g.to(dt).contiguous()
+        ws, ticket = _lj_workspace(dev)
+        _hip.lib().call("zs_logjoint_scalar_bwd" + sfx, ctypes.byref(terms), nt, _hip.ptr(g), _hip.ptr(gcoef), _hip.ptr(ws),
+                        ws.numel(), _hip.ptr(ticket), _hip.stream_for(first))
+        for i, (fam, _c, _n, _px, _pa, _pb) in enumerate(spec):
+            if fam == _hip.LJ_ROWS and need[3 * i]:
+                # a stride-0 expansion of the term's scalar: the producers' backward kernels read gradients through strides
+                grads[3 * i] = gcoef[i].expand(tensors[3 * i].shape)
+        return (None,) + tuple(grads)
+
+
+class NormalSampleLogProbMulti(torch.autograd.Function):
+    """MS1: K1 (z = mu + sigma * eps and its row-summed log-density) for SEVERAL reparameterised Normal nodes in one
+    launch, their backward in one more.  ``meta`` = per node ``(K, has_k_axis, n_fold, is_logstd, call)``; ``tensors`` =
+    ``(mu, sigma, eps)`` per node (eps None: in-kernel Philox with call id base + call).  Returns (z_0, lp_0, z_1, lp_1, ...).
+    Replaces the per-latent re-read of ELBO.forward (zhusuan/variational/elbo.py:122) for models with more than one latent
+    node (the BNN's weight matrices, examples/bayesian_neural_nets/bnn_vi.py:83-93)."""
+
+    @staticmethod
+    def forward(ctx, meta, seed, rng_state, *tensors):
+        ctx.set_materialize_grads(False)
+        nt = len(meta)
+        if not (1 <= nt <= _hip.MS_MAX_TERMS) or len(tensors) != 3 * nt:
+            raise ValueError("NormalSampleLogProbMulti takes 1..%d nodes with three operands each" % _hip.MS_MAX_TERMS)
+        _hip.require_device(*tensors)
+        sfx = _sfx(*tensors)
+        terms = (_hip.MSTerm * nt)()
+        outs, dims = [], []
+        any_philox = False
+        for i, (K, has_k, n_fold, is_logstd, call) in enumerate(meta):
+            mu, sigma, eps = tensors[3 * i:3 * i + 3]
+            shape = tuple(mu.shape)
+            M = mu.numel()
+            rest = shape[:len(shape) - n_fold]
+            D = max(_prod(shape[len(shape) - n_fold:]), 1)
+            R = _prod(rest)
+            lead = (K,) if has_k else ()
+            z = torch.empty(lead + shape, dtype=mu.dtype, device=mu.device)
+            if M == 0:
+                lp, sk, sr, buf = torch.zeros(lead + rest, dtype=mu.dtype, device=mu.device), 0, 0, None
+            else:
+                buf, lp, sk, sr = _alloc_rows(K, has_k, rest, True, mu)
+            tm = terms[i]
+            tm.mu, tm.sigma, tm.eps = mu.data_ptr(), sigma.data_ptr(), (eps.data_ptr() if eps is not None else None)
+            tm.z, tm.lp = z.data_ptr(), (buf.data_ptr() if buf is not None else None)
+            tm.K, tm.M, tm.D, tm.lp_stride_k, tm.lp_stride_r = K, M, D, sk, sr
+            tm.offset, tm.sigma_is_logstd = int(call), 1 if is_logstd else 0
+            any_philox = any_philox or eps is None
+            outs += [z, lp]
+            dims.append((K, M, D, R))
+        used = _rng_snapshot(rng_state, any_philox)
+        first = tensors[0]
+        _hip.lib().call("zs_normal_sample_logprob_multi" + sfx, ctypes.byref(terms), nt, seed, _hip.ptr(rng_state), _hip.ptr(used),
+                        _hip.stream_for(first))
+        ctx.meta, ctx.dims, ctx.seed = tuple(meta), dims, seed
+        ctx.rng_state = used if used is not None else rng_state
+        ctx.save_for_backward(*[t for t in tensors if t is not None])
+        ctx.present = [t is not None for t in tensors]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        nt = len(ctx.meta)
+        saved = list(ctx.saved_tensors)
+        tensors = [saved.pop(0) if p else None for p in ctx.present]
+        if all(g is None for g in gouts):
+            return (None,) * (3 + 3 * nt)
+        sfx = _sfx(tensors[0])
+        terms = (_hip.MSTerm * nt)()
+        grads = [None] * (3 * nt)
+        keep = []
+        for i, (K, has_k, n_fold, is_logstd, call) in enumerate(ctx.meta):
+            mu, sigma, eps = tensors[3 * i:3 * i + 3]
+            Kk, M, D, R = ctx.dims[i]
+            gz, glp = gouts[2 * i], gouts[2 * i + 1]
+            gmu, gsigma = torch.empty_like(mu), torch.empty_like(sigma)
+            grads[3 * i], grads[3 * i + 1] = gmu, gsigma
+            tm = terms[i]
+            tm.sigma, tm.eps = sigma.data_ptr(), (eps.data_ptr() if eps is not None else None)
+            tm.K, tm.M, tm.D = Kk, M, D
+            tm.offset, tm.sigma_is_logstd = int(call), 1 if is_logstd else 0
+            tm.gmu, tm.gsigma = gmu.data_ptr(), gsigma.data_ptr()
+            if gz is not None:
+                gz = gz.contiguous()
+                keep.append(gz)
+                tm.gz = gz.data_ptr()
+            if glp is not None and M > 0:
+                glp, gsk, gsr = _kr_view(glp, Kk, R)
+                keep.append(glp)
+                tm.glp, tm.glp_stride_k, tm.glp_stride_r = glp.data_ptr(), gsk, gsr
+        _hip.lib().call("zs_normal_sample_logprob_multi_bwd" + sfx, ctypes.byref(terms), nt, ctx.seed, _hip.ptr(ctx.rng_state),
+                        _hip.stream_for(tensors[0]))
+        del keep
+        return (None, None, None) + tuple(grads)
+
+
+class ParticleLinear(torch.autograd.Function):
+    """PL1: ``out[k, b, :] = act(([h[k, b, :], 1] @ w[k].T) / sqrt(n_in + 1))`` -- the BNN caller's particle-batched layer
+    (examples/bayesian_neural_nets/bnn_vi.py:36-48: repeat of w over the batch, appended column of ones, matmul, division,
+    ReLU) as one kernel forward and one backward.  ``h``: [K, B, n_in] or [B, n_in] (shared by the particles);
+    ``w``: [K, n_out, n_in + 1]."""
+
+    @staticmethod
+    def forward(ctx, h, w, relu):
+        _hip.require_device(h, w)
+        sfx = _sfx(h, w)
+        K, n_out, n_in1 = w.shape
+        n_in = n_in1 - 1
+        shared = h.dim() == 2
+        B = h.shape[-2]
+        if h.shape[-1] != n_in or (not shared and (h.dim() != 3 or h.shape[0] != K)):
+            raise RuntimeError("particle_linear: h %s does not match w %s" % (tuple(h.shape), tuple(w.shape)))
+        h, w = h.contiguous(), w.contiguous()
+        out = torch.empty((K, B, n_out), dtype=h.dtype, device=h.device)
+        _hip.lib().call("zs_particle_linear" + sfx, _hip.ptr(h), 0 if shared else B * n_in, _hip.ptr(w), _hip.ptr(out), K, B, n_in,
+                        n_out, 1 if relu else 0, _hip.stream_for(h))
+        ctx.meta = (K, B, n_in, n_out, bool(relu), shared)
+        ctx.save_for_backward(h, w, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        K, B, n_in, n_out, relu, shared = ctx.meta
+        h, w, out = ctx.saved_tensors
+        need_h, need_w = ctx.needs_input_grad[:2]
+        if not (need_h or need_w):
+            return None, None, None
+        gout = gout.contiguous()
+        gh = torch.empty((K, B, n_in), dtype=h.dtype, device=h.device) if need_h else None
+        gw = torch.empty_like(w)
+        _hip.lib().call("zs_particle_linear_bwd" + _sfx(h), _hip.ptr(h), 0 if shared else B * n_in, _hip.ptr(w), _hip.ptr(out),
+                        _hip.ptr(gout), _hip.ptr(gh), _hip.ptr(gw), K, B, n_in, n_out, 1 if relu else 0, _hip.stream_for(h))
+        if need_h and shared:
+            gh = gh.sum(0)
+        return gh, (gw if need_w else None), None

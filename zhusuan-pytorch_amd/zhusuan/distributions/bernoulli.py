@@ -85,6 +85,19 @@ class Bernoulli(Distribution):
         self.sample_cache = s
         return s
 
+    def _lj_term(self, given, n_fold):
+        """This node's contribution to a scalar log-joint as a term of the one-launch objective (LJ1), see Normal."""
+        x = self.sample_cache if given is None else given
+        if x is None:
+            raise RuntimeError("Bernoulli.log_prob(None) needs a cached sample: call sample() first")
+        par = self._param()
+        x = torch.as_tensor(x, dtype=self._dtype).to(par.device)
+        full = value_shape(x.shape, par.dim(), par.shape)
+        px, Px = _ops.periodic_operand(x, full)
+        pp, Pp = _ops.periodic_operand(par, full)
+        fam = _hip.LJ_BERNOULLI_LOGITS if self._from_logits else _hip.LJ_BERNOULLI
+        return fam, (px, pp, None), (Px, Pp, 1), _ops._prod(full)
+
     def _log_prob_sum(self, given=None, n_fold=0):
         """bernoulli.py:84-95 (+ trailing sum over `n_fold` axes)."""
         x = self.sample_cache if given is None else given

@@ -84,10 +84,11 @@ class Normal(Distribution):
     def _batch_shape(self):
         return torch.Size(broadcast_shapes(self._mean.shape, self._scale_operand().shape))
 
-    def _sample(self, n_samples=1, epsilon=None):
-        """normal.py:89-107.  The standard-normal draw has MEAN's shape (``[K] + mean.shape``), so it is
-        shared along axes where only std broadcasts.  `epsilon` (or zhusuan.inject_epsilon) supplies the
-        draw explicitly; otherwise it comes from the in-kernel Philox stream."""
+    def _sample_plan(self, n_samples=1, epsilon=None):
+        """Operands of one draw (normal.py:89-107): ``(mu, sigma, eps, K, has_k, n_fold, is_logstd, simple)``.  The
+        standard-normal draw has MEAN's shape (``[K] + mean.shape``), so it is shared along axes where only std
+        broadcasts.  `epsilon` (or zhusuan.inject_epsilon) supplies the draw explicitly; ``eps is None`` means the kernel
+        draws from its Philox stream.  ``simple``: mean and std have one shape (no expansion was needed)."""
         K = int(n_samples)
         has_k = K > 1
         mean, std = self._mean, self._scale_operand()
@@ -104,13 +105,10 @@ class Normal(Distribution):
             eps = torch.as_tensor(eps, dtype=mean.dtype).to(mean.device)
             if tuple(eps.shape) != eps_shape:
                 raise RuntimeError("epsilon has shape %s, expected %s" % (tuple(eps.shape), eps_shape))
-        seed = call = 0
-        rng_state = None
-        if tuple(mean.shape) == tuple(std.shape):
+        simple = tuple(mean.shape) == tuple(std.shape)
+        if simple:
             mu, sigma = mean.contiguous(), std.contiguous()
-            if eps is None:
-                seed, call, rng_state = _rng.next_call(mean.device)
-            else:
+            if eps is not None:
                 eps = eps.contiguous()
         else:
             if eps is None:
@@ -123,11 +121,41 @@ class Normal(Distribution):
             mu = mean.expand(bshape).contiguous()
             sigma = std.expand(bshape).contiguous()
         n_fold = min(max(1, self._group_ndims), len(bshape))
+        return mu, sigma, eps, K, has_k, n_fold, is_logstd, simple
+
+    def _sample(self, n_samples=1, epsilon=None):
+        """normal.py:89-107 through K1: the sample and its row-summed log-density in one launch."""
+        mu, sigma, eps, K, has_k, n_fold, is_logstd, _ = self._sample_plan(n_samples, epsilon)
+        seed = call = 0
+        rng_state = None
+        if eps is None:
+            seed, call, rng_state = _rng.next_call(mu.device)
         z, lp = _ops.NormalSampleLogProb.apply(mu, sigma, eps, seed, call, rng_state, K if has_k else 1, has_k, n_fold,
                                                bool(self._is_reparameterized), True, is_logstd)
+        self._adopt_draw(z, lp, n_fold)
+        return z
+
+    def _adopt_draw(self, z, lp, n_fold):
+        """Make `z` (with its fused log-density `lp`, summed over `n_fold` trailing axes) the node's current sample."""
         self.sample_cache = z
         self._fused = (z, lp, n_fold)
-        return z
+
+    def _lj_term(self, given, n_fold):
+        """This node's contribution to a scalar log-joint as a term of the one-launch objective (LJ1):
+        ``(family, (x, a, b), (px, pa, pb), n)``, or None when the fused log-density of the cached draw already exists
+        (it then enters as ready-made rows)."""
+        x = self.sample_cache if given is None else given
+        if x is None:
+            raise RuntimeError("Normal.log_prob(None) needs a cached sample: call sample() first")
+        if self._fused is not None and self._fused[0] is x and self._fused[2] == n_fold:
+            return None
+        x = torch.as_tensor(x, dtype=self._dtype).to(self._mean.device)
+        full = value_shape(x.shape, self._mean.dim(), self._mean.shape, self._scale_operand().shape)
+        px, Px = _ops.periodic_operand(x, full)
+        pm, Pm = _ops.periodic_operand(self._mean, full)
+        ps, Ps = _ops.periodic_operand(self._scale_operand(), full)
+        fam = _hip.LJ_NORMAL_LOGSTD if self._logstd_given is not None else _hip.LJ_NORMAL
+        return fam, (px, pm, ps), (Px, Pm, Ps), _ops._prod(full)
 
     def _log_prob_sum(self, given=None, n_fold=0):
         """normal.py:109-126 (+ trailing sum over `n_fold` axes)."""

@@ -3,7 +3,7 @@ observations.  Interface of zhusuan/framework/bn.py:22-240 of the reference."""
 import torch
 import torch.nn as nn
 
-from .stochastic_tensor import StochasticTensor
+from .stochastic_tensor import StochasticTensor, node_value
 from ..distributions import (Distribution, Normal, Bernoulli, Logistic, Uniform, Beta, Exponential, Gamma, Laplace, Poisson,
                              StudentT)
 
@@ -104,7 +104,7 @@ class BayesianNet(nn.Module):
             self._nodes[name] = StochasticTensor(self, name, distribution, n_samples=n_samples, **kwargs)
         else:
             raise ValueError('distribution must be name of sub class of Distribution or an instance of Distribution')
-        return self._nodes[name].tensor
+        return node_value(self._nodes[name])
 
     def _log_joint(self):
         ret = 0
@@ -130,7 +130,7 @@ class BayesianNet(nn.Module):
                               is_reparameterized=is_reparameterized, group_ndims=group_ndims,
                               device=self.device, **kwargs)
         self._nodes[name] = StochasticTensor(self, name, distribution, n_samples=n_samples, **kwargs)
-        return self._nodes[name].tensor
+        return node_value(self._nodes[name])
 
     def bernoulli(self, name, logits=None, probs=None, dtype=None, is_continuous=False, group_ndims=0,
                   n_samples=None, **kwargs):
@@ -139,7 +139,7 @@ class BayesianNet(nn.Module):
         distribution = Bernoulli(logits=logits, probs=probs, dtype=dtype, is_continuous=is_continuous,
                                  group_ndims=group_ndims, device=self.device, **kwargs)
         self._nodes[name] = StochasticTensor(self, name, distribution, n_samples=n_samples, **kwargs)
-        return self._nodes[name].tensor
+        return node_value(self._nodes[name])
 
     def uniform(self, name, low, high, dtype=None, is_continuous=True, is_reparameterized=True, group_ndims=0,
                 n_samples=None, **kwargs):
@@ -150,7 +150,7 @@ class BayesianNet(nn.Module):
                                is_reparameterized=is_reparameterized, group_ndims=group_ndims,
                                device=self.device, **kwargs)
         self._nodes[name] = StochasticTensor(self, name, distribution, n_samples=n_samples, **kwargs)
-        return self._nodes[name].tensor
+        return node_value(self._nodes[name])
 
     def logistic(self, name, loc, scale, dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):
         """As in the reference, the helper of this name builds a LAPLACE node (bn.py:336-358 constructs ``Laplace``).
@@ -163,7 +163,7 @@ class BayesianNet(nn.Module):
             raise ValueError("name of stochastic_node must be str")
         distribution = cls(device=self.device, **params, **kwargs)
         self._nodes[name] = StochasticTensor(self, name, distribution, n_samples=n_samples, **kwargs)
-        return self._nodes[name].tensor
+        return node_value(self._nodes[name])
 
     # the torch.distributions pass-through families (bn.py:242-406): plain torch ops, off the hot path
     def beta(self, name, alpha, beta, dtype=None, is_continuous=True, group_ndims=0, n_samples=None, **kwargs):

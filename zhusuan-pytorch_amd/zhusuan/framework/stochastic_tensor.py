@@ -1,10 +1,125 @@
 """StochasticTensor: a named node = (BayesianNet, Distribution, n_samples, reduction kwargs).
 Interface of zhusuan/framework/stochastic_tensor.py:5-181 of the reference."""
+import contextlib
+
 import torch
 
+from .. import _hip
 from .._shapes import broadcast_shapes
 
-__all__ = ['StochasticTensor']
+__all__ = ['StochasticTensor', 'LazyDraw', 'skip_discarded_draws']
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference draws every latent TWICE per objective evaluation: once when the variational net creates the node
+# (bn.py:158 / :216 return ``node.tensor``, a fresh sample), once more when the objective re-reads ``node.tensor``
+# (elbo.py:122, importance_weighted_objective.py:85) -- and only the second draw is used.  The first one is kept by
+# default (user code may read the value a node factory returns).  Inside ``zhusuan.skip_discarded_draws()`` an objective
+# runs its variational net with node creation DEFERRED: the factories return a ``LazyDraw`` that samples only if
+# somebody actually touches it, so a net that ignores the returned values (all three example callers) draws each latent
+# once per step.
+# ---------------------------------------------------------------------------------------------------------------------
+_skip_discarded = False
+_deferring = False
+
+
+@contextlib.contextmanager
+def skip_discarded_draws(enabled=True):
+    """Objectives evaluated inside this context do not execute the draw that the reference discards (default: they do)."""
+    global _skip_discarded
+    prev = _skip_discarded
+    _skip_discarded = bool(enabled)
+    try:
+        yield
+    finally:
+        _skip_discarded = prev
+
+
+def skipping_discarded_draws():
+    return _skip_discarded
+
+
+@contextlib.contextmanager
+def deferred_node_values():
+    """Used by the objectives around their call of the variational net (only while skip_discarded_draws is active)."""
+    global _deferring
+    prev = _deferring
+    _deferring = True
+    try:
+        yield
+    finally:
+        _deferring = prev
+
+
+def node_value(node):
+    """What a BayesianNet node factory returns: ``node.tensor`` (bn.py:158,216), or a LazyDraw while deferring."""
+    if _deferring and node.name not in node.bn.observed:
+        return LazyDraw(node)
+    return node.tensor
+
+
+def _materialize(v):
+    if isinstance(v, LazyDraw):
+        return v.materialize()
+    if isinstance(v, (list, tuple)):
+        return type(v)(_materialize(u) for u in v)
+    if isinstance(v, dict):
+        return dict((k, _materialize(u)) for k, u in v.items())
+    return v
+
+
+class LazyDraw(object):
+    """The value of a freshly created node that nobody has looked at yet.  Any use -- a torch function, a tensor method
+    or attribute, arithmetic, indexing -- draws the sample (once: ``node.tensor`` at that moment, exactly the value the
+    reference's factory would have returned) and carries on with the tensor."""
+
+    def __init__(self, node):
+        object.__setattr__(self, "_node", node)
+        object.__setattr__(self, "_value", None)
+
+    def materialize(self):
+        if self._value is None:
+            object.__setattr__(self, "_value", self._node.tensor)
+        return self._value
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return func(*_materialize(args), **_materialize(kwargs or {}))
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+    def __repr__(self):
+        return "LazyDraw(%r%s)" % (self._node.name, "" if self._value is None else ", drawn")
+
+    def __len__(self):
+        return len(self.materialize())
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __bool__(self):
+        return bool(self.materialize())
+
+    def __float__(self):
+        return float(self.materialize())
+
+    def __neg__(self):
+        return -self.materialize()
+
+
+def _binary(name):
+    def op(self, other):
+        return getattr(self.materialize(), name)(_materialize(other))
+    op.__name__ = name
+    return op
+
+
+for _n in ("add", "sub", "mul", "truediv", "matmul", "pow", "radd", "rsub", "rmul", "rtruediv", "rmatmul", "rpow",
+           "lt", "le", "gt", "ge", "eq", "ne"):
+    setattr(LazyDraw, "__%s__" % _n, _binary("__%s__" % _n))
 
 
 def _norm_dims(dims, nd):
@@ -111,11 +226,11 @@ class StochasticTensor(object):
             extra += 1
         return full, nd, mean_dims, sum_dims, extra
 
-    def _scalar_term(self, sample=None, rows=True):
+    def _scalar_coef(self, sample=None):
         """When the node's reductions collapse EVERY axis (the VAE / BNN callers), ``log_prob()`` is
-        ``coef * rows.sum()``: returns (rows, coef) so that the objective can fold all nodes into one launch
-        (zs_scalar_objective); None otherwise.  Means and sums over distinct axes commute, so
-        coef = multiplier / prod(sizes of the mean axes).  ``rows=False`` only answers the question (no kernel)."""
+        ``coef * (sum of all element-wise log-probs)``: returns ``(coef, n_fold)`` -- coef = multiplier / prod(sizes of the
+        mean axes), since means and sums over distinct axes commute; n_fold = trailing axes a row-sum kernel may fold --
+        or None when some axis survives.  Launches nothing."""
         full, nd, mean_dims, sum_dims, extra = self._reduction_plan(sample)
         if nd == 0 or set(mean_dims) | set(sum_dims) != set(range(nd)) or set(mean_dims) & set(sum_dims):
             return None
@@ -124,9 +239,27 @@ class StochasticTensor(object):
             coef /= float(full[d])
         if self._multiplier:
             coef *= float(self._multiplier)
-        if not rows:
-            return None, coef
-        return self._dist._log_prob_sum(sample, self._dist.group_ndims + extra), coef
+        return coef, self._dist.group_ndims + extra
+
+    def _scalar_term(self, sample=None):
+        """The node as one term of the one-launch scalar objective (LJ1, ``_ops.LogJointScalar``):
+        ``(family, (x, a, b), (px, pa, pb), n, coef)``.  Families with a term form (Normal, Bernoulli) are evaluated INSIDE
+        that launch; a fused log-density that the sampling kernel has already produced, and every other family's
+        ``_log_prob_sum`` result, enter as ready-made rows (``LJ_ROWS``).  None when the node does not reduce to a scalar."""
+        sc = self._scalar_coef(sample)
+        if sc is None:
+            return None
+        coef, n_fold = sc
+        term = None
+        if hasattr(self._dist, '_lj_term'):
+            term = self._dist._lj_term(sample, n_fold)
+        if term is None:
+            rows = self._dist._log_prob_sum(sample, n_fold)
+            from .._ops import _dense_flat
+            flat = _dense_flat(rows)
+            return _hip.LJ_ROWS, (flat, None, None), (flat.numel(), 1, 1), flat.numel(), coef
+        fam, operands, periods, n = term
+        return fam, operands, periods, n, coef
 
     def log_prob(self, sample=None):
         """stochastic_tensor.py:160-181: dist.log_prob -> mean over reduce_mean_dims -> sum over

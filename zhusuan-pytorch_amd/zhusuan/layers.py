@@ -1,0 +1,46 @@
+"""The particle-batched dense layer of the Bayesian-neural-network caller as one kernel (PL1, include/zs_hip.h).
+
+The reference's example writes the layer out of whole-tensor ops (examples/bayesian_neural_nets/bnn_vi.py:36-48): repeat
+the K weight particles over the batch (a 115 MB copy at K = 10, B = 4096 with 50 hidden units), append a column of ones to
+the activations, ``matmul``, divide by ``sqrt(n_in + 1)``, ReLU.  ``particle_linear`` is that layer in one launch forward
+and one backward; nothing is repeated or concatenated.
+"""
+import torch
+
+from . import _ops
+
+__all__ = ['particle_linear']
+
+
+def _fits_lds(n_in, n_out, itemsize):
+    """The kernel's own admission rule (pl_fits, csrc/zs_logjoint.hip): a particle's weights plus one 64-row tile of
+    activations / gradients must fit 60 KB of LDS."""
+    if not (1 <= n_in <= 255 and 1 <= n_out <= 256):
+        return False
+    lim = 15360 * 4 // itemsize
+    odd = lambda v: v | 1
+    fwd = n_out * odd(n_in + 1) + 64 * odd(n_in)
+    bwd_a = n_out * (n_in + 1) + 64 * odd(n_out)
+    bwd_b = 64 * odd(n_out) + 64 * odd(n_in) + 256
+    return max(fwd, bwd_a, bwd_b) <= lim
+
+
+def particle_linear(h, w, relu=False):
+    """``out[k, b, :] = act(([h[k, b, :], 1] @ w[k].T) / sqrt(n_in + 1))``.
+
+    :param h: activations ``[K, B, n_in]``, or ``[B, n_in]`` when all particles see the same input (the first layer).
+    :param w: one weight matrix per particle, ``[K, n_out, n_in + 1]``; the last column multiplies the appended 1 (bias).
+    :param relu: apply ``max(., 0)``.
+    :return: ``[K, B, n_out]``.
+
+    Layers that do not fit a workgroup's LDS (n_in > 255, n_out > 256, or more than about 15 000 fp32 weights +
+    tile elements) take the equivalent batched-GEMM formulation through torch.
+    """
+    K, n_out, n_in1 = w.shape
+    n_in = n_in1 - 1
+    if _fits_lds(n_in, n_out, w.element_size()):
+        return _ops.ParticleLinear.apply(h, w, bool(relu))
+    if h.dim() == 2:
+        h = h.unsqueeze(0).expand(K, *h.shape)
+    out = (torch.bmm(h, w[:, :, :n_in].transpose(1, 2)) + w[:, :, n_in].unsqueeze(1)) / (float(n_in + 1) ** 0.5)
+    return torch.relu(out) if relu else out

@@ -3,9 +3,14 @@
 import torch
 import torch.nn as nn
 
-from .. import _ops
+from .. import _hip, _ops, _rng
+from ..distributions.normal import Normal
+from ..framework import stochastic_tensor as _st
 
 __all__ = ['ELBO', 'EvidenceLowerBoundObjective']
+
+# the one-launch sampler (MS1) is for the launch-bound shapes: above this many elements in total each node takes K1
+_MULTI_DRAW_MAX_ELEMENTS = 1 << 20
 
 
 def latent_value(node):
@@ -20,6 +25,64 @@ def latent_value(node):
             and getattr(dist, '_nonreparam_draw_has_zero_grad', False)):
         return t.detach()
     return t
+
+
+def run_variational(net, observed):
+    """``net(observed)`` as the objectives call it (elbo.py:88).  Inside ``zhusuan.skip_discarded_draws()`` the node
+    factories of the net do not sample while it runs (their first draw is the one every objective throws away,
+    elbo.py:122): they hand out ``LazyDraw`` stand-ins that sample only if the net's own code touches them."""
+    if _st.skipping_discarded_draws():
+        with _st.deferred_node_values():
+            return net(observed)
+    return net(observed)
+
+
+def draw_latents(nodes_q):
+    """``{name: node.tensor}`` for the latents of the variational net -- the objectives' re-read of every node
+    (elbo.py:122, importance_weighted_objective.py:85): a FRESH draw per node, in node order.  Two or more unobserved,
+    reparameterised Normal nodes of launch-bound size are drawn by ONE launch (MS1, ``NormalSampleLogProbMulti``); every
+    other node draws by itself (``latent_value``).  Draw order, injected epsilons and Philox call ids are those of the
+    node-by-node loop."""
+    names = list(nodes_q.keys())
+    batch = []
+    for name in names:
+        node = nodes_q[name]
+        dist = getattr(node, 'dist', None)
+        if (type(dist) is Normal and dist.is_reparameterized and name not in node.bn.observed
+                and tuple(dist._mean.shape) == tuple(dist._scale_operand().shape) and dist._mean.numel() > 0):
+            batch.append(name)
+    total = sum(max(int(nodes_q[n]._n_samples or 1), 1) * nodes_q[n].dist._mean.numel() for n in batch)
+    devs = {(nodes_q[n].dist._mean.device, nodes_q[n].dist._mean.dtype) for n in batch}
+    if len(batch) < 2 or len(batch) > _hip.MS_MAX_TERMS or total > _MULTI_DRAW_MAX_ELEMENTS or len(devs) != 1 \
+            or _rng.reference_stream_active():
+        return {k: latent_value(v) for k, v in nodes_q.items()}
+    values = {}
+    # nodes before the first batched one keep their place in the draw order; the batched ones are consecutive from there on
+    # only if nothing else draws in between -- otherwise fall back to the plain loop
+    idx = [names.index(n) for n in batch]
+    if idx != list(range(idx[0], idx[0] + len(batch))):
+        return {k: latent_value(v) for k, v in nodes_q.items()}
+    for name in names[:idx[0]]:
+        values[name] = latent_value(nodes_q[name])
+    meta, tensors, plans = [], [], []
+    seed, rng_state = 0, None
+    for name in batch:
+        node = nodes_q[name]
+        mu, sigma, eps, K, has_k, n_fold, is_logstd, _ = node.dist._sample_plan(1 if node._n_samples is None else node._n_samples)
+        call = 0
+        if eps is None:
+            seed, call, rng_state = _rng.next_call(mu.device)
+        meta.append((K if has_k else 1, has_k, n_fold, is_logstd, call))
+        tensors += [mu, sigma, eps]
+        plans.append((node, n_fold))
+    outs = _ops.NormalSampleLogProbMulti.apply(tuple(meta), seed, rng_state, *tensors)
+    for i, (node, n_fold) in enumerate(plans):
+        z, lp = outs[2 * i], outs[2 * i + 1]
+        node.dist._adopt_draw(z, lp, n_fold)
+        values[node.name] = z
+    for name in names[idx[-1] + 1:]:
+        values[name] = latent_value(nodes_q[name])
+    return {k: values[k] for k in names}
 
 
 class ELBO(nn.Module):
@@ -59,9 +122,9 @@ class ELBO(nn.Module):
     def forward(self, observed, reduce_mean=True, **kwargs):
         """elbo.py:81-132: run q; re-read every latent's ``.tensor`` (a second, fresh draw -- the one
         that is used); run p on {latents} U observed; combine the two log-joints."""
-        self.variational(observed)
+        run_variational(self.variational, observed)
         nodes_q = self.variational.nodes
-        _v_inputs = {k: latent_value(v) for k, v in nodes_q.items()}
+        _v_inputs = draw_latents(nodes_q)
         _observed = {**_v_inputs, **observed}
         self.generator(_observed)
         nodes_p = self.generator.nodes
@@ -77,23 +140,25 @@ class ELBO(nn.Module):
 
     def _scalar_sgvb(self, nodes_p, nodes_q):
         """When every node's log-probability reduces to a scalar (the VAE and BNN callers), the whole sgvb objective
-        -(sum_p log p - sum_q log q) is a weighted sum of the kernels' row results: ONE launch (S1,
-        ``zs_scalar_objective``) instead of a mean / sum / multiply per node plus the scalar adds, the subtraction and
-        the negation of elbo.py:58-79,155-161.  Returns None when some node keeps a non-scalar shape."""
+        -(sum_p log p - sum_q log q) is ONE launch (LJ1, ``zs_logjoint_scalar``): the element-wise log-probs of every
+        Normal / Bernoulli node, the fused log-densities the sampling kernel has already produced, their reductions
+        (mean / sum over the reduce dims, multiplier: one coefficient per node) and the scalar arithmetic of
+        elbo.py:58-79,155-161 -- instead of one log-prob launch per node plus a mean / sum / multiply per node and the
+        adds; the backward of all of it is one more launch.  Returns None when some node keeps a non-scalar shape."""
         plan = [(sign, nodes[name]) for sign, nodes in ((-1.0, nodes_p), (1.0, nodes_q)) for name in nodes.keys()]
-        if not plan or len(plan) > _ops.MAX_TERMS:
+        if not plan or len(plan) > _hip.LJ_MAX_TERMS:
             return None
         for _, node in plan:                        # decide first (no kernel is launched by the question)
-            if not hasattr(node, '_scalar_term') or node._scalar_term(rows=False) is None:
+            if not hasattr(node, '_scalar_coef') or node._scalar_coef() is None:
                 return None
-        terms, coefs = [], []
+        spec, tensors = [], []
         for sign, node in plan:
-            rows, coef = node._scalar_term()
-            terms.append(rows)
-            coefs.append(sign * coef)
-        if len({t.dtype for t in terms}) != 1:
+            fam, operands, periods, n, coef = node._scalar_term()
+            spec.append((fam, sign * coef, n) + tuple(periods))
+            tensors += list(operands)
+        if len({t.dtype for t in tensors if t is not None}) != 1 or len({t.device for t in tensors if t is not None}) != 1:
             return None
-        return _ops.ScalarObjective.apply(tuple(coefs), *terms)
+        return _ops.LogJointScalar.apply(tuple(spec), *tensors)
 
     def sgvb(self, logpxz, logqz, reduce_mean=True, log_det=None):
         """elbo.py:134-161."""

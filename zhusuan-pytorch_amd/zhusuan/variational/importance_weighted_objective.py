@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from ..framework.stochastic_tensor import StochasticTensor
 from .. import _ops
-from .elbo import latent_value
+from .elbo import latent_value, draw_latents, run_variational
 from .._shapes import broadcast_shapes
 
 __all__ = ['ImportanceWeightedObjective']
@@ -51,13 +51,16 @@ class ImportanceWeightedObjective(nn.Module):
         """importance_weighted_objective.py:79-100.  The generator's log-joint is handed to the kernel as (up to) two
         terms, so that its last addition (e.g. log p(x|z) + log p(z)), the subtraction of log q, the K-particle
         reductions and the batch mean are ONE launch; the value is rounded exactly like the reference's separate ops."""
-        self.variational(observed)
+        run_variational(self.variational, observed)
         nodes_q = self.variational.nodes
-        _v_inputs = {}
-        for k, v in nodes_q.items():
-            _v_inputs[k] = latent_value(v)
-            if self.estimator == "vimco" and isinstance(v, StochasticTensor) and v.dist.is_reparameterized:
-                raise ValueError("with vimco estimator, the is_reparameterized must be false")
+        if self.estimator == "vimco":
+            _v_inputs = {}
+            for k, v in nodes_q.items():          # (the reference draws the node, then checks it: :85-89)
+                _v_inputs[k] = latent_value(v)
+                if isinstance(v, StochasticTensor) and v.dist.is_reparameterized:
+                    raise ValueError("with vimco estimator, the is_reparameterized must be false")
+        else:
+            _v_inputs = draw_latents(nodes_q)
         _observed = {**_v_inputs, **observed}
         nodes_p = self.generator(_observed).nodes
         cls = type(self)
