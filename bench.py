@@ -70,6 +70,10 @@ def parse_args(argv=None):
                     help="run although ZS_* experiment variables are set (ZS_HIP_LIBRARY: another build of the kernel library; "
                          "ZS_K*: dispatch knobs of a -DZS_EXPERIMENTS build) or the loaded library is an experiments build; the "
                          "line then says so (`env_overrides`, `library`).  Without the flag such a run is refused (exit code 2)")
+    ap.add_argument("--reference-draws", action="store_true",
+                    help="also execute the draw of every latent that the reference's objectives throw away (the node factory's "
+                         "sample, bn.py:158 / elbo.py:122): the package's default behaviour.  The bench runs inside "
+                         "zhusuan.skip_discarded_draws() unless this flag is given (one sampling launch per latent and step)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="update with torch.optim.Adam(fused=True, capturable=True) instead of zhusuan.optim.FlatAdam "
                          "(the same update over flat buckets, one launch)")
@@ -353,7 +357,7 @@ def make_optimizer(model, torch_adam, groups=None):
     return zhusuan.optim.FlatAdam(groups if groups is not None else model.parameters(), lr=1e-3)
 
 
-def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False):
+def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False, skip_discarded=True):
     """A BASELINE config other than the headline one on this GPU: full training steps replayed from one hipGraph."""
     import zhusuan
     gemm_tuning(tuned)
@@ -369,7 +373,7 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
         loss = model(obs)
         loss.backward()
         return loss.detach()
-    with zhusuan.device_rng(rng):
+    with zhusuan.device_rng(rng), zhusuan.skip_discarded_draws(skip_discarded):
         step = zhusuan.GraphedStep(compute, opt.step, rng=rng, warmup=max(3, min(warmup, 10)))
         gemm_tuning(tuned, tune=False)       # every GEMM shape of the step has been seen: keep the picks, stop timing
         for _ in range(3):
@@ -379,6 +383,7 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
     assert np.isfinite(float(last))
     return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
             "launch_mode": "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
+            "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default)",
             "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape)" if tuned else "PyTorch default",
             "optimizer": "torch.optim.Adam(fused=True, capturable=True)" if torch_adam else "zhusuan.optim.FlatAdam"}
 
@@ -441,7 +446,11 @@ def hbm_resident_kernels(klib, dev, launches=30):
 
 # kernel-name fragment -> C-ABI entry point (most specific first); logits forms carry <true, ...> as first template argument
 # (the kernels shared by the location-scale families live in namespace zs: first template argument 0 = Normal, 1 = Logistic)
-_KERNEL_ENTRY = [("k_bern_logprob_bwd", "zs_bernoulli%s_logprob_bwd_f32"), ("k_bern_logprob", "zs_bernoulli%s_logprob_f32"),
+_KERNEL_ENTRY = [("k_logjoint_bwd", "zs_logjoint_scalar_bwd_f32"), ("k_logjoint_fwd", "zs_logjoint_scalar_f32"),
+                 ("k_normal_sample_multi_bwd", "zs_normal_sample_logprob_multi_bwd_f32"),
+                 ("k_normal_sample_multi", "zs_normal_sample_logprob_multi_f32"),
+                 ("k_particle_linear_bwd", "zs_particle_linear_bwd_f32"), ("k_particle_linear", "zs_particle_linear_f32"),
+                 ("k_bern_logprob_bwd", "zs_bernoulli%s_logprob_bwd_f32"), ("k_bern_logprob", "zs_bernoulli%s_logprob_f32"),
                  ("k_sample_tile<0", "zs_normal_sample_logprob_f32"), ("k_sample_tile<1", "zs_logistic_sample_logprob_f32"),
                  ("k_logprob_bwd_ksum<0", "zs_normal_logprob_bwd_ksum_f32"), ("k_logprob_krep<0", "zs_normal_logprob_f32"),
                  ("k_adam_step", "zs_adam_step_f32"),
@@ -590,11 +599,12 @@ def main():
             sbuckets.scale(gradients=False)
             opt.step(grad_scale=sbuckets.grad_scale())
 
+    skip_discarded = not args.reference_draws
     klib = _hip.lib()
     if "experiments" in klib.build_info() and not args.allow_experiments:
         raise SystemExit("bench: %s is an experiments build (%s); pass --allow-experiments" % (klib.path, klib.build_info()))
     mode = "eager"
-    with zhusuan.device_rng(rng):
+    with zhusuan.device_rng(rng), zhusuan.skip_discarded_draws(skip_discarded):
         step = step_body
         if args.no_graph:
             for _ in range(args.warmup):
@@ -756,6 +766,11 @@ def main():
                        "optimizer": "torch.optim.Adam(lr=1e-3, fused=True, capturable=True)" if args.torch_adam else
                                     "zhusuan.optim.FlatAdam(lr=1e-3): torch.optim.Adam's update over flat buckets, one launch per "
                                     "bucket (extra_configs.c3_torch_adam: the same step with torch's multi-tensor Adam)",
+                       "discarded_draws": ("skipped: the step runs inside zhusuan.skip_discarded_draws(), so the draw of the latent "
+                                           "that the reference's objective throws away (bn.py:158 / elbo.py:122) is not executed -- "
+                                           "one fused sample + log-density launch per step; extra_configs.c3_reference_draws is the "
+                                           "same step with it executed") if skip_discarded else
+                                          "executed, as the package does by default (--reference-draws)",
                        "launch_mode": mode,
                        "timing": "median of %d trials of %d steps, each bracketed by synchronize + barrier, max over ranks"
                                  % (len(trials), args.steps)},
@@ -791,7 +806,7 @@ def main():
             for name in ("c2", "c5", "c3_probs" if args.fused_logits else "c3_logits"):
                 try:
                     out["extra_configs"][name] = run_single_gpu_config(name, dev, args.steps, args.warmup, tuned=tuned,
-                                                                       torch_adam=args.torch_adam)
+                                                                       torch_adam=args.torch_adam, skip_discarded=skip_discarded)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"][name] = {"error": repr(e)}
             if tuned:       # the headline step once more with PyTorch's default GEMM selection (what round 1 measured)
@@ -800,6 +815,13 @@ def main():
                                                                                     tuned=False, torch_adam=True)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"]["c3_default_gemm"] = {"error": repr(e)}
+            if skip_discarded:          # the headline step with the reference's discarded draw executed (the package default)
+                try:
+                    out["extra_configs"]["c3_reference_draws"] = run_single_gpu_config(
+                        "c3", dev, args.steps, args.warmup, tuned=tuned, torch_adam=args.torch_adam, fused_logits=args.fused_logits,
+                        skip_discarded=False)
+                except Exception as e:                              # noqa: BLE001
+                    out["extra_configs"]["c3_reference_draws"] = {"error": repr(e)}
             if not args.torch_adam:     # the headline step with torch's multi-tensor Adam
                 try:
                     out["extra_configs"]["c3_torch_adam"] = run_single_gpu_config("c3", dev, args.steps, args.warmup, tuned=tuned,

@@ -445,12 +445,15 @@ int zs_normal_sample_logprob_multi_bwd_f32(const zs_ms_term* terms, int n_terms,
  *     gh[k, b, i] = sum_o gpre[k, b, o] * w[k, o, i] / sqrt(n_in + 1)          (optional; [K, B, n_in] also when h is shared:
  *                                                                                the caller sums over k if it needs d/dx)
  *     gw[k, o, i] = sum_b gpre[k, b, o] * h[k, b, i] / sqrt(n_in + 1),   gw[k, o, n_in] = sum_b gpre[k, b, o] / sqrt(n_in + 1)
+ * The batch sum of gw is formed per tile of 64 rows and the tiles are added in tile order by the last workgroup of each
+ * particle (deterministic): workspace holds the tile partials, >= K * ceil(B / 64) * n_out * (n_in + 1) elements; tickets
+ * is K zero-initialised device words owned by the caller, handed back at zero.
  * -------------------------------------------------------------------------*/
 int zs_particle_linear_f32(const float* h, int64_t h_stride_k, const float* w, float* out,
                            int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, void* stream);
 int zs_particle_linear_bwd_f32(const float* h, int64_t h_stride_k, const float* w, const float* out, const float* gout,
                                float* gh, float* gw, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu,
-                               void* stream);
+                               float* workspace, int64_t workspace_len, uint32_t* tickets, void* stream);
 
 /* ---------------------------------------------------------------------------
  * float64 twins.  The reference accepts float64 parameters for Normal / Bernoulli
@@ -487,7 +490,7 @@ int zs_logjoint_scalar_bwd_f64(const zs_lj_term* terms, int n_terms, const doubl
 int zs_normal_sample_logprob_multi_f64(const zs_ms_term* terms, int n_terms, uint64_t seed, const uint64_t* rng_state, uint64_t* rng_used, void* stream);
 int zs_normal_sample_logprob_multi_bwd_f64(const zs_ms_term* terms, int n_terms, uint64_t seed, const uint64_t* rng_state, void* stream);
 int zs_particle_linear_f64(const double* h, int64_t h_stride_k, const double* w, double* out, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, void* stream);
-int zs_particle_linear_bwd_f64(const double* h, int64_t h_stride_k, const double* w, const double* out, const double* gout, double* gh, double* gw, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, void* stream);
+int zs_particle_linear_bwd_f64(const double* h, int64_t h_stride_k, const double* w, const double* out, const double* gout, double* gh, double* gw, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, double* workspace, int64_t workspace_len, uint32_t* tickets, void* stream);
 int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors, double* exp_avg, double* exp_avg_sq, int64_t* steps, uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -171,10 +171,14 @@ class Raw(object):
         gh = torch.full((K, B, n_in1 - 1), float("nan"), dtype=self.dtype, device=self.dev)
         gw = torch.full((K, n_out, n_in1), float("nan"), dtype=self.dtype, device=self.dev)
         h, w, out, gout = self.t(h), self.t(w), self.t(out), self.t(gout)
-        self.k.call("zs_particle_linear_bwd" + self.sfx, _hip.ptr(h), 0 if shared else B * (n_in1 - 1), _hip.ptr(w),
-                    _hip.ptr(out), _hip.ptr(gout), _hip.ptr(gh) if want_gh else None, _hip.ptr(gw), K, B, n_in1 - 1,
-                    n_out, int(relu), self.stream())
+        part = torch.full((K * ((B + 63) // 64) * n_out * n_in1 + 1,), float("nan"), dtype=self.dtype, device=self.dev)
+        tickets = torch.zeros(max(K, 1), dtype=torch.int32, device=self.dev)
+        for _ in range(2):          # twice: the tickets must have been handed back at zero
+            self.k.call("zs_particle_linear_bwd" + self.sfx, _hip.ptr(h), 0 if shared else B * (n_in1 - 1), _hip.ptr(w),
+                        _hip.ptr(out), _hip.ptr(gout), _hip.ptr(gh) if want_gh else None, _hip.ptr(gw), K, B, n_in1 - 1,
+                        n_out, int(relu), _hip.ptr(part), part.numel(), _hip.ptr(tickets), self.stream())
         self.sync()
+        assert int(tickets.abs().sum().item()) == 0
         return (gh.cpu().numpy() if want_gh else None), gw.cpu().numpy()
 
 

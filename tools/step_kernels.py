@@ -24,7 +24,7 @@ import zhusuan
 from examples import vae_mnist, iwae, bnn_vi
 
 
-def make(config, dev):
+def make(config, dev, bnn_layer="fused"):
     bits = lambda B: {"x": (torch.rand(B, 784, device=dev) < 0.5).float()}
     if config == "C2":
         return vae_mnist.build(512, device=dev), bits(512), 512
@@ -33,7 +33,7 @@ def make(config, dev):
     if config == "C3-logits":
         return iwae.build(50, "vimco", device=dev, fused_logits=True), bits(256), 12800
     if config == "C5":
-        return bnn_vi.build(n_particles=10, device=dev), {"x": torch.randn(512, 13, device=dev), "y": torch.randn(512, device=dev)}, 5120
+        return bnn_vi.build(n_particles=10, device=dev, layer=bnn_layer), {"x": torch.randn(512, 13, device=dev), "y": torch.randn(512, device=dev)}, 5120
     raise SystemExit("unknown config %s" % config)
 
 
@@ -44,11 +44,15 @@ def main():
     ap.add_argument("--external", action="store_true", help="an outside tracer counts; just run the steps")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused, capturable) instead of zhusuan.optim.FlatAdam")
     ap.add_argument("--tuned-gemm", action="store_true", help="PyTorch TunableOp picks the callers' GEMM solutions, as bench.py does")
+    ap.add_argument("--reference-draws", action="store_true",
+                    help="execute the draw the reference's objectives discard (package default); the tool, like bench.py, runs "
+                         "inside zhusuan.skip_discarded_draws() otherwise")
+    ap.add_argument("--bnn-layer", default="fused", choices=["fused", "bmm", "materialize"])
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    model, obs, evals = make(args.config, dev)
+    model, obs, evals = make(args.config, dev, args.bnn_layer)
     if args.tuned_gemm:
         import tempfile
         torch.cuda.tunable.enable(True)
@@ -66,22 +70,49 @@ def main():
         loss.backward()
         opt.step()
 
-    with zhusuan.device_rng(rng):
+    with zhusuan.device_rng(rng), zhusuan.skip_discarded_draws(not args.reference_draws):
         if args.external:
             for _ in range(args.steps):
                 step()
             torch.cuda.synchronize()
             return
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
+        # the step replayed from a hipGraph, timed from the host (what bench.py's extra_configs report).  FIRST: autograd's
+        # AccumulateGrad nodes remember the stream of their first use, and eager steps on the default stream before a capture
+        # break it (zhusuan.GraphedStep warms up on its own capture stream)
+        import time
+
+        def compute():
+            rng.begin_step()
+            for p in model.parameters():
+                p.grad = None
+            loss = model(obs)
+            loss.backward()
+            return loss.detach()
+        gstep = zhusuan.GraphedStep(compute, opt.step, rng=rng, warmup=5)
         if args.tuned_gemm:
             torch.cuda.tunable.tuning_enable(False)
+        for _ in range(20):
+            gstep()
+        torch.cuda.synchronize()
+        reps = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(200):
+                gstep()
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0) / 200)
+        graph_ms = 1e3 * sorted(reps)[len(reps) // 2]
+        side = torch.cuda.Stream()           # eager launches next to a captured graph: stay off the default stream
+        side.wait_stream(torch.cuda.current_stream())
         from torch.profiler import profile, ProfilerActivity
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            for _ in range(args.steps):
+        with torch.cuda.stream(side):
+            for _ in range(5):
                 step()
             torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
     acc = {}
     for e in prof.events():
         d = getattr(e, "device_time", None) or getattr(e, "cuda_time", 0.0)
@@ -91,21 +122,30 @@ def main():
             a[1] += float(d)
     rows = []
     for name, (n, tot) in acc.items():
-        hot = "k_" in name and ("zs" in name or name.lstrip("void ").startswith(("(anonymous namespace)::k_", "k_")))
-        rows.append({"kernel": name[:140], "hot_path": bool(hot), "launches_per_step": n / args.steps,
+        ours = "k_" in name and ("zs" in name or name.lstrip("void ").startswith(("(anonymous namespace)::k_", "k_")))
+        # kernels of this package: HOT = the distribution / objective / update kernels of the hot path; LAYER = the BNN caller's
+        # particle-batched layer (PL1: the caller's code in the reference, a kernel of this package here)
+        kind = "" if not ours else ("LAYER" if "k_particle_linear" in name else "HOT")
+        rows.append({"kernel": name[:140], "hot_path": kind == "HOT", "kind": kind or "other", "launches_per_step": n / args.steps,
                      "avg_us": tot / n, "us_per_step": tot / args.steps})
     rows.sort(key=lambda r: -r["us_per_step"])
-    hot = [r for r in rows if r["hot_path"]]
-    glue = [r for r in rows if not r["hot_path"]]
-    summary = {"config": args.config, "steps": args.steps, "launch_mode": "eager",
-               "hot_path": {"launches_per_step": sum(r["launches_per_step"] for r in hot), "us_per_step": sum(r["us_per_step"] for r in hot)},
-               "other": {"launches_per_step": sum(r["launches_per_step"] for r in glue), "us_per_step": sum(r["us_per_step"] for r in glue)},
-               "kernels": rows}
-    print("%s: hot-path %.1f launches / %.1f us per step; other %.1f launches / %.1f us per step" % (
-        args.config, summary["hot_path"]["launches_per_step"], summary["hot_path"]["us_per_step"],
-        summary["other"]["launches_per_step"], summary["other"]["us_per_step"]))
+
+    def tot(kind):
+        sel = [r for r in rows if r["kind"] == kind]
+        return {"launches_per_step": sum(r["launches_per_step"] for r in sel), "us_per_step": sum(r["us_per_step"] for r in sel)}
+    summary = {"config": args.config, "steps": args.steps, "launch_mode": "eager (per-kernel rows); hipgraph_ms_per_step: replayed",
+               "discarded_draws": "executed" if args.reference_draws else "skipped (zhusuan.skip_discarded_draws)",
+               "hipgraph_ms_per_step": graph_ms,
+               "hot_path": tot("HOT"), "caller_layer_kernels_of_this_package": tot("LAYER"), "other": tot("other"), "kernels": rows}
+    print("%s: hot-path %.1f launches / %.1f us per step; this package's layer kernels %.1f / %.1f us; other (torch, BLAS) %.1f launches "
+          "/ %.1f us per step; the step replayed from a hipGraph: %.4f ms" % (
+              args.config, summary["hot_path"]["launches_per_step"], summary["hot_path"]["us_per_step"],
+              summary["caller_layer_kernels_of_this_package"]["launches_per_step"],
+              summary["caller_layer_kernels_of_this_package"]["us_per_step"],
+              summary["other"]["launches_per_step"], summary["other"]["us_per_step"], graph_ms))
     for r in rows:
-        print("  %-5s %5.2f x %8.2f us  %s" % ("HOT" if r["hot_path"] else "", r["launches_per_step"], r["avg_us"], r["kernel"][:110]))
+        print("  %-5s %5.2f x %8.2f us  %s" % (r["kind"].upper() if r["kind"] != "other" else "", r["launches_per_step"], r["avg_us"],
+                                            r["kernel"][:110]))
     if args.out:
         with open(args.out, "w") as f:
             json.dump(summary, f, indent=1)

@@ -71,18 +71,32 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
 }
 
 // ================================================================ LJ1
+// Launch layout: every term owns a run of workgroups (a table in the kernel arguments, as zs_adam.hip has for 32 tensors).
+// A thread handles LJ_U groups of 4 consecutive elements per round and issues ALL their loads before any arithmetic: at
+// these sizes a load is a 1-2 us round trip and the duration of the kernel is the number of DEPENDENT rounds, not its
+// bytes.  The loops are compiled per (family, operand pattern): inside them there is no branch between two loads (a
+// uniform branch there makes the compiler wait for the first load before it issues the second):
+//   vector form   every non-scalar operand is 16-byte aligned with a period that is a multiple of 4 (and at least one
+//                 operand has full size): one dwordx4 load per operand and group; a scalar operand's load is redirected
+//                 to a full-size operand's address (harmless) and its value selected from a register;
+//   element form  anything else: one element per thread and load, index i, i % P or 0 chosen by a select.
+// Indices are 32-bit (n < 2^31 per term; larger problems are not launch-bound and take the per-node kernels).
 constexpr int LJ_BLOCK = 256;
+constexpr int LJ_U = 4;                      // groups (vector form) / elements (element form) a thread has in flight
 constexpr unsigned LJ_MAX_BLOCKS = 2048;      // 3 doubles of workspace per workgroup: 6144 <= ZS_LJ_WORKSPACE
+enum { CLS_NONE = 0, CLS_SCALAR = 1, CLS_FULL = 2, CLS_PERIODIC = 3 };
 
 template <typename T>
 struct LJTerm {
   const T *x, *a, *b;
+  const T* dummy;             // vector form: a full-size, aligned operand (where the loads of scalar operands are pointed)
   T *gx, *ga, *gb;
-  int64_t n, px, pa, pb;
+  uint32_t n, px, pa, pb;
   double coef;
   int family;
   unsigned block0, nblocks;   // the element-wise workgroups of this term
-  unsigned vec;               // bit o: operand o (0 = x, 1 = a, 2 = b) can be read / written 4 elements at a time
+  unsigned char cx, ca, cb;   // operand classes (CLS_*)
+  unsigned char vec, periodic;   // vector form; some operand is CLS_PERIODIC (the vector loop then computes i % P)
 };
 struct LJFold {                // backward: the gradient of an operand of period 1 < P < n, one thread per element of it
   int term, operand;
@@ -96,36 +110,51 @@ struct LJArgs {
   unsigned n_elem_blocks, n_blocks;
 };
 
-template <typename T>
-__device__ __forceinline__ void lj_load4(const T* __restrict__ p, int64_t P, int64_t n, bool vec, int64_t i0, int cnt, T v[4]) {
-  if (P == 1) {
-    const T s = p[0];
-    v[0] = v[1] = v[2] = v[3] = s;
-    return;
+// ---- per-family element arithmetic
+template <typename T, int FAM>
+struct Fam {
+  static constexpr bool has_a = FAM != ZS_LJ_ROWS;
+  static constexpr bool has_b = FAM == ZS_LJ_NORMAL || FAM == ZS_LJ_NORMAL_LOGSTD;
+  static __device__ __forceinline__ T term(T x, T a, T b) {
+    typedef Mth<T> M;
+    if (FAM == ZS_LJ_ROWS) return x;
+    if (has_b) {
+      const T sg = M::sigma_of(b, FAM == ZS_LJ_NORMAL_LOGSTD);
+      T logstd, prec;
+      M::parts(sg, logstd, prec);
+      return M::normal_term(x - a, logstd, prec);
+    }
+    return M::bern_term(FAM == ZS_LJ_BERNOULLI_LOGITS ? M::sigmoid(a) : a, x);
   }
-  if (vec && cnt == 4) {                       // P % 4 == 0 and 4-element aligned base: the group does not wrap
-    const int64_t j = (P == n) ? i0 : mod_fast(i0, P);
-    const V4<T> q = *reinterpret_cast<const V4<T>*>(p + j);
-    v[0] = q.v[0]; v[1] = q.v[1]; v[2] = q.v[2]; v[3] = q.v[3];
-    return;
+  // d term / d (x, a, b) times gc = g * coef
+  static __device__ __forceinline__ void partials(T x, T a, T b, T gc, T& dx, T& da, T& db) {
+    typedef Mth<T> M;
+    if (has_b) {
+      const bool ls = FAM == ZS_LJ_NORMAL_LOGSTD;
+      const T sg = M::sigma_of(b, ls);
+      T logstd, prec;
+      M::parts(sg, logstd, prec);
+      const T d = x - a;
+      const T u = gc * prec * d;
+      dx = -u;
+      da = u;
+      const T v = gc * (prec * d * d - (T)1);
+      db = ls ? v : v / sg;                     // d/d log std = sigma * d/d sigma
+    } else {                                    // Bernoulli: d/d probs, or d/d logits = d/dp * p * (1 - p)
+      dx = (T)0;
+      db = (T)0;
+      if (FAM == ZS_LJ_BERNOULLI_LOGITS) {
+        const T p = M::sigmoid(a);
+        da = gc * M::bern_dp(p, x) * p * ((T)1 - p);
+      } else {
+        da = gc * M::bern_dp(a, x);
+      }
+    }
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t i = i0 + (j < cnt ? j : 0);  // clamped: unconditional loads
-    v[j] = p[(P == n) ? i : mod_fast(i, P)];
-  }
-}
-template <typename T>
-__device__ __forceinline__ void lj_store4(T* __restrict__ p, bool vec, int64_t i0, int cnt, const T v[4]) {
-  if (vec && cnt == 4) {
-    V4<T> q;
-    q.v[0] = v[0]; q.v[1] = v[1]; q.v[2] = v[2]; q.v[3] = v[3];
-    *reinterpret_cast<V4<T>*>(p + i0) = q;
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (j < cnt) p[i0 + j] = v[j];
+};
+
+__device__ __forceinline__ uint32_t lj_idx(unsigned cls, uint32_t i, uint32_t P) {
+  return cls == CLS_FULL ? i : (cls == CLS_PERIODIC ? i % P : 0u);
 }
 
 // which term owns this workgroup (uniform; the table lives in the kernel-argument segment: scalar loads)
@@ -137,28 +166,73 @@ __device__ __forceinline__ int lj_term_of(const LJArgs<T>& A, unsigned blk) {
   return __builtin_amdgcn_readfirstlane(ti);
 }
 
-// log-density terms of 4 consecutive elements
-template <typename T>
-__device__ __forceinline__ T lj_terms4(int family, const T x[4], const T a[4], const T b[4], int cnt) {
-  typedef Mth<T> M;
-  T s = (T)0;
+// ---- forward loops: the sum of this thread's terms
+template <typename T, int FAM, bool PER>
+__device__ __forceinline__ double lj_fwd_vec(const LJTerm<T>& t, unsigned blk) {
+  typedef Fam<T, FAM> F;
+  const uint32_t n = t.n, ng = n >> 2, stride = t.nblocks * LJ_BLOCK;
+  const bool sx = t.cx == CLS_SCALAR, sa = t.ca == CLS_SCALAR, sb = t.cb == CLS_SCALAR;
+  const T xs = t.x[0], as = F::has_a ? t.a[0] : (T)0, bs = F::has_b ? t.b[0] : (T)1;
+  const T* __restrict__ px = sx ? t.dummy : t.x;
+  const T* __restrict__ pa = (!F::has_a || sa) ? t.dummy : t.a;
+  const T* __restrict__ pb = (!F::has_b || sb) ? t.dummy : t.b;
+  const bool mx = PER && t.cx == CLS_PERIODIC, ma = PER && t.ca == CLS_PERIODIC, mb = PER && t.cb == CLS_PERIODIC;
+  double acc = 0.0;
+  for (uint32_t g0 = blk * LJ_BLOCK + threadIdx.x; g0 < ng; g0 += stride * LJ_U) {
+    V4<T> x[LJ_U], a[LJ_U], b[LJ_U];
+    bool live[LJ_U];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    T t;
-    if (family == ZS_LJ_ROWS) {
-      t = x[j];
-    } else if (family == ZS_LJ_NORMAL || family == ZS_LJ_NORMAL_LOGSTD) {
-      const T sg = M::sigma_of(b[j], family == ZS_LJ_NORMAL_LOGSTD);
-      T logstd, prec;
-      M::parts(sg, logstd, prec);
-      t = M::normal_term(x[j] - a[j], logstd, prec);
-    } else {
-      const T p = family == ZS_LJ_BERNOULLI_LOGITS ? M::sigmoid(a[j]) : a[j];
-      t = M::bern_term(p, x[j]);
+    for (int u = 0; u < LJ_U; ++u) {
+      const uint32_t g = g0 + u * stride;
+      live[u] = g < ng;
+      const uint32_t i0 = (live[u] ? g : ng - 1) << 2;           // clamped: unconditional loads
+      x[u] = *reinterpret_cast<const V4<T>*>(px + (mx ? i0 % t.px : i0));
+      if (F::has_a) a[u] = *reinterpret_cast<const V4<T>*>(pa + (ma ? i0 % t.pa : i0));
+      if (F::has_b) b[u] = *reinterpret_cast<const V4<T>*>(pb + (mb ? i0 % t.pb : i0));
     }
-    if (j < cnt) s += t;
+#pragma unroll
+    for (int u = 0; u < LJ_U; ++u) {
+      T s = (T)0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        s += F::term(sx ? xs : x[u].v[j], F::has_a ? (sa ? as : a[u].v[j]) : (T)0, F::has_b ? (sb ? bs : b[u].v[j]) : (T)1);
+      acc += live[u] ? (double)s : 0.0;
+    }
   }
-  return s;
+  // the n % 4 elements after the last full group: the first threads of the term's first workgroup
+  if (blk == 0 && threadIdx.x < (n & 3u)) {
+    const uint32_t i = (ng << 2) + threadIdx.x;
+    acc += (double)F::term(t.x[lj_idx(t.cx, i, t.px)], F::has_a ? t.a[lj_idx(t.ca, i, t.pa)] : (T)0,
+                           F::has_b ? t.b[lj_idx(t.cb, i, t.pb)] : (T)1);
+  }
+  return acc;
+}
+template <typename T, int FAM>
+__device__ __forceinline__ double lj_fwd_elem(const LJTerm<T>& t, unsigned blk) {
+  typedef Fam<T, FAM> F;
+  const uint32_t n = t.n, stride = t.nblocks * LJ_BLOCK;
+  double acc = 0.0;
+  for (uint32_t e0 = blk * LJ_BLOCK + threadIdx.x; e0 < n; e0 += stride * LJ_U) {
+    T x[LJ_U], a[LJ_U], b[LJ_U];
+    bool live[LJ_U];
+#pragma unroll
+    for (int u = 0; u < LJ_U; ++u) {
+      const uint32_t e = e0 + u * stride;
+      live[u] = e < n;
+      const uint32_t i = live[u] ? e : n - 1;
+      x[u] = t.x[lj_idx(t.cx, i, t.px)];
+      a[u] = F::has_a ? t.a[lj_idx(t.ca, i, t.pa)] : (T)0;
+      b[u] = F::has_b ? t.b[lj_idx(t.cb, i, t.pb)] : (T)1;
+    }
+#pragma unroll
+    for (int u = 0; u < LJ_U; ++u) acc += live[u] ? (double)F::term(x[u], a[u], b[u]) : 0.0;
+  }
+  return acc;
+}
+template <typename T, int FAM>
+__device__ __forceinline__ double lj_fwd_family(const LJTerm<T>& t, unsigned blk) {
+  if (!t.vec) return lj_fwd_elem<T, FAM>(t, blk);
+  return t.periodic ? lj_fwd_vec<T, FAM, true>(t, blk) : lj_fwd_vec<T, FAM, false>(t, blk);
 }
 
 template <typename T>
@@ -168,19 +242,16 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_fwd(const LJArgs<T> A, T*
   __shared__ bool last;
   const int ti = lj_term_of(A, blockIdx.x);
   const LJTerm<T>& t = A.t[ti];
-  const int family = t.family;
-  const int64_t n = t.n, groups = (n + 3) >> 2;
-  const bool vx = t.vec & 1u, va = t.vec & 2u, vb = t.vec & 4u;
-  const bool has_a = family != ZS_LJ_ROWS, has_b = family == ZS_LJ_NORMAL || family == ZS_LJ_NORMAL_LOGSTD;
+  const unsigned blk = blockIdx.x - t.block0;
   double acc = 0.0;
-  for (int64_t g = (int64_t)(blockIdx.x - t.block0) * LJ_BLOCK + threadIdx.x; g < groups; g += (int64_t)t.nblocks * LJ_BLOCK) {
-    const int64_t i0 = g << 2;
-    const int cnt = n - i0 < 4 ? (int)(n - i0) : 4;
-    T x[4], a[4] = {(T)0, (T)0, (T)0, (T)0}, b[4] = {(T)1, (T)1, (T)1, (T)1};
-    lj_load4(t.x, t.px, n, vx, i0, cnt, x);
-    if (has_a) lj_load4(t.a, t.pa, n, va, i0, cnt, a);
-    if (has_b) lj_load4(t.b, t.pb, n, vb, i0, cnt, b);
-    acc += (double)lj_terms4<T>(family, x, a, b, cnt);
+  if (t.n > 0) {
+    switch (t.family) {                          // uniform
+      case ZS_LJ_ROWS: acc = lj_fwd_family<T, ZS_LJ_ROWS>(t, blk); break;
+      case ZS_LJ_NORMAL: acc = lj_fwd_family<T, ZS_LJ_NORMAL>(t, blk); break;
+      case ZS_LJ_NORMAL_LOGSTD: acc = lj_fwd_family<T, ZS_LJ_NORMAL_LOGSTD>(t, blk); break;
+      case ZS_LJ_BERNOULLI: acc = lj_fwd_family<T, ZS_LJ_BERNOULLI>(t, blk); break;
+      default: acc = lj_fwd_family<T, ZS_LJ_BERNOULLI_LOGITS>(t, blk); break;
+    }
   }
   acc = block_sum_256(acc, sh);
   if (threadIdx.x == 0) {
@@ -190,11 +261,11 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_fwd(const LJArgs<T> A, T*
     last = (tk == gridDim.x - 1);
   }
   __syncthreads();
-  if (last && threadIdx.x < 64) {
+  if (last) {                                   // (uniform) one round of loads for up to 256 partials, fixed combination order
     double s = 0.0;
-    for (unsigned i = threadIdx.x; i < gridDim.x; i += 64)
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += LJ_BLOCK)
       s += __hip_atomic_load(ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s = wave_sum_d(s);
+    s = block_sum_256(s, sh);
     if (threadIdx.x == 0) {
       out[0] = (T)s;
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -202,31 +273,108 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_fwd(const LJArgs<T> A, T*
   }
 }
 
-// d term / d (x, a, b) of one element, times gc = g * coef
-template <typename T>
-__device__ __forceinline__ void lj_partials(int family, T x, T a, T b, T gc, T& dx, T& da, T& db) {
-  typedef Mth<T> M;
-  if (family == ZS_LJ_NORMAL || family == ZS_LJ_NORMAL_LOGSTD) {
-    const bool ls = family == ZS_LJ_NORMAL_LOGSTD;
-    const T sg = M::sigma_of(b, ls);
-    T logstd, prec;
-    M::parts(sg, logstd, prec);
-    const T d = x - a;
-    const T u = gc * prec * d;
-    dx = -u;
-    da = u;
-    const T v = gc * (prec * d * d - (T)1);
-    db = ls ? v : v / sg;                       // d/d log std = sigma * d/d sigma
-  } else {                                      // Bernoulli: d/d probs, or d/d logits = d/dp * p * (1 - p)
-    dx = (T)0;
-    db = (T)0;
-    if (family == ZS_LJ_BERNOULLI_LOGITS) {
-      const T p = M::sigmoid(a);
-      da = gc * M::bern_dp(p, x) * p * ((T)1 - p);
-    } else {
-      da = gc * M::bern_dp(a, x);
+// ---- backward loops: full-size gradients are written, the sums for scalar operands returned through (sx, sa, sb)
+template <typename T, int FAM, bool PER>
+__device__ __forceinline__ void lj_bwd_vec(const LJTerm<T>& t, unsigned blk, T gc, double& rx, double& ra, double& rb) {
+  typedef Fam<T, FAM> F;
+  const uint32_t n = t.n, ng = n >> 2, stride = t.nblocks * LJ_BLOCK;
+  const bool sx = t.cx == CLS_SCALAR, sa = t.ca == CLS_SCALAR, sb = t.cb == CLS_SCALAR;
+  const T xs = t.x[0], as = t.a[0], bs = F::has_b ? t.b[0] : (T)1;
+  const T* __restrict__ px = sx ? t.dummy : t.x;
+  const T* __restrict__ pa = sa ? t.dummy : t.a;
+  const T* __restrict__ pb = (!F::has_b || sb) ? t.dummy : t.b;
+  const bool mx = PER && t.cx == CLS_PERIODIC, ma = PER && t.ca == CLS_PERIODIC, mb = PER && t.cb == CLS_PERIODIC;
+  const bool full_x = F::has_b && t.gx && t.cx == CLS_FULL, full_a = t.ga && t.ca == CLS_FULL,
+             full_b = F::has_b && t.gb && t.cb == CLS_FULL;
+  for (uint32_t g0 = blk * LJ_BLOCK + threadIdx.x; g0 < ng; g0 += stride * LJ_U) {
+    V4<T> x[LJ_U], a[LJ_U], b[LJ_U];
+    uint32_t i0s[LJ_U];
+    bool live[LJ_U];
+#pragma unroll
+    for (int u = 0; u < LJ_U; ++u) {
+      const uint32_t g = g0 + u * stride;
+      live[u] = g < ng;
+      const uint32_t i0 = (live[u] ? g : ng - 1) << 2;
+      i0s[u] = i0;
+      x[u] = *reinterpret_cast<const V4<T>*>(px + (mx ? i0 % t.px : i0));
+      a[u] = *reinterpret_cast<const V4<T>*>(pa + (ma ? i0 % t.pa : i0));
+      if (F::has_b) b[u] = *reinterpret_cast<const V4<T>*>(pb + (mb ? i0 % t.pb : i0));
+    }
+#pragma unroll
+    for (int u = 0; u < LJ_U; ++u) {
+      V4<T> dx, da, db;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        F::partials(sx ? xs : x[u].v[j], sa ? as : a[u].v[j], F::has_b ? (sb ? bs : b[u].v[j]) : (T)1, gc, dx.v[j], da.v[j], db.v[j]);
+        if (live[u]) { rx += (double)dx.v[j]; ra += (double)da.v[j]; rb += (double)db.v[j]; }
+      }
+      if (live[u]) {
+        if (full_x) *reinterpret_cast<V4<T>*>(t.gx + i0s[u]) = dx;
+        if (full_a) *reinterpret_cast<V4<T>*>(t.ga + i0s[u]) = da;
+        if (full_b) *reinterpret_cast<V4<T>*>(t.gb + i0s[u]) = db;
+      }
     }
   }
+  if (blk == 0 && threadIdx.x < (n & 3u)) {
+    const uint32_t i = (ng << 2) + threadIdx.x;
+    T dx, da, db;
+    F::partials(t.x[lj_idx(t.cx, i, t.px)], t.a[lj_idx(t.ca, i, t.pa)], F::has_b ? t.b[lj_idx(t.cb, i, t.pb)] : (T)1, gc, dx, da, db);
+    rx += (double)dx; ra += (double)da; rb += (double)db;
+    if (full_x) t.gx[i] = dx;
+    if (full_a) t.ga[i] = da;
+    if (full_b) t.gb[i] = db;
+  }
+}
+template <typename T, int FAM>
+__device__ __forceinline__ void lj_bwd_elem(const LJTerm<T>& t, unsigned blk, T gc, double& rx, double& ra, double& rb) {
+  typedef Fam<T, FAM> F;
+  const uint32_t n = t.n, stride = t.nblocks * LJ_BLOCK;
+  const bool full_x = F::has_b && t.gx && t.cx == CLS_FULL, full_a = t.ga && t.ca == CLS_FULL,
+             full_b = F::has_b && t.gb && t.cb == CLS_FULL;
+  for (uint32_t e0 = blk * LJ_BLOCK + threadIdx.x; e0 < n; e0 += stride * LJ_U) {
+    T x[LJ_U], a[LJ_U], b[LJ_U];
+    uint32_t is[LJ_U];
+    bool live[LJ_U];
+#pragma unroll
+    for (int u = 0; u < LJ_U; ++u) {
+      const uint32_t e = e0 + u * stride;
+      live[u] = e < n;
+      const uint32_t i = live[u] ? e : n - 1;
+      is[u] = i;
+      x[u] = t.x[lj_idx(t.cx, i, t.px)];
+      a[u] = t.a[lj_idx(t.ca, i, t.pa)];
+      b[u] = F::has_b ? t.b[lj_idx(t.cb, i, t.pb)] : (T)1;
+    }
+#pragma unroll
+    for (int u = 0; u < LJ_U; ++u) {
+      T dx, da, db;
+      F::partials(x[u], a[u], b[u], gc, dx, da, db);
+      if (live[u]) {
+        rx += (double)dx; ra += (double)da; rb += (double)db;
+        if (full_x) t.gx[is[u]] = dx;
+        if (full_a) t.ga[is[u]] = da;
+        if (full_b) t.gb[is[u]] = db;
+      }
+    }
+  }
+}
+template <typename T, int FAM>
+__device__ __forceinline__ void lj_bwd_family(const LJTerm<T>& t, unsigned blk, T gc, double& rx, double& ra, double& rb) {
+  if (!t.vec) lj_bwd_elem<T, FAM>(t, blk, gc, rx, ra, rb);
+  else if (t.periodic) lj_bwd_vec<T, FAM, true>(t, blk, gc, rx, ra, rb);
+  else lj_bwd_vec<T, FAM, false>(t, blk, gc, rx, ra, rb);
+}
+// one element's contribution to the gradient of operand `o` (fold role)
+template <typename T, int FAM>
+__device__ __forceinline__ T lj_fold_sum(const LJTerm<T>& t, int o, uint32_t j, uint32_t P, T gc) {
+  typedef Fam<T, FAM> F;
+  T acc = (T)0;
+  for (uint32_t i = j; i < t.n; i += P) {
+    T dx, da, db;
+    F::partials(t.x[lj_idx(t.cx, i, t.px)], t.a[lj_idx(t.ca, i, t.pa)], F::has_b ? t.b[lj_idx(t.cb, i, t.pb)] : (T)1, gc, dx, da, db);
+    acc += o == 0 ? dx : (o == 1 ? da : db);
+  }
+  return acc;
 }
 
 template <typename T>
@@ -239,30 +387,17 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_bwd(const LJArgs<T> A, co
     // ---- element-wise role: full-size gradients are written here, gradients of scalar operands leave as partials
     const int ti = lj_term_of(A, blockIdx.x);
     const LJTerm<T>& t = A.t[ti];
-    const int family = t.family;
-    const int64_t n = t.n, groups = (n + 3) >> 2;
-    const bool vx = t.vec & 1u, va = t.vec & 2u, vb = t.vec & 4u;
-    const bool has_b = family == ZS_LJ_NORMAL || family == ZS_LJ_NORMAL_LOGSTD;
+    const unsigned blk = blockIdx.x - t.block0;
     const T gc = (T)(t.coef * (double)g);
-    const bool full_x = t.gx && t.px == n, full_a = t.ga && t.pa == n, full_b = t.gb && t.pb == n;
-    const bool sc_x = t.gx && t.px == 1 && n > 1, sc_a = t.ga && t.pa == 1 && n > 1, sc_b = t.gb && t.pb == 1 && n > 1;
     double sx = 0.0, sa = 0.0, sb = 0.0;
-    for (int64_t gi = (int64_t)(blockIdx.x - t.block0) * LJ_BLOCK + threadIdx.x; gi < groups; gi += (int64_t)t.nblocks * LJ_BLOCK) {
-      const int64_t i0 = gi << 2;
-      const int cnt = n - i0 < 4 ? (int)(n - i0) : 4;
-      T x[4], a[4], b[4] = {(T)1, (T)1, (T)1, (T)1}, dx[4], da[4], db[4];
-      lj_load4(t.x, t.px, n, vx, i0, cnt, x);
-      lj_load4(t.a, t.pa, n, va, i0, cnt, a);
-      if (has_b) lj_load4(t.b, t.pb, n, vb, i0, cnt, b);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lj_partials<T>(family, x[j], a[j], b[j], gc, dx[j], da[j], db[j]);
-        if (j < cnt) { sx += (double)dx[j]; sa += (double)da[j]; sb += (double)db[j]; }
-      }
-      if (full_x) lj_store4(t.gx, vx, i0, cnt, dx);
-      if (full_a) lj_store4(t.ga, va, i0, cnt, da);
-      if (full_b) lj_store4(t.gb, vb, i0, cnt, db);
+    switch (t.family) {                          // uniform (ZS_LJ_ROWS terms own no workgroups here)
+      case ZS_LJ_NORMAL: lj_bwd_family<T, ZS_LJ_NORMAL>(t, blk, gc, sx, sa, sb); break;
+      case ZS_LJ_NORMAL_LOGSTD: lj_bwd_family<T, ZS_LJ_NORMAL_LOGSTD>(t, blk, gc, sx, sa, sb); break;
+      case ZS_LJ_BERNOULLI: lj_bwd_family<T, ZS_LJ_BERNOULLI>(t, blk, gc, sx, sa, sb); break;
+      default: lj_bwd_family<T, ZS_LJ_BERNOULLI_LOGITS>(t, blk, gc, sx, sa, sb); break;
     }
+    const bool sc_x = t.gx && t.cx == CLS_SCALAR && t.n > 1, sc_a = t.ga && t.ca == CLS_SCALAR && t.n > 1,
+               sc_b = t.gb && t.cb == CLS_SCALAR && t.n > 1;
     if (sc_x) sx = block_sum_256(sx, sh);
     if (sc_a) sa = block_sum_256(sa, sh);
     if (sc_b) sb = block_sum_256(sb, sh);
@@ -279,23 +414,18 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_bwd(const LJArgs<T> A, co
     fi = __builtin_amdgcn_readfirstlane(fi);
     const LJFold& f = A.f[fi];
     const LJTerm<T>& t = A.t[f.term];
-    const int family = t.family;
     const T gc = (T)(t.coef * (double)g);
-    const int64_t n = t.n;
-    const int64_t P = f.operand == 0 ? t.px : (f.operand == 1 ? t.pa : t.pb);
+    const uint32_t P = f.operand == 0 ? t.px : (f.operand == 1 ? t.pa : t.pb);
     T* __restrict__ dst = f.operand == 0 ? t.gx : (f.operand == 1 ? t.ga : t.gb);
-    const bool has_b = family == ZS_LJ_NORMAL || family == ZS_LJ_NORMAL_LOGSTD;
-    for (int64_t j = (int64_t)(blockIdx.x - f.block0) * LJ_BLOCK + threadIdx.x; j < P; j += (int64_t)f.nblocks * LJ_BLOCK) {
-      T acc = (T)0;
-      for (int64_t i = j; i < n; i += P) {
-        const T x = t.x[t.px == n ? i : mod_fast(i, t.px)];
-        const T a = t.a[t.pa == n ? i : mod_fast(i, t.pa)];
-        const T b = has_b ? t.b[t.pb == n ? i : mod_fast(i, t.pb)] : (T)1;
-        T dx, da, db;
-        lj_partials<T>(family, x, a, b, gc, dx, da, db);
-        acc += f.operand == 0 ? dx : (f.operand == 1 ? da : db);
+    for (uint32_t j = (blockIdx.x - f.block0) * LJ_BLOCK + threadIdx.x; j < P; j += f.nblocks * LJ_BLOCK) {
+      T v;
+      switch (t.family) {
+        case ZS_LJ_NORMAL: v = lj_fold_sum<T, ZS_LJ_NORMAL>(t, f.operand, j, P, gc); break;
+        case ZS_LJ_NORMAL_LOGSTD: v = lj_fold_sum<T, ZS_LJ_NORMAL_LOGSTD>(t, f.operand, j, P, gc); break;
+        case ZS_LJ_BERNOULLI: v = lj_fold_sum<T, ZS_LJ_BERNOULLI>(t, f.operand, j, P, gc); break;
+        default: v = lj_fold_sum<T, ZS_LJ_BERNOULLI_LOGITS>(t, f.operand, j, P, gc); break;
       }
-      dst[j] = acc;
+      dst[j] = v;
     }
   }
   __syncthreads();
@@ -311,8 +441,8 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_bwd(const LJArgs<T> A, co
       if (t.family == ZS_LJ_ROWS || t.n <= 1) continue;
       for (int o = 0; o < 3; ++o) {
         T* dst = o == 0 ? t.gx : (o == 1 ? t.ga : t.gb);
-        const int64_t P = o == 0 ? t.px : (o == 1 ? t.pa : t.pb);
-        if (!dst || P != 1) continue;
+        const unsigned cls = o == 0 ? t.cx : (o == 1 ? t.ca : t.cb);
+        if (!dst || cls != CLS_SCALAR) continue;
         double s = 0.0;
         for (unsigned i = threadIdx.x; i < t.nblocks; i += 64)
           s += __hip_atomic_load(ws + 3 * (t.block0 + i) + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -339,19 +469,23 @@ int lj_build(const zs_lj_term* terms, int n_terms, bool backward, LJArgs<T>& A) 
     const zs_lj_term& s = terms[i];
     LJTerm<T>& t = A.t[i];
     if (s.family < ZS_LJ_ROWS || s.family > ZS_LJ_BERNOULLI_LOGITS || s.n < 0) return ZS_EINVAL;
+    if (s.n >= (int64_t(1) << 31)) return ZS_ENOTSUP;        // 32-bit indices: this path is for the launch-bound sizes
     const bool rows = s.family == ZS_LJ_ROWS, normal = s.family == ZS_LJ_NORMAL || s.family == ZS_LJ_NORMAL_LOGSTD;
     t.family = s.family;
-    t.n = s.n;
+    t.n = (uint32_t)s.n;
     t.coef = s.coef;
     t.x = (const T*)s.x; t.a = (const T*)s.a; t.b = (const T*)s.b;
-    t.px = rows ? s.n : s.px; t.pa = s.pa; t.pb = s.pb;
+    const int64_t px = rows ? s.n : s.px, pa = rows ? 1 : s.pa, pb = normal ? s.pb : 1;
     want[i] = 0;
     if (s.n == 0) continue;
-    if (!s.x || t.px < 1 || s.n % t.px) return ZS_EINVAL;
-    if (!rows && (!s.a || s.pa < 1 || s.n % s.pa)) return ZS_EINVAL;
-    if (normal && (!s.b || s.pb < 1 || s.n % s.pb)) return ZS_EINVAL;
-    if (rows) { t.pa = t.pb = 1; }
-    if (!normal) t.pb = 1;
+    if (!s.x || px < 1 || s.n % px) return ZS_EINVAL;
+    if (!rows && (!s.a || pa < 1 || s.n % pa)) return ZS_EINVAL;
+    if (normal && (!s.b || pb < 1 || s.n % pb)) return ZS_EINVAL;
+    t.px = (uint32_t)px; t.pa = (uint32_t)pa; t.pb = (uint32_t)pb;
+    const auto cls = [&](int64_t P) { return (unsigned char)(P == s.n ? CLS_FULL : (P == 1 ? CLS_SCALAR : CLS_PERIODIC)); };
+    t.cx = cls(px);
+    t.ca = rows ? (unsigned char)CLS_NONE : cls(pa);
+    t.cb = normal ? cls(pb) : (unsigned char)CLS_NONE;
     if (backward) {
       t.gx = (T*)s.gx; t.ga = (T*)s.ga; t.gb = (T*)s.gb;
       if (rows) { t.gx = t.ga = t.gb = nullptr; }
@@ -361,12 +495,28 @@ int lj_build(const zs_lj_term* terms, int n_terms, bool backward, LJArgs<T>& A) 
       }
       if (rows || !(t.gx || t.ga || t.gb)) continue;     // nothing to compute element-wise for this term
     }
-    t.vec = 0;
-    if ((t.px % 4) == 0 && lj_aligned<T>(t.x) && (!backward || !t.gx || lj_aligned<T>(t.gx))) t.vec |= 1u;
-    if (!rows && (t.pa % 4) == 0 && lj_aligned<T>(t.a) && (!backward || !t.ga || lj_aligned<T>(t.ga))) t.vec |= 2u;
-    if (normal && (t.pb % 4) == 0 && lj_aligned<T>(t.b) && (!backward || !t.gb || lj_aligned<T>(t.gb))) t.vec |= 4u;
-    // a thread takes ~4 groups of 4 elements before it strides
-    want[i] = (((s.n + 3) / 4) + LJ_BLOCK * 4 - 1) / (LJ_BLOCK * 4);
+    // vector form: every present non-scalar operand (and every full-size gradient) 4-element aligned with a period that is a
+    // multiple of 4, and at least one full-size operand to point the scalar operands' loads at
+    bool vec = s.n >= 4;
+    const T* dummy = nullptr;
+    const struct { const T* p; const T* g; unsigned char c; int64_t P; } ops[3] = {
+        {t.x, t.gx, t.cx, px}, {t.a, t.ga, t.ca, pa}, {t.b, t.gb, t.cb, pb}};
+    for (int o = 0; o < 3; ++o) {
+      if (ops[o].c == CLS_NONE || ops[o].c == CLS_SCALAR) continue;
+      if ((ops[o].c == CLS_PERIODIC && (ops[o].P % 4)) || !lj_aligned<T>(ops[o].p)) vec = false;
+      if (ops[o].c == CLS_FULL) {
+        if (backward && ops[o].g && !lj_aligned<T>(ops[o].g)) vec = false;
+        if (!dummy && lj_aligned<T>(ops[o].p)) dummy = ops[o].p;
+      }
+      if (ops[o].c == CLS_PERIODIC) t.periodic = 1;
+    }
+    if (!dummy) vec = false;
+    t.vec = vec ? 1 : 0;
+    t.dummy = dummy;
+    // one round per thread (LJ_U groups of 4 elements, or LJ_U elements) until the grid cap makes it stride
+    const int64_t items = vec ? (s.n >> 2) : s.n;
+    want[i] = (items + LJ_BLOCK * LJ_U - 1) / (LJ_BLOCK * LJ_U);
+    if (want[i] < 1) want[i] = 1;
     total += want[i];
   }
   int64_t fold_want[3 * ZS_LJ_MAX_TERMS];
@@ -377,8 +527,9 @@ int lj_build(const zs_lj_term* terms, int n_terms, bool backward, LJArgs<T>& A) 
       if (t.family == ZS_LJ_ROWS || t.n == 0) continue;
       for (int o = 0; o < 3; ++o) {
         const T* dst = o == 0 ? t.gx : (o == 1 ? t.ga : t.gb);
+        const unsigned cls = o == 0 ? t.cx : (o == 1 ? t.ca : t.cb);
         const int64_t P = o == 0 ? t.px : (o == 1 ? t.pa : t.pb);
-        if (!dst || P == 1 || P == t.n) continue;
+        if (!dst || cls != CLS_PERIODIC) continue;
         LJFold& f = A.f[A.n_folds];
         f.term = i;
         f.operand = o;
@@ -452,17 +603,19 @@ struct MSTerm {
   int64_t K, M, D, R, sk, sr;
   uint64_t offset;
   int ls;
-  int64_t row0;               // forward: first wavefront (= row) of this term
+  int wpr;                    // forward: wavefronts per row (1, 2 or 4: a row's Philox groups in ONE round of lanes)
+  int64_t wave0;              // forward: first wavefront of this term (a multiple of 4: rows never straddle workgroups)
   const T *gz, *glp;
   int64_t gsk, gsr;
   T *gmu, *gsigma;
-  unsigned block0, nblocks;   // backward: workgroups of this term (256 parameter elements each)
+  int ks;                     // backward: particle slices per parameter element (power of two <= 16)
+  unsigned block0, nblocks;   // backward: workgroups of this term (256 / ks parameter elements each)
 };
 template <typename T>
 struct MSArgs {
   MSTerm<T> t[ZS_MS_MAX_TERMS];
   int n_terms;
-  int64_t total_rows;
+  int64_t total_waves;
 };
 
 template <typename T>
@@ -478,58 +631,79 @@ __device__ __forceinline__ T wave_sum_t(T v) {
   return v;
 }
 
-// one wavefront per (term, particle, row): lanes walk the Philox groups (4 consecutive flat elements) that touch the row
+// forward: `wpr` wavefronts per (term, particle, row); lanes take the Philox groups (4 consecutive flat elements) that touch
+// the row -- for the shapes this kernel is for (rows of up to ~1000 elements) every lane has at most one group: ONE round
+// of parameter loads, the draw, one round of stores.  A workgroup's four wavefronts belong to one term (its Philox call id
+// is wave-uniform, the contract of philox4x32_10) and to whole rows (partial row sums meet in LDS).
 template <typename T>
 __global__ __launch_bounds__(256) void k_normal_sample_multi(const MSArgs<T> A, uint64_t seed, const uint64_t* __restrict__ rs,
                                                              uint64_t* __restrict__ rng_used) {
   typedef Mth<T> Mh;
+  __shared__ T part[4];
   uint64_t base = 0;
   if (rs) { seed = rs[0]; base = rs[1]; }
   if (rng_used && blockIdx.x == 0 && threadIdx.x == 0) { rng_used[0] = seed; rng_used[1] = base; }
-  const int lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= A.total_rows) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * 4;
   int ti = 0;
   for (int j = 1; j < A.n_terms; ++j)
-    if (w >= A.t[j].row0) ti = j;
-  ti = __builtin_amdgcn_readfirstlane(ti);         // a wavefront serves ONE term: its Philox call id is wave-uniform
+    if (A.t[j].M > 0 && w0 >= A.t[j].wave0) ti = j;
+  ti = __builtin_amdgcn_readfirstlane(ti);
   const MSTerm<T>& t = A.t[ti];
-  int64_t k, r;
-  divmod(w - t.row0, t.R, k, r);
-  const uint64_t call = base + t.offset;
-  const bool ls = t.ls != 0;
-  const int64_t start = k * t.M + r * t.D, end = start + t.D;
+  const int wpr = t.wpr;
+  const int64_t row = (w0 - t.wave0 + wv) / wpr;
+  const int sub = (int)((w0 - t.wave0 + wv) - row * wpr);
+  const bool active = t.M > 0 && row < t.K * t.R;
   T acc = (T)0;
-  for (int64_t g = (start >> 2) + lane; g <= ((end - 1) >> 2); g += 64) {
-    const int64_t i0 = g << 2;
-    float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!t.eps) n4 = philox_normal4((uint64_t)g, call, seed);
+  int64_t k = 0, r = 0;
+  if (active) {
+    divmod(row, t.R, k, r);
+    const uint64_t call = base + t.offset;
+    const bool ls = t.ls != 0;
+    const int64_t start = k * t.M + r * t.D, end = start + t.D;
+    for (int64_t g = (start >> 2) + sub * 64 + lane; g <= ((end - 1) >> 2); g += 64 * wpr) {
+      const int64_t i0 = g << 2;
+      float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!t.eps) n4 = philox_normal4((uint64_t)g, call, seed);
+      T mu[4], sg[4], e[4];
+      bool in[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t i = i0 + j;
-      if (i < start || i >= end) continue;
-      const int64_t m = i - k * t.M;
-      const T e = t.eps ? t.eps[i] : (T)f4_get(n4, j);
-      const T mu = t.mu[m], sg = Mh::sigma_of(t.sigma[m], ls);
-      const T zz = ms_mul_add_2round<T>(mu, sg, e);
-      t.z[i] = zz;
-      if (t.lp) {
+      for (int j = 0; j < 4; ++j) {              // all loads first (clamped, unconditional)
+        const int64_t i = i0 + j;
+        in[j] = i >= start && i < end;
+        const int64_t ic = in[j] ? i : start;
+        const int64_t m = ic - k * t.M;
+        mu[j] = t.mu[m];
+        sg[j] = t.sigma[m];
+        e[j] = t.eps ? t.eps[ic] : (T)f4_get(n4, j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const T s = Mh::sigma_of(sg[j], ls);
+        const T zz = ms_mul_add_2round<T>(mu[j], s, e[j]);
+        if (in[j]) t.z[i0 + j] = zz;
         T logstd, prec;
-        Mh::parts(sg, logstd, prec);
-        acc += Mh::normal_term(zz - mu, logstd, prec);
+        Mh::parts(s, logstd, prec);
+        if (in[j]) acc += Mh::normal_term(zz - mu[j], logstd, prec);
       }
     }
-  }
-  if (t.lp) {
     acc = wave_sum_t<T>(acc);
-    if (lane == 0) t.lp[k * t.sk + r * t.sr] = acc;
+  }
+  if (lane == 0) part[wv] = acc;
+  __syncthreads();
+  if (active && t.lp && sub == 0 && lane == 0) {
+    T s = part[wv];
+    for (int j = 1; j < wpr; ++j) s += part[wv + j];         // the row's wavefronts, in order
+    t.lp[k * t.sk + r * t.sr] = s;
   }
 }
 
-// backward: one thread per parameter element, the K particles in order; workgroups belong to ONE term (uniform call id)
+// backward: thread = (parameter element, particle slice); the slices of an element meet in LDS and are added in slice order.
+// (One thread per element walking all K particles was K dependent rounds of loads + K Philox regenerations in sequence.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_normal_sample_multi_bwd(const MSArgs<T> A, uint64_t seed, const uint64_t* __restrict__ rs) {
   typedef Mth<T> Mh;
+  __shared__ T red[3][256];
   uint64_t base = 0;
   if (rs) { seed = rs[0]; base = rs[1]; }
   int ti = 0;
@@ -537,13 +711,15 @@ __global__ __launch_bounds__(256) void k_normal_sample_multi_bwd(const MSArgs<T>
     if (A.t[j].nblocks && blockIdx.x >= A.t[j].block0) ti = j;
   ti = __builtin_amdgcn_readfirstlane(ti);
   const MSTerm<T>& t = A.t[ti];
-  const int64_t m = (int64_t)(blockIdx.x - t.block0) * 256 + threadIdx.x;
-  if (m >= t.M) return;
+  const int KS = t.ks, MP = 256 / KS;
+  const int ks = threadIdx.x / MP, mp = threadIdx.x - ks * MP;
+  const int64_t m = (int64_t)(blockIdx.x - t.block0) * MP + mp;
+  const bool live = m < t.M;
   const uint64_t call = base + t.offset;
-  const int64_t r = m / t.D;
+  const int64_t mc = live ? m : 0, r = mc / t.D;
   T a = (T)0, b = (T)0, g = (T)0;
-  for (int64_t k = 0; k < t.K; ++k) {
-    const int64_t i = k * t.M + m;
+  for (int64_t k = ks; k < t.K; k += KS) {
+    const int64_t i = k * t.M + mc;
     if (t.gz) {
       const T gzv = t.gz[i];
       const T e = t.eps ? t.eps[i] : (T)f4_get(philox_normal4((uint64_t)(i >> 2), call, seed), (int)(i & 3));
@@ -552,9 +728,20 @@ __global__ __launch_bounds__(256) void k_normal_sample_multi_bwd(const MSArgs<T>
     }
     if (t.glp) g += t.glp[k * t.gsk + r * t.gsr];
   }
-  t.gmu[m] = a;
-  const T sg = Mh::sigma_of(t.sigma[m], t.ls != 0);
-  t.gsigma[m] = t.ls ? b * sg - g : b - g / sg;
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  red[2][threadIdx.x] = g;
+  __syncthreads();
+  if (ks == 0 && live) {
+    for (int j = 1; j < KS; ++j) {
+      a += red[0][j * MP + mp];
+      b += red[1][j * MP + mp];
+      g += red[2][j * MP + mp];
+    }
+    t.gmu[m] = a;
+    const T sg = Mh::sigma_of(t.sigma[m], t.ls != 0);
+    t.gsigma[m] = t.ls ? b * sg - g : b - g / sg;
+  }
 }
 
 template <typename T>
@@ -563,7 +750,7 @@ int ms_build(const zs_ms_term* terms, int n_terms, bool backward, MSArgs<T>& A, 
   if (n_terms > ZS_MS_MAX_TERMS) return ZS_ENOTSUP;
   memset(&A, 0, sizeof(A));
   A.n_terms = n_terms;
-  int64_t rows = 0;
+  int64_t waves = 0;
   unsigned blk = 0;
   for (int i = 0; i < n_terms; ++i) {
     const zs_ms_term& s = terms[i];
@@ -574,23 +761,32 @@ int ms_build(const zs_ms_term* terms, int n_terms, bool backward, MSArgs<T>& A, 
     t.K = s.K; t.M = s.M; t.D = s.D; t.R = s.M / s.D; t.sk = s.lp_stride_k; t.sr = s.lp_stride_r;
     t.offset = s.offset;
     t.ls = s.sigma_is_logstd;
-    t.row0 = rows;
+    t.wave0 = waves;
     t.block0 = blk;
+    t.wpr = 1;
+    t.ks = 1;
     if (s.M == 0) continue;
     if (!backward) {
       if (!s.mu || !s.sigma || !s.z) return ZS_EINVAL;
-      rows += s.K * t.R;
+      t.wpr = s.D > 512 ? 4 : (s.D > 256 ? 2 : 1);            // (D + 3) / 4 + 1 groups on 64 * wpr lanes
+      const int64_t wv = s.K * t.R * t.wpr;
+      waves += (wv + 3) / 4 * 4;
     } else {
       if (!s.sigma || !s.gmu || !s.gsigma) return ZS_EINVAL;
       t.gz = (const T*)s.gz; t.glp = (const T*)s.glp; t.gsk = s.glp_stride_k; t.gsr = s.glp_stride_r;
       t.gmu = (T*)s.gmu; t.gsigma = (T*)s.gsigma;
-      t.nblocks = (unsigned)((s.M + 255) / 256);
+      int ks = 1;
+      while (ks < 16 && ks < s.K) ks *= 2;
+      if (s.M >= 65536) ks = 1;                               // plenty of elements: one thread per element
+      t.ks = ks;
+      const int64_t mp = 256 / ks;
+      t.nblocks = (unsigned)((s.M + mp - 1) / mp);
       blk += t.nblocks;
     }
   }
-  if (rows > (int64_t(1) << 31) || blk > (1u << 30)) return ZS_ENOTSUP;
-  A.total_rows = rows;
-  grid = backward ? blk : (unsigned)((rows + 3) / 4);
+  if (waves > (int64_t(1) << 31) || blk > (1u << 30)) return ZS_ENOTSUP;
+  A.total_waves = waves;
+  grid = backward ? blk : (unsigned)(waves / 4);
   return 0;
 }
 
@@ -660,35 +856,48 @@ __global__ __launch_bounds__(256) void k_particle_linear(const T* __restrict__ h
   }
 }
 
-// backward, two roles in one launch:
-//   blockIdx <  n_gh : (tile, k)  gh tile = gpre tile x w[k] / p          (skipped when gh == NULL)
-//   blockIdx >= n_gh : (chunk of 256 / slices weight elements of particle k) gw = sum over ALL rows b of gpre[b, o] * [h | 1][b, i] / p,
-//                      the rows split over `slices` thread groups whose partial sums are added in slice order
+// backward: workgroup = (tile of PL_BT rows, particle k), as in the forward kernel.  Each workgroup stages w[k], its tile of
+// gpre = gout * (out > 0) and its tile of h ONCE (one round of loads), then
+//   - writes its tile of gh = gpre x w[k] / p (when wanted), and
+//   - writes the tile's PARTIAL weight gradient part[k, tile, o, i] = sum_{b in tile} gpre[b, o] * [h | 1][b, i];
+// the last workgroup of particle k to finish (a ticket per particle) adds the partials of all tiles in tile order and writes
+// gw[k] = sum / p: deterministic, one launch, every workgroup busy for one short round (the first version gave each weight
+// element one thread that walked all B rows: 10-30 workgroups of 8 dependent rounds, 62 us at B = 512).
 template <typename T>
 __global__ __launch_bounds__(256) void k_particle_linear_bwd(const T* __restrict__ h, int64_t hsk, const T* __restrict__ w,
                                                              const T* __restrict__ out, const T* __restrict__ gout,
-                                                             T* __restrict__ gh, T* __restrict__ gw, int B, int n_in, int n_out,
-                                                             int relu, int ntiles, unsigned n_gh, int slices, int chunks) {
+                                                             T* __restrict__ gh, T* __restrict__ gw, T* __restrict__ part,
+                                                             unsigned* __restrict__ tickets, int B, int n_in, int n_out, int relu,
+                                                             int ntiles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
+  __shared__ bool last;
   const T p = Mth<T>::rsqrt_n(n_in + 1);
-  const int GS = pl_odd(n_out), HS = pl_odd(n_in);
-  if (blockIdx.x < n_gh) {
-    const int WS = n_in + 1;                                  // read along i by consecutive lanes
-    T* ws = smem;
-    T* gs = ws + n_out * WS;
-    const int k = blockIdx.x / ntiles, bt = blockIdx.x - k * ntiles;
-    const int b0 = bt * PL_BT, nb = B - b0 < PL_BT ? B - b0 : PL_BT;
-    const T* __restrict__ wk = w + (int64_t)k * n_out * (n_in + 1);
-    for (int e = threadIdx.x; e < n_out * (n_in + 1); e += 256) ws[e] = wk[e];
-    const int64_t ob = ((int64_t)k * B + b0) * n_out;
-    for (int e = threadIdx.x; e < nb * n_out; e += 256) {
-      const int r = e / n_out, c = e - r * n_out;
-      T g = gout[ob + e];
-      if (relu && !(out[ob + e] > (T)0)) g = (T)0;
-      gs[r * GS + c] = g;
-    }
-    __syncthreads();
+  const int GS = pl_odd(n_out), HS = pl_odd(n_in), WS = n_in + 1;
+  const int nW = n_out * (n_in + 1);
+  T* gs = smem;                       // [PL_BT][GS]
+  T* hs = gs + PL_BT * GS;            // [PL_BT][HS]
+  T* ws = hs + PL_BT * HS;            // [n_out][WS]   (only when gh is wanted)
+  const int k = blockIdx.x / ntiles, bt = blockIdx.x - k * ntiles;
+  const int b0 = bt * PL_BT, nb = B - b0 < PL_BT ? B - b0 : PL_BT;
+  const int64_t ob = ((int64_t)k * B + b0) * n_out;
+  for (int e = threadIdx.x; e < nb * n_out; e += 256) {
+    const int r = e / n_out, c = e - r * n_out;
+    T g = gout[ob + e];
+    if (relu && !(out[ob + e] > (T)0)) g = (T)0;
+    gs[r * GS + c] = g;
+  }
+  const T* __restrict__ hk = h + (int64_t)k * hsk + (int64_t)b0 * n_in;
+  for (int e = threadIdx.x; e < nb * n_in; e += 256) {
+    const int r = e / n_in, c = e - r * n_in;
+    hs[r * HS + c] = hk[e];
+  }
+  if (gh) {
+    const T* __restrict__ wk = w + (int64_t)k * nW;
+    for (int e = threadIdx.x; e < nW; e += 256) ws[e] = wk[e];
+  }
+  __syncthreads();
+  if (gh) {
     T* __restrict__ ghk = gh + ((int64_t)k * B + b0) * n_in;
     for (int e = threadIdx.x; e < nb * n_in; e += 256) {
       const int b = e / n_in, i = e - b * n_in;
@@ -697,50 +906,33 @@ __global__ __launch_bounds__(256) void k_particle_linear_bwd(const T* __restrict
       for (int o = 0; o < n_out; ++o) acc += gr[o] * ws[o * WS + i];
       ghk[e] = acc / p;
     }
-    return;
   }
-  // ---- gw role
-  const int per = 256 / slices;                               // weight elements per workgroup
-  const int blk = blockIdx.x - n_gh;
-  const int k = blk / chunks, ch = blk - k * chunks;
-  const int nW = n_out * (n_in + 1);
-  const int sl = threadIdx.x / per, el = ch * per + (threadIdx.x - sl * per);
-  const bool live = el < nW;
-  const int o = live ? el / (n_in + 1) : 0, i = live ? el - o * (n_in + 1) : 0;
-  T* gs = smem;                       // [PL_BT][GS]
-  T* hs = gs + PL_BT * GS;            // [PL_BT][HS]
-  T* red = hs + PL_BT * HS;           // [256] slice partials
-  const T* __restrict__ hk = h + (int64_t)k * hsk;
-  T acc = (T)0;
-  for (int b0 = 0; b0 < B; b0 += PL_BT) {
-    const int nb = B - b0 < PL_BT ? B - b0 : PL_BT;
-    const int64_t ob = ((int64_t)k * B + b0) * n_out;
-    __syncthreads();
-    for (int e = threadIdx.x; e < nb * n_out; e += 256) {
-      const int r = e / n_out, c = e - r * n_out;
-      T g = gout[ob + e];
-      if (relu && !(out[ob + e] > (T)0)) g = (T)0;
-      gs[r * GS + c] = g;
+  T* __restrict__ pk = part + ((int64_t)k * ntiles + bt) * nW;
+  for (int e = threadIdx.x; e < nW; e += 256) {
+    const int o = e / (n_in + 1), i = e - o * (n_in + 1);
+    T acc = (T)0;
+    if (i < n_in) {
+      for (int b = 0; b < nb; ++b) acc += gs[b * GS + o] * hs[b * HS + i];
+    } else {
+      for (int b = 0; b < nb; ++b) acc += gs[b * GS + o];
     }
-    for (int e = threadIdx.x; e < nb * n_in; e += 256) {
-      const int r = e / n_in, c = e - r * n_in;
-      hs[r * HS + c] = hk[(int64_t)b0 * n_in + e];
-    }
-    __syncthreads();
-    if (live) {
-      if (i < n_in) {
-        for (int b = sl; b < nb; b += slices) acc += gs[b * GS + o] * hs[b * HS + i];
-      } else {
-        for (int b = sl; b < nb; b += slices) acc += gs[b * GS + o];
-      }
-    }
+    __hip_atomic_store(pk + e, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  red[threadIdx.x] = acc;
   __syncthreads();
-  if (sl == 0 && live) {
-    T s = (T)0;
-    for (int j = 0; j < slices; ++j) s += red[j * per + threadIdx.x];      // slice order: deterministic
-    gw[(int64_t)k * nW + el] = s / p;
+  if (threadIdx.x == 0) {
+    // release: this tile's partials are visible to whoever observes the increment; acquire: the last arrival sees all tiles
+    const unsigned tk = __hip_atomic_fetch_add(tickets + k, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = (tk == (unsigned)ntiles - 1u);
+  }
+  __syncthreads();
+  if (last) {
+    const T* __restrict__ p0 = part + (int64_t)k * ntiles * nW;
+    for (int e = threadIdx.x; e < nW; e += 256) {
+      T s = (T)0;
+      for (int t = 0; t < ntiles; ++t) s += __hip_atomic_load(p0 + (int64_t)t * nW + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gw[(int64_t)k * nW + e] = s / p;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(tickets + k, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -749,9 +941,8 @@ bool pl_fits(int64_t n_in, int64_t n_out) {
   if (n_in < 1 || n_out < 1 || n_in > 255 || n_out > 256) return false;
   const int64_t lim = PL_LDS_FLOATS * (int64_t)sizeof(float) / (int64_t)sizeof(T);
   const int64_t fwd = n_out * pl_odd((int)n_in + 1) + PL_BT * pl_odd((int)n_in);
-  const int64_t bwd_a = n_out * (n_in + 1) + PL_BT * pl_odd((int)n_out);
-  const int64_t bwd_b = PL_BT * pl_odd((int)n_out) + PL_BT * pl_odd((int)n_in) + 256;
-  return fwd <= lim && bwd_a <= lim && bwd_b <= lim;
+  const int64_t bwd = PL_BT * pl_odd((int)n_out) + PL_BT * pl_odd((int)n_in) + n_out * (n_in + 1);
+  return fwd <= lim && bwd <= lim;
 }
 
 template <typename T>
@@ -772,25 +963,25 @@ int particle_linear(const T* h, int64_t hsk, const T* w, T* out, int64_t K, int6
 
 template <typename T>
 int particle_linear_bwd(const T* h, int64_t hsk, const T* w, const T* out, const T* gout, T* gh, T* gw, int64_t K, int64_t B,
-                        int64_t n_in, int64_t n_out, int relu, void* stream) {
+                        int64_t n_in, int64_t n_out, int relu, T* workspace, int64_t workspace_len, uint32_t* tickets,
+                        void* stream) {
   if (K < 0 || B < 0 || n_in < 1 || n_out < 1 || (hsk != 0 && hsk != B * n_in)) return ZS_EINVAL;
   if (!pl_fits<T>(n_in, n_out) || B > (1 << 24) || K > (1 << 20)) return ZS_ENOTSUP;
   if (K == 0) return 0;
   if (!gw) return ZS_EINVAL;
-  if (B > 0 && (!h || !w || !gout || (relu && !out))) return ZS_EINVAL;
+  const int64_t nW = n_out * (n_in + 1);
+  if (B == 0) {                                   // no rows: the weight gradient is zero
+    const hipError_t e = hipMemsetAsync(gw, 0, sizeof(T) * (size_t)(K * nW), (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+  }
+  if (!h || !w || !gout || (relu && !out)) return ZS_EINVAL;
   const int ntiles = (int)((B + PL_BT - 1) / PL_BT);
-  const unsigned n_gh = gh ? (unsigned)(ntiles * K) : 0u;
-  const int nW = (int)(n_out * (n_in + 1));
-  // few weight elements (the last layer: n_out = 1): split the batch loop over up to 8 thread groups
-  int slices = 1;
-  while (slices < 8 && nW * slices * 2 <= 256) slices *= 2;
-  const int per = 256 / slices, chunks = (nW + per - 1) / per;
-  if ((int64_t)n_gh + (int64_t)chunks * K > (int64_t(1) << 30)) return ZS_ENOTSUP;
-  const size_t sm_a = sizeof(T) * (size_t)(n_out * (n_in + 1) + PL_BT * pl_odd((int)n_out));
-  const size_t sm_b = sizeof(T) * (size_t)(PL_BT * pl_odd((int)n_out) + PL_BT * pl_odd((int)n_in) + 256);
-  const size_t smem = sm_a > sm_b ? sm_a : sm_b;
-  ZS_LAUNCH_SMEM(KID_PARTICLE_LINEAR_BWD, (k_particle_linear_bwd<T>), dim3(n_gh + (unsigned)(chunks * K)), dim3(256), smem,
-                 (hipStream_t)stream, h, hsk, w, out, gout, gh, gw, (int)B, (int)n_in, (int)n_out, relu, ntiles, n_gh, slices, chunks);
+  if ((int64_t)ntiles * K > (int64_t(1) << 30)) return ZS_ENOTSUP;
+  if (!workspace || !tickets || workspace_len < K * ntiles * nW) return ZS_EINVAL;
+  const size_t smem = sizeof(T) * (size_t)(PL_BT * pl_odd((int)n_out) + PL_BT * pl_odd((int)n_in) + nW);
+  ZS_LAUNCH_SMEM(KID_PARTICLE_LINEAR_BWD, (k_particle_linear_bwd<T>), dim3((unsigned)(ntiles * K)), dim3(256), smem,
+                 (hipStream_t)stream, h, hsk, w, out, gout, gh, gw, workspace, (unsigned*)tickets, (int)B, (int)n_in, (int)n_out, relu,
+                 ntiles);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -839,11 +1030,14 @@ extern "C" int zs_particle_linear_f64(const double* h, int64_t h_stride_k, const
 }
 extern "C" int zs_particle_linear_bwd_f32(const float* h, int64_t h_stride_k, const float* w, const float* out, const float* gout,
                                           float* gh, float* gw, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu,
-                                          void* stream) {
-  return particle_linear_bwd<float>(h, h_stride_k, w, out, gout, gh, gw, K, B, n_in, n_out, relu, stream);
+                                          float* workspace, int64_t workspace_len, uint32_t* tickets, void* stream) {
+  return particle_linear_bwd<float>(h, h_stride_k, w, out, gout, gh, gw, K, B, n_in, n_out, relu, workspace, workspace_len, tickets,
+                                    stream);
 }
 extern "C" int zs_particle_linear_bwd_f64(const double* h, int64_t h_stride_k, const double* w, const double* out,
                                           const double* gout, double* gh, double* gw, int64_t K, int64_t B, int64_t n_in,
-                                          int64_t n_out, int relu, void* stream) {
-  return particle_linear_bwd<double>(h, h_stride_k, w, out, gout, gh, gw, K, B, n_in, n_out, relu, stream);
+                                          int64_t n_out, int relu, double* workspace, int64_t workspace_len, uint32_t* tickets,
+                                          void* stream) {
+  return particle_linear_bwd<double>(h, h_stride_k, w, out, gout, gh, gw, K, B, n_in, n_out, relu, workspace, workspace_len, tickets,
+                                     stream);
 }

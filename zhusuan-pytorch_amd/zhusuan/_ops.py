@@ -907,6 +907,21 @@ class NormalSampleLogProbMulti(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+_PL_TICKETS = {}       # (device, stream) -> int32 [n]: one ticket per particle, handed back at zero by the kernel
+
+
+def _pl_tickets(device, K):
+    """Zero-initialised ticket words of PL1's backward, one set per (device, stream) -- same rules as ``_iw_workspace``."""
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (str(device), stream)
+    t = _PL_TICKETS.get(key)
+    if t is None or t.numel() < K:
+        t = torch.zeros(max(K, 64), dtype=torch.int32, device=device)
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _PL_TICKETS[key] = t
+    return t
+
+
 class ParticleLinear(torch.autograd.Function):
     """PL1: ``out[k, b, :] = act(([h[k, b, :], 1] @ w[k].T) / sqrt(n_in + 1))`` -- the BNN caller's particle-batched layer
     (examples/bayesian_neural_nets/bnn_vi.py:36-48: repeat of w over the batch, appended column of ones, matmul, division,
@@ -941,8 +956,11 @@ class ParticleLinear(torch.autograd.Function):
         gout = gout.contiguous()
         gh = torch.empty((K, B, n_in), dtype=h.dtype, device=h.device) if need_h else None
         gw = torch.empty_like(w)
+        part = torch.empty(K * ((B + 63) // 64) * n_out * (n_in + 1), dtype=h.dtype, device=h.device)      # tile partials of gw
+        tickets = _pl_tickets(h.device, K)
         _hip.lib().call("zs_particle_linear_bwd" + _sfx(h), _hip.ptr(h), 0 if shared else B * n_in, _hip.ptr(w), _hip.ptr(out),
-                        _hip.ptr(gout), _hip.ptr(gh), _hip.ptr(gw), K, B, n_in, n_out, 1 if relu else 0, _hip.stream_for(h))
+                        _hip.ptr(gout), _hip.ptr(gh), _hip.ptr(gw), K, B, n_in, n_out, 1 if relu else 0, _hip.ptr(part), part.numel(),
+                        _hip.ptr(tickets), _hip.stream_for(h))
         if need_h and shared:
             gh = gh.sum(0)
         return gh, (gw if need_w else None), None

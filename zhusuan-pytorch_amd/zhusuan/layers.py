@@ -20,9 +20,8 @@ def _fits_lds(n_in, n_out, itemsize):
     lim = 15360 * 4 // itemsize
     odd = lambda v: v | 1
     fwd = n_out * odd(n_in + 1) + 64 * odd(n_in)
-    bwd_a = n_out * (n_in + 1) + 64 * odd(n_out)
-    bwd_b = 64 * odd(n_out) + 64 * odd(n_in) + 256
-    return max(fwd, bwd_a, bwd_b) <= lim
+    bwd = 64 * odd(n_out) + 64 * odd(n_in) + n_out * (n_in + 1)
+    return max(fwd, bwd) <= lim
 
 
 def particle_linear(h, w, relu=False):
