@@ -445,9 +445,10 @@ int zs_normal_sample_logprob_multi_bwd_f32(const zs_ms_term* terms, int n_terms,
  *     gh[k, b, i] = sum_o gpre[k, b, o] * w[k, o, i] / sqrt(n_in + 1)          (optional; [K, B, n_in] also when h is shared:
  *                                                                                the caller sums over k if it needs d/dx)
  *     gw[k, o, i] = sum_b gpre[k, b, o] * h[k, b, i] / sqrt(n_in + 1),   gw[k, o, n_in] = sum_b gpre[k, b, o] / sqrt(n_in + 1)
- * The batch sum of gw is formed per tile of 64 rows and the tiles are added in tile order by the last workgroup of each
- * particle (deterministic): workspace holds the tile partials, >= K * ceil(B / 64) * n_out * (n_in + 1) elements; tickets
- * is K zero-initialised device words owned by the caller, handed back at zero.
+ * The batch sum of gw is formed per tile of 16 to 64 rows (the kernel picks the tile so that the launch fills the chip) and
+ * the tiles are added in tile order by the last workgroup of each particle (deterministic): workspace holds the tile
+ * partials, >= K * ceil(B / 16) * n_out * (n_in + 1) elements always suffices; tickets is K zero-initialised device words
+ * owned by the caller, handed back at zero.
  * -------------------------------------------------------------------------*/
 int zs_particle_linear_f32(const float* h, int64_t h_stride_k, const float* w, float* out,
                            int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, void* stream);

@@ -68,7 +68,11 @@ class Raw(object):
         out = torch.full((1,), float("nan"), dtype=self.dtype, device=self.dev)
         ws = torch.zeros(_hip.LJ_WORKSPACE, dtype=torch.float64, device=self.dev)
         ticket = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        for _ in range(2):          # twice: the ticket must have been handed back at zero
+        # twice on ONE workspace, the first time with other coefficients: the ticket must come back at zero, and the second
+        # launch must not see the first one's partial sums (stale lines in an L1 / another XCD's L2)
+        for scale in (3.0, 1.0):
+            for i, tm in enumerate(terms):
+                tab[i].coef = tm["coef"] * scale
             self.k.call("zs_logjoint_scalar" + self.sfx, ctypes.byref(tab), len(terms), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
                         _hip.ptr(ticket), self.stream())
         self.sync()
@@ -82,7 +86,9 @@ class Raw(object):
         gcoef = torch.full((len(terms),), float("nan"), dtype=self.dtype, device=self.dev)
         ws = torch.zeros(_hip.LJ_WORKSPACE, dtype=torch.float64, device=self.dev)
         ticket = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        for _ in range(2):
+        for scale in (3.0, 1.0):      # (as in lj_fwd: same workspace, other numbers first)
+            for i, tm in enumerate(terms):
+                tab[i].coef = tm["coef"] * scale
             self.k.call("zs_logjoint_scalar_bwd" + self.sfx, ctypes.byref(tab), len(terms), _hip.ptr(gout), _hip.ptr(gcoef),
                         _hip.ptr(ws), ws.numel(), _hip.ptr(ticket), self.stream())
         self.sync()
@@ -171,11 +177,14 @@ class Raw(object):
         gh = torch.full((K, B, n_in1 - 1), float("nan"), dtype=self.dtype, device=self.dev)
         gw = torch.full((K, n_out, n_in1), float("nan"), dtype=self.dtype, device=self.dev)
         h, w, out, gout = self.t(h), self.t(w), self.t(out), self.t(gout)
-        part = torch.full((K * ((B + 63) // 64) * n_out * n_in1 + 1,), float("nan"), dtype=self.dtype, device=self.dev)
+        part = torch.full((K * ((B + 15) // 16) * n_out * n_in1 + 1,), float("nan"), dtype=self.dtype, device=self.dev)
         tickets = torch.zeros(max(K, 1), dtype=torch.int32, device=self.dev)
-        for _ in range(2):          # twice: the tickets must have been handed back at zero
+        # twice on ONE workspace, the first time with another upstream gradient: the tickets must come back at zero, and the
+        # second launch must not see the first one's tile partials (stale lines in an L1 / another XCD's L2)
+        other = gout * 3.0 + 1.0
+        for go in (other, gout):
             self.k.call("zs_particle_linear_bwd" + self.sfx, _hip.ptr(h), 0 if shared else B * (n_in1 - 1), _hip.ptr(w),
-                        _hip.ptr(out), _hip.ptr(gout), _hip.ptr(gh) if want_gh else None, _hip.ptr(gw), K, B, n_in1 - 1,
+                        _hip.ptr(out), _hip.ptr(go), _hip.ptr(gh) if want_gh else None, _hip.ptr(gw), K, B, n_in1 - 1,
                         n_out, int(relu), _hip.ptr(part), part.numel(), _hip.ptr(tickets), self.stream())
         self.sync()
         assert int(tickets.abs().sum().item()) == 0
@@ -402,7 +411,8 @@ PL_SHAPES = [  # (K, B, n_in, n_out, shared, relu)
     (10, 512, 13, 50, True, True), (10, 512, 50, 1, False, False),       # the layers of BASELINE config 5, per GPU
     (4, 16, 13, 50, True, True), (4, 16, 50, 1, False, False),           # the small golden's
     (1, 1, 1, 1, False, True), (3, 65, 7, 5, False, True), (2, 130, 100, 50, True, False), (5, 63, 31, 33, False, True),
-    (2, 3, 255, 4, False, False), (2, 70, 3, 200, True, True), (7, 0, 4, 4, False, True)]
+    (2, 3, 255, 4, False, False), (2, 70, 3, 200, True, True), (7, 0, 4, 4, False, True),
+    (10, 4096, 13, 50, True, True), (3, 2000, 50, 1, False, False)]      # many tiles per particle: the cross-workgroup hand-off
 
 
 def test_c_oracle_particle_linear_is_the_reference_layer(orc, orc64):

@@ -70,6 +70,30 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// ---------------------------------------------------------------- cross-workgroup hand-off without a release fence
+// "Every workgroup writes partial results, the LAST one to arrive combines them" needs the partials to be visible across
+// CUs and XCDs (per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by other CUs' stores).  An
+// agent-scope RELEASE on the ticket does that by writing back the XCD's whole dirty L2 (buffer_wbl2: 1.7 us clean, 6.5 us
+// with 16 KB freshly dirtied, per workgroup) -- it was most of these kernels' time.  The cheaper valid form
+// (MI355X_MICROARCH.md, inter-workgroup visibility: "ONE lane of each storing workgroup adds to one counter; the workgroup
+// whose add came last consumes"):
+//   producer  every byte of the hand-off is stored WRITE-THROUGH (relaxed agent-scope atomic store = global_store ... sc1);
+//             every storing wave waits for its stores (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane adds to the ticket
+//             with a RELAXED agent-scope atomic;
+//   consumer  the workgroup whose add returned count - 1: either it reads the hand-off with sc1 loads only (relaxed agent
+//             atomic loads; at most a couple per thread: they are issued one after the other), after a workgroup barrier
+//             behind the adding lane -- or that lane runs ONE agent-scope acquire (buffer_inv sc1: invalidates this CU's
+//             L1), waits for it, and after a barrier the workgroup reads with plain loads (many per thread, batched).
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <typename T>
+__device__ __forceinline__ void store_wt(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T load_wt(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ticket_take(unsigned* t) {
+  return __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ticket_return(unsigned* t) { __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ================================================================ LJ1
 // Launch layout: every term owns a run of workgroups (a table in the kernel arguments, as zs_adam.hip has for 32 tensors).
 // A thread handles LJ_U groups of 4 consecutive elements per round and issues ALL their loads before any arithmetic: at
@@ -255,20 +279,18 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_fwd(const LJArgs<T> A, T*
   }
   acc = block_sum_256(acc, sh);
   if (threadIdx.x == 0) {
-    __hip_atomic_store(ws + blockIdx.x, t.coef * acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // release: the partial is visible to whoever observes this increment; acquire: the last arrival sees all of them
-    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last = (tk == gridDim.x - 1);
+    store_wt(ws + blockIdx.x, t.coef * acc);      // the only byte handed over: written through by the lane that signals
+    drain_stores();
+    last = (ticket_take(ticket) == gridDim.x - 1);
   }
   __syncthreads();
-  if (last) {                                   // (uniform) one round of loads for up to 256 partials, fixed combination order
+  if (last) {                                   // (uniform) one round of sc1 loads for up to 256 partials, fixed combination order
     double s = 0.0;
-    for (unsigned i = threadIdx.x; i < gridDim.x; i += LJ_BLOCK)
-      s += __hip_atomic_load(ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += LJ_BLOCK) s += load_wt(ws + i);
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) {
       out[0] = (T)s;
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      ticket_return(ticket);
     }
   }
 }
@@ -401,10 +423,10 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_bwd(const LJArgs<T> A, co
     if (sc_x) sx = block_sum_256(sx, sh);
     if (sc_a) sa = block_sum_256(sa, sh);
     if (sc_b) sb = block_sum_256(sb, sh);
-    if (threadIdx.x == 0) {
-      if (sc_x) __hip_atomic_store(ws + 3 * blockIdx.x + 0, sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (sc_a) __hip_atomic_store(ws + 3 * blockIdx.x + 1, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (sc_b) __hip_atomic_store(ws + 3 * blockIdx.x + 2, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {                      // the hand-off: written through by the lane that takes the ticket below
+      if (sc_x) store_wt(ws + 3 * blockIdx.x + 0, sx);
+      if (sc_a) store_wt(ws + 3 * blockIdx.x + 1, sa);
+      if (sc_b) store_wt(ws + 3 * blockIdx.x + 2, sb);
     }
   } else if (A.n_folds > 0) {
     // ---- fold role: operand of period 1 < P < n: thread j adds the contributions of elements j, j + P, j + 2P, ... in order
@@ -430,8 +452,8 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_bwd(const LJArgs<T> A, co
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last = (tk == gridDim.x - 1);
+    drain_stores();
+    last = (ticket_take(ticket) == gridDim.x - 1);
   }
   __syncthreads();
   if (last && threadIdx.x < 64) {
@@ -444,13 +466,12 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_bwd(const LJArgs<T> A, co
         const unsigned cls = o == 0 ? t.cx : (o == 1 ? t.ca : t.cb);
         if (!dst || cls != CLS_SCALAR) continue;
         double s = 0.0;
-        for (unsigned i = threadIdx.x; i < t.nblocks; i += 64)
-          s += __hip_atomic_load(ws + 3 * (t.block0 + i) + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned i = threadIdx.x; i < t.nblocks; i += 64) s += load_wt(ws + 3 * (t.block0 + i) + o);
         s = wave_sum_d(s);
         if (threadIdx.x == 0) dst[0] = (T)s;
       }
     }
-    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) ticket_return(ticket);
   }
 }
 
@@ -814,40 +835,79 @@ int ms_bwd(const zs_ms_term* terms, int n_terms, uint64_t seed, const uint64_t* 
 }
 
 // ================================================================ PL1
-constexpr int PL_BT = 64;        // batch rows per tile
-constexpr int PL_LDS_FLOATS = 15360;   // 60 KB of fp32 (30 K doubles would not fit: the double twin halves the limits)
+// Workgroup = (tile of `bt` batch rows, particle k); bt is 64, 32 or 16 -- the smallest that still leaves >= ~256
+// workgroups, so that a K = 10, B = 512 layer (80 tiles of 64 rows) spreads over the chip instead of 80 of its 256 CUs.
+// Tiles of h / gout / out are CONTIGUOUS in memory: they are staged into LDS as flat copies, four elements per load when the
+// tile is 16-byte aligned (one round of loads for the whole tile; a per-element (row, column) split costs an integer division
+// per element and the 8-deep batches the compiler forms made four dependent rounds of it).
+constexpr int PL_BT_MAX = 64;
+constexpr int PL_LDS_FLOATS = 15360;   // 60 KB of fp32 (the double twin: half as many elements)
 
 __host__ __device__ __forceinline__ int pl_odd(int v) { return v | 1; }     // odd leading dimension: conflict-free columns
 
-// forward: workgroup = (tile of PL_BT rows, particle k); w[k] and the h tile are staged in LDS; outputs of the tile are one
-// contiguous run of PL_BT * n_out values: consecutive lanes take consecutive (b, o) pairs -> coalesced stores
+// flat copy of `n` elements global -> LDS (vectorised when `vec`: src 4-element aligned; dst is)
+template <typename T>
+__device__ __forceinline__ void pl_stage(T* __restrict__ dst, const T* __restrict__ src, int n, bool vec) {
+  if (vec) {
+    const int n4 = n >> 2;
+    for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<V4<T>*>(dst)[e] = reinterpret_cast<const V4<T>*>(src)[e];
+    for (int e = (n4 << 2) + threadIdx.x; e < n; e += 256) dst[e] = src[e];
+  } else {
+    for (int e = threadIdx.x; e < n; e += 256) dst[e] = src[e];
+  }
+}
+// the same with the ReLU mask applied on the way: dst = (out > 0) ? gout : 0
+template <typename T>
+__device__ __forceinline__ void pl_stage_gpre(T* __restrict__ dst, const T* __restrict__ gout, const T* __restrict__ out, int n,
+                                              bool vec, bool relu) {
+  if (vec) {
+    const int n4 = n >> 2;
+    for (int e = threadIdx.x; e < n4; e += 256) {
+      V4<T> g = reinterpret_cast<const V4<T>*>(gout)[e];
+      if (relu) {
+        const V4<T> o = reinterpret_cast<const V4<T>*>(out)[e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g.v[j] = o.v[j] > (T)0 ? g.v[j] : (T)0;
+      }
+      reinterpret_cast<V4<T>*>(dst)[e] = g;
+    }
+    for (int e = (n4 << 2) + threadIdx.x; e < n; e += 256) dst[e] = (!relu || out[e] > (T)0) ? gout[e] : (T)0;
+  } else {
+    for (int e = threadIdx.x; e < n; e += 256) dst[e] = (!relu || out[e] > (T)0) ? gout[e] : (T)0;
+  }
+}
+template <typename T>
+__host__ __device__ __forceinline__ bool pl_al(const void* p) { return (((uintptr_t)p) & (4 * sizeof(T) - 1)) == 0; }
+
+// forward: w[k] (padded rows: lanes of a wavefront differ in the output unit o) and the h tile (flat) are staged in LDS;
+// the outputs of a tile are one contiguous run of nb * n_out values: consecutive lanes take consecutive (b, o) pairs ->
+// coalesced stores
 template <typename T>
 __global__ __launch_bounds__(256) void k_particle_linear(const T* __restrict__ h, int64_t hsk, const T* __restrict__ w,
-                                                         T* __restrict__ out, int B, int n_in, int n_out, int relu, int ntiles) {
+                                                         T* __restrict__ out, int B, int n_in, int n_out, int relu, int ntiles,
+                                                         int bt) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* ws = reinterpret_cast<T*>(smem_raw);
-  const int WS = pl_odd(n_in + 1), HS = pl_odd(n_in);
-  T* hs = ws + n_out * WS;
-  const int k = blockIdx.x / ntiles, bt = blockIdx.x - k * ntiles;
-  const int b0 = bt * PL_BT, nb = B - b0 < PL_BT ? B - b0 : PL_BT;
+  T* hs = reinterpret_cast<T*>(smem_raw);                      // [bt][n_in] flat (16-byte aligned: vector stores)
+  const int WS = pl_odd(n_in + 1);
+  T* ws = hs + ((bt * n_in + 3) & ~3);                          // [n_out][WS]
+  const int k = blockIdx.x / ntiles, tile = blockIdx.x - k * ntiles;
+  const int b0 = tile * bt, nb = B - b0 < bt ? B - b0 : bt;
+  const T* __restrict__ hk = h + (int64_t)k * hsk + (int64_t)b0 * n_in;
+  pl_stage<T>(hs, hk, nb * n_in, pl_al<T>(hk));
   const T* __restrict__ wk = w + (int64_t)k * n_out * (n_in + 1);
   for (int e = threadIdx.x; e < n_out * (n_in + 1); e += 256) {
     const int o = e / (n_in + 1), i = e - o * (n_in + 1);
     ws[o * WS + i] = wk[e];
-  }
-  const T* __restrict__ hk = h + (int64_t)k * hsk + (int64_t)b0 * n_in;
-  for (int e = threadIdx.x; e < nb * n_in; e += 256) {
-    const int r = e / n_in, c = e - r * n_in;
-    hs[r * HS + c] = hk[e];
   }
   __syncthreads();
   const T p = Mth<T>::rsqrt_n(n_in + 1);                           // torch.sqrt(torch.as_tensor(h.shape[2])), bnn_vi.py:42
   T* __restrict__ ok = out + ((int64_t)k * B + b0) * n_out;
   for (int e = threadIdx.x; e < nb * n_out; e += 256) {
     const int b = e / n_out, o = e - b * n_out;
-    const T* __restrict__ hr = hs + b * HS;
+    const T* __restrict__ hr = hs + b * n_in;
     const T* __restrict__ wr = ws + o * WS;
     T acc = (T)0;
+#pragma unroll 8
     for (int i = 0; i < n_in; ++i) acc += hr[i] * wr[i];
     acc += wr[n_in];                                                // the appended column of ones (bnn_vi.py:40)
     acc = acc / p;
@@ -856,8 +916,8 @@ __global__ __launch_bounds__(256) void k_particle_linear(const T* __restrict__ h
   }
 }
 
-// backward: workgroup = (tile of PL_BT rows, particle k), as in the forward kernel.  Each workgroup stages w[k], its tile of
-// gpre = gout * (out > 0) and its tile of h ONCE (one round of loads), then
+// backward: workgroup = (tile, particle k), as in the forward kernel.  Each workgroup stages its tile of
+// gpre = gout * (out > 0), its tile of h and (for gh) w[k] ONCE -- one round of loads -- then
 //   - writes its tile of gh = gpre x w[k] / p (when wanted), and
 //   - writes the tile's PARTIAL weight gradient part[k, tile, o, i] = sum_{b in tile} gpre[b, o] * [h | 1][b, i];
 // the last workgroup of particle k to finish (a ticket per particle) adds the partials of all tiles in tile order and writes
@@ -868,80 +928,104 @@ __global__ __launch_bounds__(256) void k_particle_linear_bwd(const T* __restrict
                                                              const T* __restrict__ out, const T* __restrict__ gout,
                                                              T* __restrict__ gh, T* __restrict__ gw, T* __restrict__ part,
                                                              unsigned* __restrict__ tickets, int B, int n_in, int n_out, int relu,
-                                                             int ntiles) {
+                                                             int ntiles, int bt) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
   __shared__ bool last;
   const T p = Mth<T>::rsqrt_n(n_in + 1);
-  const int GS = pl_odd(n_out), HS = pl_odd(n_in), WS = n_in + 1;
-  const int nW = n_out * (n_in + 1);
-  T* gs = smem;                       // [PL_BT][GS]
-  T* hs = gs + PL_BT * GS;            // [PL_BT][HS]
-  T* ws = hs + PL_BT * HS;            // [n_out][WS]   (only when gh is wanted)
-  const int k = blockIdx.x / ntiles, bt = blockIdx.x - k * ntiles;
-  const int b0 = bt * PL_BT, nb = B - b0 < PL_BT ? B - b0 : PL_BT;
+  const int WS = n_in + 1, nW = n_out * (n_in + 1);
+  T* gs = reinterpret_cast<T*>(smem_raw);                     // [bt][n_out] flat
+  T* hs = gs + ((bt * n_out + 3) & ~3);                        // [bt][n_in] flat
+  T* ws = hs + ((bt * n_in + 3) & ~3);                         // [n_out][n_in + 1] flat (only when gh is wanted)
+  const int k = blockIdx.x / ntiles, tile = blockIdx.x - k * ntiles;
+  const int b0 = tile * bt, nb = B - b0 < bt ? B - b0 : bt;
   const int64_t ob = ((int64_t)k * B + b0) * n_out;
-  for (int e = threadIdx.x; e < nb * n_out; e += 256) {
-    const int r = e / n_out, c = e - r * n_out;
-    T g = gout[ob + e];
-    if (relu && !(out[ob + e] > (T)0)) g = (T)0;
-    gs[r * GS + c] = g;
-  }
+  pl_stage_gpre<T>(gs, gout + ob, out + ob, nb * n_out, pl_al<T>(gout + ob) && pl_al<T>(out + ob), relu != 0);
   const T* __restrict__ hk = h + (int64_t)k * hsk + (int64_t)b0 * n_in;
-  for (int e = threadIdx.x; e < nb * n_in; e += 256) {
-    const int r = e / n_in, c = e - r * n_in;
-    hs[r * HS + c] = hk[e];
-  }
+  pl_stage<T>(hs, hk, nb * n_in, pl_al<T>(hk));
   if (gh) {
     const T* __restrict__ wk = w + (int64_t)k * nW;
-    for (int e = threadIdx.x; e < nW; e += 256) ws[e] = wk[e];
+    pl_stage<T>(ws, wk, nW, pl_al<T>(wk));
   }
   __syncthreads();
   if (gh) {
     T* __restrict__ ghk = gh + ((int64_t)k * B + b0) * n_in;
     for (int e = threadIdx.x; e < nb * n_in; e += 256) {
       const int b = e / n_in, i = e - b * n_in;
-      const T* __restrict__ gr = gs + b * GS;
+      const T* __restrict__ gr = gs + b * n_out;
       T acc = (T)0;
-      for (int o = 0; o < n_out; ++o) acc += gr[o] * ws[o * WS + i];
+#pragma unroll 8
+      for (int o = 0; o < n_out; ++o) acc += gr[o] * ws[o * WS + i];      // (8 independent LDS read pairs in flight)
       ghk[e] = acc / p;
     }
   }
-  T* __restrict__ pk = part + ((int64_t)k * ntiles + bt) * nW;
+  T* __restrict__ pk = part + ((int64_t)k * ntiles + tile) * nW;
   for (int e = threadIdx.x; e < nW; e += 256) {
     const int o = e / (n_in + 1), i = e - o * (n_in + 1);
     T acc = (T)0;
     if (i < n_in) {
-      for (int b = 0; b < nb; ++b) acc += gs[b * GS + o] * hs[b * HS + i];
+#pragma unroll 8
+      for (int b = 0; b < nb; ++b) acc += gs[b * n_out + o] * hs[b * n_in + i];
     } else {
-      for (int b = 0; b < nb; ++b) acc += gs[b * GS + o];
+#pragma unroll 8
+      for (int b = 0; b < nb; ++b) acc += gs[b * n_out + o];
     }
-    __hip_atomic_store(pk + e, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    store_wt(pk + e, acc);                       // written through: no release fence below (see the hand-off note at the top)
   }
-  __syncthreads();
+  drain_stores();                                // every storing wave waits for its own stores ...
+  __syncthreads();                               // ... before the lane that signals for all of them takes the ticket
   if (threadIdx.x == 0) {
-    // release: this tile's partials are visible to whoever observes the increment; acquire: the last arrival sees all tiles
-    const unsigned tk = __hip_atomic_fetch_add(tickets + k, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last = (tk == (unsigned)ntiles - 1u);
+    last = (ticket_take(tickets + k) == (unsigned)ntiles - 1u);
+    if (last) {
+      // the last arrival reads ntiles partials per weight element: ONE agent acquire by this lane (invalidates this CU's L1),
+      // waited for, then PLAIN loads behind the barrier -- sc1 (atomic) loads are issued one after the other: 8 tiles = 8
+      // dependent round trips, 7 us of the first version's 18 at B = 512 and 50 us at B = 4096
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      drain_stores();
+    }
   }
   __syncthreads();
   if (last) {
+    // four consecutive weight elements per thread and load (the partials of a tile are nW contiguous values, 16-byte aligned
+    // when nW % 4 == 0), 16 tiles in flight: ntiles = 64 (B = 4096) is 4 rounds instead of 3 x 8 rounds of single floats
     const T* __restrict__ p0 = part + (int64_t)k * ntiles * nW;
-    for (int e = threadIdx.x; e < nW; e += 256) {
-      T s = (T)0;
-      for (int t = 0; t < ntiles; ++t) s += __hip_atomic_load(p0 + (int64_t)t * nW + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      gw[(int64_t)k * nW + e] = s / p;
+    T* __restrict__ gk = gw + (int64_t)k * nW;
+    const bool v4 = (nW & 3) == 0 && pl_al<T>(p0) && pl_al<T>(gk);
+    const int nv = v4 ? (nW >> 2) : 0;
+    for (int e = threadIdx.x; e < nv; e += 256) {
+      V4<T> s = {{(T)0, (T)0, (T)0, (T)0}};
+#pragma unroll 16
+      for (int t = 0; t < ntiles; ++t) {                                    // tile order: deterministic
+        const V4<T> q = reinterpret_cast<const V4<T>*>(p0 + (int64_t)t * nW)[e];
+        s.v[0] += q.v[0]; s.v[1] += q.v[1]; s.v[2] += q.v[2]; s.v[3] += q.v[3];
+      }
+      s.v[0] /= p; s.v[1] /= p; s.v[2] /= p; s.v[3] /= p;
+      reinterpret_cast<V4<T>*>(gk)[e] = s;
     }
-    if (threadIdx.x == 0) __hip_atomic_store(tickets + k, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    for (int e = (nv << 2) + threadIdx.x; e < nW; e += 256) {
+      T s = (T)0;
+#pragma unroll 16
+      for (int t = 0; t < ntiles; ++t) s += p0[(int64_t)t * nW + e];
+      gk[e] = s / p;
+    }
+    if (threadIdx.x == 0) ticket_return(tickets + k);
   }
 }
 
+// rows per tile: the largest of 64 / 32 / 16 that still leaves at least `want` workgroups (never below 16).  Forward: 256
+// (every CU busy: K = 10, B = 512 -> 320 tiles of 16 rows, 4.4 us against 8.0 with 80 tiles of 64).  Backward: 128 -- every
+// tile costs a hand-off (write-through partials, a ticket, a share of the last arrival's reduction): measured at K = 10,
+// B = 512, 13 -> 50: 16 rows 12.6 us, 32 rows 10.4, 64 rows 11.6; B = 4096: 68.6 / 37.2 / 25.2
+inline int pl_tile_rows(int64_t K, int64_t B, int64_t want) {
+  int bt = PL_BT_MAX;
+  while (bt > 16 && K * ((B + bt - 1) / bt) < want) bt >>= 1;
+  return bt;
+}
 template <typename T>
 bool pl_fits(int64_t n_in, int64_t n_out) {
   if (n_in < 1 || n_out < 1 || n_in > 255 || n_out > 256) return false;
   const int64_t lim = PL_LDS_FLOATS * (int64_t)sizeof(float) / (int64_t)sizeof(T);
-  const int64_t fwd = n_out * pl_odd((int)n_in + 1) + PL_BT * pl_odd((int)n_in);
-  const int64_t bwd = PL_BT * pl_odd((int)n_out) + PL_BT * pl_odd((int)n_in) + n_out * (n_in + 1);
+  const int64_t fwd = PL_BT_MAX * n_in + 4 + n_out * pl_odd((int)n_in + 1);
+  const int64_t bwd = PL_BT_MAX * n_out + PL_BT_MAX * n_in + 8 + n_out * (n_in + 1);
   return fwd <= lim && bwd <= lim;
 }
 
@@ -952,11 +1036,12 @@ int particle_linear(const T* h, int64_t hsk, const T* w, T* out, int64_t K, int6
   if (!pl_fits<T>(n_in, n_out) || B > (1 << 24) || K > (1 << 20)) return ZS_ENOTSUP;
   if (K == 0 || B == 0) return 0;
   if (!h || !w || !out) return ZS_EINVAL;
-  const int ntiles = (int)((B + PL_BT - 1) / PL_BT);
+  const int bt = pl_tile_rows(K, B, 256);
+  const int ntiles = (int)((B + bt - 1) / bt);
   if ((int64_t)ntiles * K > (int64_t(1) << 30)) return ZS_ENOTSUP;
-  const size_t smem = sizeof(T) * (size_t)(n_out * pl_odd((int)n_in + 1) + PL_BT * pl_odd((int)n_in));
+  const size_t smem = sizeof(T) * (size_t)(((bt * n_in + 3) & ~3) + n_out * pl_odd((int)n_in + 1));
   ZS_LAUNCH_SMEM(KID_PARTICLE_LINEAR, (k_particle_linear<T>), dim3((unsigned)(ntiles * K)), dim3(256), smem, (hipStream_t)stream, h,
-                 hsk, w, out, (int)B, (int)n_in, (int)n_out, relu, ntiles);
+                 hsk, w, out, (int)B, (int)n_in, (int)n_out, relu, ntiles, bt);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -975,13 +1060,15 @@ int particle_linear_bwd(const T* h, int64_t hsk, const T* w, const T* out, const
     return e == hipSuccess ? 0 : (int)e;
   }
   if (!h || !w || !gout || (relu && !out)) return ZS_EINVAL;
-  const int ntiles = (int)((B + PL_BT - 1) / PL_BT);
+  static const int bt_env = env_knob("ZS_PL_BWD_BT", 0);          // experiments only (zs_common.h)
+  const int bt = (bt_env == 16 || bt_env == 32 || bt_env == 64) ? bt_env : pl_tile_rows(K, B, 128);
+  const int ntiles = (int)((B + bt - 1) / bt);
   if ((int64_t)ntiles * K > (int64_t(1) << 30)) return ZS_ENOTSUP;
   if (!workspace || !tickets || workspace_len < K * ntiles * nW) return ZS_EINVAL;
-  const size_t smem = sizeof(T) * (size_t)(PL_BT * pl_odd((int)n_out) + PL_BT * pl_odd((int)n_in) + nW);
+  const size_t smem = sizeof(T) * (size_t)(((bt * n_out + 3) & ~3) + ((bt * n_in + 3) & ~3) + nW);
   ZS_LAUNCH_SMEM(KID_PARTICLE_LINEAR_BWD, (k_particle_linear_bwd<T>), dim3((unsigned)(ntiles * K)), dim3(256), smem,
-                 (hipStream_t)stream, h, hsk, w, out, gout, gh, gw, workspace, (unsigned*)tickets, (int)B, (int)n_in, (int)n_out, relu,
-                 ntiles);
+                 (hipStream_t)stream, h, hsk, w, out ? out : gout, gout, gh, gw, workspace, (unsigned*)tickets, (int)B, (int)n_in,
+                 (int)n_out, relu, ntiles, bt);
   ZS_CHECK_LAUNCH();
   return 0;
 }

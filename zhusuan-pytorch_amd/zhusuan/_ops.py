@@ -956,7 +956,7 @@ class ParticleLinear(torch.autograd.Function):
         gout = gout.contiguous()
         gh = torch.empty((K, B, n_in), dtype=h.dtype, device=h.device) if need_h else None
         gw = torch.empty_like(w)
-        part = torch.empty(K * ((B + 63) // 64) * n_out * (n_in + 1), dtype=h.dtype, device=h.device)      # tile partials of gw
+        part = torch.empty(K * ((B + 15) // 16) * n_out * (n_in + 1), dtype=h.dtype, device=h.device)      # tile partials of gw
         tickets = _pl_tickets(h.device, K)
         _hip.lib().call("zs_particle_linear_bwd" + _sfx(h), _hip.ptr(h), 0 if shared else B * n_in, _hip.ptr(w), _hip.ptr(out),
                         _hip.ptr(gout), _hip.ptr(gh), _hip.ptr(gw), K, B, n_in, n_out, 1 if relu else 0, _hip.ptr(part), part.numel(),

@@ -19,8 +19,8 @@ def _fits_lds(n_in, n_out, itemsize):
         return False
     lim = 15360 * 4 // itemsize
     odd = lambda v: v | 1
-    fwd = n_out * odd(n_in + 1) + 64 * odd(n_in)
-    bwd = 64 * odd(n_out) + 64 * odd(n_in) + n_out * (n_in + 1)
+    fwd = 64 * n_in + 4 + n_out * odd(n_in + 1)
+    bwd = 64 * n_out + 64 * n_in + 8 + n_out * (n_in + 1)
     return max(fwd, bwd) <= lim
 
 
