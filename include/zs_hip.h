@@ -309,11 +309,16 @@ int zs_philox_uniform_f32(float* out, int64_t N, uint64_t seed, uint64_t offset,
  * moving_mean (float, 1 element) and local_step (int32, 1 element) are DEVICE state, read and written by the kernel
  * (the module buffers of elbo.py:45-49), so the call is hipGraph-capturable.  resid may be NULL when baseline is.
  * Derivatives for the caller: d c_i / d logp_i = -1,  d c_i / d logq_i = -signal_i,  d c_i / d baseline_i = -resid_i.
+ * workspace / ticket (optional; >= ZS_LJ_WORKSPACE doubles and one zero-initialised device word handed back at zero, as
+ * for LJ1): with them, vectors of more than 16 384 elements are spread over many workgroups (one pass that also yields the
+ * moving mean, then an element-wise launch that centres the learning signal: ~12 us at 10^6 elements); without them one
+ * workgroup walks the vector (300 us at 10^6 elements).
  * -------------------------------------------------------------------------*/
 int zs_reinforce_f32(const float* logp, const float* logq, const float* baseline, int64_t Pb, int64_t n,
                      int variance_reduction, int do_mean, double decay,
                      float* moving_mean, int32_t* local_step,
-                     float* signal, float* cost, float* resid, void* stream);
+                     float* signal, float* cost, float* resid,
+                     double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
 
 /* ---------------------------------------------------------------------------
  * S1  Scalar ELBO epilogue: out[0] = sum_t coef[t] * sum_i rows_t[i]  for up to ZS_MAX_TERMS dense vectors.
@@ -484,7 +489,7 @@ int zs_logistic_logprob_bwd_ksum_f64(const double* x, const double* loc, const d
 int zs_uniform_sample_f64(const double* low, int64_t Pl, const double* high, int64_t Ph, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* out, double* cache, int64_t N, int reparam, void* stream);
 int zs_uniform_logprob_f64(const double* x, int64_t Px, const double* low, int64_t Pl, const double* high, int64_t Ph, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
 int zs_philox_uniform_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
-int zs_reinforce_f64(const double* logp, const double* logq, const double* baseline, int64_t Pb, int64_t n, int variance_reduction, int do_mean, double decay, float* moving_mean, int32_t* local_step, double* signal, double* cost, double* resid, void* stream);
+int zs_reinforce_f64(const double* logp, const double* logq, const double* baseline, int64_t Pb, int64_t n, int variance_reduction, int do_mean, double decay, float* moving_mean, int32_t* local_step, double* signal, double* cost, double* resid, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
 int zs_scalar_objective_f64(const double* r0, int64_t n0, double c0, const double* r1, int64_t n1, double c1, const double* r2, int64_t n2, double c2, const double* r3, int64_t n3, double c3, const double* r4, int64_t n4, double c4, const double* r5, int64_t n5, double c5, double* out, double* coef_out, void* stream);
 int zs_logjoint_scalar_f64(const zs_lj_term* terms, int n_terms, double* out, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
 int zs_logjoint_scalar_bwd_f64(const zs_lj_term* terms, int n_terms, const double* gout, double* gcoef, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);

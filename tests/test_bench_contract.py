@@ -80,6 +80,11 @@ def test_bench_line_single_rank():
     assert rec["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     # a 6-step trial is ~7 ms: the timed region is repeated until it covers at least half a second, median reported
     assert rec["trials"] >= 3 and rec["timed_seconds_total"] >= 0.45
+    k1 = roof["k1_fused_sample_logprob"]          # the north-star kernel's own fraction, in the driver-visible record
+    for label in ("rows_1M", "rows_4M"):
+        assert k1[label]["rows"] > 1000000 and 0.2 < k1[label]["frac"] <= 1.0
+        assert abs(k1[label]["frac"] - k1[label]["achieved"] / 8000.0) < 1e-9
+    assert rec["config"]["discarded_draws"].startswith("skipped") and "c3_reference_draws" in rec["extra_configs"]
     lib = rec["library"]
     assert lib["abi"] == 10 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
     assert lib["path"].endswith("lib/libzs_hip.so") and rec["env_overrides"] == {}

@@ -99,7 +99,7 @@ def test_reinforce_shape_errors_match_the_reference(dev):
     assert int(e.local_step) == 0
 
 
-def _raw(klib, dev, logp, logq, base, vr, do_mean, mm, step, dtype=torch.float32, Pb=None):
+def _raw(klib, dev, logp, logq, base, vr, do_mean, mm, step, dtype=torch.float32, Pb=None, workspace=True):
     sfx = "_f32" if dtype == torch.float32 else "_f64"
     t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev)
     lp, lq, b = t(logp), t(logq), t(base)
@@ -110,12 +110,21 @@ def _raw(klib, dev, logp, logq, base, vr, do_mean, mm, step, dtype=torch.float32
     res = torch.full((n,), float("nan"), dtype=dtype, device=dev)
     cost = torch.full((1 if do_mean else n,), float("nan"), dtype=dtype, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if torch.device(dev).type == "cuda" else None
-    klib.call("zs_reinforce" + sfx, _hip.ptr(lp), _hip.ptr(lq), _hip.ptr(b),
-              Pb if Pb is not None else (1 if (b is None or b.numel() == 1) else n), n,
-              int(vr), int(do_mean), 0.8, _hip.ptr(mmt), _hip.ptr(stt), _hip.ptr(sig), _hip.ptr(cost),
-              _hip.ptr(res) if b is not None else None, st)
+    # workspace + ticket: long vectors then take the many-workgroup path (twice on one workspace: the ticket must come back
+    # at zero and the second call must not see the first one's partial sums)
+    ws = torch.zeros(_hip.LJ_WORKSPACE, dtype=torch.float64, device=dev) if workspace else None
+    tk = torch.zeros(1, dtype=torch.int32, device=dev) if workspace else None
+    for rep in range(2 if workspace else 1):
+        mmt.fill_(mm)
+        stt.fill_(step)
+        first = rep == 0 and workspace
+        klib.call("zs_reinforce" + sfx, _hip.ptr(lp * 0.5 if first else lp), _hip.ptr(lq), _hip.ptr(b),
+                  Pb if Pb is not None else (1 if (b is None or b.numel() == 1) else n), n,
+                  int(vr), int(do_mean), 0.8, _hip.ptr(mmt), _hip.ptr(stt), _hip.ptr(sig), _hip.ptr(cost),
+                  _hip.ptr(res) if b is not None else None, _hip.ptr(ws), _hip.LJ_WORKSPACE if workspace else 0, _hip.ptr(tk), st)
     if torch.device(dev).type == "cuda":
         torch.cuda.synchronize()
+    assert tk is None or int(tk.item()) == 0
     return dict(cost=cost.cpu().numpy(), signal=sig.cpu().numpy(), resid=res.cpu().numpy() if b is not None else None,
                 mm=float(mmt), step=int(stt))
 
@@ -130,7 +139,7 @@ def test_c_oracle_rejects_bad_reinforce_arguments():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 7, 64, 65, 300, 1024, 5000, 1000003])
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 300, 1024, 5000, 16384, 16385, 70001, 1000003])
 @pytest.mark.parametrize("bkind", [0, 1, 2])
 @pytest.mark.parametrize("vr", [True, False])
 def test_hip_reinforce_vs_c_oracle(n, bkind, vr):
@@ -147,6 +156,10 @@ def test_hip_reinforce_vs_c_oracle(n, bkind, vr):
         if base is not None and vr:
             np.testing.assert_allclose(a["resid"], b["resid"], rtol=1e-6, atol=1e-5)
         assert abs(a["mm"] - b["mm"]) <= 2e-6 * max(1.0, abs(b["mm"])) and a["step"] == b["step"] == (3 if vr else 2)
+        if n > 16384:       # without a workspace one workgroup walks the vector: same numbers
+            c = _raw(hipk, "cuda:0", logp, logq, base, vr, do_mean, 0.3, 2, workspace=False)
+            np.testing.assert_allclose(c["cost"], a["cost"], rtol=2e-6, atol=2e-4)
+            np.testing.assert_allclose(c["signal"], a["signal"], rtol=1e-6, atol=2e-5)
     for dt in (torch.float64,):
         a = _raw(hipk, "cuda:0", logp, logq, base, vr, True, 0.3, 2, dt)
         b = _raw(orc, "cpu", logp, logq, base, vr, True, 0.3, 2, dt)

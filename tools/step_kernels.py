@@ -62,12 +62,14 @@ def main():
         zhusuan.optim.FlatAdam(model.parameters(), lr=1e-3)
     rng = zhusuan.DeviceRNG(dev, seed=1)
 
+    one = torch.ones((), device=dev)          # backward's seed, allocated once (as bench.py does)
+
     def step():
         rng.begin_step()
         for p in model.parameters():
             p.grad = None
         loss = model(obs)
-        loss.backward()
+        loss.backward(one)
         opt.step()
 
     with zhusuan.device_rng(rng), zhusuan.skip_discarded_draws(not args.reference_draws):
@@ -86,7 +88,7 @@ def main():
             for p in model.parameters():
                 p.grad = None
             loss = model(obs)
-            loss.backward()
+            loss.backward(one)
             return loss.detach()
         gstep = zhusuan.GraphedStep(compute, opt.step, rng=rng, warmup=5)
         if args.tuned_gemm:

@@ -48,7 +48,8 @@ PROTOTYPES = {
     "zs_uniform_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_philox_uniform_f32": [_p, _i64, _u64, _u64, _p, _p],
     # ELBO.reinforce epilogue
-    "zs_reinforce_f32": [_p, _p, _p, _i64, _i64, _int, _int, ctypes.c_double, _p, _p, _p, _p, _p, _p],
+    # ..., signal, cost, resid, workspace, workspace_len, ticket, stream
+    "zs_reinforce_f32": [_p, _p, _p, _i64, _i64, _int, _int, ctypes.c_double, _p, _p, _p, _p, _p, _p, _i64, _p, _p],
     # the whole importance-weighted objective in one launch
     "zs_iw_objective_f32": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _i64, _p, _p],
     # scalar ELBO epilogue: six (rows, n, coef) slots, out, coef_out, stream

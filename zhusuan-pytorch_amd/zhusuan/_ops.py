@@ -663,10 +663,11 @@ class ReinforceEpilogue(torch.autograd.Function):
         resid = torch.empty(shape, dtype=lq.dtype, device=lq.device) if use_b else None
         cost = torch.empty((() if do_mean else shape), dtype=lq.dtype, device=lq.device)
         if n:
+            ws, ticket = _lj_workspace(lq.device) if n > 16384 else (None, None)      # long vectors: many workgroups
             _hip.lib().call("zs_reinforce" + sfx, _hip.ptr(lp), _hip.ptr(lq), _hip.ptr(b), Pb, n,
                             1 if variance_reduction else 0, 1 if do_mean else 0, float(decay),
                             _hip.ptr(moving_mean), _hip.ptr(local_step), _hip.ptr(signal), _hip.ptr(cost), _hip.ptr(resid),
-                            _hip.stream_for(lq))
+                            _hip.ptr(ws), ws.numel() if ws is not None else 0, _hip.ptr(ticket), _hip.stream_for(lq))
         ctx.meta = (n, bool(do_mean), use_b, tuple(baseline.shape) if use_b else None)
         ctx.save_for_backward(signal, resid)
         return cost
