@@ -205,6 +205,18 @@ static void test_iw_particle() {
         expect(isfinite(w) && isfinite(ct) && isfinite(c), "iw_particle finite", c, 0);
       }
       expect(close_rel(got_cost, cost, 2e-5, 1e-3), "iw row cost", got_cost, cost);
+      // the quarter-rate-instruction form of the lane-group kernel (iw_particle_fast): same gates
+      const float invS = 1.0f / r.S;
+      double fast_cost = 0;
+      for (int j = 0; j < K; ++j) {
+        float w, ct, c;
+        zs::iw_particle_fast(r, invS, lf[j], lqf[j], zs::exp_fast(lf[j] - r.m1), j, est, w, ct, c);
+        fast_cost += ct;
+        expect(close_rel(w, wt[j], 2e-5, 1e-7), "iw_particle_fast weight", w, wt[j]);
+        expect(close_rel(c, cq[j], 2e-4, 2e-5), "iw_particle_fast d cost / d logq", c, cq[j]);
+        expect(isfinite(w) && isfinite(ct) && isfinite(c), "iw_particle_fast finite", c, 0);
+      }
+      expect(close_rel(fast_cost, cost, 2e-5, 1e-3), "iw row cost (fast form)", fast_cost, cost);
     }
   }
 }

@@ -168,6 +168,42 @@ __global__ __launch_bounds__(256) void v4(const float4* __restrict__ p, const fl
   }
 }
 
+// V5 (round 3): one wave takes RPW consecutive rows per item, ALL their loads issued up front, clamped instead of
+// predicated (lane + 64 * 3 >= D4 reads the row's last chunk again and its term is dropped): 16 (RPW = 2) or 32 (RPW = 4)
+// independent 16-byte loads per lane, no branch between them
+template <int RPW>
+__global__ __launch_bounds__(256) void v5(const float4* __restrict__ p, const float4* __restrict__ x, float* __restrict__ lp,
+                                          int K, int B, int D4) {
+  const int lane = threadIdx.x & 63;
+  const long rows = (long)K * B;
+  const long items = (rows + RPW - 1) / RPW;
+  const long nw = (long)gridDim.x * 4;
+  for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += nw) {
+    float4 pv[RPW][4], xv[RPW][4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ok[u] = lane + 64 * u < D4;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      long row = it * RPW + r;
+      if (row >= rows) row = rows - 1;
+      const float4* pr = p + row * D4;
+      const float4* xr = x + (row % B) * D4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int c = ok[u] ? lane + 64 * u : D4 - 1; pv[r][u] = pr[c]; xv[r][u] = xr[c]; }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const long row = it * RPW + r;
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const float t = term4(pv[r][u], xv[r][u]); acc += ok[u] ? t : 0.f; }
+      acc = wsum(acc);
+      if (lane == 0 && row < rows) { const long k = row / B, b = row - k * B; lp[b * K + k] = acc * LN2; }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void vproduce(const float4* __restrict__ q, float4* __restrict__ p, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     float4 v = q[i]; v.x = 0.5f * v.x + 0.25f; v.y = 0.5f * v.y + 0.25f; v.z = 0.5f * v.z + 0.25f; v.w = 0.5f * v.w + 0.25f; p[i] = v;
@@ -206,8 +242,9 @@ struct Timer {
 int main(int argc, char** argv) {
   const int K = 50, D = 784, D4 = D / 4;
   int Bs[] = {256, 2048, 16384};
+  if (argc > 1) { Bs[0] = Bs[1] = Bs[2] = atoi(argv[1]); }
   const int iters = 30;
-  for (int bi = 0; bi < 3; ++bi) {
+  for (int bi = 0; bi < (argc > 1 ? 1 : 3); ++bi) {
     const int B = Bs[bi];
     const long rows = (long)K * B, n = rows * D;
     // rotate buffers for the small sizes: 3 (all stay in the 256 MB Infinity Cache) and 10 (400 MB: every launch reads HBM)
@@ -257,6 +294,10 @@ int main(int argc, char** argv) {
         RUN("v2 2-in-flight KC=10", (v2<10>), g, 256, P, (const float4*)x, lp, K, B, D4); }
       { unsigned g = (unsigned)std::min<long>(((long)B * ((K + 5) / 6) + 3) / 4, 4096);
         RUN("v2 2-in-flight KC=6", (v2<6>), g, 256, P, (const float4*)x, lp, K, B, D4); }
+      RUN("v5 2 rows/wave clamped", (v5<2>), (unsigned)((rows / 2 + 3) / 4), 256, P, (const float4*)x, lp, K, B, D4);
+      RUN("v5 2 rows/wave grid 2048", (v5<2>), 2048, 256, P, (const float4*)x, lp, K, B, D4);
+      RUN("v5 1 row/wave clamped", (v5<1>), (unsigned)((rows + 3) / 4), 256, P, (const float4*)x, lp, K, B, D4);
+      RUN("v5 4 rows/wave clamped", (v5<4>), (unsigned)((rows / 4 + 3) / 4), 256, P, (const float4*)x, lp, K, B, D4);
     }
     for (int i = 0; i < NBUF; ++i) CK(hipFree(p[i]));
     CK(hipFree(x)); CK(hipFree(lp));

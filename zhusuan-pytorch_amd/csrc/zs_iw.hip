@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_iw_reduce_group(
       const bool on = k < K;
       if (k != r.jstar) m2 = fmaxf(m2, l[i]);
       sl += on ? l[i] : 0.f;
-      e[i] = on ? expf(l[i] - r.m1) : 0.f;
+      e[i] = on ? exp_fast(l[i] - r.m1) : 0.f;          // (v_exp_f32: see iw_particle_fast)
       s += e[i];
     }
     r.m2 = group_max<LPR>(m2);
@@ -225,13 +225,14 @@ __global__ __launch_bounds__(256) void k_iw_reduce_group(
     }
     r.invK = 1.0f / (float)K;
     r.invKm1 = K > 1 ? 1.0f / (float)(K - 1) : 0.f;
+    const float invS = 1.0f / r.S;                           // one division per lane instead of two per particle
     float ct = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = q + i * LPR;
       if (k < K) {
         float wt, c1, cq;
-        iw_particle_e(r, l[i], lq[i], e[i], k, estimator, wt, c1, cq);
+        iw_particle_fast(r, invS, l[i], lq[i], e[i], k, estimator, wt, c1, cq);
         ct += c1;
         if (row_on) {
           if (coef_p) coef_p[b * K + k] = -wt * ext.scale;

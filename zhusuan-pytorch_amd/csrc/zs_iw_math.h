@@ -37,6 +37,34 @@ ZS_HD void iw_particle_e(const IwRow& r, float l, float lq, float e, int j, int 
     cq = wt - signal;
   }
 }
+// The same with the quarter-rate instructions only (K4 with thousands of datapoints, where the precise expf / log1pf / two
+// divisions per particle set the pace): 1 / S once per lane (`invS`), exp as v_exp_f32 of x * log2(e), log1p as a cubic for
+// |u| < 2^-5 and v_log_f32(1 + u) otherwise.  Relative error of the exponentials 6e-8 * |x| (the particles that matter have
+// |x| < ~15), of log1p < 3e-7 for small and 6e-8 / |u| <= 2e-6 for large arguments: checked against the float64 truth by the
+// same gate as the precise form (tests/test_cabi.py::test_hip_iw_reduce_lane_groups, tests/host_math).
+ZS_HD float log1p_fast(float u) {
+  const float small = u * (1.0f - u * (0.5f - u * 0.33333334f));
+  const float big = ln_fast(1.0f + u);
+  return (u < 0.03125f && u > -0.03125f) ? small : big;
+}
+ZS_HD void iw_particle_fast(const IwRow& r, float invS, float l, float lq, float e, int j, int estimator,
+                            float& wt, float& cost_term, float& cq) {
+  wt = e * invS;
+  cost_term = -wt * l;
+  cq = wt;
+  if (estimator == ZS_IW_VIMCO) {
+    const float sub = (r.sumL - l) * r.invKm1;
+    float signal;
+    if (j != r.jstar || r.S >= 2.0f) {
+      signal = -log1p_fast((exp_fast(sub - r.m1) - e) * invS);
+    } else {
+      const float sx = r.S2 + expf(sub - r.m2);
+      signal = (r.logS - logf(sx)) + (r.m1 - r.m2);
+    }
+    cost_term -= lq * signal;
+    cq = wt - signal;
+  }
+}
 ZS_HD void iw_particle(const IwRow& r, float l, float lq, int j, int estimator,
                                             float& wt, float& cost_term, float& cq) {
   iw_particle_e(r, l, lq, expf(l - r.m1), j, estimator, wt, cost_term, cq);
