@@ -114,6 +114,15 @@ def main():
         cp, cq = torch.empty(B, K, device=dev), torch.empty(B, K, device=dev)
         timed("K4 iw reduce (vimco)", "zs_iw_reduce_f32", 16 * N + 8 * B,
               lambda: lib.call("zs_iw_reduce_f32", P(logp), K, P(logq), K, B, K, 1, P(cost), P(bound), P(cp), P(cq), st), tag)
+        # ---------------- R1: the REINFORCE epilogue over N log-joints (variance reduction, batch mean): 8 N read, 4 N written
+        mmt, stt = torch.zeros(1, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        sig, rcost = torch.empty(N, device=dev), torch.empty(1, device=dev)
+        lpv, lqv = logp.reshape(-1), logq.reshape(-1)
+        rws = torch.zeros(_hip.LJ_WORKSPACE, dtype=torch.float64, device=dev)
+        rtk = torch.zeros(1, dtype=torch.int32, device=dev)
+        timed("R1 reinforce epilogue", "zs_reinforce_f32", 12 * N,
+              lambda: lib.call("zs_reinforce_f32", P(lpv), P(lqv), None, 1, N, 1, 1, 0.8, P(mmt), P(stt), P(sig), P(rcost), None,
+                               P(rws), rws.numel(), P(rtk), st), tag + (" (2 launches: avg is per launch)" if N > 16384 else ""))
         # ---------------- A1: Adam (first size: the parameter tensors of the VAE / IWAE models; then one flat tensor)
         sizes = [392000, 500, 250000, 500, 20000, 40, 20000, 40, 20000, 500, 250000, 500, 392000, 784] if N == 12800 else [N * D]
         n_par = sum(sizes)
