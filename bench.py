@@ -74,6 +74,10 @@ def parse_args(argv=None):
                     help="also execute the draw of every latent that the reference's objectives throw away (the node factory's "
                          "sample, bn.py:158 / elbo.py:122): the package's default behaviour.  The bench runs inside "
                          "zhusuan.skip_discarded_draws() unless this flag is given (one sampling launch per latent and step)")
+    ap.add_argument("--torch-linear", action="store_true",
+                    help="build the callers' MLPs from torch.nn.Linear (as the reference's examples do) instead of zhusuan.Linear -- "
+                         "the same layer whose bias gradient is ONE deterministic column-sum launch (CS1) instead of torch's generic "
+                         "reduction (12.4 us x 7 layers per IWAE step); extra_configs.c3_torch_linear in the default run")
     ap.add_argument("--torch-adam", action="store_true",
                     help="update with torch.optim.Adam(fused=True, capturable=True) instead of zhusuan.optim.FlatAdam "
                          "(the same update over flat buckets, one launch)")
@@ -204,7 +208,7 @@ def pmc_traffic(entry, fused_logits, abi_version):
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-def make_workload(name, dev, seed_rank=0, fused_logits=False):
+def make_workload(name, dev, seed_rank=0, fused_logits=False, dense="zhusuan"):
     """(model, observations, ELBO-evals per step, description) of a BASELINE config on one GPU."""
     from examples import iwae, vae_mnist, bnn_vi
     rs = np.random.RandomState(1234 + seed_rank)
@@ -212,12 +216,12 @@ def make_workload(name, dev, seed_rank=0, fused_logits=False):
     if name in ("c3", "c3_logits", "c3_probs"):
         fused = name == "c3_logits" or (fused_logits and name != "c3_probs")
         model = iwae.build(n_samples=PARTICLES, estimator="vimco", x_dim=X_DIM, z_dim=Z_DIM, hidden=HIDDEN, device=dev,
-                           fused_logits=fused)
+                           fused_logits=fused, dense=dense)
         return model, {"x": bits(BATCH_PER_GPU)}, BATCH_PER_GPU * PARTICLES, \
             "IWAE-MNIST VIMCO, batch=256, K=50, " + ("Bernoulli from logits (the decoder's sigmoid inside the log-prob kernel)"
                                                       if fused else "Bernoulli from probabilities (nn.Sigmoid pass, as the reference's example)")
     if name == "c2":
-        return vae_mnist.build(512, device=dev), {"x": bits(512)}, 512, "VAE-MNIST SGVB, batch=512, K=1 (BASELINE configs[1])"
+        return vae_mnist.build(512, device=dev, dense=dense), {"x": bits(512)}, 512, "VAE-MNIST SGVB, batch=512, K=1 (BASELINE configs[1])"
     if name == "c5":
         x = torch.tensor(rs.standard_normal((512, 13)).astype(np.float32), device=dev)
         y = torch.tensor(rs.standard_normal(512).astype(np.float32), device=dev)
@@ -357,12 +361,13 @@ def make_optimizer(model, torch_adam, groups=None):
     return zhusuan.optim.FlatAdam(groups if groups is not None else model.parameters(), lr=1e-3)
 
 
-def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False, skip_discarded=True):
+def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False, skip_discarded=True,
+                          dense="zhusuan"):
     """A BASELINE config other than the headline one on this GPU: full training steps replayed from one hipGraph."""
     import zhusuan
     gemm_tuning(tuned)
     torch.manual_seed(0)
-    model, obs, evals, label = make_workload(name, dev, fused_logits=fused_logits)
+    model, obs, evals, label = make_workload(name, dev, fused_logits=fused_logits, dense=dense)
     opt = make_optimizer(model, torch_adam)
     rng = zhusuan.DeviceRNG(dev, seed=1)
 
@@ -386,6 +391,7 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
     return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
             "launch_mode": "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
             "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default)",
+            "dense_layers": "zhusuan.Linear (bias gradient: CS1)" if dense == "zhusuan" else "torch.nn.Linear",
             "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape)" if tuned else "PyTorch default",
             "optimizer": "torch.optim.Adam(fused=True, capturable=True)" if torch_adam else "zhusuan.optim.FlatAdam"}
 
@@ -466,7 +472,7 @@ def hbm_resident_kernels(klib, dev, launches=30):
 
 # kernel-name fragment -> C-ABI entry point (most specific first); logits forms carry <true, ...> as first template argument
 # (the kernels shared by the location-scale families live in namespace zs: first template argument 0 = Normal, 1 = Logistic)
-_KERNEL_ENTRY = [("k_logjoint_bwd", "zs_logjoint_scalar_bwd_f32"), ("k_logjoint_fwd", "zs_logjoint_scalar_f32"),
+_KERNEL_ENTRY = [("k_column_sum", "zs_column_sum_f32"), ("k_logjoint_bwd", "zs_logjoint_scalar_bwd_f32"), ("k_logjoint_fwd", "zs_logjoint_scalar_f32"),
                  ("k_normal_sample_multi_bwd", "zs_normal_sample_logprob_multi_bwd_f32"),
                  ("k_normal_sample_multi", "zs_normal_sample_logprob_multi_f32"),
                  ("k_particle_linear_bwd", "zs_particle_linear_bwd_f32"), ("k_particle_linear", "zs_particle_linear_f32"),
@@ -556,7 +562,8 @@ def main():
         except Exception as e:                                      # noqa: BLE001
             k1_first = {"error": repr(e)}
     torch.manual_seed(0)
-    model, obs, evals_per_step, _ = make_workload("c3", dev, seed_rank=rank, fused_logits=args.fused_logits)
+    dense = "torch" if args.torch_linear else "zhusuan"
+    model, obs, evals_per_step, _ = make_workload("c3", dev, seed_rank=rank, fused_logits=args.fused_logits, dense=dense)
     dataparallel.broadcast_parameters(model)
     rng = zhusuan.DeviceRNG(dev, seed=1000 + rank)          # per-rank Philox stream, state in device memory
 
@@ -787,6 +794,10 @@ def main():
                                          if args.fused_logits else
                                          "probs (nn.Sigmoid pass, as the reference's example is written; extra_configs.c3_logits: the "
                                          "same step with the sigmoid inside the Bernoulli log-prob kernel)",
+                       "dense_layers": ("zhusuan.Linear: torch.nn.Linear's parameters, forward GEMM and backward GEMMs; the bias gradient "
+                                        "(grad_output.sum(0)) is one deterministic column-sum launch (CS1) instead of torch's generic "
+                                        "reduction (extra_configs.c3_torch_linear: the same step built from torch.nn.Linear)")
+                                       if dense == "zhusuan" else "torch.nn.Linear (--torch-linear)",
                        "mlp_gemm_library": args.blas,
                        "mlp_gemm_selection": ("PyTorch TunableOp: fastest fp32 hipBLASLt / rocBLAS solution per GEMM shape, picked during "
                                               "warm-up (callers' nn.Linear stack, outside the hot path; extra_configs.c3_default_gemm "
@@ -847,7 +858,8 @@ def main():
             for name in ("c2", "c5", "c3_probs" if args.fused_logits else "c3_logits"):
                 try:
                     out["extra_configs"][name] = run_single_gpu_config(name, dev, args.steps, args.warmup, tuned=tuned,
-                                                                       torch_adam=args.torch_adam, skip_discarded=skip_discarded)
+                                                                       torch_adam=args.torch_adam, skip_discarded=skip_discarded,
+                                                                       dense=dense)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"][name] = {"error": repr(e)}
             if tuned:       # the headline step once more with PyTorch's default GEMM selection (what round 1 measured)
@@ -856,11 +868,18 @@ def main():
                                                                                     tuned=False, torch_adam=True)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"]["c3_default_gemm"] = {"error": repr(e)}
+            if dense == "zhusuan":      # the headline step built from torch.nn.Linear, as the reference's example is
+                try:
+                    out["extra_configs"]["c3_torch_linear"] = run_single_gpu_config(
+                        "c3", dev, args.steps, args.warmup, tuned=tuned, torch_adam=args.torch_adam, fused_logits=args.fused_logits,
+                        skip_discarded=skip_discarded, dense="torch")
+                except Exception as e:                              # noqa: BLE001
+                    out["extra_configs"]["c3_torch_linear"] = {"error": repr(e)}
             if skip_discarded:          # the headline step with the reference's discarded draw executed (the package default)
                 try:
                     out["extra_configs"]["c3_reference_draws"] = run_single_gpu_config(
                         "c3", dev, args.steps, args.warmup, tuned=tuned, torch_adam=args.torch_adam, fused_logits=args.fused_logits,
-                        skip_discarded=False)
+                        skip_discarded=False, dense=dense)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"]["c3_reference_draws"] = {"error": repr(e)}
             if not args.torch_adam:     # the headline step with torch's multi-tensor Adam

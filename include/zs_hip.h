@@ -462,6 +462,17 @@ int zs_particle_linear_bwd_f32(const float* h, int64_t h_stride_k, const float* 
                                float* workspace, int64_t workspace_len, uint32_t* tickets, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * CS1  Column sums of a row-major [rows, cols] matrix: out[c] = sum_r x[r, c].  The bias gradient of the callers' dense
+ * layers (torch.nn.Linear in the reference's examples, variational_autoencoder/vae_mnist.py:22-28, iwae.py:40-47:
+ * grad_bias = grad_output.sum(0)) -- the one reduction of their backward pass that is not a GEMM; caller-side glue like
+ * PL1, not part of the distribution / objective path.  Deterministic (row chunks combined in chunk order).
+ * workspace: >= ceil(cols / 64) * 64 * 64 elements; tickets: n_tickets >= ceil(cols / 64) zero-initialised device words,
+ * handed back at zero (both unused, and may be NULL, when the matrix has fewer than 64 rows).
+ * -------------------------------------------------------------------------*/
+int zs_column_sum_f32(const float* x, float* out, int64_t rows, int64_t cols, float* workspace, int64_t workspace_len,
+                      uint32_t* tickets, int64_t n_tickets, void* stream);
+
+/* ---------------------------------------------------------------------------
  * float64 twins.  The reference accepts float64 parameters for Normal / Bernoulli
  * (zhusuan/distributions/utils.py:5,57-64); every entry point above exists with the suffix _f64,
  * identical argument meaning, double* instead of float*.  They are plain (untuned) kernels: none of the
@@ -497,6 +508,7 @@ int zs_normal_sample_logprob_multi_f64(const zs_ms_term* terms, int n_terms, uin
 int zs_normal_sample_logprob_multi_bwd_f64(const zs_ms_term* terms, int n_terms, uint64_t seed, const uint64_t* rng_state, void* stream);
 int zs_particle_linear_f64(const double* h, int64_t h_stride_k, const double* w, double* out, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, void* stream);
 int zs_particle_linear_bwd_f64(const double* h, int64_t h_stride_k, const double* w, const double* out, const double* gout, double* gh, double* gw, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, double* workspace, int64_t workspace_len, uint32_t* tickets, void* stream);
+int zs_column_sum_f64(const double* x, double* out, int64_t rows, int64_t cols, double* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream);
 int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors, double* exp_avg, double* exp_avg_sq, int64_t* steps, uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -158,6 +158,22 @@ class Raw(object):
         self.sync()
         return z.cpu().numpy(), lp.cpu().numpy()
 
+    # ---- CS1
+    def colsum(self, x):
+        rows, cols = x.shape
+        xt = self.t(x)
+        ctiles = max((cols + 63) // 64, 1)
+        ws = torch.full((ctiles * 4096,), float("nan"), dtype=self.dtype, device=self.dev)
+        tk = torch.zeros(ctiles, dtype=torch.int32, device=self.dev)
+        out = torch.full((cols,), float("nan"), dtype=self.dtype, device=self.dev)
+        for scale in (3.0, 1.0):       # twice on one workspace, other numbers first (tickets back at zero, no stale partials)
+            xs = xt * scale
+            self.k.call("zs_column_sum" + self.sfx, _hip.ptr(xs), _hip.ptr(out), rows, cols, _hip.ptr(ws), ws.numel(), _hip.ptr(tk),
+                        tk.numel(), self.stream())
+            self.sync()
+        assert int(tk.abs().sum().item()) == 0
+        return out.cpu().numpy()
+
     # ---- PL1
     def pl(self, h, w, relu):
         K, n_out, n_in1 = w.shape
@@ -535,3 +551,30 @@ def test_hip_particle_linear(hip, orc, hip64, orc64, K, B, n_in, n_out, shared, 
                 np.testing.assert_allclose(gha, ghb, rtol=tol * 10, atol=tol * 10 * max(np.abs(ghb).max(), 1))
     with pytest.raises(RuntimeError, match="code -2"):
         hip.pl(np.zeros((1, 2, 300)), np.zeros((1, 2, 301)), False)
+
+
+CS_SHAPES = [(12800, 500), (12800, 784), (12800, 40), (512, 500), (512, 784), (1, 7), (3, 1), (0, 5), (63, 64), (65, 257), (70000, 3),
+             (129, 1000), (5000, 13)]
+
+
+def test_c_oracle_column_sum(orc, orc64):
+    rng = np.random.RandomState(4)
+    for rows, cols in CS_SHAPES:
+        if rows * cols > 2000000:
+            continue
+        x = rng.standard_normal((rows, cols))
+        np.testing.assert_allclose(orc64.colsum(x), x.sum(0), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(orc.colsum(x), x.astype(np.float32).astype(np.float64).sum(0), rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", CS_SHAPES)
+def test_hip_column_sum(hip, hip64, rows, cols):
+    rng = np.random.RandomState(rows + cols)
+    x = rng.standard_normal((rows, cols)).astype(np.float32)
+    ref = x.astype(np.float64).sum(0)
+    a = hip.colsum(x)
+    np.testing.assert_allclose(a, ref, rtol=2e-6, atol=3e-7 * max(np.sqrt(rows), 1) * 4)
+    assert np.array_equal(a, hip.colsum(x))                                      # deterministic
+    if rows * cols <= 1000000:
+        np.testing.assert_allclose(hip64.colsum(x), ref, rtol=1e-13, atol=1e-12)

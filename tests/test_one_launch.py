@@ -241,3 +241,41 @@ def test_particle_linear_layer_against_torch(dev):
         np.testing.assert_allclose(gw.cpu().numpy(), rw.numpy(), rtol=2e-4, atol=2e-4 * max(float(rw.abs().max()), 1))
     with pytest.raises(RuntimeError, match="does not match"):
         zs.particle_linear(torch.zeros(2, 3, 4, device=dev), torch.zeros(2, 5, 7, device=dev))
+
+
+def test_zhusuan_linear_is_nn_linear_with_a_one_launch_bias_gradient(dev):
+    """zhusuan.Linear: same parameters, same forward, same gradients as torch.nn.Linear; the bias gradient comes from CS1."""
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(37, 23).to(dev)
+    lin = zs.Linear(37, 23).to(dev)
+    lin.load_state_dict(ref.state_dict())
+    assert [n for n, _ in lin.named_parameters()] == [n for n, _ in ref.named_parameters()]
+    for shape in [(50, 37), (4, 11, 37)]:
+        x1 = torch.randn(*shape, device=dev, requires_grad=True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        with launches() as names:
+            y = lin(x1)
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+        assert names == ["zs_column_sum"]
+        yr = ref(x2)
+        (yr * torch.linspace(-1, 1, yr.numel(), device=dev).view_as(yr)).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(lin.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(lin.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        lin.zero_grad(); ref.zero_grad()
+    with torch.no_grad():
+        assert torch.equal(lin(x1), ref(x1))
+    # the example callers accept it: same objective value as with torch.nn.Linear on the same weights and draws
+    x, e1, e2 = H.vae_data(16)
+    xb = torch.tensor(x, device=dev)
+    ma, mb = vae_mnist.build(16, hidden=32, device=dev, dense='torch'), vae_mnist.build(16, hidden=32, device=dev, dense='zhusuan')
+    mb.load_state_dict(ma.state_dict())
+    with zs.inject_epsilon([e1, e2]):
+        la = ma({"x": xb})
+    with zs.inject_epsilon([e1, e2]):
+        lb = mb({"x": xb})
+    ga, gb = _grads(ma, la), _grads(mb, lb)
+    assert float(la.detach()) == float(lb.detach())
+    for a, b in zip(ga, gb):
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6 * max(np.abs(a).max(), 1))

@@ -24,14 +24,14 @@ import zhusuan
 from examples import vae_mnist, iwae, bnn_vi
 
 
-def make(config, dev, bnn_layer="fused"):
+def make(config, dev, bnn_layer="fused", dense="zhusuan"):
     bits = lambda B: {"x": (torch.rand(B, 784, device=dev) < 0.5).float()}
     if config == "C2":
-        return vae_mnist.build(512, device=dev), bits(512), 512
+        return vae_mnist.build(512, device=dev, dense=dense), bits(512), 512
     if config == "C3":
-        return iwae.build(50, "vimco", device=dev), bits(256), 12800
+        return iwae.build(50, "vimco", device=dev, dense=dense), bits(256), 12800
     if config == "C3-logits":
-        return iwae.build(50, "vimco", device=dev, fused_logits=True), bits(256), 12800
+        return iwae.build(50, "vimco", device=dev, fused_logits=True, dense=dense), bits(256), 12800
     if config == "C5":
         return bnn_vi.build(n_particles=10, device=dev, layer=bnn_layer), {"x": torch.randn(512, 13, device=dev), "y": torch.randn(512, device=dev)}, 5120
     raise SystemExit("unknown config %s" % config)
@@ -48,11 +48,12 @@ def main():
                     help="execute the draw the reference's objectives discard (package default); the tool, like bench.py, runs "
                          "inside zhusuan.skip_discarded_draws() otherwise")
     ap.add_argument("--bnn-layer", default="fused", choices=["fused", "bmm", "materialize"])
+    ap.add_argument("--dense", default="zhusuan", choices=["zhusuan", "torch"], help="zhusuan.Linear (CS1 bias gradient) or torch.nn.Linear")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    model, obs, evals = make(args.config, dev, args.bnn_layer)
+    model, obs, evals = make(args.config, dev, args.bnn_layer, args.dense)
     if args.tuned_gemm:
         import tempfile
         torch.cuda.tunable.enable(True)
@@ -127,7 +128,7 @@ def main():
         ours = "k_" in name and ("zs" in name or name.lstrip("void ").startswith(("(anonymous namespace)::k_", "k_")))
         # kernels of this package: HOT = the distribution / objective / update kernels of the hot path; LAYER = the BNN caller's
         # particle-batched layer (PL1: the caller's code in the reference, a kernel of this package here)
-        kind = "" if not ours else ("LAYER" if "k_particle_linear" in name else "HOT")
+        kind = "" if not ours else ("LAYER" if ("k_particle_linear" in name or "k_column_sum" in name) else "HOT")
         rows.append({"kernel": name[:140], "hot_path": kind == "HOT", "kind": kind or "other", "launches_per_step": n / args.steps,
                      "avg_us": tot / n, "us_per_step": tot / args.steps})
     rows.sort(key=lambda r: -r["us_per_step"])

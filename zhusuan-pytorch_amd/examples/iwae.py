@@ -17,17 +17,26 @@ from zhusuan import distributions
 from zhusuan.variational.importance_weighted_objective import ImportanceWeightedObjective
 
 
+def dense_layer(dense):
+    if dense == 'torch':
+        return nn.Linear
+    if dense == 'zhusuan':
+        import zhusuan
+        return zhusuan.Linear
+    raise ValueError("dense: 'torch' or 'zhusuan'")
+
+
 class Generator(BayesianNet):
-    def __init__(self, x_dim, z_dim, n_samples, hidden=500, fused_logits=False):
+    def __init__(self, x_dim, z_dim, n_samples, hidden=500, fused_logits=False, Linear=nn.Linear):
         super().__init__()
         self.x_dim = x_dim
         self.z_dim = z_dim
         self.n_samples = n_samples
         self.fused_logits = fused_logits
         self.gen_sq = nn.Sequential(
-            nn.Linear(z_dim, hidden), nn.ReLU(),
-            nn.Linear(hidden, hidden), nn.ReLU(),
-            nn.Linear(hidden, x_dim), nn.Sigmoid())
+            Linear(z_dim, hidden), nn.ReLU(),
+            Linear(hidden, hidden), nn.ReLU(),
+            Linear(hidden, x_dim), nn.Sigmoid())
         self._prior = None
 
     def _prior_params(self, batch_len):
@@ -59,15 +68,15 @@ class Generator(BayesianNet):
 
 
 class Variational(BayesianNet):
-    def __init__(self, x_dim, z_dim, n_samples, hidden=500, reparameterized=False):
+    def __init__(self, x_dim, z_dim, n_samples, hidden=500, reparameterized=False, Linear=nn.Linear):
         super().__init__()
         self.x_dim = x_dim
         self.z_dim = z_dim
         self.n_samples = n_samples
         self.reparameterized = reparameterized
-        self.output_logits = nn.Sequential(nn.Linear(x_dim, hidden), nn.ReLU(), nn.Linear(hidden, hidden), nn.ReLU())
-        self.output_mean = nn.Linear(hidden, z_dim)
-        self.output_logstd = nn.Linear(hidden, z_dim)
+        self.output_logits = nn.Sequential(Linear(x_dim, hidden), nn.ReLU(), Linear(hidden, hidden), nn.ReLU())
+        self.output_mean = Linear(hidden, z_dim)
+        self.output_logstd = Linear(hidden, z_dim)
 
     def forward(self, observed):
         self.observe(observed)
@@ -80,9 +89,12 @@ class Variational(BayesianNet):
         return self
 
 
-def build(n_samples=50, estimator='vimco', x_dim=784, z_dim=40, hidden=500, device='cuda', fused_logits=False):
-    generator = Generator(x_dim, z_dim, n_samples, hidden, fused_logits)
-    variational = Variational(x_dim, z_dim, n_samples, hidden, reparameterized=(estimator == 'sgvb'))
+def build(n_samples=50, estimator='vimco', x_dim=784, z_dim=40, hidden=500, device='cuda', fused_logits=False, dense='torch'):
+    """`dense`: 'torch' = torch.nn.Linear as in the reference's example; 'zhusuan' = zhusuan.Linear, the same layer (same
+    parameters and names) whose bias gradient is one deterministic column-sum launch (CS1) instead of torch's reduction."""
+    Linear = dense_layer(dense)
+    generator = Generator(x_dim, z_dim, n_samples, hidden, fused_logits, Linear)
+    variational = Variational(x_dim, z_dim, n_samples, hidden, reparameterized=(estimator == 'sgvb'), Linear=Linear)
     return ImportanceWeightedObjective(generator, variational, axis=0, estimator=estimator).to(device)
 
 

@@ -17,15 +17,15 @@ from zhusuan.variational.elbo import ELBO
 
 
 class Generator(BayesianNet):
-    def __init__(self, x_dim, z_dim, batch_size, hidden=500):
+    def __init__(self, x_dim, z_dim, batch_size, hidden=500, Linear=nn.Linear):
         super().__init__()
         self.x_dim = x_dim
         self.z_dim = z_dim
         self.batch_size = batch_size
         self.sequential = nn.Sequential(
-            nn.Linear(z_dim, hidden), nn.ReLU(),
-            nn.Linear(hidden, hidden), nn.ReLU(),
-            nn.Linear(hidden, x_dim), nn.Sigmoid())
+            Linear(z_dim, hidden), nn.ReLU(),
+            Linear(hidden, hidden), nn.ReLU(),
+            Linear(hidden, x_dim), nn.Sigmoid())
         self._prior = None
 
     def _prior_params(self):
@@ -46,14 +46,14 @@ class Generator(BayesianNet):
 
 
 class Variational(BayesianNet):
-    def __init__(self, x_dim, z_dim, batch_size, hidden=500):
+    def __init__(self, x_dim, z_dim, batch_size, hidden=500, Linear=nn.Linear):
         super().__init__()
         self.x_dim = x_dim
         self.z_dim = z_dim
         self.batch_size = batch_size
-        self.sq = nn.Sequential(nn.Linear(x_dim, hidden), nn.ReLU(), nn.Linear(hidden, hidden), nn.ReLU())
-        self.fc3 = nn.Linear(hidden, z_dim)
-        self.fc4 = nn.Linear(hidden, z_dim)
+        self.sq = nn.Sequential(Linear(x_dim, hidden), nn.ReLU(), Linear(hidden, hidden), nn.ReLU())
+        self.fc3 = Linear(hidden, z_dim)
+        self.fc4 = Linear(hidden, z_dim)
 
     def forward(self, observed):
         self.observe(observed)
@@ -65,9 +65,12 @@ class Variational(BayesianNet):
         return self
 
 
-def build(batch_size=64, x_dim=784, z_dim=40, hidden=500, device='cuda'):
-    generator = Generator(x_dim, z_dim, batch_size, hidden)
-    variational = Variational(x_dim, z_dim, batch_size, hidden)
+def build(batch_size=64, x_dim=784, z_dim=40, hidden=500, device='cuda', dense='torch'):
+    """`dense`: 'torch' = torch.nn.Linear as in the reference's example; 'zhusuan' = zhusuan.Linear (see examples/iwae.py)."""
+    from .iwae import dense_layer
+    Linear = dense_layer(dense)
+    generator = Generator(x_dim, z_dim, batch_size, hidden, Linear)
+    variational = Variational(x_dim, z_dim, batch_size, hidden, Linear)
     return ELBO(generator, variational).to(device)
 
 

@@ -89,6 +89,8 @@ PROTOTYPES.update({
     "zs_normal_sample_logprob_multi_bwd_f32": [_p, _int, _u64, _p, _p],
     # h, h_stride_k, w, out, K, B, n_in, n_out, relu, stream
     "zs_particle_linear_f32": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
+    # x, out, rows, cols, workspace, workspace_len, tickets, n_tickets, stream
+    "zs_column_sum_f32": [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _p],
     # h, h_stride_k, w, out, gout, gh, gw, K, B, n_in, n_out, relu, workspace, workspace_len, tickets, stream
     "zs_particle_linear_bwd_f32": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p, _p],
 })

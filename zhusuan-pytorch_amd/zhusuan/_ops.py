@@ -965,3 +965,53 @@ class ParticleLinear(torch.autograd.Function):
         if need_h and shared:
             gh = gh.sum(0)
         return gh, (gw if need_w else None), None
+
+
+_CS_SCRATCH = {}       # (device, stream, dtype) -> (workspace, tickets)
+
+
+def column_sum(x2d):
+    """CS1: ``x2d.sum(0)`` of a contiguous [rows, cols] matrix in one launch, deterministic (include/zs_hip.h)."""
+    _hip.require_device(x2d)
+    sfx = _sfx(x2d)
+    rows, cols = x2d.shape
+    dev = x2d.device
+    out = torch.empty(cols, dtype=x2d.dtype, device=dev)
+    if cols == 0:
+        return out
+    ctiles = (cols + 63) // 64
+    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+    key = (str(dev), stream, x2d.dtype)
+    sc = _CS_SCRATCH.get(key)
+    if sc is None or sc[0].numel() < ctiles * 4096 or sc[1].numel() < ctiles:
+        sc = (torch.empty(max(ctiles, 16) * 4096, dtype=x2d.dtype, device=dev),
+              torch.zeros(max(ctiles, 16), dtype=torch.int32, device=dev))
+        if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _CS_SCRATCH[key] = sc
+    _hip.lib().call("zs_column_sum" + sfx, _hip.ptr(x2d), _hip.ptr(out), rows, cols, _hip.ptr(sc[0]), sc[0].numel(), _hip.ptr(sc[1]),
+                    sc[1].numel(), _hip.stream_for(x2d))
+    return out
+
+
+class DenseLayer(torch.autograd.Function):
+    """``F.linear(x, w, b)`` whose backward forms the bias gradient with CS1 instead of torch's generic reduction; the two
+    GEMMs of the backward (grad_input = g @ w, grad_weight = g.T @ x) are torch's."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ w).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            gw = g2.t() @ x.reshape(-1, x.shape[-1])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = column_sum(g2.contiguous())
+        return gx, gw, gb
