@@ -466,7 +466,7 @@ int zs_particle_linear_bwd_f32(const float* h, int64_t h_stride_k, const float* 
  * layers (torch.nn.Linear in the reference's examples, variational_autoencoder/vae_mnist.py:22-28, iwae.py:40-47:
  * grad_bias = grad_output.sum(0)) -- the one reduction of their backward pass that is not a GEMM; caller-side glue like
  * PL1, not part of the distribution / objective path.  Deterministic (row chunks combined in chunk order).
- * workspace: >= ceil(cols / 64) * 64 * 64 elements; tickets: n_tickets >= ceil(cols / 64) zero-initialised device words,
+ * workspace: >= 128 * (cols + 256) elements; tickets: n_tickets >= ceil(cols / 64) zero-initialised device words,
  * handed back at zero (both unused, and may be NULL, when the matrix has fewer than 64 rows).
  * -------------------------------------------------------------------------*/
 int zs_column_sum_f32(const float* x, float* out, int64_t rows, int64_t cols, float* workspace, int64_t workspace_len,

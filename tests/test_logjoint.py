@@ -163,7 +163,7 @@ class Raw(object):
         rows, cols = x.shape
         xt = self.t(x)
         ctiles = max((cols + 63) // 64, 1)
-        ws = torch.full((ctiles * 4096,), float("nan"), dtype=self.dtype, device=self.dev)
+        ws = torch.full((128 * (cols + 256),), float("nan"), dtype=self.dtype, device=self.dev)
         tk = torch.zeros(ctiles, dtype=torch.int32, device=self.dev)
         out = torch.full((cols,), float("nan"), dtype=self.dtype, device=self.dev)
         for scale in (3.0, 1.0):       # twice on one workspace, other numbers first (tickets back at zero, no stale partials)

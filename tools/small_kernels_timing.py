@@ -55,6 +55,22 @@ def main():
         timed("PL1 bwd " + tag + (" (gw only)" if shared else ""), "zs_particle_linear_bwd_f32",
               lambda: lib.call("zs_particle_linear_bwd_f32", P(h), hsk, P(w), P(out), P(gout), None if shared else P(gh), P(gw), K, B,
                                n_in, n_out, int(relu), P(part), part.numel(), P(tk), st))
+    # ---- CS1: the bias gradients of the IWAE (12 800 rows) and VAE (512 rows) steps
+    for rows, cols in [(12800, 500), (12800, 784), (12800, 40), (512, 500), (512, 784)]:
+        x = torch.randn(rows, cols, device=dev)
+        o = torch.empty(cols, device=dev)
+        ws = torch.empty(128 * (cols + 256), device=dev)
+        tk = torch.zeros(16, dtype=torch.int32, device=dev)
+        timed("CS1 column sum [%d, %d]  (%.1f MB)" % (rows, cols, rows * cols * 4 / 1e6), "zs_column_sum_f32",
+              lambda: lib.call("zs_column_sum_f32", P(x), P(o), rows, cols, P(ws), ws.numel(), P(tk), tk.numel(), st))
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            x.sum(0)
+        t0.record()
+        for _ in range(50):
+            x.sum(0)
+        t1.record(); torch.cuda.synchronize()
+        print("%-58s %6.2f us per call (stream time, 50 calls back to back)" % ("   torch x.sum(0) of the same matrix", t0.elapsed_time(t1) * 1e3 / 50))
     # ---- LJ1: the BNN objective's five terms and the VAE objective's three
     N, NL, Bn, R = LJ.LJ_NORMAL, LJ.LJ_NORMAL_LOGSTD, LJ.LJ_BERNOULLI, LJ.LJ_ROWS
     cases = {

@@ -1137,7 +1137,10 @@ extern "C" int zs_particle_linear_bwd_f64(const double* h, int64_t h_stride_k, c
 // workgroups of a column tile split the rows; the row-chunk partials meet in LDS, then in a workspace whose last arrival
 // (a ticket per column tile; fence-free hand-off, see the top of this file) adds them in chunk order: deterministic.
 namespace {
-constexpr int CS_MAX_CHUNKS = 64;
+constexpr int CS_MAX_CHUNKS = 128;
+#ifndef CS_U
+#define CS_U 8                   // rows a wavefront has in flight (16: no faster, measured)
+#endif
 
 template <typename T, int V>      // V = 4: dwordx4 lanes (cols % 4 == 0, aligned), V = 1: one column per lane
 __global__ __launch_bounds__(256) void k_column_sum(const T* __restrict__ x, T* __restrict__ out, T* __restrict__ part,
@@ -1147,7 +1150,8 @@ __global__ __launch_bounds__(256) void k_column_sum(const T* __restrict__ x, T* 
   __shared__ bool last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ctile = blockIdx.x / nchunks, chunk = blockIdx.x - ctile * nchunks;
-  const int c0 = (ctile * 64 + lane) * V;
+  const int ncol_tile = 64 * V;
+  const int c0 = ctile * ncol_tile + lane * V;
   const bool on = c0 < cols;
   const int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
   T acc[V];
@@ -1155,38 +1159,33 @@ __global__ __launch_bounds__(256) void k_column_sum(const T* __restrict__ x, T* 
   for (int j = 0; j < V; ++j) acc[j] = (T)0;
   if (on) {
     const T* __restrict__ p = x + c0;
-    int64_t r = r0 + wv;
-    for (; r + 12 < r1; r += 16) {                   // four rows of this wavefront in flight
-      T v[4][V];
+    // a wavefront takes rows r0 + wv, r0 + wv + 4, ...: CS_U of them in flight (8 KB per wavefront with 16-byte lanes),
+    // clamped to the chunk's last row so that the loads are unconditional; a clamped row's contribution is dropped
+    for (int64_t r = r0 + wv; r < r1; r += 4 * CS_U) {
+      T v[CS_U][V];
+      bool live[CS_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < CS_U; ++u) {
+        const int64_t ru = r + 4 * u;
+        live[u] = ru < r1;
+        const int64_t rc = live[u] ? ru : r;
         if (V == 4) {
-          const V4<T> q = *reinterpret_cast<const V4<T>*>(p + (r + 4 * u) * cols);
+          const V4<T> q = *reinterpret_cast<const V4<T>*>(p + rc * cols);
 #pragma unroll
           for (int j = 0; j < V; ++j) v[u][j] = q.v[j];
         } else {
-          v[u][0] = p[(r + 4 * u) * cols];
+          v[u][0] = p[rc * cols];
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < CS_U; ++u)
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] += v[u][j];
-    }
-    for (; r < r1; r += 4) {
-      if (V == 4) {
-        const V4<T> q = *reinterpret_cast<const V4<T>*>(p + r * cols);
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] += q.v[j];
-      } else {
-        acc[0] += p[r * cols];
-      }
+        for (int j = 0; j < V; ++j) acc[j] += live[u] ? v[u][j] : (T)0;
     }
   }
 #pragma unroll
   for (int j = 0; j < V; ++j) red[wv][lane * V + j] = acc[j];
   __syncthreads();
-  const int ncol_tile = 64 * V;
   T* __restrict__ pk = part + ((int64_t)ctile * nchunks + chunk) * ncol_tile;
   if (threadIdx.x < ncol_tile) {                       // (V = 4: all 256 threads; V = 1: the first wavefront)
     const int c = threadIdx.x;
@@ -1209,13 +1208,29 @@ __global__ __launch_bounds__(256) void k_column_sum(const T* __restrict__ x, T* 
   }
   __syncthreads();
   if (last) {
+    // wavefront wv adds the partials of chunks wv, wv + 4, ... (V columns per lane, 16 loads in flight); the four slices meet
+    // in LDS and are added in slice order: a fixed order of additions whatever the arrival order was
+    const T* __restrict__ p0 = part + (int64_t)ctile * nchunks * ncol_tile + lane * V;
+    T s[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = (T)0;
+#pragma unroll 16
+    for (int t = wv; t < nchunks; t += 4) {
+      if (V == 4) {
+        const V4<T> q = *reinterpret_cast<const V4<T>*>(p0 + (int64_t)t * ncol_tile);
+#pragma unroll
+        for (int j = 0; j < V; ++j) s[j] += q.v[j];
+      } else {
+        s[0] += p0[(int64_t)t * ncol_tile];
+      }
+    }
+    __syncthreads();                                   // (uniform: `last` is a workgroup-wide flag)
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[wv][lane * V + j] = s[j];
+    __syncthreads();
     if (threadIdx.x < ncol_tile) {
       const int c = threadIdx.x;
-      const T* __restrict__ p0 = part + (int64_t)ctile * nchunks * ncol_tile + c;
-      T s = (T)0;
-#pragma unroll 16
-      for (int t = 0; t < nchunks; ++t) s += p0[(int64_t)t * ncol_tile];       // chunk order: deterministic
-      if (ctile * ncol_tile + c < cols) out[ctile * ncol_tile + c] = s;
+      if (ctile * ncol_tile + c < cols) out[ctile * ncol_tile + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
     }
     if (threadIdx.x == 0) ticket_return(tickets + ctile);
   }
@@ -1236,8 +1251,8 @@ int column_sum(const T* x, T* out, int64_t rows, int64_t cols, T* workspace, int
   const bool v4 = (cols % 4) == 0 && pl_al<T>(x);
   const int ncol_tile = v4 ? 256 : 64;
   const int64_t ctiles = (cols + ncol_tile - 1) / ncol_tile;
-  // row chunks: enough workgroups to fill the chip (~1024), at least 32 rows each, at most CS_MAX_CHUNKS per column tile
-  int64_t nchunks = (1024 + ctiles - 1) / ctiles;
+  // row chunks: enough workgroups to fill the chip (~512), at least 32 rows each, at most CS_MAX_CHUNKS per column tile
+  int64_t nchunks = (512 + ctiles - 1) / ctiles;
   if (nchunks > CS_MAX_CHUNKS) nchunks = CS_MAX_CHUNKS;
   if (nchunks > (rows + 31) / 32) nchunks = (rows + 31) / 32;
   if (nchunks < 1) nchunks = 1;

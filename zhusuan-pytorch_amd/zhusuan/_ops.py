@@ -983,8 +983,8 @@ def column_sum(x2d):
     stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
     key = (str(dev), stream, x2d.dtype)
     sc = _CS_SCRATCH.get(key)
-    if sc is None or sc[0].numel() < ctiles * 4096 or sc[1].numel() < ctiles:
-        sc = (torch.empty(max(ctiles, 16) * 4096, dtype=x2d.dtype, device=dev),
+    if sc is None or sc[0].numel() < 128 * (cols + 256) or sc[1].numel() < ctiles:
+        sc = (torch.empty(128 * (max(cols, 1024) + 256), dtype=x2d.dtype, device=dev),
               torch.zeros(max(ctiles, 16), dtype=torch.int32, device=dev))
         if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             _CS_SCRATCH[key] = sc
