@@ -91,3 +91,95 @@ def test_graphed_forward_only():
     step = zs.GraphedStep(compute, None, rng=rng)
     vals = [float(step()) for _ in range(4)]
     assert len(set(vals)) == 4 and all(np.isfinite(vals))
+
+
+def _make_bnn(dev, seed=5):
+    from examples import bnn_vi
+    torch.manual_seed(seed)
+    model = bnn_vi.build(n_particles=6, device=dev)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    obs = {"x": torch.randn(96, 13, device=dev), "y": torch.randn(96, device=dev)}
+    opt = zs.optim.FlatAdam(model.parameters(), lr=1e-2)
+    return model, opt, zs.DeviceRNG(dev, seed=77), obs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skip", [False, True])
+def test_one_launch_paths_replay_from_a_graph(skip):
+    """The BNN step -- MS1 (both weight matrices in one sampling launch), PL1 (its two layers), LJ1 (all five log-probs and the
+    objective), A1 -- captured in one hipGraph trains exactly like the eager step, with and without the discarded draws; the
+    workspaces and tickets of the hand-offs inside LJ1 / PL1 survive capture and replay."""
+    dev = torch.device("cuda:0")
+    model_e, opt_e, rng_e, obs = _make_bnn(dev)
+    model_g, opt_g, rng_g, _ = _make_bnn(dev)
+    with zs.skip_discarded_draws(skip):
+        step = zs.GraphedStep(_compute(model_g, rng_g, obs), opt_g.step, rng=rng_g, warmup=3, restore=True)
+        comp_e = _compute(model_e, rng_e, obs)
+        le, lg = [], []
+        with zs.device_rng(rng_e):
+            for _ in range(5):
+                le.append(float(comp_e()))
+                opt_e.step()
+        for _ in range(5):
+            lg.append(float(step()))
+    np.testing.assert_allclose(lg, le, rtol=2e-5)
+    assert len(set(lg)) == 5
+    for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_staged_graphs_with_the_scalar_objective():
+    """zhusuan.GraphedStages (the multi-rank step's shape: backward in two stages around eagerly launched collectives) over
+    the VAE, whose objective is ONE LJ1 launch: stage 2 runs LJ1's backward a second time on the retained graph.  Equal to
+    the eager staged step."""
+    from zhusuan import dataparallel
+    dev = torch.device("cuda:0")
+
+    def make():
+        torch.manual_seed(3)
+        model = vae_mnist.build(32, hidden=64, device=dev, dense="zhusuan")
+        x = (torch.rand(32, 784, device=dev) < 0.5).float()
+        sb = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()])
+        opt = zs.optim.FlatAdam([list(model.generator.parameters()), list(model.variational.parameters())], lr=1e-3)
+        return model, {"x": x}, sb, opt, zs.DeviceRNG(dev, seed=9)
+
+    def stages(model, obs, sb, opt, rng, held):
+        def s1():
+            rng.begin_step()
+            sb.zero()
+            held["loss"] = model(obs)
+            sb.backward_stage(held["loss"], 0)
+            return held["loss"].detach()
+
+        def s2():
+            sb.backward_stage(held["loss"], 1)
+
+        def s3():
+            sb.scale(gradients=False)
+            opt.step(grad_scale=sb.grad_scale())
+        return [("graph", s1), ("eager", lambda: sb.launch(0)), ("graph", s2), ("eager", lambda: (sb.launch(1), sb.wait())),
+                ("graph", s3)]
+    me, oe, sbe, ope, re_ = make()
+    mg, og, sbg, opg, rg = make()
+    gs = zs.GraphedStages(stages(mg, og, sbg, opg, rg, {}), rng=rg, warmup=3, restore=True, optimizer=opg)
+    for pe, pg in zip(me.parameters(), mg.parameters()):
+        assert torch.equal(pe, pg), "restore=True must undo the warm-up passes"
+    assert torch.equal(rg.state, re_.state)
+    eager = stages(me, oe, sbe, ope, re_, {})
+    le, lg = [], []
+    with zs.device_rng(re_):
+        for _ in range(4):
+            first = None
+            for kind, fn in eager:
+                out = fn()
+                if kind == "graph" and first is None:
+                    first = out
+            le.append(float(first))
+    for _ in range(4):
+        lg.append(float(gs()))
+    np.testing.assert_allclose(lg, le, rtol=2e-5)
+    for pe, pg in zip(me.parameters(), mg.parameters()):
+        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
