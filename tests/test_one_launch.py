@@ -222,6 +222,29 @@ def test_objective_with_more_nodes_than_the_table_falls_back(dev):
         assert abs(float(loss.detach())) < 1e-5
 
 
+def test_large_objectives_keep_the_streaming_kernels(dev):
+    """Beyond the launch-bound regime the nodes' own log-prob kernels run (K2 / K3) and LJ1 only adds their rows up."""
+    from zhusuan.variational import elbo as elbo_mod
+    vae = vae_mnist.build(16, hidden=32, device=dev)
+    x, e1, e2 = H.vae_data(16)
+    xb = torch.tensor(x, device=dev)
+    with zs.inject_epsilon([e1, e2]):
+        ref = vae({"x": xb})
+    g_ref = _grads(vae, ref)
+    limit = elbo_mod._LOGJOINT_MAX_ELEMENTS
+    elbo_mod._LOGJOINT_MAX_ELEMENTS = 1000          # the Bernoulli term alone has 16 * 784 elements
+    try:
+        with launches() as names, zs.inject_epsilon([e1, e2]):
+            loss = vae({"x": xb})
+            g = _grads(vae, loss)
+    finally:
+        elbo_mod._LOGJOINT_MAX_ELEMENTS = limit
+    assert "zs_bernoulli_logprob" in names and "zs_normal_logprob" in names and names.count("zs_logjoint_scalar") == 1
+    np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=2e-6)
+    for a, b in zip(g, g_ref):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6 * max(np.abs(b).max(), 1))
+
+
 def test_particle_linear_layer_against_torch(dev):
     rng = np.random.RandomState(8)
     for (K, B, n_in, n_out, shared, relu) in [(4, 16, 13, 50, True, True), (4, 16, 50, 1, False, False), (3, 70, 300, 5, False, True)]:

@@ -241,17 +241,18 @@ class StochasticTensor(object):
             coef *= float(self._multiplier)
         return coef, self._dist.group_ndims + extra
 
-    def _scalar_term(self, sample=None):
+    def _scalar_term(self, sample=None, rows_only=False):
         """The node as one term of the one-launch scalar objective (LJ1, ``_ops.LogJointScalar``):
         ``(family, (x, a, b), (px, pa, pb), n, coef)``.  Families with a term form (Normal, Bernoulli) are evaluated INSIDE
         that launch; a fused log-density that the sampling kernel has already produced, and every other family's
-        ``_log_prob_sum`` result, enter as ready-made rows (``LJ_ROWS``).  None when the node does not reduce to a scalar."""
+        ``_log_prob_sum`` result, enter as ready-made rows (``LJ_ROWS``; with ``rows_only`` every node does: its own tuned
+        log-prob kernel runs, LJ1 only adds the rows up).  None when the node does not reduce to a scalar."""
         sc = self._scalar_coef(sample)
         if sc is None:
             return None
         coef, n_fold = sc
         term = None
-        if hasattr(self._dist, '_lj_term'):
+        if not rows_only and hasattr(self._dist, '_lj_term'):
             term = self._dist._lj_term(sample, n_fold)
         if term is None:
             rows = self._dist._log_prob_sum(sample, n_fold)

@@ -11,6 +11,9 @@ __all__ = ['ELBO', 'EvidenceLowerBoundObjective']
 
 # the one-launch sampler (MS1) is for the launch-bound shapes: above this many elements in total each node takes K1
 _MULTI_DRAW_MAX_ELEMENTS = 1 << 20
+# ... and so is the element-wise part of the one-launch objective (LJ1): beyond this many elements the nodes' own streaming
+# kernels (K2 / K3: 72-83 % of the HBM roofline at that size) evaluate the log-probs and LJ1 only adds their rows up
+_LOGJOINT_MAX_ELEMENTS = 1 << 22
 
 
 def latent_value(node):
@@ -151,11 +154,16 @@ class ELBO(nn.Module):
         for _, node in plan:                        # decide first (no kernel is launched by the question)
             if not hasattr(node, '_scalar_coef') or node._scalar_coef() is None:
                 return None
-        spec, tensors = [], []
-        for sign, node in plan:
-            fam, operands, periods, n, coef = node._scalar_term()
-            spec.append((fam, sign * coef, n) + tuple(periods))
-            tensors += list(operands)
+        def collect(rows_only):
+            spec, tensors = [], []
+            for sign, node in plan:
+                fam, operands, periods, n, coef = node._scalar_term(rows_only=rows_only)
+                spec.append((fam, sign * coef, n) + tuple(periods))
+                tensors += list(operands)
+            return spec, tensors
+        spec, tensors = collect(False)
+        if sum(t[2] for t in spec if t[0] != _hip.LJ_ROWS) > _LOGJOINT_MAX_ELEMENTS:
+            spec, tensors = collect(True)
         if len({t.dtype for t in tensors if t is not None}) != 1 or len({t.device for t in tensors if t is not None}) != 1:
             return None
         return _ops.LogJointScalar.apply(tuple(spec), *tensors)
