@@ -294,23 +294,41 @@ class IWReduce(torch.autograd.Function):
         return gp, gq, None
 
 
-_IW_WORKSPACE = {}     # (device, dtype, stream) -> (partials [4096], ticket [1] int32): scratch of the deterministic batch mean
+_SCRATCH = {}     # (device, stream | 'capture', kind) -> tuple of tensors
+
+
+def _scratch(device, kind, fits, make):
+    """Scratch of the kernels that combine per-workgroup partial results in-kernel (workspaces, zero-initialised ticket words
+    that the kernels hand back at zero): one set per (device, STREAM, kind).  Launches on one stream are ordered, so they
+    share it; objectives evaluated concurrently on different streams of a device each get their own.
+
+    While a hipGraph is being captured nothing may be cached that lives in the graph's private memory pool (it would dangle
+    once the graph is destroyed), and allocating + zero-filling a fresh set per call would put a fill launch in front of
+    every such kernel of every replay (seven per IWAE step for the bias gradients alone).  So every EAGER request also makes
+    sure a per-device 'capture' set exists -- ordinary memory, allocated outside any capture -- and a capture uses that one
+    (warm-up steps always run eagerly before a capture: zhusuan.GraphedStep / GraphedStages, bench.py).  All graphs of a device
+    share it: their replays must not run concurrently on two streams (ordinary training never does).  A capture with no
+    eager call before it falls back to a graph-private set per call."""
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if capturing:
+        sc = _SCRATCH.get((str(device), "capture", kind))
+        return sc if (sc is not None and fits(sc)) else make()
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key, ckey = (str(device), stream, kind), (str(device), "capture", kind)
+    sc = _SCRATCH.get(key)
+    if sc is None or not fits(sc):
+        sc = _SCRATCH[key] = make()
+    if device.type == "cuda":
+        c = _SCRATCH.get(ckey)
+        if c is None or not fits(c):
+            _SCRATCH[ckey] = make()
+    return sc
 
 
 def _iw_workspace(device, dtype):
-    """Scratch of K4b's batch mean: one per (device, dtype, STREAM).  Launches on one stream are ordered, so they can
-    share it (the kernel hands the ticket back at zero); objectives evaluated concurrently on different streams of a
-    device each get their own.  While a hipGraph is being captured a not-yet-cached workspace is allocated for that
-    graph only -- caching a tensor that lives in a graph's private pool would dangle once the graph is destroyed."""
-    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
-    key = (str(device), dtype, stream)
-    ws = _IW_WORKSPACE.get(key)
-    if ws is None:
-        ws = (torch.zeros(4096, dtype=dtype, device=device), torch.zeros(1, dtype=torch.int32, device=device))
-        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-        if not capturing:
-            _IW_WORKSPACE[key] = ws
-    return ws
+    """(partials [4096], ticket [1] int32) of K4b's deterministic batch mean (see _scratch)."""
+    return _scratch(device, ("iw", dtype), lambda sc: True,
+                    lambda: (torch.empty(4096, dtype=dtype, device=device), torch.zeros(1, dtype=torch.int32, device=device)))
 
 
 def _rows_for_iw(t, K):
@@ -731,19 +749,11 @@ def periodic_operand(t, full_shape):
 # ------------------------------------------------------------------------------------------------
 # One-launch pieces for the launch-bound shapes (include/zs_hip.h: LJ1, MS1, PL1)
 # ------------------------------------------------------------------------------------------------
-_LJ_WORKSPACE = {}     # (device, stream) -> (double [ZS_LJ_WORKSPACE], ticket int32 [1])
-
-
 def _lj_workspace(device):
-    """Scratch of LJ1's deterministic sums, one per (device, stream) -- same rules as ``_iw_workspace``."""
-    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
-    key = (str(device), stream)
-    ws = _LJ_WORKSPACE.get(key)
-    if ws is None:
-        ws = (torch.zeros(_hip.LJ_WORKSPACE, dtype=torch.float64, device=device), torch.zeros(1, dtype=torch.int32, device=device))
-        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-            _LJ_WORKSPACE[key] = ws
-    return ws
+    """(double [ZS_LJ_WORKSPACE], ticket int32 [1]) of LJ1's (and R1's) deterministic sums (see _scratch)."""
+    return _scratch(device, "lj", lambda sc: True,
+                    lambda: (torch.empty(_hip.LJ_WORKSPACE, dtype=torch.float64, device=device),
+                             torch.zeros(1, dtype=torch.int32, device=device)))
 
 
 class LogJointScalar(torch.autograd.Function):
@@ -908,19 +918,10 @@ class NormalSampleLogProbMulti(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
-_PL_TICKETS = {}       # (device, stream) -> int32 [n]: one ticket per particle, handed back at zero by the kernel
-
-
 def _pl_tickets(device, K):
-    """Zero-initialised ticket words of PL1's backward, one set per (device, stream) -- same rules as ``_iw_workspace``."""
-    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
-    key = (str(device), stream)
-    t = _PL_TICKETS.get(key)
-    if t is None or t.numel() < K:
-        t = torch.zeros(max(K, 64), dtype=torch.int32, device=device)
-        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-            _PL_TICKETS[key] = t
-    return t
+    """Zero-initialised ticket words of PL1's backward, one per particle (see _scratch)."""
+    return _scratch(device, "pl", lambda sc: sc[0].numel() >= K,
+                    lambda: (torch.zeros(max(K, 64), dtype=torch.int32, device=device),))[0]
 
 
 class ParticleLinear(torch.autograd.Function):
@@ -967,9 +968,6 @@ class ParticleLinear(torch.autograd.Function):
         return gh, (gw if need_w else None), None
 
 
-_CS_SCRATCH = {}       # (device, stream, dtype) -> (workspace, tickets)
-
-
 def column_sum(x2d):
     """CS1: ``x2d.sum(0)`` of a contiguous [rows, cols] matrix in one launch, deterministic (include/zs_hip.h)."""
     _hip.require_device(x2d)
@@ -980,16 +978,11 @@ def column_sum(x2d):
     if cols == 0:
         return out
     ctiles = (cols + 63) // 64
-    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-    key = (str(dev), stream, x2d.dtype)
-    sc = _CS_SCRATCH.get(key)
-    if sc is None or sc[0].numel() < 128 * (cols + 256) or sc[1].numel() < ctiles:
-        sc = (torch.empty(128 * (max(cols, 1024) + 256), dtype=x2d.dtype, device=dev),
-              torch.zeros(max(ctiles, 16), dtype=torch.int32, device=dev))
-        if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-            _CS_SCRATCH[key] = sc
-    _hip.lib().call("zs_column_sum" + sfx, _hip.ptr(x2d), _hip.ptr(out), rows, cols, _hip.ptr(sc[0]), sc[0].numel(), _hip.ptr(sc[1]),
-                    sc[1].numel(), _hip.stream_for(x2d))
+    ws, tickets = _scratch(dev, ("cs", x2d.dtype), lambda sc: sc[0].numel() >= 128 * (cols + 256) and sc[1].numel() >= ctiles,
+                           lambda: (torch.empty(128 * (max(cols, 1024) + 256), dtype=x2d.dtype, device=dev),
+                                    torch.zeros(max(ctiles, 16), dtype=torch.int32, device=dev)))
+    _hip.lib().call("zs_column_sum" + sfx, _hip.ptr(x2d), _hip.ptr(out), rows, cols, _hip.ptr(ws), ws.numel(), _hip.ptr(tickets),
+                    tickets.numel(), _hip.stream_for(x2d))
     return out
 
 
