@@ -75,9 +75,14 @@ def parse_args(argv=None):
                          "sample, bn.py:158 / elbo.py:122): the package's default behaviour.  The bench runs inside "
                          "zhusuan.skip_discarded_draws() unless this flag is given (one sampling launch per latent and step)")
     ap.add_argument("--torch-linear", action="store_true",
-                    help="build the callers' MLPs from torch.nn.Linear (as the reference's examples do) instead of zhusuan.Linear -- "
-                         "the same layer whose bias gradient is ONE deterministic column-sum launch (CS1) instead of torch's generic "
-                         "reduction (12.4 us x 7 layers per IWAE step); extra_configs.c3_torch_linear in the default run")
+                    help="build the callers' MLPs from torch.nn.Linear / Sequential (as the reference's examples do) instead of "
+                         "zhusuan.Linear / zhusuan.Sequential -- the same layers (parameters, names, GEMMs) with the ReLU in the forward "
+                         "GEMM's epilogue and the activation's backward + the bias gradient as ONE deterministic launch (AB1 / CS1) "
+                         "instead of torch's clamp, threshold_backward and generic reduction; extra_configs.c3_torch_linear in the "
+                         "default run")
+    ap.add_argument("--unfused-activations", action="store_true",
+                    help="zhusuan.Linear inside torch.nn.Sequential: only the bias gradient is this package's (CS1), the activations "
+                         "are torch's passes (round 3's first setting; extra_configs.c3_unfused_activations in the default run)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="update with torch.optim.Adam(fused=True, capturable=True) instead of zhusuan.optim.FlatAdam "
                          "(the same update over flat buckets, one launch)")
@@ -208,7 +213,7 @@ def pmc_traffic(entry, fused_logits, abi_version):
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-def make_workload(name, dev, seed_rank=0, fused_logits=False, dense="zhusuan"):
+def make_workload(name, dev, seed_rank=0, fused_logits=False, dense="fused"):
     """(model, observations, ELBO-evals per step, description) of a BASELINE config on one GPU."""
     from examples import iwae, vae_mnist, bnn_vi
     rs = np.random.RandomState(1234 + seed_rank)
@@ -362,7 +367,7 @@ def make_optimizer(model, torch_adam, groups=None):
 
 
 def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False, skip_discarded=True,
-                          dense="zhusuan"):
+                          dense="fused"):
     """A BASELINE config other than the headline one on this GPU: full training steps replayed from one hipGraph."""
     import zhusuan
     gemm_tuning(tuned)
@@ -391,9 +396,14 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
     return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
             "launch_mode": "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
             "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default)",
-            "dense_layers": "zhusuan.Linear (bias gradient: CS1)" if dense == "zhusuan" else "torch.nn.Linear",
+            "dense_layers": DENSE_LABEL[dense],
             "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape)" if tuned else "PyTorch default",
             "optimizer": "torch.optim.Adam(fused=True, capturable=True)" if torch_adam else "zhusuan.optim.FlatAdam"}
+
+
+DENSE_LABEL = {"fused": "zhusuan.Linear in zhusuan.Sequential (ReLU in the GEMM epilogue; activation backward + bias gradient: AB1)",
+               "zhusuan": "zhusuan.Linear in torch.nn.Sequential (bias gradient: CS1; torch's activation passes)",
+               "torch": "torch.nn.Linear in torch.nn.Sequential"}
 
 
 def _timed_launches(klib, out, launches):
@@ -495,6 +505,9 @@ def _entry_of_kernel(name):
     for frag, entry in _KERNEL_ENTRY:
         i = name.find(frag)
         if i >= 0:
+            if frag == "k_column_sum":          # k_column_sum<T, V, ACT>: ACT != 0 is AB1 (activation backward + column sum)
+                targs = name[name.find("<", i) + 1:name.find(">", i)].replace(" ", "").split(",")
+                return entry if len(targs) < 3 or targs[2] == "0" else "zs_dense_act_bwd_f32"
             if "%s" in entry:
                 j = name.find("<", i)
                 logits = j >= 0 and name[j + 1:j + 5] == "true"
@@ -568,7 +581,7 @@ def main():
         except Exception as e:                                      # noqa: BLE001
             k1_first = {"error": repr(e)}
     torch.manual_seed(0)
-    dense = "torch" if args.torch_linear else "zhusuan"
+    dense = "torch" if args.torch_linear else ("zhusuan" if args.unfused_activations else "fused")
     model, obs, evals_per_step, _ = make_workload("c3", dev, seed_rank=rank, fused_logits=args.fused_logits, dense=dense)
     dataparallel.broadcast_parameters(model)
     rng = zhusuan.DeviceRNG(dev, seed=1000 + rank)          # per-rank Philox stream, state in device memory
@@ -800,10 +813,11 @@ def main():
                                          if args.fused_logits else
                                          "probs (nn.Sigmoid pass, as the reference's example is written; extra_configs.c3_logits: the "
                                          "same step with the sigmoid inside the Bernoulli log-prob kernel)",
-                       "dense_layers": ("zhusuan.Linear: torch.nn.Linear's parameters, forward GEMM and backward GEMMs; the bias gradient "
-                                        "(grad_output.sum(0)) is one deterministic column-sum launch (CS1) instead of torch's generic "
-                                        "reduction (extra_configs.c3_torch_linear: the same step built from torch.nn.Linear)")
-                                       if dense == "zhusuan" else "torch.nn.Linear (--torch-linear)",
+                       "dense_layers": DENSE_LABEL[dense] + (
+                           ": torch.nn.Linear's parameters, names and fp32 GEMMs (forward with torch._addmm_activation, the same "
+                           "hipBLASLt solution with the ReLU in its epilogue); per layer one launch of this package forms the "
+                           "activation's backward and the bias gradient (extra_configs.c3_torch_linear: the same step built from "
+                           "torch.nn modules; c3_unfused_activations: only the bias gradient taken over)" if dense == "fused" else ""),
                        "mlp_gemm_library": args.blas,
                        "mlp_gemm_selection": ("PyTorch TunableOp: fastest fp32 hipBLASLt / rocBLAS solution per GEMM shape, picked during "
                                               "warm-up (callers' nn.Linear stack, outside the hot path; extra_configs.c3_default_gemm "
@@ -876,13 +890,16 @@ def main():
                                                                                     tuned=False, torch_adam=True)
                 except Exception as e:                              # noqa: BLE001
                     out["extra_configs"]["c3_default_gemm"] = {"error": repr(e)}
-            if dense == "zhusuan":      # the headline step built from torch.nn.Linear, as the reference's example is
+            # the headline step built from torch.nn modules, as the reference's example is; and with only the bias gradient taken over
+            for key, other in (("c3_torch_linear", "torch"), ("c3_unfused_activations", "zhusuan")):
+                if dense != "fused":
+                    break
                 try:
-                    out["extra_configs"]["c3_torch_linear"] = run_single_gpu_config(
+                    out["extra_configs"][key] = run_single_gpu_config(
                         "c3", dev, args.steps, args.warmup, tuned=tuned, torch_adam=args.torch_adam, fused_logits=args.fused_logits,
-                        skip_discarded=skip_discarded, dense="torch")
+                        skip_discarded=skip_discarded, dense=other)
                 except Exception as e:                              # noqa: BLE001
-                    out["extra_configs"]["c3_torch_linear"] = {"error": repr(e)}
+                    out["extra_configs"][key] = {"error": repr(e)}
             if skip_discarded:          # the headline step with the reference's discarded draw executed (the package default)
                 try:
                     out["extra_configs"]["c3_reference_draws"] = run_single_gpu_config(

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 10
+#define ZS_ABI_VERSION 11
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -473,6 +473,21 @@ int zs_column_sum_f32(const float* x, float* out, int64_t rows, int64_t cols, fl
                       uint32_t* tickets, int64_t n_tickets, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * AB1  Backward of a dense layer's activation and its bias gradient in one pass over the gradient:
+ *   gpre[r, c] = g[r, c] * act'(y[r, c]),   gbias[c] = sum_r gpre[r, c]
+ * with y the layer's ACTIVATED output: ZS_ACT_RELU g * [y > 0] (torch's threshold_backward), ZS_ACT_SIGMOID
+ * g * (1 - y) * y (torch's sigmoid_backward).  The callers' MLPs are Linear -> ReLU (-> ... -> Sigmoid) stacks
+ * (variational_autoencoder/vae_mnist.py:22-28,44-48, iwae.py:40-47,68-75); torch runs the activation's backward and the
+ * bias reduction as two passes.  gpre may be g itself (in place).  Workspace / tickets / determinism as CS1; caller-side
+ * glue like CS1 and PL1.
+ * -------------------------------------------------------------------------*/
+#define ZS_ACT_NONE 0
+#define ZS_ACT_RELU 1
+#define ZS_ACT_SIGMOID 2
+int zs_dense_act_bwd_f32(const float* g, const float* y, int act, float* gpre, float* gbias, int64_t rows, int64_t cols,
+                         float* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream);
+
+/* ---------------------------------------------------------------------------
  * float64 twins.  The reference accepts float64 parameters for Normal / Bernoulli
  * (zhusuan/distributions/utils.py:5,57-64); every entry point above exists with the suffix _f64,
  * identical argument meaning, double* instead of float*.  They are plain (untuned) kernels: none of the
@@ -509,6 +524,7 @@ int zs_normal_sample_logprob_multi_bwd_f64(const zs_ms_term* terms, int n_terms,
 int zs_particle_linear_f64(const double* h, int64_t h_stride_k, const double* w, double* out, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, void* stream);
 int zs_particle_linear_bwd_f64(const double* h, int64_t h_stride_k, const double* w, const double* out, const double* gout, double* gh, double* gw, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, double* workspace, int64_t workspace_len, uint32_t* tickets, void* stream);
 int zs_column_sum_f64(const double* x, double* out, int64_t rows, int64_t cols, double* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream);
+int zs_dense_act_bwd_f64(const double* g, const double* y, int act, double* gpre, double* gbias, int64_t rows, int64_t cols, double* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream);
 int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors, double* exp_avg, double* exp_avg_sq, int64_t* steps, uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------

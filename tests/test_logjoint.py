@@ -174,6 +174,24 @@ class Raw(object):
         assert int(tk.abs().sum().item()) == 0
         return out.cpu().numpy()
 
+    # ---- AB1
+    def actbwd(self, g, y, act, in_place=False):
+        rows, cols = g.shape
+        gt, yt = self.t(g), self.t(y)
+        ctiles = max((cols + 63) // 64, 1)
+        ws = torch.full((128 * (cols + 256),), float("nan"), dtype=self.dtype, device=self.dev)
+        tk = torch.zeros(ctiles, dtype=torch.int32, device=self.dev)
+        gb = torch.full((cols,), float("nan"), dtype=self.dtype, device=self.dev)
+        gpre = None
+        for scale in (3.0, 1.0):       # twice on one workspace (tickets back at zero, no stale partials)
+            gs = gt * scale
+            gpre = gs if in_place else torch.full((rows, cols), float("nan"), dtype=self.dtype, device=self.dev)
+            self.k.call("zs_dense_act_bwd" + self.sfx, _hip.ptr(gs), _hip.ptr(yt), act, _hip.ptr(gpre), _hip.ptr(gb), rows, cols,
+                        _hip.ptr(ws), ws.numel(), _hip.ptr(tk), tk.numel(), self.stream())
+            self.sync()
+        assert int(tk.abs().sum().item()) == 0
+        return gpre.cpu().numpy(), gb.cpu().numpy()
+
     # ---- PL1
     def pl(self, h, w, relu):
         K, n_out, n_in1 = w.shape
@@ -578,3 +596,68 @@ def test_hip_column_sum(hip, hip64, rows, cols):
     assert np.array_equal(a, hip.colsum(x))                                      # deterministic
     if rows * cols <= 1000000:
         np.testing.assert_allclose(hip64.colsum(x), ref, rtol=1e-13, atol=1e-12)
+
+
+# ---------------------------------------------------------------- AB1: activation backward + bias gradient
+def _act_ref(g, y, act):
+    g, y = g.astype(np.float64), y.astype(np.float64)
+    gpre = np.where(y > 0, g, 0.0) if act == 1 else g * (1.0 - y) * y
+    return gpre, gpre.sum(0)
+
+
+def _act_inputs(rows, cols, act, seed):
+    rng = np.random.RandomState(seed)
+    g = rng.standard_normal((rows, cols)).astype(np.float32)
+    pre = rng.standard_normal((rows, cols)).astype(np.float32)
+    y = np.maximum(pre, 0) if act == 1 else (1.0 / (1.0 + np.exp(-3.0 * pre))).astype(np.float32)   # (with exact zeros / ~0, ~1)
+    return g, y.astype(np.float32)
+
+
+def test_c_oracle_dense_act_bwd_matches_torch(orc, orc64):
+    for act, tfn in ((1, torch.relu), (2, torch.sigmoid)):
+        for rows, cols in ((5, 7), (64, 12), (0, 3), (129, 100)):
+            rng = np.random.RandomState(rows + cols)
+            pre = torch.tensor(rng.standard_normal((rows, cols)), dtype=torch.float64, requires_grad=True)
+            g = rng.standard_normal((rows, cols))
+            yv = tfn(pre)
+            yv.backward(torch.tensor(g))
+            gpre, gb = orc64.actbwd(g, yv.detach().numpy(), act)
+            np.testing.assert_allclose(gpre, pre.grad.numpy(), rtol=1e-13, atol=1e-15)     # torch's own backward formulas
+            np.testing.assert_allclose(gb, pre.grad.numpy().sum(0), rtol=1e-12, atol=1e-12)
+            g32, y32 = _act_inputs(rows, cols, act, 3)
+            a, b = orc.actbwd(g32, y32, act)
+            ra, rb = _act_ref(g32, y32, act)
+            np.testing.assert_allclose(a, ra, rtol=3e-7, atol=1e-30)
+            np.testing.assert_allclose(b, rb, rtol=1e-6, atol=1e-5)
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.actbwd(np.zeros((2, 2)), np.zeros((2, 2)), 0)
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.actbwd(np.zeros((2, 2)), np.zeros((2, 2)), 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("rows,cols", CS_SHAPES)
+def test_hip_dense_act_bwd(hip, hip64, orc, rows, cols, act):
+    g, y = _act_inputs(rows, cols, act, rows + 7 * cols + act)
+    ra, rb = _act_ref(g, y, act)
+    a, b = hip.actbwd(g, y, act)
+    if rows * cols <= 2000000:
+        oa, _ = orc.actbwd(g, y, act)
+        assert np.array_equal(a, oa) or np.allclose(a, oa, rtol=2e-7, atol=0)      # elementwise: the oracle's arithmetic
+    np.testing.assert_allclose(a, ra, rtol=3e-7, atol=1e-30)
+    np.testing.assert_allclose(b, rb, rtol=2e-6, atol=3e-7 * max(np.sqrt(rows), 1) * 4)
+    a2, b2 = hip.actbwd(g, y, act, in_place=True)                                  # gpre = g: in place
+    assert np.array_equal(a, a2) and np.array_equal(b, b2)
+    if rows * cols <= 1000000:
+        a64, b64 = hip64.actbwd(g, y, act)
+        np.testing.assert_allclose(a64, ra, rtol=1e-14, atol=0)
+        np.testing.assert_allclose(b64, rb, rtol=1e-13, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_dense_act_bwd_rejects(hip):
+    with pytest.raises(RuntimeError, match="code -1"):
+        hip.actbwd(np.zeros((2, 2)), np.zeros((2, 2)), 0)
+    with pytest.raises(RuntimeError, match="code -1"):
+        hip.actbwd(np.zeros((2, 2)), np.zeros((2, 2)), 5)

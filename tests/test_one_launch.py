@@ -302,3 +302,70 @@ def test_zhusuan_linear_is_nn_linear_with_a_one_launch_bias_gradient(dev):
     assert float(la.detach()) == float(lb.detach())
     for a, b in zip(ga, gb):
         np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6 * max(np.abs(a).max(), 1))
+
+
+def test_zhusuan_sequential_fuses_linear_with_its_activation(dev):
+    """zhusuan.Sequential: torch.nn.Sequential's children, indices, names and slices; every zhusuan.Linear -> ReLU / Sigmoid pair
+    runs as one fused layer (ReLU in the GEMM's epilogue; activation backward + bias gradient = AB1).  Same value and gradients
+    as torch.nn's modules on the same weights."""
+    torch.manual_seed(1)
+    ref = torch.nn.Sequential(torch.nn.Linear(19, 24), torch.nn.ReLU(), torch.nn.Linear(24, 12), torch.nn.ReLU(),
+                              torch.nn.Linear(12, 8), torch.nn.Sigmoid()).to(dev)
+    seq = zs.Sequential(zs.Linear(19, 24), torch.nn.ReLU(), zs.Linear(24, 12), torch.nn.ReLU(), zs.Linear(12, 8),
+                        torch.nn.Sigmoid()).to(dev)
+    seq.load_state_dict(ref.state_dict())
+    assert [n for n, _ in seq.named_parameters()] == [n for n, _ in ref.named_parameters()]
+    assert type(seq[:-1]) is zs.Sequential and len(seq[:-1]) == 5
+    for shape in [(33, 19), (3, 7, 19)]:
+        x1 = torch.randn(*shape, device=dev, requires_grad=True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        with launches() as names:
+            y = seq(x1)
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+        assert names == ["zs_dense_act_bwd"] * 3
+        yr = ref(x2)
+        (yr * torch.linspace(-1, 1, yr.numel(), device=dev).view_as(yr)).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        for (n, a), (_, b) in zip(seq.named_parameters(), ref.named_parameters()):
+            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-5, err_msg=n)
+        seq.zero_grad(); ref.zero_grad()
+        with launches() as names:                                              # the slice (logits: no Sigmoid) keeps fusing
+            yl = seq[:-1](x1)
+            yl.sum().backward()
+        assert names == ["zs_dense_act_bwd"] * 2 + ["zs_column_sum"] or names == ["zs_column_sum"] + ["zs_dense_act_bwd"] * 2
+        np.testing.assert_allclose(yl.detach().cpu().numpy(), ref[:-1](x2).detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+        seq.zero_grad()
+    with torch.no_grad():
+        np.testing.assert_allclose(seq(x1).cpu().numpy(), ref(x1).cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # own activation argument; without bias; a layer that is not followed by an activation; a foreign module in between
+    lin = zs.Linear(19, 5, bias=False, activation='relu').to(dev)
+    xa = torch.randn(9, 19, device=dev, requires_grad=True)
+    out = lin(xa)
+    out.sum().backward()
+    with torch.no_grad():
+        assert torch.equal(out, torch.relu(xa @ lin.weight.t()))
+    wref = lin.weight.detach().clone().requires_grad_(True)
+    xb = xa.detach().clone().requires_grad_(True)
+    torch.relu(xb @ wref.t()).sum().backward()
+    np.testing.assert_allclose(lin.weight.grad.cpu().numpy(), wref.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError, match="activation"):
+        zs.Linear(3, 3, activation='tanh')
+    mixed = zs.Sequential(zs.Linear(19, 6), torch.nn.Tanh(), torch.nn.Linear(6, 4), torch.nn.ReLU()).to(dev)
+    with launches() as names:
+        mixed(xa).sum().backward()
+    assert names == ["zs_column_sum"]
+    # the example callers: dense='fused' equals dense='torch' on the same weights and draws
+    x, e1, e2 = H.vae_data(16)
+    xt = torch.tensor(x, device=dev)
+    ma, mb = vae_mnist.build(16, hidden=32, device=dev, dense='torch'), vae_mnist.build(16, hidden=32, device=dev, dense='fused')
+    mb.load_state_dict(ma.state_dict())
+    with zs.inject_epsilon([e1, e2]):
+        la = ma({"x": xt})
+    with zs.inject_epsilon([e1, e2]):
+        lb = mb({"x": xt})
+    ga, gb = _grads(ma, la), _grads(mb, lb)
+    np.testing.assert_allclose(float(lb.detach()), float(la.detach()), rtol=1e-6)
+    for a, b in zip(ga, gb):
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6 * max(np.abs(a).max(), 1))

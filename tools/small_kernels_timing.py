@@ -63,6 +63,11 @@ def main():
         tk = torch.zeros(16, dtype=torch.int32, device=dev)
         timed("CS1 column sum [%d, %d]  (%.1f MB)" % (rows, cols, rows * cols * 4 / 1e6), "zs_column_sum_f32",
               lambda: lib.call("zs_column_sum_f32", P(x), P(o), rows, cols, P(ws), ws.numel(), P(tk), tk.numel(), st))
+        yv, gp = torch.relu(torch.randn(rows, cols, device=dev)), torch.empty(rows, cols, device=dev)
+        timed("AB1 relu backward + column sum [%d, %d]" % (rows, cols), "zs_dense_act_bwd_f32",
+              lambda: lib.call("zs_dense_act_bwd_f32", P(x), P(yv), 1, P(gp), P(o), rows, cols, P(ws), ws.numel(), P(tk), tk.numel(), st))
+        timed("AB1 sigmoid backward + column sum [%d, %d]" % (rows, cols), "zs_dense_act_bwd_f32",
+              lambda: lib.call("zs_dense_act_bwd_f32", P(x), P(yv), 2, P(gp), P(o), rows, cols, P(ws), ws.numel(), P(tk), tk.numel(), st))
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
         for _ in range(5):
             x.sum(0)

@@ -24,7 +24,7 @@ import zhusuan
 from examples import vae_mnist, iwae, bnn_vi
 
 
-def make(config, dev, bnn_layer="fused", dense="zhusuan"):
+def make(config, dev, bnn_layer="fused", dense="fused"):
     bits = lambda B: {"x": (torch.rand(B, 784, device=dev) < 0.5).float()}
     if config == "C2":
         return vae_mnist.build(512, device=dev, dense=dense), bits(512), 512
@@ -48,7 +48,8 @@ def main():
                     help="execute the draw the reference's objectives discard (package default); the tool, like bench.py, runs "
                          "inside zhusuan.skip_discarded_draws() otherwise")
     ap.add_argument("--bnn-layer", default="fused", choices=["fused", "bmm", "materialize"])
-    ap.add_argument("--dense", default="zhusuan", choices=["zhusuan", "torch"], help="zhusuan.Linear (CS1 bias gradient) or torch.nn.Linear")
+    ap.add_argument("--dense", default="fused", choices=["fused", "zhusuan", "torch"],
+                    help="fused: zhusuan.Linear in zhusuan.Sequential (AB1); zhusuan: zhusuan.Linear (CS1 bias gradient) in nn.Sequential; torch: torch.nn")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")

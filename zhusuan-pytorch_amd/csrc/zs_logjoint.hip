@@ -1142,10 +1142,20 @@ constexpr int CS_MAX_CHUNKS = 128;
 #define CS_U 8                   // rows a wavefront has in flight (16: no faster, measured)
 #endif
 
-template <typename T, int V>      // V = 4: dwordx4 lanes (cols % 4 == 0, aligned), V = 1: one column per lane
-__global__ __launch_bounds__(256) void k_column_sum(const T* __restrict__ x, T* __restrict__ out, T* __restrict__ part,
+// ACT != 0 (AB1, below): x is the gradient w.r.t. a dense layer's ACTIVATED output y; the kernel forms the gradient w.r.t.
+// the pre-activation on the way (ReLU: g * [y > 0]; sigmoid: g * y * (1 - y)), writes it to `gpre` (which may be x itself)
+// and sums THAT by columns: the activation's backward pass and the bias gradient in the one pass over the gradient.
+template <typename T, int ACT>
+__device__ __forceinline__ T act_bwd(T g, T y) {
+  if (ACT == ZS_ACT_RELU) return y > (T)0 ? g : (T)0;
+  if (ACT == ZS_ACT_SIGMOID) return g * ((T)1 - y) * y;          // (torch's sigmoid_backward: grad * (1 - y) * y)
+  return g;
+}
+
+template <typename T, int V, int ACT = 0>      // V = 4: dwordx4 lanes (cols % 4 == 0, aligned), V = 1: one column per lane
+__global__ __launch_bounds__(256) void k_column_sum(const T* x, T* __restrict__ out, T* __restrict__ part,
                                                     unsigned* __restrict__ tickets, int64_t rows, int cols, int nchunks,
-                                                    int64_t rows_per_chunk) {
+                                                    int64_t rows_per_chunk, const T* __restrict__ y = nullptr, T* gpre = nullptr) {
   __shared__ T red[4][64 * V];
   __shared__ bool last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1158,11 +1168,11 @@ __global__ __launch_bounds__(256) void k_column_sum(const T* __restrict__ x, T* 
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = (T)0;
   if (on) {
-    const T* __restrict__ p = x + c0;
+    const T* p = x + c0;
     // a wavefront takes rows r0 + wv, r0 + wv + 4, ...: CS_U of them in flight (8 KB per wavefront with 16-byte lanes),
     // clamped to the chunk's last row so that the loads are unconditional; a clamped row's contribution is dropped
     for (int64_t r = r0 + wv; r < r1; r += 4 * CS_U) {
-      T v[CS_U][V];
+      T v[CS_U][V], a[ACT ? CS_U : 1][V];
       bool live[CS_U];
 #pragma unroll
       for (int u = 0; u < CS_U; ++u) {
@@ -1173,8 +1183,32 @@ __global__ __launch_bounds__(256) void k_column_sum(const T* __restrict__ x, T* 
           const V4<T> q = *reinterpret_cast<const V4<T>*>(p + rc * cols);
 #pragma unroll
           for (int j = 0; j < V; ++j) v[u][j] = q.v[j];
+          if (ACT) {
+            const V4<T> qa = *reinterpret_cast<const V4<T>*>(y + c0 + rc * cols);
+#pragma unroll
+            for (int j = 0; j < V; ++j) a[u][j] = qa.v[j];
+          }
         } else {
           v[u][0] = p[rc * cols];
+          if (ACT) a[u][0] = y[c0 + rc * cols];
+        }
+      }
+      if (ACT) {
+#pragma unroll
+        for (int u = 0; u < CS_U; ++u) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) v[u][j] = act_bwd<T, ACT>(v[u][j], a[u][j]);
+          if (live[u]) {
+            T* o = gpre + c0 + (r + 4 * u) * cols;
+            if (V == 4) {
+              V4<T> q;
+#pragma unroll
+              for (int j = 0; j < V; ++j) q.v[j] = v[u][j];
+              *reinterpret_cast<V4<T>*>(o) = q;
+            } else {
+              o[0] = v[u][0];
+            }
+          }
         }
       }
 #pragma unroll
@@ -1238,8 +1272,9 @@ __global__ __launch_bounds__(256) void k_column_sum(const T* __restrict__ x, T* 
 
 template <typename T>
 int column_sum(const T* x, T* out, int64_t rows, int64_t cols, T* workspace, int64_t workspace_len, uint32_t* tickets,
-               int64_t n_tickets, void* stream) {
+               int64_t n_tickets, void* stream, int act = ZS_ACT_NONE, const T* y = nullptr, T* gpre = nullptr) {
   if (rows < 0 || cols < 0) return ZS_EINVAL;
+  if (act != ZS_ACT_NONE && act != ZS_ACT_RELU && act != ZS_ACT_SIGMOID) return ZS_EINVAL;
   if (cols == 0) return 0;
   if (!out) return ZS_EINVAL;
   if (cols > (1 << 24)) return ZS_ENOTSUP;
@@ -1248,7 +1283,8 @@ int column_sum(const T* x, T* out, int64_t rows, int64_t cols, T* workspace, int
     return e == hipSuccess ? 0 : (int)e;
   }
   if (!x) return ZS_EINVAL;
-  const bool v4 = (cols % 4) == 0 && pl_al<T>(x);
+  if (act != ZS_ACT_NONE && (!y || !gpre)) return ZS_EINVAL;
+  const bool v4 = (cols % 4) == 0 && pl_al<T>(x) && (act == ZS_ACT_NONE || (pl_al<T>(y) && pl_al<T>(gpre)));
   const int ncol_tile = v4 ? 256 : 64;
   const int64_t ctiles = (cols + ncol_tile - 1) / ncol_tile;
   // row chunks: enough workgroups to fill the chip (~512), at least 32 rows each, at most CS_MAX_CHUNKS per column tile
@@ -1262,12 +1298,17 @@ int column_sum(const T* x, T* out, int64_t rows, int64_t cols, T* workspace, int
   if (nchunks > 1 && (!workspace || !tickets || workspace_len < ctiles * nchunks * ncol_tile || n_tickets < ctiles)) return ZS_EINVAL;
   if (ctiles * nchunks > (int64_t(1) << 30)) return ZS_ENOTSUP;
   const dim3 grid((unsigned)(ctiles * nchunks));
-  if (v4)
-    ZS_LAUNCH(KID_COLUMN_SUM, (k_column_sum<T, 4>), grid, dim3(256), (hipStream_t)stream, x, out, workspace, (unsigned*)tickets, rows,
-              (int)cols, (int)nchunks, rpc);
-  else
-    ZS_LAUNCH(KID_COLUMN_SUM, (k_column_sum<T, 1>), grid, dim3(256), (hipStream_t)stream, x, out, workspace, (unsigned*)tickets, rows,
-              (int)cols, (int)nchunks, rpc);
+#define ZS_CS_LAUNCH(KID, VV, AA)                                                                                            \
+  ZS_LAUNCH(KID, (k_column_sum<T, VV, AA>), grid, dim3(256), (hipStream_t)stream, x, out, workspace, (unsigned*)tickets, rows, \
+            (int)cols, (int)nchunks, rpc, y, gpre)
+  if (act == ZS_ACT_RELU) {
+    if (v4) ZS_CS_LAUNCH(KID_DENSE_ACT_BWD, 4, ZS_ACT_RELU); else ZS_CS_LAUNCH(KID_DENSE_ACT_BWD, 1, ZS_ACT_RELU);
+  } else if (act == ZS_ACT_SIGMOID) {
+    if (v4) ZS_CS_LAUNCH(KID_DENSE_ACT_BWD, 4, ZS_ACT_SIGMOID); else ZS_CS_LAUNCH(KID_DENSE_ACT_BWD, 1, ZS_ACT_SIGMOID);
+  } else {
+    if (v4) ZS_CS_LAUNCH(KID_COLUMN_SUM, 4, 0); else ZS_CS_LAUNCH(KID_COLUMN_SUM, 1, 0);
+  }
+#undef ZS_CS_LAUNCH
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -1280,4 +1321,20 @@ extern "C" int zs_column_sum_f32(const float* x, float* out, int64_t rows, int64
 extern "C" int zs_column_sum_f64(const double* x, double* out, int64_t rows, int64_t cols, double* workspace, int64_t workspace_len,
                                  uint32_t* tickets, int64_t n_tickets, void* stream) {
   return column_sum<double>(x, out, rows, cols, workspace, workspace_len, tickets, n_tickets, stream);
+}
+
+// ================================================================ AB1: activation backward + bias gradient of a dense layer
+// gpre = g * act'(y), out[c] = sum_r gpre[r, c] in one pass (k_column_sum<., ., ACT>): what the backward of
+// `act(linear(x))` needs before its two GEMMs.  torch runs threshold_backward / sigmoid_backward (read g, y; write gpre) and then
+// a reduction that reads gpre again.
+extern "C" int zs_dense_act_bwd_f32(const float* g, const float* y, int act, float* gpre, float* gbias, int64_t rows, int64_t cols,
+                                    float* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream) {
+  if (act == ZS_ACT_NONE) return ZS_EINVAL;
+  return column_sum<float>(g, gbias, rows, cols, workspace, workspace_len, tickets, n_tickets, stream, act, y, gpre);
+}
+extern "C" int zs_dense_act_bwd_f64(const double* g, const double* y, int act, double* gpre, double* gbias, int64_t rows,
+                                    int64_t cols, double* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets,
+                                    void* stream) {
+  if (act == ZS_ACT_NONE) return ZS_EINVAL;
+  return column_sum<double>(g, gbias, rows, cols, workspace, workspace_len, tickets, n_tickets, stream, act, y, gpre);
 }

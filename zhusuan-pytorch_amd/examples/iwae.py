@@ -17,23 +17,33 @@ from zhusuan import distributions
 from zhusuan.variational.importance_weighted_objective import ImportanceWeightedObjective
 
 
-def dense_layer(dense):
+def dense_modules(dense):
+    """(Linear, Sequential) classes of the callers' MLPs: 'torch' = torch.nn's, as in the reference's example; 'zhusuan' =
+    zhusuan.Linear (bias gradient: one column-sum launch) inside torch.nn.Sequential; 'fused' = zhusuan.Linear inside
+    zhusuan.Sequential (ReLU in the GEMM's epilogue, activation backward fused with the bias gradient).  Same parameters,
+    names and order in all three."""
     if dense == 'torch':
-        return nn.Linear
+        return nn.Linear, nn.Sequential
+    import zhusuan
     if dense == 'zhusuan':
-        import zhusuan
-        return zhusuan.Linear
-    raise ValueError("dense: 'torch' or 'zhusuan'")
+        return zhusuan.Linear, nn.Sequential
+    if dense == 'fused':
+        return zhusuan.Linear, zhusuan.Sequential
+    raise ValueError("dense: 'torch', 'zhusuan' or 'fused'")
+
+
+def dense_layer(dense):
+    return dense_modules(dense)[0]
 
 
 class Generator(BayesianNet):
-    def __init__(self, x_dim, z_dim, n_samples, hidden=500, fused_logits=False, Linear=nn.Linear):
+    def __init__(self, x_dim, z_dim, n_samples, hidden=500, fused_logits=False, Linear=nn.Linear, Sequential=nn.Sequential):
         super().__init__()
         self.x_dim = x_dim
         self.z_dim = z_dim
         self.n_samples = n_samples
         self.fused_logits = fused_logits
-        self.gen_sq = nn.Sequential(
+        self.gen_sq = Sequential(
             Linear(z_dim, hidden), nn.ReLU(),
             Linear(hidden, hidden), nn.ReLU(),
             Linear(hidden, x_dim), nn.Sigmoid())
@@ -68,13 +78,13 @@ class Generator(BayesianNet):
 
 
 class Variational(BayesianNet):
-    def __init__(self, x_dim, z_dim, n_samples, hidden=500, reparameterized=False, Linear=nn.Linear):
+    def __init__(self, x_dim, z_dim, n_samples, hidden=500, reparameterized=False, Linear=nn.Linear, Sequential=nn.Sequential):
         super().__init__()
         self.x_dim = x_dim
         self.z_dim = z_dim
         self.n_samples = n_samples
         self.reparameterized = reparameterized
-        self.output_logits = nn.Sequential(Linear(x_dim, hidden), nn.ReLU(), Linear(hidden, hidden), nn.ReLU())
+        self.output_logits = Sequential(Linear(x_dim, hidden), nn.ReLU(), Linear(hidden, hidden), nn.ReLU())
         self.output_mean = Linear(hidden, z_dim)
         self.output_logstd = Linear(hidden, z_dim)
 
@@ -90,11 +100,11 @@ class Variational(BayesianNet):
 
 
 def build(n_samples=50, estimator='vimco', x_dim=784, z_dim=40, hidden=500, device='cuda', fused_logits=False, dense='torch'):
-    """`dense`: 'torch' = torch.nn.Linear as in the reference's example; 'zhusuan' = zhusuan.Linear, the same layer (same
-    parameters and names) whose bias gradient is one deterministic column-sum launch (CS1) instead of torch's reduction."""
-    Linear = dense_layer(dense)
-    generator = Generator(x_dim, z_dim, n_samples, hidden, fused_logits, Linear)
-    variational = Variational(x_dim, z_dim, n_samples, hidden, reparameterized=(estimator == 'sgvb'), Linear=Linear)
+    """`dense`: see dense_modules."""
+    Linear, Sequential = dense_modules(dense)
+    generator = Generator(x_dim, z_dim, n_samples, hidden, fused_logits, Linear, Sequential)
+    variational = Variational(x_dim, z_dim, n_samples, hidden, reparameterized=(estimator == 'sgvb'), Linear=Linear,
+                              Sequential=Sequential)
     return ImportanceWeightedObjective(generator, variational, axis=0, estimator=estimator).to(device)
 
 

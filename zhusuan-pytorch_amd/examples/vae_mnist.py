@@ -17,12 +17,12 @@ from zhusuan.variational.elbo import ELBO
 
 
 class Generator(BayesianNet):
-    def __init__(self, x_dim, z_dim, batch_size, hidden=500, Linear=nn.Linear):
+    def __init__(self, x_dim, z_dim, batch_size, hidden=500, Linear=nn.Linear, Sequential=nn.Sequential):
         super().__init__()
         self.x_dim = x_dim
         self.z_dim = z_dim
         self.batch_size = batch_size
-        self.sequential = nn.Sequential(
+        self.sequential = Sequential(
             Linear(z_dim, hidden), nn.ReLU(),
             Linear(hidden, hidden), nn.ReLU(),
             Linear(hidden, x_dim), nn.Sigmoid())
@@ -46,12 +46,12 @@ class Generator(BayesianNet):
 
 
 class Variational(BayesianNet):
-    def __init__(self, x_dim, z_dim, batch_size, hidden=500, Linear=nn.Linear):
+    def __init__(self, x_dim, z_dim, batch_size, hidden=500, Linear=nn.Linear, Sequential=nn.Sequential):
         super().__init__()
         self.x_dim = x_dim
         self.z_dim = z_dim
         self.batch_size = batch_size
-        self.sq = nn.Sequential(Linear(x_dim, hidden), nn.ReLU(), Linear(hidden, hidden), nn.ReLU())
+        self.sq = Sequential(Linear(x_dim, hidden), nn.ReLU(), Linear(hidden, hidden), nn.ReLU())
         self.fc3 = Linear(hidden, z_dim)
         self.fc4 = Linear(hidden, z_dim)
 
@@ -66,11 +66,11 @@ class Variational(BayesianNet):
 
 
 def build(batch_size=64, x_dim=784, z_dim=40, hidden=500, device='cuda', dense='torch'):
-    """`dense`: 'torch' = torch.nn.Linear as in the reference's example; 'zhusuan' = zhusuan.Linear (see examples/iwae.py)."""
-    from .iwae import dense_layer
-    Linear = dense_layer(dense)
-    generator = Generator(x_dim, z_dim, batch_size, hidden, Linear)
-    variational = Variational(x_dim, z_dim, batch_size, hidden, Linear)
+    """`dense`: 'torch' | 'zhusuan' | 'fused' (examples/iwae.py: dense_modules)."""
+    from .iwae import dense_modules
+    Linear, Sequential = dense_modules(dense)
+    generator = Generator(x_dim, z_dim, batch_size, hidden, Linear, Sequential)
+    variational = Variational(x_dim, z_dim, batch_size, hidden, Linear, Sequential)
     return ELBO(generator, variational).to(device)
 
 

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # The in-tree library.  ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments: tools/); bench.py
 # records which file was loaded (path, sha256, zs_build_info) and refuses an override unless --allow-experiments is given.
 LIB_PATH = os.environ.get("ZS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -91,6 +91,8 @@ PROTOTYPES.update({
     "zs_particle_linear_f32": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
     # x, out, rows, cols, workspace, workspace_len, tickets, n_tickets, stream
     "zs_column_sum_f32": [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _p],
+    # g, y, act, gpre, gbias, rows, cols, workspace, workspace_len, tickets, n_tickets, stream
+    "zs_dense_act_bwd_f32": [_p, _p, _int, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _p],
     # h, h_stride_k, w, out, gout, gh, gw, K, B, n_in, n_out, relu, workspace, workspace_len, tickets, stream
     "zs_particle_linear_bwd_f32": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p, _p],
 })

@@ -977,34 +977,77 @@ def column_sum(x2d):
     out = torch.empty(cols, dtype=x2d.dtype, device=dev)
     if cols == 0:
         return out
-    ctiles = (cols + 63) // 64
-    ws, tickets = _scratch(dev, ("cs", x2d.dtype), lambda sc: sc[0].numel() >= 128 * (cols + 256) and sc[1].numel() >= ctiles,
-                           lambda: (torch.empty(128 * (max(cols, 1024) + 256), dtype=x2d.dtype, device=dev),
-                                    torch.zeros(max(ctiles, 16), dtype=torch.int32, device=dev)))
+    ws, tickets = _cs_scratch(dev, x2d.dtype, cols)
     _hip.lib().call("zs_column_sum" + sfx, _hip.ptr(x2d), _hip.ptr(out), rows, cols, _hip.ptr(ws), ws.numel(), _hip.ptr(tickets),
                     tickets.numel(), _hip.stream_for(x2d))
     return out
 
 
+def _cs_scratch(dev, dtype, cols):
+    ctiles = (cols + 63) // 64
+    return _scratch(dev, ("cs", dtype), lambda sc: sc[0].numel() >= 128 * (cols + 256) and sc[1].numel() >= ctiles,
+                    lambda: (torch.empty(128 * (max(cols, 1024) + 256), dtype=dtype, device=dev),
+                             torch.zeros(max(ctiles, 16), dtype=torch.int32, device=dev)))
+
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2          # ZS_ACT_* of include/zs_hip.h
+
+
+def dense_act_bwd(g2d, y2d, act):
+    """AB1: ``(g * act'(y), (g * act'(y)).sum(0))`` of contiguous [rows, cols] matrices in one launch (include/zs_hip.h)."""
+    _hip.require_device(g2d)
+    sfx = _sfx(g2d)
+    rows, cols = g2d.shape
+    dev = g2d.device
+    gpre = torch.empty_like(g2d)
+    gb = torch.empty(cols, dtype=g2d.dtype, device=dev)
+    if cols == 0:
+        return gpre, gb
+    ws, tickets = _cs_scratch(dev, g2d.dtype, cols)
+    _hip.lib().call("zs_dense_act_bwd" + sfx, _hip.ptr(g2d), _hip.ptr(y2d), int(act), _hip.ptr(gpre), _hip.ptr(gb), rows, cols,
+                    _hip.ptr(ws), ws.numel(), _hip.ptr(tickets), tickets.numel(), _hip.stream_for(g2d))
+    return gpre, gb
+
+
 class DenseLayer(torch.autograd.Function):
-    """``F.linear(x, w, b)`` whose backward forms the bias gradient with CS1 instead of torch's generic reduction; the two
-    GEMMs of the backward (grad_input = g @ w, grad_weight = g.T @ x) are torch's."""
+    """``act(F.linear(x, w, b))``, act in {none, ReLU, sigmoid}.  Forward: torch's GEMM, the bias and a ReLU riding in its
+    epilogue (``torch._addmm_activation``: the same hipBLASLt solution as ``F.linear``, bit-identical, minus torch's clamp
+    pass).  Backward: the activation's backward and the bias gradient in one pass over the gradient (AB1; CS1 for a layer
+    without activation) instead of torch's threshold_backward / sigmoid_backward pass plus its generic reduction; the two
+    GEMMs (grad_input = g @ w, grad_weight = g.T @ x) are torch's."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, b, act=ACT_NONE):
         ctx.has_bias = b is not None
-        return torch.nn.functional.linear(x, w, b)
+        ctx.act = act
+        if act == ACT_RELU and b is not None and x.dim() >= 1 and x.shape[-1] == w.shape[1] and b.dim() == 1:
+            y = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]), w.t()).reshape(*x.shape[:-1], w.shape[0])
+        else:
+            y = torch.nn.functional.linear(x, w, b)
+            if act == ACT_RELU:
+                y = torch.relu_(y)
+            elif act == ACT_SIGMOID:
+                y = torch.sigmoid_(y)
+        if act == ACT_NONE:
+            ctx.save_for_backward(x, w)
+        else:
+            ctx.save_for_backward(x, w, y)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
-        g2 = g.reshape(-1, g.shape[-1])
+        x, w = ctx.saved_tensors[:2]
+        g2 = g.reshape(-1, g.shape[-1]).contiguous()
         gx = gw = gb = None
+        if ctx.act != ACT_NONE:
+            y = ctx.saved_tensors[2]
+            g2, gb = dense_act_bwd(g2, y.reshape(-1, y.shape[-1]), ctx.act)
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = column_sum(g2)
+        if not (ctx.has_bias and ctx.needs_input_grad[2]):
+            gb = None
         if ctx.needs_input_grad[0]:
             gx = (g2 @ w).reshape(x.shape)
         if ctx.needs_input_grad[1]:
             gw = g2.t() @ x.reshape(-1, x.shape[-1])
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = column_sum(g2.contiguous())
-        return gx, gw, gb
+        return gx, gw, gb, None

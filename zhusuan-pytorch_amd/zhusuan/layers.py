@@ -9,7 +9,7 @@ import torch
 
 from . import _ops
 
-__all__ = ['particle_linear', 'Linear']
+__all__ = ['particle_linear', 'Linear', 'Sequential']
 
 
 def _fits_lds(n_in, n_out, itemsize):
@@ -45,14 +45,49 @@ def particle_linear(h, w, relu=False):
     return torch.relu(out) if relu else out
 
 
+_ACTS = {None: _ops.ACT_NONE, 'relu': _ops.ACT_RELU, 'sigmoid': _ops.ACT_SIGMOID}
+
+
 class Linear(torch.nn.Linear):
-    """``torch.nn.Linear`` (same parameters, same names, same forward GEMM) whose backward computes the bias gradient with
-    the column-sum kernel CS1 (one launch, deterministic) instead of torch's generic reduction -- 12.4 us per layer for the
-    [12 800, 500] gradients of the IWAE step, seven layers per step.  The callers' MLPs of the reference's examples
-    (examples/variational_autoencoder/vae_mnist.py:22-28,44-48, iwae.py:40-47,68-75) are stacks of these; this is glue on
-    the caller's side of the boundary (like ``particle_linear``), not part of the distribution / objective path."""
+    """``torch.nn.Linear`` (same parameters, same names, same forward GEMM) with the non-GEMM passes of a dense layer folded
+    into one kernel each way.  The callers' MLPs of the reference's examples
+    (examples/variational_autoencoder/vae_mnist.py:22-28,44-48, iwae.py:40-47,68-75) are stacks of Linear -> ReLU (-> Sigmoid);
+    this is glue on the caller's side of the boundary (like ``particle_linear``), not part of the distribution / objective path.
+
+    * backward: the bias gradient is one deterministic column-sum launch (CS1) instead of torch's generic reduction
+      (12.4 us per layer for the [12 800, 500] gradients of the IWAE step, seven layers per step);
+    * ``activation='relu' | 'sigmoid'`` (or a following ``nn.ReLU`` / ``nn.Sigmoid`` inside a ``zhusuan.Sequential``): the
+      ReLU rides in the forward GEMM's epilogue, and the activation's backward is fused with the bias gradient (AB1).
+    """
+
+    def __init__(self, in_features, out_features, bias=True, device=None, dtype=None, activation=None):
+        super().__init__(in_features, out_features, bias=bias, device=device, dtype=dtype)
+        if activation not in _ACTS:
+            raise ValueError("activation: None, 'relu' or 'sigmoid'")
+        self.activation = activation
+
+    def forward(self, x, activation='own'):
+        act = self.activation if activation == 'own' else activation
+        if x.requires_grad or self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad):
+            return _ops.DenseLayer.apply(x, self.weight, self.bias, _ACTS[act])
+        y = torch.nn.functional.linear(x, self.weight, self.bias)
+        return y if act is None else (torch.relu_(y) if act == 'relu' else torch.sigmoid_(y))
+
+
+class Sequential(torch.nn.Sequential):
+    """``torch.nn.Sequential`` (same children, same indices, same parameter names, slicing included) that runs every
+    ``zhusuan.Linear`` followed by an ``nn.ReLU`` / ``nn.Sigmoid`` as one fused layer."""
 
     def forward(self, x):
-        if x.requires_grad or self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad):
-            return _ops.DenseLayer.apply(x, self.weight, self.bias)
-        return torch.nn.functional.linear(x, self.weight, self.bias)
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, Linear) and m.activation is None and type(nxt) in (torch.nn.ReLU, torch.nn.Sigmoid):
+                x = m(x, activation='relu' if type(nxt) is torch.nn.ReLU else 'sigmoid')
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
