@@ -488,6 +488,17 @@ int zs_dense_act_bwd_f32(const float* g, const float* y, int act, float* gpre, f
                          float* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * PR1  RMSE of the particle-mean prediction, the diagnostic of the BNN caller's forward pass
+ * (examples/bayesian_neural_nets/bnn_vi.py:84-87: y_pred = mean(y_mean, 0); rmse = sqrt(mean((y - y_pred) ** 2))):
+ *   out[0] = sqrt( (1 / B) * sum_b (y[b] - (1 / K) * sum_k pred[k * B + b])^2 )
+ * pred [K, B] contiguous, y [B].  NaN when K == 0 or B == 0 (torch's mean of nothing).  Caller-side glue like PL1.
+ * workspace (DOUBLE, for both precisions): >= 1024 elements; ticket: one zero-initialised device word, handed back at
+ * zero; both unused (may be NULL) when B <= 4096.  Deterministic.
+ * -------------------------------------------------------------------------*/
+int zs_particle_rmse_f32(const float* pred, const float* y, float* out, int64_t K, int64_t B, double* workspace,
+                         int64_t workspace_len, uint32_t* ticket, void* stream);
+
+/* ---------------------------------------------------------------------------
  * float64 twins.  The reference accepts float64 parameters for Normal / Bernoulli
  * (zhusuan/distributions/utils.py:5,57-64); every entry point above exists with the suffix _f64,
  * identical argument meaning, double* instead of float*.  They are plain (untuned) kernels: none of the
@@ -525,6 +536,7 @@ int zs_particle_linear_f64(const double* h, int64_t h_stride_k, const double* w,
 int zs_particle_linear_bwd_f64(const double* h, int64_t h_stride_k, const double* w, const double* out, const double* gout, double* gh, double* gw, int64_t K, int64_t B, int64_t n_in, int64_t n_out, int relu, double* workspace, int64_t workspace_len, uint32_t* tickets, void* stream);
 int zs_column_sum_f64(const double* x, double* out, int64_t rows, int64_t cols, double* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream);
 int zs_dense_act_bwd_f64(const double* g, const double* y, int act, double* gpre, double* gbias, int64_t rows, int64_t cols, double* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream);
+int zs_particle_rmse_f64(const double* pred, const double* y, double* out, int64_t K, int64_t B, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
 int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors, double* exp_avg, double* exp_avg_sq, int64_t* steps, uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -192,6 +192,21 @@ class Raw(object):
         assert int(tk.abs().sum().item()) == 0
         return gpre.cpu().numpy(), gb.cpu().numpy()
 
+    # ---- PR1
+    def rmse(self, pred, y):
+        K, B = pred.shape
+        pt, yt = self.t(pred), self.t(y)
+        ws = torch.full((1024,), float("nan"), dtype=torch.float64, device=self.dev)
+        tk = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        out = torch.full((1,), 123.0, dtype=self.dtype, device=self.dev)
+        for scale in (3.0, 1.0):       # twice on one workspace (ticket back at zero, no stale partials)
+            ps = pt * scale
+            self.k.call("zs_particle_rmse" + self.sfx, _hip.ptr(ps), _hip.ptr(yt), _hip.ptr(out), K, B, _hip.ptr(ws), ws.numel(),
+                        _hip.ptr(tk), self.stream())
+            self.sync()
+        assert int(tk.abs().sum().item()) == 0
+        return float(out.cpu().numpy()[0])
+
     # ---- PL1
     def pl(self, h, w, relu):
         K, n_out, n_in1 = w.shape
@@ -661,3 +676,44 @@ def test_hip_dense_act_bwd_rejects(hip):
         hip.actbwd(np.zeros((2, 2)), np.zeros((2, 2)), 0)
     with pytest.raises(RuntimeError, match="code -1"):
         hip.actbwd(np.zeros((2, 2)), np.zeros((2, 2)), 5)
+
+
+# ---------------------------------------------------------------- PR1: RMSE of the particle-mean prediction
+PR_SHAPES = [(10, 512), (10, 4096), (10, 4097), (1, 1), (4, 16), (512, 114), (3, 70001), (7, 1200000), (0, 5), (5, 0)]
+
+
+def _rmse_ref(pred, y):
+    if pred.shape[0] == 0 or pred.shape[1] == 0:
+        return float("nan")
+    return float(np.sqrt(np.mean((y.astype(np.float64) - pred.astype(np.float64).mean(0)) ** 2)))
+
+
+def test_c_oracle_particle_rmse_matches_torch(orc, orc64):
+    rng = np.random.RandomState(8)
+    for K, B in PR_SHAPES:
+        if K * B > 500000:
+            continue
+        pred, y = rng.standard_normal((K, B)).astype(np.float32), rng.standard_normal(B).astype(np.float32)
+        t = torch.sqrt(torch.mean((torch.tensor(y) - torch.mean(torch.tensor(pred), 0)) ** 2))      # the caller's expression
+        for o, tol in ((orc, 2e-6), (orc64, 1e-12)):
+            got = o.rmse(pred, y)
+            if K == 0 or B == 0:
+                assert np.isnan(got) and np.isnan(float(t))
+            else:
+                np.testing.assert_allclose(got, _rmse_ref(pred, y), rtol=tol)
+                np.testing.assert_allclose(got, float(t), rtol=3e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,B", PR_SHAPES)
+def test_hip_particle_rmse(hip, hip64, K, B):
+    rng = np.random.RandomState(K + B)
+    pred, y = rng.standard_normal((K, B)).astype(np.float32), rng.standard_normal(B).astype(np.float32)
+    ref = _rmse_ref(pred, y)
+    a = hip.rmse(pred, y)
+    if K == 0 or B == 0:
+        assert np.isnan(a) and np.isnan(hip64.rmse(pred, y))
+        return
+    np.testing.assert_allclose(a, ref, rtol=2e-6)
+    assert a == hip.rmse(pred, y)                                       # deterministic
+    np.testing.assert_allclose(hip64.rmse(pred, y), ref, rtol=1e-12)

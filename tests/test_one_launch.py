@@ -59,7 +59,7 @@ def test_bnn_step_is_five_kernels_each_way_and_equals_the_reference_op_sequence(
         n_fwd = len(names)
         g = _grads(model, loss)
     assert names[:n_fwd] == ["zs_normal_sample_logprob"] * 2 + ["zs_normal_sample_logprob_multi"] + ["zs_particle_linear"] * 2 + \
-        ["zs_logjoint_scalar"]
+        ["zs_particle_rmse", "zs_logjoint_scalar"]
     assert names[n_fwd:] == ["zs_logjoint_scalar_bwd"] + ["zs_particle_linear_bwd"] * 2 + ["zs_normal_sample_logprob_multi_bwd"]
     rmse = float(model.generator.cache["rmse"])
     ref_model, _, _ = _bnn(dev, "materialize")
@@ -86,7 +86,7 @@ def test_skip_discarded_draws_draws_each_latent_once(dev):
         ref = float(model(obs).detach())
     with zs.skip_discarded_draws(), launches() as names, zs.inject_epsilon(eps[2:]):      # only the USED draws are consumed
         loss = model(obs)
-    assert names == ["zs_normal_sample_logprob_multi"] + ["zs_particle_linear"] * 2 + ["zs_logjoint_scalar"]
+    assert names == ["zs_normal_sample_logprob_multi"] + ["zs_particle_linear"] * 2 + ["zs_particle_rmse", "zs_logjoint_scalar"]
     assert float(loss.detach()) == ref
     # VAE: sample + objective = 2 launches forward, objective + sampler backward
     vae = vae_mnist.build(16, hidden=32, device=dev)

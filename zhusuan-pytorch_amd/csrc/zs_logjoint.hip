@@ -1338,3 +1338,91 @@ extern "C" int zs_dense_act_bwd_f64(const double* g, const double* y, int act, d
   if (act == ZS_ACT_NONE) return ZS_EINVAL;
   return column_sum<double>(g, gbias, rows, cols, workspace, workspace_len, tickets, n_tickets, stream, act, y, gpre);
 }
+
+// ================================================================ PR1: RMSE of the particle-mean prediction
+// out = sqrt(mean_b (y[b] - mean_k pred[k, b])^2) -- the diagnostic the BNN caller evaluates in every forward pass
+// (examples/bayesian_neural_nets/bnn_vi.py:84-87: mean over particles, sub, pow, mean, sqrt: five launches at a size where a
+// launch is the cost).  Lanes run along b (coalesced rows of pred), K loads per lane in flight; squared errors are summed in
+// double.  Up to 4096 datapoints one workgroup does it all; beyond, workgroups of 1024 datapoints hand their partial sums
+// to the last arrival (fence-free hand-off, top of this file), added in workgroup order: deterministic.
+namespace {
+constexpr int PR_BLOCK = 1024;
+constexpr int PR_ONE_BLOCK_MAX = 4096;
+constexpr int PR_MAX_BLOCKS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(PR_BLOCK) void k_particle_rmse(const T* __restrict__ pred, const T* __restrict__ y, T* __restrict__ out,
+                                                            int64_t K, int64_t B, double* __restrict__ ws, unsigned* __restrict__ ticket) {
+  __shared__ double sh[PR_BLOCK / 64];
+  __shared__ bool last;
+  const T invK = (T)1 / (T)K;
+  double acc = 0.0;
+  for (int64_t b = (int64_t)blockIdx.x * PR_BLOCK + threadIdx.x; b < B; b += (int64_t)gridDim.x * PR_BLOCK) {
+    T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+    int64_t k = 0;
+    for (; k + 4 <= K; k += 4) {                      // four rows in flight; one fixed order of additions
+      const T v0 = pred[k * B + b], v1 = pred[(k + 1) * B + b], v2 = pred[(k + 2) * B + b], v3 = pred[(k + 3) * B + b];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; k < K; ++k) s0 += pred[k * B + b];
+    const T d = y[b] - ((s0 + s1) + (s2 + s3)) * invK;
+    acc += (double)d * (double)d;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  double tot = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < PR_BLOCK / 64; ++w) tot += sh[w];
+  }
+  if (gridDim.x == 1) {
+    if (threadIdx.x == 0) out[0] = (T)sqrt(tot / (double)B);
+    return;
+  }
+  if (threadIdx.x == 0) {
+    store_wt(ws + blockIdx.x, tot);
+    drain_stores();
+    last = ticket_take(ticket) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  double s = 0.0;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += PR_BLOCK) s += load_wt(ws + i);    // (<= PR_MAX_BLOCKS: one load per thread)
+  s = wave_sum_d(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < PR_BLOCK / 64; ++w) t2 += sh[w];
+    out[0] = (T)sqrt(t2 / (double)B);
+    ticket_return(ticket);
+  }
+}
+
+template <typename T>
+int particle_rmse(const T* pred, const T* y, T* out, int64_t K, int64_t B, double* workspace, int64_t workspace_len, uint32_t* ticket,
+                  void* stream) {
+  if (K < 0 || B < 0 || !out) return ZS_EINVAL;
+  // (K == 0 or B == 0: torch's mean of nothing is NaN; the kernel's 0 * (1 / 0) and 0 / 0 produce it)
+  if (B > 0 && (!y || (K > 0 && !pred))) return ZS_EINVAL;
+  int64_t nb = B <= PR_ONE_BLOCK_MAX ? 1 : (B + PR_BLOCK - 1) / PR_BLOCK;
+  if (nb > PR_MAX_BLOCKS) nb = PR_MAX_BLOCKS;
+  if (nb > 1 && (!workspace || !ticket || workspace_len < nb)) return ZS_EINVAL;
+  ZS_LAUNCH(KID_PARTICLE_RMSE, (k_particle_rmse<T>), dim3((unsigned)nb), dim3(PR_BLOCK), (hipStream_t)stream, pred, y, out, K, B, workspace,
+            (unsigned*)ticket);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace
+
+extern "C" int zs_particle_rmse_f32(const float* pred, const float* y, float* out, int64_t K, int64_t B, double* workspace,
+                                    int64_t workspace_len, uint32_t* ticket, void* stream) {
+  return particle_rmse<float>(pred, y, out, K, B, workspace, workspace_len, ticket, stream);
+}
+extern "C" int zs_particle_rmse_f64(const double* pred, const double* y, double* out, int64_t K, int64_t B, double* workspace,
+                                    int64_t workspace_len, uint32_t* ticket, void* stream) {
+  return particle_rmse<double>(pred, y, out, K, B, workspace, workspace_len, ticket, stream);
+}

@@ -68,9 +68,13 @@ class Net(BayesianNet):
                 h = torch.relu(h)
         y_mean = torch.squeeze(h, 2)
         y = self.observed['y']
-        y_pred = torch.mean(y_mean, 0)
-        # sqrt(mean((y - y_pred)^2)) (bnn_vi.py:87) as norm / sqrt(B): one reduction launch instead of pow + mean + sqrt
-        self.cache['rmse'] = torch.linalg.vector_norm(y - y_pred) * (1.0 / math.sqrt(max(y.numel(), 1)))
+        if self.layer == 'fused':
+            # sqrt(mean((y - mean(y_mean, 0))^2)) (bnn_vi.py:84-87) as one launch
+            self.cache['rmse'] = zhusuan.particle_rmse(y_mean, y)
+        else:
+            y_pred = torch.mean(y_mean, 0)
+            # ... as norm / sqrt(B): one reduction launch instead of pow + mean + sqrt
+            self.cache['rmse'] = torch.linalg.vector_norm(y - y_pred) * (1.0 / math.sqrt(max(y.numel(), 1)))
         self.normal(name='y', mean=y_mean, logstd=self.y_logstd, reduce_mean_dims=[0, 1],
                     multiplier=self.multiplier)
         return self

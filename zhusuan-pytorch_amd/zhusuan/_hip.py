@@ -93,6 +93,8 @@ PROTOTYPES.update({
     "zs_column_sum_f32": [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _p],
     # g, y, act, gpre, gbias, rows, cols, workspace, workspace_len, tickets, n_tickets, stream
     "zs_dense_act_bwd_f32": [_p, _p, _int, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _p],
+    # pred, y, out, K, B, workspace (double), workspace_len, ticket, stream
+    "zs_particle_rmse_f32": [_p, _p, _p, _i64, _i64, _p, _i64, _p, _p],
     # h, h_stride_k, w, out, gout, gh, gw, K, B, n_in, n_out, relu, workspace, workspace_len, tickets, stream
     "zs_particle_linear_bwd_f32": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p, _p],
 })

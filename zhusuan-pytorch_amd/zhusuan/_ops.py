@@ -983,6 +983,24 @@ def column_sum(x2d):
     return out
 
 
+def particle_rmse(pred, y):
+    """PR1: ``sqrt(mean((y - pred.mean(0)) ** 2))`` of ``pred`` [K, B] and ``y`` [B] in one launch (include/zs_hip.h).  A
+    diagnostic: the result carries no autograd history."""
+    pred, y = pred.detach(), y.detach()
+    _hip.require_device(pred, y)
+    if pred.dim() != 2 or y.dim() != 1 or pred.shape[1] != y.shape[0] or pred.dtype != y.dtype:
+        raise RuntimeError("particle_rmse: pred [K, B] and y [B] of one dtype expected, got %s and %s" % (
+            tuple(pred.shape), tuple(y.shape)))
+    sfx = _sfx(pred)
+    pred, y = pred.contiguous(), y.contiguous()
+    K, B = pred.shape
+    out = torch.empty((), dtype=pred.dtype, device=pred.device)
+    ws, ticket = _lj_workspace(pred.device) if B > 4096 else (None, None)
+    _hip.lib().call("zs_particle_rmse" + sfx, _hip.ptr(pred), _hip.ptr(y), _hip.ptr(out), K, B, _hip.ptr(ws) if ws is not None else None,
+                    ws.numel() if ws is not None else 0, _hip.ptr(ticket) if ticket is not None else None, _hip.stream_for(pred))
+    return out
+
+
 def _cs_scratch(dev, dtype, cols):
     ctiles = (cols + 63) // 64
     return _scratch(dev, ("cs", dtype), lambda sc: sc[0].numel() >= 128 * (cols + 256) and sc[1].numel() >= ctiles,

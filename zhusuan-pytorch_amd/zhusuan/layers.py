@@ -9,7 +9,7 @@ import torch
 
 from . import _ops
 
-__all__ = ['particle_linear', 'Linear', 'Sequential']
+__all__ = ['particle_linear', 'particle_rmse', 'Linear', 'Sequential']
 
 
 def _fits_lds(n_in, n_out, itemsize):
@@ -43,6 +43,13 @@ def particle_linear(h, w, relu=False):
         h = h.unsqueeze(0).expand(K, *h.shape)
     out = (torch.bmm(h, w[:, :, :n_in].transpose(1, 2)) + w[:, :, n_in].unsqueeze(1)) / (float(n_in + 1) ** 0.5)
     return torch.relu(out) if relu else out
+
+
+def particle_rmse(pred, y):
+    """``sqrt(mean((y - pred.mean(0)) ** 2))``: the error of the particle-mean prediction ``pred`` [K, B] against ``y`` [B], the
+    diagnostic the BNN caller evaluates in every forward pass (examples/bayesian_neural_nets/bnn_vi.py:84-87: five torch
+    launches), as one kernel (PR1).  Returned without autograd history."""
+    return _ops.particle_rmse(pred, y)
 
 
 _ACTS = {None: _ops.ACT_NONE, 'relu': _ops.ACT_RELU, 'sigmoid': _ops.ACT_SIGMOID}
