@@ -80,7 +80,7 @@ __global__ __launch_bounds__(1024) void k_reinforce(const T* __restrict__ logp, 
 //                                                             = -(logp_i + l0_i * logq_i) + b_i  +  mm * logq_i,
 // so ONE pass suffices although the moving mean mm depends on every element: each workgroup adds up S1 = sum l0 (for the
 // moving mean), S2 = sum(-(logp + l0 * logq) + b) and S3 = sum logq (in double: the two products cancel to the small
-// (l0 - mm) * logq) and writes l0 / resid; the last workgroup to arrive (ticket; hand-off as in zs_logjoint.hip: partials
+// (l0 - mm) * logq) and writes l0 / resid; the last workgroup to arrive (ticket; hand-off as in zs_onelaunch.h: partials
 // written through, relaxed ticket) updates the moving mean and writes  cost = (S2 + mm * S3) / n.  The learning signal the
 // backward pass needs is l0 - mm: a second, element-wise launch subtracts mm in place (reading it from the module buffer
 // the first launch has just written) -- two launches of ~6 us at 10^6 elements instead of one 1024-thread workgroup's 300 us.

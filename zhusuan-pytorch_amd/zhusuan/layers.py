@@ -13,7 +13,7 @@ __all__ = ['particle_linear', 'particle_rmse', 'Linear', 'Sequential']
 
 
 def _fits_lds(n_in, n_out, itemsize):
-    """The kernel's own admission rule (pl_fits, csrc/zs_logjoint.hip): a particle's weights plus one 64-row tile of
+    """The kernel's own admission rule (pl_fits, csrc/zs_layers.hip): a particle's weights plus one 64-row tile of
     activations / gradients must fit 60 KB of LDS."""
     if not (1 <= n_in <= 255 and 1 <= n_out <= 256):
         return False
