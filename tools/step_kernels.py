@@ -128,8 +128,8 @@ def main():
     for name, (n, tot) in acc.items():
         ours = "k_" in name and ("zs" in name or name.lstrip("void ").startswith(("(anonymous namespace)::k_", "k_")))
         # kernels of this package: HOT = the distribution / objective / update kernels of the hot path; LAYER = the BNN caller's
-        # particle-batched layer (PL1: the caller's code in the reference, a kernel of this package here)
-        kind = "" if not ours else ("LAYER" if ("k_particle_linear" in name or "k_column_sum" in name) else "HOT")
+        # layers (PL1, CS1 / AB1, PR1: the caller's code in the reference, kernels of this package here)
+        kind = "" if not ours else ("LAYER" if any(f in name for f in ("k_particle_linear", "k_column_sum", "k_particle_rmse")) else "HOT")
         rows.append({"kernel": name[:140], "hot_path": kind == "HOT", "kind": kind or "other", "launches_per_step": n / args.steps,
                      "avg_us": tot / n, "us_per_step": tot / args.steps})
     rows.sort(key=lambda r: -r["us_per_step"])
