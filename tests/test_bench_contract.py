@@ -85,8 +85,11 @@ def test_bench_line_single_rank():
         assert k1[label]["rows"] > 1000000 and 0.2 < k1[label]["frac"] <= 1.0
         assert abs(k1[label]["frac"] - k1[label]["achieved"] / 8000.0) < 1e-9
     assert rec["config"]["discarded_draws"].startswith("skipped") and "c3_reference_draws" in rec["extra_configs"]
+    assert rec["config"]["dense_layers"].startswith("zhusuan.Linear in zhusuan.Sequential")
+    for key in ("c3_torch_linear", "c3_unfused_activations"):      # the same step from torch.nn modules / with torch's activation passes
+        assert rec["extra_configs"][key]["value"] > 1e5 and "torch.nn" in rec["extra_configs"][key]["dense_layers"]
     lib = rec["library"]
-    assert lib["abi"] == 10 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
+    assert lib["abi"] == 11 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
     assert lib["path"].endswith("lib/libzs_hip.so") and rec["env_overrides"] == {}
     assert rec["trial_ms_per_step"]["min"] <= rec["ms_per_step"] <= rec["trial_ms_per_step"]["max"]
     assert roof["traffic_source"] is None or roof["traffic_source"]["measured_in_this_run"] is False

@@ -51,6 +51,29 @@ __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __re
   // thread 2s + 1 forms 1 / sqrt(1 - beta2^t_s); beta^t by squaring (<= 62 double multiplies).  A workgroup has at least
   // 64 threads = 2 * ZS_ADAM_MAX_TENSORS (checked on the host).
   __shared__ T c_step[ZS_ADAM_MAX_TENSORS], c_isq[ZS_ADAM_MAX_TENSORS];
+  const int64_t groups = (n + 3) >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // VEC: every tensor starts at a multiple of 4 and is 16-byte aligned (checked on the host): one tensor per group of four
+  // elements, one 16-byte load per operand.  The loads of a thread's NEXT group are in flight while it works on the current
+  // one, and those of its FIRST group while the workgroup forms the bias corrections below (the step counts are a memory
+  // round trip of their own: at the BNN's 1 503 parameters the kernel is that chain of round trips and nothing else).
+  struct Group { Vec4<T> p, g, m, v; int s; int64_t off; bool live; };
+  auto fetch = [&](int64_t gi) {
+    Group q;
+    q.s = tensor_of(ts, gi << 2);
+    q.off = (gi << 2) - ts.start[q.s];
+    q.live = ts.grad[q.s] != nullptr;                 // no gradient this step: the tensor is left alone
+    const T* gp = q.live ? ts.grad[q.s] + q.off : m + (gi << 2);      // (an address that is valid either way: no branch between loads)
+    q.p = *reinterpret_cast<const Vec4<T>*>(ts.param[q.s] + q.off);
+    q.m = *reinterpret_cast<const Vec4<T>*>(m + (gi << 2));
+    q.v = *reinterpret_cast<const Vec4<T>*>(v + (gi << 2));
+    q.g = *reinterpret_cast<const Vec4<T>*>(gp);
+    return q;
+  };
+  Group cur;
+  bool have = VEC && g < groups;
+  if (have) cur = fetch(g);
   if (hyper) { lr = hyper[0]; beta1 = hyper[1]; beta2 = hyper[2]; eps = hyper[3]; }     // device-resident: graph replays see updates
   if ((int)threadIdx.x < 2 * ts.n_tensors) {
     const int s = threadIdx.x >> 1;
@@ -63,27 +86,38 @@ __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __re
   }
   __syncthreads();
   const T b1w = (T)(1.0 - beta1), b2 = (T)beta2, b2w = (T)(1.0 - beta2), e = (T)eps, gs = (T)grad_scale;
-  const int64_t groups = (n + 3) >> 2;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i0 = g << 2;
-    const int cnt = n - i0 < 4 ? (int)(n - i0) : 4;
-    T pp[4], gg[4], mm[4], vv[4], ss[4], iq[4];
-    bool live[4];
-    T* pdst[4];
-    if (VEC) {
-      // every tensor starts at a multiple of 4 and is 16-byte aligned (checked on the host): one tensor per group
-      const int s = tensor_of(ts, i0);
-      if (!ts.grad[s]) continue;                       // no gradient this step: the tensor is left alone
-      const int64_t off = i0 - ts.start[s];
-      pdst[0] = ts.param[s] + off;
-      const Vec4<T> a = *reinterpret_cast<const Vec4<T>*>(pdst[0]), c = *reinterpret_cast<const Vec4<T>*>(m + i0),
-                    d = *reinterpret_cast<const Vec4<T>*>(v + i0), b = *reinterpret_cast<const Vec4<T>*>(ts.grad[s] + off);
+  auto update = [&](T& pp, T& mm, T& vv, T gg, T ss, T iq) {
+    const T gr = gs * gg;
+    mm = mm + b1w * (gr - mm);                               // exp_avg.lerp_(grad, 1 - beta1)
+    vv = b2 * vv + b2w * (gr * gr);                          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const T denom = sqrt(vv) * iq + e;                       // sqrt(v) / sqrt(bc2) + eps
+    pp = pp - ss * (mm / denom);                             // param.addcdiv_(exp_avg, denom, -lr / bc1)
+  };
+  if (VEC) {
+    while (have) {
+      const int64_t g2 = g + stride;
+      const bool have2 = g2 < groups;
+      Group nxt;
+      if (have2) nxt = fetch(g2);
+      if (cur.live) {
+        const T ss = c_step[cur.s], iq = c_isq[cur.s];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        pp[j] = a.v[j]; gg[j] = b.v[j]; mm[j] = c.v[j]; vv[j] = d.v[j];
-        ss[j] = c_step[s]; iq[j] = c_isq[s]; live[j] = true;
+        for (int j = 0; j < 4; ++j) update(cur.p.v[j], cur.m.v[j], cur.v.v[j], cur.g.v[j], ss, iq);
+        *reinterpret_cast<Vec4<T>*>(ts.param[cur.s] + cur.off) = cur.p;
+        *reinterpret_cast<Vec4<T>*>(m + (g << 2)) = cur.m;
+        *reinterpret_cast<Vec4<T>*>(v + (g << 2)) = cur.v;
       }
-    } else {
+      if (have2) cur = nxt;
+      g = g2;
+      have = have2;
+    }
+  } else {
+    for (; g < groups; g += stride) {
+      const int64_t i0 = g << 2;
+      const int cnt = n - i0 < 4 ? (int)(n - i0) : 4;
+      T pp[4], gg[4], mm[4], vv[4], ss[4], iq[4];
+      bool live[4];
+      T* pdst[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t i = i0 + (j < cnt ? j : 0);   // clamped: unconditional loads
@@ -95,23 +129,8 @@ __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __re
         gg[j] = ts.grad[s] ? ts.grad[s][off] : (T)0;
         ss[j] = c_step[s]; iq[j] = c_isq[s];
       }
-    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const T gr = gs * gg[j];
-      mm[j] = mm[j] + b1w * (gr - mm[j]);                      // exp_avg.lerp_(grad, 1 - beta1)
-      vv[j] = b2 * vv[j] + b2w * (gr * gr);                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-      const T denom = sqrt(vv[j]) * iq[j] + e;                 // sqrt(v) / sqrt(bc2) + eps
-      pp[j] = pp[j] - ss[j] * (mm[j] / denom);                 // param.addcdiv_(exp_avg, denom, -lr / bc1)
-    }
-    if (VEC) {
-      Vec4<T> a, c, d;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { a.v[j] = pp[j]; c.v[j] = mm[j]; d.v[j] = vv[j]; }
-      *reinterpret_cast<Vec4<T>*>(pdst[0]) = a;
-      *reinterpret_cast<Vec4<T>*>(m + i0) = c;
-      *reinterpret_cast<Vec4<T>*>(v + i0) = d;
-    } else {
+      for (int j = 0; j < 4; ++j) update(pp[j], mm[j], vv[j], gg[j], ss[j], iq[j]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (live[j]) { *pdst[j] = pp[j]; m[i0 + j] = mm[j]; v[i0 + j] = vv[j]; }
