@@ -71,9 +71,31 @@ __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __re
     q.g = *reinterpret_cast<const Vec4<T>*>(gp);
     return q;
   };
+  // element form (tensors of any length and alignment): four consecutive elements, each finds its own tensor
+  struct Scalars { T p[4], g[4], m[4], v[4]; T* dst[4]; int s[4]; bool live[4]; };
+  auto fetch_scalars = [&](int64_t gi) {
+    Scalars q;
+    const int64_t i0 = gi << 2;
+    const int cnt = n - i0 < 4 ? (int)(n - i0) : 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = i0 + (j < cnt ? j : 0);   // clamped: unconditional loads
+      const int s = tensor_of(ts, i);
+      const int64_t off = i - ts.start[s];
+      q.s[j] = s;
+      q.dst[j] = ts.param[s] + off;
+      q.live[j] = j < cnt && ts.grad[s] != nullptr;
+      const T* gp = ts.grad[s] ? ts.grad[s] + off : m + i;
+      q.p[j] = *q.dst[j]; q.m[j] = m[i]; q.v[j] = v[i]; q.g[j] = *gp;
+    }
+    return q;
+  };
   Group cur;
+  Scalars curS;
   bool have = VEC && g < groups;
+  int64_t gS = g;
   if (have) cur = fetch(g);
+  if (!VEC && gS < groups) curS = fetch_scalars(gS);
   if (hyper) { lr = hyper[0]; beta1 = hyper[1]; beta2 = hyper[2]; eps = hyper[3]; }     // device-resident: graph replays see updates
   if ((int)threadIdx.x < 2 * ts.n_tensors) {
     const int s = threadIdx.x >> 1;
@@ -112,28 +134,21 @@ __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __re
       have = have2;
     }
   } else {
-    for (; g < groups; g += stride) {
-      const int64_t i0 = g << 2;
-      const int cnt = n - i0 < 4 ? (int)(n - i0) : 4;
-      T pp[4], gg[4], mm[4], vv[4], ss[4], iq[4];
-      bool live[4];
-      T* pdst[4];
+    bool haveS = gS < groups;
+    while (haveS) {
+      const int64_t i0 = gS << 2, g2 = gS + stride;
+      const bool have2 = g2 < groups;
+      Scalars nxt;
+      if (have2) nxt = fetch_scalars(g2);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t i = i0 + (j < cnt ? j : 0);   // clamped: unconditional loads
-        const int s = tensor_of(ts, i);
-        const int64_t off = i - ts.start[s];
-        pdst[j] = ts.param[s] + off;
-        pp[j] = *pdst[j]; mm[j] = m[i]; vv[j] = v[i];
-        live[j] = j < cnt && ts.grad[s] != nullptr;
-        gg[j] = ts.grad[s] ? ts.grad[s][off] : (T)0;
-        ss[j] = c_step[s]; iq[j] = c_isq[s];
+        T pp = curS.p[j], mm = curS.m[j], vv = curS.v[j];
+        update(pp, mm, vv, curS.g[j], c_step[curS.s[j]], c_isq[curS.s[j]]);
+        if (curS.live[j]) { *curS.dst[j] = pp; m[i0 + j] = mm; v[i0 + j] = vv; }
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) update(pp[j], mm[j], vv[j], gg[j], ss[j], iq[j]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (live[j]) { *pdst[j] = pp[j]; m[i0 + j] = mm[j]; v[i0 + j] = vv[j]; }
+      if (have2) curS = nxt;
+      gS = g2;
+      haveS = have2;
     }
   }
   // Every workgroup has read the step counts -- the values have come back and gone into LDS -- before it takes its
