@@ -502,6 +502,7 @@ _KERNEL_ENTRY = [("k_column_sum", "zs_column_sum_f32"), ("k_logjoint_bwd", "zs_l
                  ("k_normal_sample_multi_bwd", "zs_normal_sample_logprob_multi_bwd_f32"),
                  ("k_normal_sample_multi", "zs_normal_sample_logprob_multi_f32"),
                  ("k_particle_linear_bwd", "zs_particle_linear_bwd_f32"), ("k_particle_linear", "zs_particle_linear_f32"),
+                 ("k_particle_mlp_bwd", "zs_particle_mlp_bwd_f32"), ("k_particle_mlp", "zs_particle_mlp_f32"), ("k_particle_rmse", "zs_particle_rmse_f32"),
                  ("k_bern_logprob_bwd", "zs_bernoulli%s_logprob_bwd_f32"), ("k_bern_logprob", "zs_bernoulli%s_logprob_f32"),
                  ("k_sample_tile<0", "zs_normal_sample_logprob_f32"), ("k_sample_tile<1", "zs_logistic_sample_logprob_f32"),
                  ("k_logprob_bwd_ksum<0", "zs_normal_logprob_bwd_ksum_f32"), ("k_logprob_krep<0", "zs_normal_logprob_f32"),

@@ -462,6 +462,30 @@ int zs_particle_linear_bwd_f32(const float* h, int64_t h_stride_k, const float* 
                                float* workspace, int64_t workspace_len, uint32_t* tickets, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * PM1  The whole particle-batched network of the BNN caller (bnn_vi.py:27-48: the loop over layers, each PL1 above, ReLU after
+ * every layer but the last) in one launch forward and one backward.  layers[l] describes layer l: w [K, n_out, n_in + 1],
+ * out [K, B, n_out] (written by the forward call -- every layer's activation, the last one is the network's output -- and read
+ * back by the backward call), gw [K, n_out, n_in + 1] (written by the backward call); layers[l].n_in == layers[l - 1].n_out.
+ * x: [B, n_0] shared by the particles (x_stride_k = 0) or [K, B, n_0] (x_stride_k = B * n_0).  Backward: gout is the gradient
+ * w.r.t. the last layer's output [K, B, n_L]; gx [K, B, n_0] optional (NULL: not formed).  Outputs equal a chain of PL1 calls bit
+ * for bit.  1 <= n_layers <= ZS_PM_MAX_LAYERS, widths as PL1, and the LDS layouts of both directions must fit (ZS_ENOTSUP
+ * otherwise: use PL1 per layer).  workspace: >= K * ceil(B / 16) * sum_l (n_out_l * (n_in_l + 1) + 3) elements always suffices;
+ * tickets: K zero-initialised device words, handed back at zero.  The table is a HOST array (copied into the kernel arguments).
+ * -------------------------------------------------------------------------*/
+#define ZS_PM_MAX_LAYERS 4
+typedef struct zs_pm_layer {
+  const void* w;
+  void* out;
+  void* gw;      /* backward only */
+  int64_t n_in, n_out;
+} zs_pm_layer;
+int zs_particle_mlp_f32(const float* x, int64_t x_stride_k, const zs_pm_layer* layers, int n_layers, int64_t K, int64_t B,
+                        void* stream);
+int zs_particle_mlp_bwd_f32(const float* x, int64_t x_stride_k, const zs_pm_layer* layers, int n_layers, const float* gout,
+                            float* gx, int64_t K, int64_t B, float* workspace, int64_t workspace_len, uint32_t* tickets,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------
  * CS1  Column sums of a row-major [rows, cols] matrix: out[c] = sum_r x[r, c].  The bias gradient of the callers' dense
  * layers (torch.nn.Linear in the reference's examples, variational_autoencoder/vae_mnist.py:22-28, iwae.py:40-47:
  * grad_bias = grad_output.sum(0)) -- the one reduction of their backward pass that is not a GEMM; caller-side glue like
@@ -537,6 +561,8 @@ int zs_particle_linear_bwd_f64(const double* h, int64_t h_stride_k, const double
 int zs_column_sum_f64(const double* x, double* out, int64_t rows, int64_t cols, double* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream);
 int zs_dense_act_bwd_f64(const double* g, const double* y, int act, double* gpre, double* gbias, int64_t rows, int64_t cols, double* workspace, int64_t workspace_len, uint32_t* tickets, int64_t n_tickets, void* stream);
 int zs_particle_rmse_f64(const double* pred, const double* y, double* out, int64_t K, int64_t B, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
+int zs_particle_mlp_f64(const double* x, int64_t x_stride_k, const zs_pm_layer* layers, int n_layers, int64_t K, int64_t B, void* stream);
+int zs_particle_mlp_bwd_f64(const double* x, int64_t x_stride_k, const zs_pm_layer* layers, int n_layers, const double* gout, double* gx, int64_t K, int64_t B, double* workspace, int64_t workspace_len, uint32_t* tickets, void* stream);
 int zs_adam_step_f64(double* const* param_ptrs, const double* const* grad_ptrs, const int64_t* starts, int n_tensors, double* exp_avg, double* exp_avg_sq, int64_t* steps, uint32_t* ticket, int64_t n, double lr, double beta1, double beta2, double eps, double grad_scale, const double* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -192,6 +192,46 @@ class Raw(object):
         assert int(tk.abs().sum().item()) == 0
         return gpre.cpu().numpy(), gb.cpu().numpy()
 
+    # ---- PM1
+    def _pm_table(self, ws, outs, gws):
+        L = len(ws)
+        table = (_hip.PMLayer * L)()
+        for l in range(L):
+            table[l].w, table[l].out = _hip.ptr(ws[l]), _hip.ptr(outs[l])
+            table[l].gw = _hip.ptr(gws[l]) if gws is not None else None
+            table[l].n_in, table[l].n_out = ws[l].shape[2] - 1, ws[l].shape[1]
+        return table
+
+    def pm(self, x, ws):
+        K, B = ws[0].shape[0], x.shape[-2]
+        shared = x.ndim == 2
+        xt, wt = self.t(x), [self.t(w) for w in ws]
+        outs = [torch.full((K, B, w.shape[1]), float("nan"), dtype=self.dtype, device=self.dev) for w in ws]
+        table = self._pm_table(wt, outs, None)
+        self.k.call("zs_particle_mlp" + self.sfx, _hip.ptr(xt), 0 if shared else B * x.shape[-1], ctypes.byref(table), len(ws), K, B,
+                    self.stream())
+        self.sync()
+        return [o.cpu().numpy() for o in outs]
+
+    def pm_bwd(self, x, ws, outs, gout, want_gx):
+        K, B = ws[0].shape[0], x.shape[-2]
+        shared = x.ndim == 2
+        xt, wt, ot, gt = self.t(x), [self.t(w) for w in ws], [self.t(o) for o in outs], self.t(gout)
+        slab = sum(w.shape[1] * w.shape[2] + 3 for w in ws)
+        part = torch.full((K * ((B + 15) // 16) * slab + 4,), float("nan"), dtype=self.dtype, device=self.dev)
+        tk = torch.zeros(max(K, 1), dtype=torch.int32, device=self.dev)
+        gx = gws = None
+        for scale in (3.0, 1.0):       # twice on one workspace (tickets back at zero, no stale partials)
+            gs = gt * scale
+            gws = [torch.full(tuple(w.shape), float("nan"), dtype=self.dtype, device=self.dev) for w in ws]
+            gx = torch.full((K, B, x.shape[-1]), float("nan"), dtype=self.dtype, device=self.dev) if want_gx else None
+            table = self._pm_table(wt, ot, gws)
+            self.k.call("zs_particle_mlp_bwd" + self.sfx, _hip.ptr(xt), 0 if shared else B * x.shape[-1], ctypes.byref(table), len(ws),
+                        _hip.ptr(gs), _hip.ptr(gx), K, B, _hip.ptr(part), part.numel(), _hip.ptr(tk), self.stream())
+            self.sync()
+        assert int(tk.abs().sum().item()) == 0
+        return (gx.cpu().numpy() if want_gx else None), [g.cpu().numpy() for g in gws]
+
     # ---- PR1
     def rmse(self, pred, y):
         K, B = pred.shape
@@ -717,3 +757,88 @@ def test_hip_particle_rmse(hip, hip64, K, B):
     np.testing.assert_allclose(a, ref, rtol=2e-6)
     assert a == hip.rmse(pred, y)                                       # deterministic
     np.testing.assert_allclose(hip64.rmse(pred, y), ref, rtol=1e-12)
+
+
+# ---------------------------------------------------------------- PM1: the whole particle-batched network in one launch each way
+PM_NETS = [((13, 50, 1), 10, 512, True), ((13, 50, 1), 10, 4096, True), ((13, 50, 1), 3, 7, False), ((5, 8, 8, 3), 4, 70, False),
+           ((4, 4, 4, 4, 2), 2, 33, True), ((13, 50, 1), 512, 114, True), ((7, 9), 3, 20, True), ((3, 16, 2), 1, 1, False),
+           ((13, 50, 1), 10, 0, True)]
+
+
+def _pm_inputs(sizes, K, B, shared, seed):
+    rng = np.random.RandomState(seed)
+    x = rng.standard_normal((B, sizes[0]) if shared else (K, B, sizes[0])).astype(np.float32)
+    ws = [rng.standard_normal((K, sizes[l + 1], sizes[l] + 1)).astype(np.float32) for l in range(len(sizes) - 1)]
+    gout = rng.standard_normal((K, B, sizes[-1])).astype(np.float32)
+    return x, ws, gout
+
+
+def _pm_truth(x, ws, gout, shared):
+    """The caller's op sequence (bnn_vi.py:36-48) in float64 through torch autograd."""
+    K = ws[0].shape[0]
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in ws]
+    h = xt.unsqueeze(0).expand(K, *xt.shape) if shared else xt
+    for l, w in enumerate(wt):
+        h = torch.cat((h, torch.ones(*h.shape[:-1], 1, dtype=torch.float64)), -1)
+        h = torch.matmul(w.unsqueeze(1), h.unsqueeze(-1)).squeeze(-1) / np.sqrt(h.shape[2])
+        if l < len(wt) - 1:
+            h = torch.relu(h)
+    gs = torch.autograd.grad(h, [xt] + wt, torch.tensor(gout, dtype=torch.float64)) if h.numel() else [torch.zeros_like(xt)] + [torch.zeros_like(w) for w in wt]
+    return h.detach().numpy(), gs[0].numpy(), [g.numpy() for g in gs[1:]]
+
+
+def _pm_check(raw, raw_chain, sizes, K, B, shared, tol):
+    x, ws, gout = _pm_inputs(sizes, K, B, shared, K + B + len(sizes))
+    outs = raw.pm(x, ws)
+    truth, tgx, tgw = _pm_truth(x, ws, gout, shared)
+    if B:
+        np.testing.assert_allclose(outs[-1], truth, rtol=tol, atol=tol * max(np.abs(truth).max(), 1))
+    # the chain of PL1 calls: bit-identical
+    h = x
+    for l, w in enumerate(ws):
+        h = raw_chain.pl(h, w, l < len(ws) - 1)
+        assert np.array_equal(h, outs[l]), l
+    for want_gx in (False, True):
+        gx, gws = raw.pm_bwd(x, ws, outs, gout, want_gx)
+        for l in range(len(ws)):
+            np.testing.assert_allclose(gws[l], tgw[l], rtol=tol * 20, atol=tol * 20 * max(np.abs(tgw[l]).max(), 1), err_msg="gw%d" % l)
+        if want_gx and B:
+            ref = tgx if not shared else None
+            if ref is not None:
+                np.testing.assert_allclose(gx, ref, rtol=tol * 20, atol=tol * 20 * max(np.abs(ref).max(), 1))
+            else:
+                np.testing.assert_allclose(gx.astype(np.float64).sum(0), tgx, rtol=tol * 40, atol=tol * 40 * max(np.abs(tgx).max(), 1))
+
+
+def test_c_oracle_particle_mlp(orc, orc64):
+    for sizes, K, B, shared in PM_NETS:
+        if K * B > 6000:
+            continue
+        _pm_check(orc, orc, sizes, K, B, shared, 2e-6)
+        _pm_check(orc64, orc64, sizes, K, B, shared, 1e-13)
+    x, ws, gout = _pm_inputs((13, 50, 1), 2, 4, True, 0)
+    with pytest.raises(RuntimeError, match="code -2"):
+        orc.pm(x, ws * 3)                                    # six layers
+    with pytest.raises(RuntimeError, match="code -1"):
+        orc.pm(x, [ws[0], ws[0]])                            # widths do not chain
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,K,B,shared", PM_NETS)
+def test_hip_particle_mlp(hip, hip64, sizes, K, B, shared):
+    _pm_check(hip, hip, sizes, K, B, shared, 3e-6)
+    if K * B <= 6000:
+        _pm_check(hip64, hip64, sizes, K, B, shared, 1e-13)
+
+
+@pytest.mark.gpu
+def test_hip_particle_mlp_rejects(hip):
+    x, ws, gout = _pm_inputs((13, 50, 1), 2, 4, True, 0)
+    with pytest.raises(RuntimeError, match="code -2"):
+        hip.pm(x, ws * 3)
+    with pytest.raises(RuntimeError, match="code -1"):
+        hip.pm(x, [ws[0], ws[0]])
+    big = [np.zeros((1, 200, 201), np.float32), np.zeros((1, 200, 201), np.float32)]          # does not fit the LDS
+    with pytest.raises(RuntimeError, match="code -2"):
+        hip.pm(np.zeros((2, 200), np.float32), big)

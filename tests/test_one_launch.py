@@ -48,20 +48,27 @@ def _grads(model, loss):
     return [g.detach().cpu().numpy() for g in torch.autograd.grad(loss, list(model.parameters()))]
 
 
-def test_bnn_step_is_five_kernels_each_way_and_equals_the_reference_op_sequence(dev):
-    """BNN-VI (examples/bayesian_neural_nets/bnn_vi.py): with the fused layer the forward of the objective is
-    [the two discarded draws] + ONE sampling launch for both weight matrices + one launch per layer + ONE launch for all five
-    log-probs and the objective; backward mirrors it.  Value and gradients equal the reference's op sequence (repeat + cat +
+def test_bnn_step_is_one_launch_per_phase_and_equals_the_reference_op_sequence(dev):
+    """BNN-VI (examples/bayesian_neural_nets/bnn_vi.py): with the fused network the forward of the objective is
+    [the two discarded draws] + ONE sampling launch for both weight matrices + ONE launch for the network + the RMSE diagnostic
+    + ONE launch for all five log-probs and the objective; backward mirrors it (three launches).  Value and gradients equal the reference's op sequence (repeat + cat +
     matmul + div + relu, one log-prob kernel per node) on the same epsilons."""
     model, obs, eps = _bnn(dev, "fused")
     with launches() as names, zs.inject_epsilon(eps):
         loss = model(obs)
         n_fwd = len(names)
         g = _grads(model, loss)
-    assert names[:n_fwd] == ["zs_normal_sample_logprob"] * 2 + ["zs_normal_sample_logprob_multi"] + ["zs_particle_linear"] * 2 + \
-        ["zs_particle_rmse", "zs_logjoint_scalar"]
-    assert names[n_fwd:] == ["zs_logjoint_scalar_bwd"] + ["zs_particle_linear_bwd"] * 2 + ["zs_normal_sample_logprob_multi_bwd"]
+    assert names[:n_fwd] == ["zs_normal_sample_logprob"] * 2 + ["zs_normal_sample_logprob_multi", "zs_particle_mlp", "zs_particle_rmse",
+                             "zs_logjoint_scalar"]
+    assert names[n_fwd:] == ["zs_logjoint_scalar_bwd", "zs_particle_mlp_bwd", "zs_normal_sample_logprob_multi_bwd"]
     rmse = float(model.generator.cache["rmse"])
+    # one launch per layer (PL1): the same numbers bit for bit
+    pl_model, _, _ = _bnn(dev, "per_layer")
+    with launches() as pl_names, zs.inject_epsilon(eps):
+        pl_loss = pl_model(obs)
+        g_pl = _grads(pl_model, pl_loss)
+    assert pl_names.count("zs_particle_linear") == 2 and pl_names.count("zs_particle_linear_bwd") == 2
+    assert float(pl_loss.detach()) == float(loss.detach()) and all(np.array_equal(a, b) for a, b in zip(g, g_pl))
     ref_model, _, _ = _bnn(dev, "materialize")
     with zs.inject_epsilon(eps):
         ref_loss = ref_model(obs)
@@ -86,7 +93,7 @@ def test_skip_discarded_draws_draws_each_latent_once(dev):
         ref = float(model(obs).detach())
     with zs.skip_discarded_draws(), launches() as names, zs.inject_epsilon(eps[2:]):      # only the USED draws are consumed
         loss = model(obs)
-    assert names == ["zs_normal_sample_logprob_multi"] + ["zs_particle_linear"] * 2 + ["zs_particle_rmse", "zs_logjoint_scalar"]
+    assert names == ["zs_normal_sample_logprob_multi", "zs_particle_mlp", "zs_particle_rmse", "zs_logjoint_scalar"]
     assert float(loss.detach()) == ref
     # VAE: sample + objective = 2 launches forward, objective + sampler backward
     vae = vae_mnist.build(16, hidden=32, device=dev)
@@ -369,3 +376,30 @@ def test_zhusuan_sequential_fuses_linear_with_its_activation(dev):
     np.testing.assert_allclose(float(lb.detach()), float(la.detach()), rtol=1e-6)
     for a, b in zip(ga, gb):
         np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6 * max(np.abs(a).max(), 1))
+
+
+def test_particle_mlp_is_the_layer_chain_in_one_launch(dev):
+    """zhusuan.particle_mlp: up to four layers that fit the LDS = one launch each way (PM1), bit-identical to the chain of
+    zhusuan.particle_linear calls; deeper / wider networks take the chain."""
+    for sizes, K, B, shared, fused in [((13, 50, 1), 4, 33, True, True), ((6, 10, 10, 3), 3, 20, False, True),
+                                       ((4, 4, 4, 4, 4, 2), 2, 9, True, False), ((300, 8, 2), 2, 5, True, False)]:
+        torch.manual_seed(len(sizes) + B)
+        x = torch.randn(*((B, sizes[0]) if shared else (K, B, sizes[0])), device=dev, requires_grad=True)
+        ws = [torch.randn(K, sizes[l + 1], sizes[l] + 1, device=dev, requires_grad=True) for l in range(len(sizes) - 1)]
+        with launches() as names:
+            y = zs.particle_mlp(x, ws)
+            coef = torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)
+            g = torch.autograd.grad((y * coef).sum(), [x] + ws)
+        assert (names == ["zs_particle_mlp", "zs_particle_mlp_bwd"]) == fused, names
+        h = x
+        for l, w in enumerate(ws):
+            h = zs.particle_linear(h, w, relu=l < len(ws) - 1)
+        g_ref = torch.autograd.grad((h * coef).sum(), [x] + ws)
+        assert torch.equal(y, h)
+        for a, b in zip(g[1:], g_ref[1:]):
+            assert torch.equal(a, b)
+        np.testing.assert_allclose(g[0].cpu().numpy(), g_ref[0].cpu().numpy(), rtol=1e-5, atol=1e-6)     # (shared x: summed over K by torch)
+    with pytest.raises(RuntimeError, match="does not match"):
+        zs.particle_mlp(torch.zeros(3, 4, device=dev), [torch.zeros(2, 5, 5, device=dev), torch.zeros(2, 2, 7, device=dev)])
+    with pytest.raises(ValueError, match="at least one layer"):
+        zs.particle_mlp(torch.zeros(3, 4, device=dev), [])

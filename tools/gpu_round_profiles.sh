@@ -10,6 +10,7 @@ done
 echo "step tables done"
 # the same tables with the reference's discarded draw executed (the package default) and, for the BNN, round 2's batched-GEMM layer
 python tools/step_kernels.py --config C5 --tuned-gemm --reference-draws 2>/dev/null | grep -v amdgpu.ids | head -1 > gpurun_out/${TAG}_step_variants.txt
+python tools/step_kernels.py --config C5 --tuned-gemm --bnn-layer per_layer 2>/dev/null | grep -v amdgpu.ids | head -1 >> gpurun_out/${TAG}_step_variants.txt
 python tools/step_kernels.py --config C5 --tuned-gemm --bnn-layer bmm 2>/dev/null | grep -v amdgpu.ids | head -1 >> gpurun_out/${TAG}_step_variants.txt
 python tools/step_kernels.py --config C2 --tuned-gemm --reference-draws 2>/dev/null | grep -v amdgpu.ids | head -1 >> gpurun_out/${TAG}_step_variants.txt
 python tools/small_kernels_timing.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${TAG}_small_kernels.txt; echo "small kernels rc=$?"

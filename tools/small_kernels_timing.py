@@ -55,6 +55,26 @@ def main():
         timed("PL1 bwd " + tag + (" (gw only)" if shared else ""), "zs_particle_linear_bwd_f32",
               lambda: lib.call("zs_particle_linear_bwd_f32", P(h), hsk, P(w), P(out), P(gout), None if shared else P(gh), P(gw), K, B,
                                n_in, n_out, int(relu), P(part), part.numel(), P(tk), st))
+    # ---- PM1: config 5's whole network [13, 50, 1] in one launch each way
+    for (K, B) in [(10, 512), (10, 4096)]:
+        sizes = (13, 50, 1)
+        x = torch.randn(B, sizes[0], device=dev)
+        ws = [torch.randn(K, sizes[l + 1], sizes[l] + 1, device=dev) for l in range(2)]
+        outs = [torch.empty(K, B, sizes[l + 1], device=dev) for l in range(2)]
+        gws = [torch.empty_like(w) for w in ws]
+        gout = torch.randn(K, B, 1, device=dev)
+        slab = sum(w.shape[1] * w.shape[2] + 3 for w in ws)
+        part = torch.empty(K * ((B + 15) // 16) * slab, device=dev)
+        tk = torch.zeros(64, dtype=torch.int32, device=dev)
+        table = (_hip.PMLayer * 2)()
+        for l in range(2):
+            table[l].w, table[l].out, table[l].gw = P(ws[l]), P(outs[l]), P(gws[l])
+            table[l].n_in, table[l].n_out = sizes[l], sizes[l + 1]
+        tag = "K=%d B=%d 13->50->1" % (K, B)
+        timed("PM1 fwd " + tag, "zs_particle_mlp_f32",
+              lambda: lib.call("zs_particle_mlp_f32", P(x), 0, ctypes.byref(table), 2, K, B, st))
+        timed("PM1 bwd " + tag, "zs_particle_mlp_bwd_f32",
+              lambda: lib.call("zs_particle_mlp_bwd_f32", P(x), 0, ctypes.byref(table), 2, P(gout), None, K, B, P(part), part.numel(), P(tk), st))
     # ---- CS1: the bias gradients of the IWAE (12 800 rows) and VAE (512 rows) steps
     for rows, cols in [(12800, 500), (12800, 784), (12800, 40), (512, 500), (512, 784)]:
         x = torch.randn(rows, cols, device=dev)

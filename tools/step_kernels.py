@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--reference-draws", action="store_true",
                     help="execute the draw the reference's objectives discard (package default); the tool, like bench.py, runs "
                          "inside zhusuan.skip_discarded_draws() otherwise")
-    ap.add_argument("--bnn-layer", default="fused", choices=["fused", "bmm", "materialize"])
+    ap.add_argument("--bnn-layer", default="fused", choices=["fused", "per_layer", "bmm", "materialize"])
     ap.add_argument("--dense", default="fused", choices=["fused", "zhusuan", "torch"],
                     help="fused: zhusuan.Linear in zhusuan.Sequential (AB1); zhusuan: zhusuan.Linear (CS1 bias gradient) in nn.Sequential; torch: torch.nn")
     ap.add_argument("--out", default=None)
@@ -129,7 +129,7 @@ def main():
         ours = "k_" in name and ("zs" in name or name.lstrip("void ").startswith(("(anonymous namespace)::k_", "k_")))
         # kernels of this package: HOT = the distribution / objective / update kernels of the hot path; LAYER = the BNN caller's
         # layers (PL1, CS1 / AB1, PR1: the caller's code in the reference, kernels of this package here)
-        kind = "" if not ours else ("LAYER" if any(f in name for f in ("k_particle_linear", "k_column_sum", "k_particle_rmse")) else "HOT")
+        kind = "" if not ours else ("LAYER" if any(f in name for f in ("k_particle_linear", "k_particle_mlp", "k_column_sum", "k_particle_rmse")) else "HOT")
         rows.append({"kernel": name[:140], "hot_path": kind == "HOT", "kind": kind or "other", "launches_per_step": n / args.steps,
                      "avg_us": tot / n, "us_per_step": tot / args.steps})
     rows.sort(key=lambda r: -r["us_per_step"])

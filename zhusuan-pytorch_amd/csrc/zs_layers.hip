@@ -53,6 +53,32 @@ __device__ __forceinline__ void pl_stage_gpre(T* __restrict__ dst, const T* __re
 template <typename T>
 __host__ __device__ __forceinline__ bool pl_al(const void* p) { return (((uintptr_t)p) & (4 * sizeof(T) - 1)) == 0; }
 
+// the last arrival's reduction: gk[e] = (sum over the tiles t, in tile order, of p0[t * tile_stride + e]) / p for e < nW.
+// Four consecutive weight elements per thread and load when everything is 16-byte aligned, 16 tiles in flight: ntiles = 64
+// (B = 4096) is 4 rounds instead of 3 x 8 rounds of single floats.  Deterministic.
+template <typename T>
+__device__ __forceinline__ void pl_reduce_tiles(const T* __restrict__ p0, int64_t tile_stride, T* __restrict__ gk, int nW, int ntiles,
+                                                T p) {
+  const bool v4 = (tile_stride & 3) == 0 && pl_al<T>(p0) && pl_al<T>(gk);
+  const int nv = v4 ? (nW >> 2) : 0;
+  for (int e = threadIdx.x; e < nv; e += 256) {
+    V4<T> s = {{(T)0, (T)0, (T)0, (T)0}};
+#pragma unroll 16
+    for (int t = 0; t < ntiles; ++t) {
+      const V4<T> q = reinterpret_cast<const V4<T>*>(p0 + (int64_t)t * tile_stride)[e];
+      s.v[0] += q.v[0]; s.v[1] += q.v[1]; s.v[2] += q.v[2]; s.v[3] += q.v[3];
+    }
+    s.v[0] /= p; s.v[1] /= p; s.v[2] /= p; s.v[3] /= p;
+    reinterpret_cast<V4<T>*>(gk)[e] = s;
+  }
+  for (int e = (nv << 2) + threadIdx.x; e < nW; e += 256) {
+    T s = (T)0;
+#pragma unroll 16
+    for (int t = 0; t < ntiles; ++t) s += p0[(int64_t)t * tile_stride + e];
+    gk[e] = s / p;
+  }
+}
+
 // forward: w[k] (padded rows: lanes of a wavefront differ in the output unit o) and the h tile (flat) are staged in LDS;
 // the outputs of a tile are one contiguous run of nb * n_out values: consecutive lanes take consecutive (b, o) pairs ->
 // coalesced stores
@@ -159,28 +185,7 @@ __global__ __launch_bounds__(256) void k_particle_linear_bwd(const T* __restrict
   }
   __syncthreads();
   if (last) {
-    // four consecutive weight elements per thread and load (the partials of a tile are nW contiguous values, 16-byte aligned
-    // when nW % 4 == 0), 16 tiles in flight: ntiles = 64 (B = 4096) is 4 rounds instead of 3 x 8 rounds of single floats
-    const T* __restrict__ p0 = part + (int64_t)k * ntiles * nW;
-    T* __restrict__ gk = gw + (int64_t)k * nW;
-    const bool v4 = (nW & 3) == 0 && pl_al<T>(p0) && pl_al<T>(gk);
-    const int nv = v4 ? (nW >> 2) : 0;
-    for (int e = threadIdx.x; e < nv; e += 256) {
-      V4<T> s = {{(T)0, (T)0, (T)0, (T)0}};
-#pragma unroll 16
-      for (int t = 0; t < ntiles; ++t) {                                    // tile order: deterministic
-        const V4<T> q = reinterpret_cast<const V4<T>*>(p0 + (int64_t)t * nW)[e];
-        s.v[0] += q.v[0]; s.v[1] += q.v[1]; s.v[2] += q.v[2]; s.v[3] += q.v[3];
-      }
-      s.v[0] /= p; s.v[1] /= p; s.v[2] /= p; s.v[3] /= p;
-      reinterpret_cast<V4<T>*>(gk)[e] = s;
-    }
-    for (int e = (nv << 2) + threadIdx.x; e < nW; e += 256) {
-      T s = (T)0;
-#pragma unroll 16
-      for (int t = 0; t < ntiles; ++t) s += p0[(int64_t)t * nW + e];
-      gk[e] = s / p;
-    }
+    pl_reduce_tiles<T>(part + (int64_t)k * ntiles * nW, nW, gw + (int64_t)k * nW, nW, ntiles, p);
     if (threadIdx.x == 0) ticket_return(tickets + k);
   }
 }
@@ -247,8 +252,307 @@ int particle_linear_bwd(const T* h, int64_t hsk, const T* w, const T* out, const
   return 0;
 }
 
+// ================================================================ PM1: the whole particle-batched network in one launch each way
+// The BNN caller's network is a loop over PL1 layers (bnn_vi.py:27-48); at its shapes ([13, 50, 1]: 751 weights per particle)
+// every layer is a launch and, backward, a cross-workgroup hand-off of its own.  PM1 walks all layers inside ONE workgroup per
+// (tile of batch rows, particle): forward, the weights of every layer and the input tile are staged in LDS in one round of
+// loads and the activations ping-pong between two LDS buffers (each layer's output also goes to global memory: backward needs
+// it); backward, the tile's activations, the incoming gradient and the weights are staged once, the gradient walks the layers
+// in reverse inside LDS, every layer's PARTIAL weight gradient goes to the tile's slab of the workspace, and ONE hand-off (a
+// ticket per particle) lets the last tile of a particle add up the slabs of all layers in tile order.  ReLU after every layer
+// but the last, as the caller has it.  Same arithmetic, in the same order, as a chain of PL1 launches (bit-identical outputs).
+constexpr int PM_MAX_LAYERS = ZS_PM_MAX_LAYERS;
+template <typename T>
+struct PMArgs {
+  const T* w[PM_MAX_LAYERS];
+  T* out[PM_MAX_LAYERS];
+  T* gw[PM_MAX_LAYERS];
+  int n[PM_MAX_LAYERS + 1];      // widths: n[0] inputs, n[l + 1] outputs of layer l
+  int woff[PM_MAX_LAYERS];       // LDS offset of layer l's staged weights (forward: rows padded to an odd length; backward: flat)
+  int ioff[PM_MAX_LAYERS];       // backward: LDS offset of the tile of layer l's INPUT (x for l = 0, the activation of layer l - 1)
+  int poff[PM_MAX_LAYERS];       // offset of layer l's partial weight gradient inside a tile's workspace slab (multiples of 4)
+  int L, maxw, slab;
+};
+__host__ __device__ __forceinline__ int pm_pad4(int v) { return (v + 3) & ~3; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_particle_mlp(const PMArgs<T> A, const T* __restrict__ x, int64_t xsk, int B, int ntiles,
+                                                      int bt) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int AS = pm_pad4(bt * A.maxw);
+  T* cur = reinterpret_cast<T*>(smem_raw);         // [bt][width] flat: the input of the layer at hand
+  T* nxt = cur + AS;
+  T* wsm = nxt + AS;
+  const int k = blockIdx.x / ntiles, tile = blockIdx.x - k * ntiles;
+  const int b0 = tile * bt, nb = B - b0 < bt ? B - b0 : bt;
+  const T* __restrict__ xk = x + (int64_t)k * xsk + (int64_t)b0 * A.n[0];
+  pl_stage<T>(cur, xk, nb * A.n[0], pl_al<T>(xk));
+#pragma unroll
+  for (int l = 0; l < PM_MAX_LAYERS; ++l) {
+    if (l >= A.L) break;
+    const int n_in = A.n[l], n_out = A.n[l + 1], WS = pl_odd(n_in + 1);
+    const T* __restrict__ wk = A.w[l] + (int64_t)k * n_out * (n_in + 1);
+    T* __restrict__ wl = wsm + A.woff[l];
+    for (int e = threadIdx.x; e < n_out * (n_in + 1); e += 256) {
+      const int o = e / (n_in + 1), i = e - o * (n_in + 1);
+      wl[o * WS + i] = wk[e];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < PM_MAX_LAYERS; ++l) {
+    if (l >= A.L) break;
+    const int n_in = A.n[l], n_out = A.n[l + 1], WS = pl_odd(n_in + 1);
+    const bool relu = l < A.L - 1;
+    const T p = Mth<T>::rsqrt_n(n_in + 1);
+    const T* __restrict__ wl = wsm + A.woff[l];
+    T* __restrict__ ok = A.out[l] + ((int64_t)k * B + b0) * n_out;
+    for (int e = threadIdx.x; e < nb * n_out; e += 256) {
+      const int b = e / n_out, o = e - b * n_out;
+      const T* __restrict__ hr = cur + b * n_in;
+      const T* __restrict__ wr = wl + o * WS;
+      T acc = (T)0;
+#pragma unroll 8
+      for (int i = 0; i < n_in; ++i) acc += hr[i] * wr[i];
+      acc += wr[n_in];
+      acc = acc / p;
+      if (relu) acc = acc > (T)0 ? acc : (T)0;
+      ok[e] = acc;
+      nxt[e] = acc;
+    }
+    __syncthreads();
+    T* t = cur; cur = nxt; nxt = t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_particle_mlp_bwd(const PMArgs<T> A, const T* __restrict__ x, int64_t xsk,
+                                                          const T* __restrict__ gout, T* __restrict__ gx, T* __restrict__ part,
+                                                          unsigned* __restrict__ tickets, int B, int ntiles, int bt) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ bool last;
+  const int AS = pm_pad4(bt * A.maxw);
+  T* cur = reinterpret_cast<T*>(smem_raw);         // gradient w.r.t. the OUTPUT of the layer at hand (ReLU mask applied), [bt][n_out]
+  T* nxt = cur + AS;
+  T* sm = nxt + AS;                                 // inputs of all layers, then the weights
+  const int k = blockIdx.x / ntiles, tile = blockIdx.x - k * ntiles;
+  const int b0 = tile * bt, nb = B - b0 < bt ? B - b0 : bt;
+  const int L = A.L;
+  {                                                 // one round of loads: gradient tile, every layer's input tile, the weights
+    const int nL = A.n[L];
+    const T* __restrict__ gk = gout + ((int64_t)k * B + b0) * nL;
+    pl_stage<T>(cur, gk, nb * nL, pl_al<T>(gk));
+    const T* __restrict__ xk = x + (int64_t)k * xsk + (int64_t)b0 * A.n[0];
+    pl_stage<T>(sm + A.ioff[0], xk, nb * A.n[0], pl_al<T>(xk));
+#pragma unroll
+    for (int l = 1; l < PM_MAX_LAYERS; ++l) {
+      if (l >= L) break;
+      const T* __restrict__ ak = A.out[l - 1] + ((int64_t)k * B + b0) * A.n[l];
+      pl_stage<T>(sm + A.ioff[l], ak, nb * A.n[l], pl_al<T>(ak));
+    }
+#pragma unroll
+    for (int l = 0; l < PM_MAX_LAYERS; ++l) {
+      if (l >= L) break;
+      if (l == 0 && !gx) continue;                  // the first layer's weights are only needed for the input gradient
+      const int nW = A.n[l + 1] * (A.n[l] + 1);
+      const T* __restrict__ wk = A.w[l] + (int64_t)k * nW;
+      pl_stage<T>(sm + A.woff[l], wk, nW, pl_al<T>(wk));
+    }
+  }
+  __syncthreads();
+  T* __restrict__ slab = part + ((int64_t)k * ntiles + tile) * A.slab;
+#pragma unroll
+  for (int ll = 0; ll < PM_MAX_LAYERS; ++ll) {
+    const int l = L - 1 - ll;
+    if (l < 0) break;
+    const int n_in = A.n[l], n_out = A.n[l + 1], nW = n_out * (n_in + 1), WS = n_in + 1;
+    const T p = Mth<T>::rsqrt_n(n_in + 1);
+    const T* __restrict__ in = sm + A.ioff[l];
+    T* __restrict__ pk = slab + A.poff[l];
+    for (int e = threadIdx.x; e < nW; e += 256) {   // the tile's partial weight gradient (unscaled: / p in the reduction)
+      const int o = e / (n_in + 1), i = e - o * (n_in + 1);
+      T acc = (T)0;
+      if (i < n_in) {
+#pragma unroll 8
+        for (int b = 0; b < nb; ++b) acc += cur[b * n_out + o] * in[b * n_in + i];
+      } else {
+#pragma unroll 8
+        for (int b = 0; b < nb; ++b) acc += cur[b * n_out + o];
+      }
+      store_wt(pk + e, acc);
+    }
+    if (l > 0 || gx) {                              // gradient w.r.t. the layer's input; below a hidden layer: its ReLU mask
+      const T* __restrict__ wl = sm + A.woff[l];
+      T* __restrict__ gxk = gx ? gx + ((int64_t)k * B + b0) * n_in : nullptr;
+      for (int e = threadIdx.x; e < nb * n_in; e += 256) {
+        const int b = e / n_in, i = e - b * n_in;
+        const T* __restrict__ gr = cur + b * n_out;
+        T acc = (T)0;
+#pragma unroll 8
+        for (int o = 0; o < n_out; ++o) acc += gr[o] * wl[o * WS + i];
+        acc = acc / p;
+        if (l > 0) nxt[e] = in[e] > (T)0 ? acc : (T)0;
+        else gxk[e] = acc;
+      }
+    }
+    __syncthreads();
+    T* t = cur; cur = nxt; nxt = t;
+  }
+  drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    last = (ticket_take(tickets + k) == (unsigned)ntiles - 1u);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      drain_stores();
+    }
+  }
+  __syncthreads();
+  if (last) {
+    const T* __restrict__ p0 = part + (int64_t)k * ntiles * A.slab;
+#pragma unroll
+    for (int l = 0; l < PM_MAX_LAYERS; ++l) {
+      if (l >= L) break;
+      const int nW = A.n[l + 1] * (A.n[l] + 1);
+      pl_reduce_tiles<T>(p0 + A.poff[l], A.slab, A.gw[l] + (int64_t)k * nW, nW, ntiles, Mth<T>::rsqrt_n(A.n[l] + 1));
+    }
+    if (threadIdx.x == 0) ticket_return(tickets + k);
+  }
+}
+
+// admission: every width within PL1's limits and both directions' LDS layouts (at the largest tile) within 60 KB
+template <typename T>
+bool pm_build(const zs_pm_layer* layers, int L, bool backward, bool want_gx, PMArgs<T>& A, int64_t& lds_fwd, int64_t& lds_bwd) {
+  if (L < 1 || L > PM_MAX_LAYERS || !layers) return false;
+  memset(&A, 0, sizeof(A));
+  A.L = L;
+  int maxw = 0;
+  for (int l = 0; l < L; ++l) {
+    const int64_t n_in = layers[l].n_in, n_out = layers[l].n_out;
+    if (n_in < 1 || n_out < 1 || n_in > 255 || n_out > 256) return false;
+    if (l > 0 && n_in != layers[l - 1].n_out) return false;
+    A.n[l] = (int)n_in;
+    A.n[l + 1] = (int)n_out;
+    if (n_in > maxw) maxw = (int)n_in;
+    if (n_out > maxw) maxw = (int)n_out;
+    A.w[l] = static_cast<const T*>(layers[l].w);
+    A.out[l] = static_cast<T*>(layers[l].out);
+    A.gw[l] = static_cast<T*>(layers[l].gw);
+  }
+  A.maxw = maxw;
+  const int bt = PL_BT_MAX;
+  int64_t wf = 0, wb = 0, in = 0, slab = 0;
+  for (int l = 0; l < L; ++l) {
+    const int nW = A.n[l + 1] * (A.n[l] + 1);
+    if (!backward) { A.woff[l] = (int)wf; }
+    wf += pm_pad4(A.n[l + 1] * pl_odd(A.n[l] + 1));
+    A.ioff[l] = (int)in;
+    in += pm_pad4(bt * A.n[l]);
+    A.poff[l] = (int)slab;
+    slab += pm_pad4(nW);
+  }
+  if (backward) {
+    for (int l = 0; l < L; ++l) {
+      A.woff[l] = (int)(in + wb);
+      if (l > 0 || want_gx) wb += pm_pad4(A.n[l + 1] * (A.n[l] + 1));
+    }
+  }
+  A.slab = (int)slab;
+  int64_t wall = 0;
+  for (int l = 0; l < L; ++l) wall += pm_pad4(A.n[l + 1] * (A.n[l] + 1));
+  lds_fwd = 2 * (int64_t)pm_pad4(bt * maxw) + wf;
+  lds_bwd = 2 * (int64_t)pm_pad4(bt * maxw) + in + wall;        // (admission counts the first layer's weights: one rule either way)
+  const int64_t lim = PL_LDS_FLOATS * (int64_t)sizeof(float) / (int64_t)sizeof(T);
+  return lds_fwd <= lim && lds_bwd <= lim;
+}
+
+template <typename T>
+int particle_mlp(const T* x, int64_t xsk, const zs_pm_layer* layers, int L, int64_t K, int64_t B, void* stream) {
+  if (K < 0 || B < 0 || !layers || L < 1) return ZS_EINVAL;
+  if (L > PM_MAX_LAYERS) return ZS_ENOTSUP;
+  for (int l = 0; l < L; ++l)
+    if (layers[l].n_in < 1 || layers[l].n_out < 1 || (l > 0 && layers[l].n_in != layers[l - 1].n_out)) return ZS_EINVAL;
+  if (xsk != 0 && xsk != B * layers[0].n_in) return ZS_EINVAL;
+  PMArgs<T> A;
+  int64_t lf, lb;
+  if (!pm_build<T>(layers, L, false, false, A, lf, lb) || B > (1 << 24) || K > (1 << 20)) return ZS_ENOTSUP;
+  if (K == 0 || B == 0) return 0;
+  if (!x) return ZS_EINVAL;
+  for (int l = 0; l < L; ++l)
+    if (!A.w[l] || !A.out[l]) return ZS_EINVAL;
+  const int bt = pl_tile_rows(K, B, 256);
+  const int ntiles = (int)((B + bt - 1) / bt);
+  if ((int64_t)ntiles * K > (int64_t(1) << 30)) return ZS_ENOTSUP;
+  int64_t wf = 0;
+  for (int l = 0; l < L; ++l) wf += pm_pad4(A.n[l + 1] * pl_odd(A.n[l] + 1));
+  const size_t smem = sizeof(T) * (size_t)(2 * pm_pad4(bt * A.maxw) + wf);
+  ZS_LAUNCH_SMEM(KID_PARTICLE_MLP, (k_particle_mlp<T>), dim3((unsigned)(ntiles * K)), dim3(256), smem, (hipStream_t)stream, A, x, xsk,
+                 (int)B, ntiles, bt);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+int particle_mlp_bwd(const T* x, int64_t xsk, const zs_pm_layer* layers, int L, const T* gout, T* gx, int64_t K, int64_t B,
+                     T* workspace, int64_t workspace_len, uint32_t* tickets, void* stream) {
+  if (K < 0 || B < 0 || !layers || L < 1) return ZS_EINVAL;
+  if (L > PM_MAX_LAYERS) return ZS_ENOTSUP;
+  for (int l = 0; l < L; ++l)
+    if (layers[l].n_in < 1 || layers[l].n_out < 1 || (l > 0 && layers[l].n_in != layers[l - 1].n_out)) return ZS_EINVAL;
+  if (xsk != 0 && xsk != B * layers[0].n_in) return ZS_EINVAL;
+  PMArgs<T> A;
+  int64_t lf, lb;
+  if (!pm_build<T>(layers, L, true, gx != nullptr, A, lf, lb) || B > (1 << 24) || K > (1 << 20)) return ZS_ENOTSUP;
+  if (K == 0) return 0;
+  for (int l = 0; l < L; ++l)
+    if (!A.gw[l]) return ZS_EINVAL;
+  if (B == 0) {                                   // no rows: the weight gradients are zero
+    for (int l = 0; l < L; ++l) {
+      const hipError_t e = hipMemsetAsync(A.gw[l], 0, sizeof(T) * (size_t)(K * A.n[l + 1] * (A.n[l] + 1)), (hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+  }
+  if (!x || !gout) return ZS_EINVAL;
+  for (int l = 0; l < L; ++l)
+    if (!A.w[l] || (l < L - 1 && !A.out[l])) return ZS_EINVAL;
+  const int bt = pl_tile_rows(K, B, 128);
+  const int ntiles = (int)((B + bt - 1) / bt);
+  if ((int64_t)ntiles * K > (int64_t(1) << 30)) return ZS_ENOTSUP;
+  if (!workspace || !tickets || workspace_len < K * ntiles * (int64_t)A.slab) return ZS_EINVAL;
+  // LDS offsets were laid out for the largest tile (input tiles of PL_BT_MAX rows): valid for any bt <= PL_BT_MAX
+  int64_t in = 0, wb = 0;
+  for (int l = 0; l < L; ++l) {
+    in += pm_pad4(PL_BT_MAX * A.n[l]);
+    if (l > 0 || gx) wb += pm_pad4(A.n[l + 1] * (A.n[l] + 1));
+  }
+  const size_t smem = sizeof(T) * (size_t)(2 * pm_pad4(bt * A.maxw) + in + wb);
+  ZS_LAUNCH_SMEM(KID_PARTICLE_MLP_BWD, (k_particle_mlp_bwd<T>), dim3((unsigned)(ntiles * K)), dim3(256), smem, (hipStream_t)stream, A,
+                 x, xsk, gout, gx, workspace, (unsigned*)tickets, (int)B, ntiles, bt);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace
 
+extern "C" int zs_particle_mlp_f32(const float* x, int64_t x_stride_k, const zs_pm_layer* layers, int n_layers, int64_t K, int64_t B,
+                                   void* stream) {
+  return particle_mlp<float>(x, x_stride_k, layers, n_layers, K, B, stream);
+}
+extern "C" int zs_particle_mlp_f64(const double* x, int64_t x_stride_k, const zs_pm_layer* layers, int n_layers, int64_t K, int64_t B,
+                                   void* stream) {
+  return particle_mlp<double>(x, x_stride_k, layers, n_layers, K, B, stream);
+}
+extern "C" int zs_particle_mlp_bwd_f32(const float* x, int64_t x_stride_k, const zs_pm_layer* layers, int n_layers, const float* gout,
+                                       float* gx, int64_t K, int64_t B, float* workspace, int64_t workspace_len, uint32_t* tickets,
+                                       void* stream) {
+  return particle_mlp_bwd<float>(x, x_stride_k, layers, n_layers, gout, gx, K, B, workspace, workspace_len, tickets, stream);
+}
+extern "C" int zs_particle_mlp_bwd_f64(const double* x, int64_t x_stride_k, const zs_pm_layer* layers, int n_layers, const double* gout,
+                                       double* gx, int64_t K, int64_t B, double* workspace, int64_t workspace_len, uint32_t* tickets,
+                                       void* stream) {
+  return particle_mlp_bwd<double>(x, x_stride_k, layers, n_layers, gout, gx, K, B, workspace, workspace_len, tickets, stream);
+}
 extern "C" int zs_particle_linear_f32(const float* h, int64_t h_stride_k, const float* w, float* out, int64_t K, int64_t B,
                                       int64_t n_in, int64_t n_out, int relu, void* stream) {
   return particle_linear<float>(h, h_stride_k, w, out, K, B, n_in, n_out, relu, stream);

@@ -2,10 +2,11 @@
 
 Counterpart of the reference caller examples/bayesian_neural_nets/bnn_vi.py:16-99: a prior node and a
 variational node per weight matrix (``group_ndims=2``, K particles, ``reduce_mean_dims=[0]``), a Normal
-likelihood with ``multiplier`` = training-set size.  The particle-batched layer -- in the reference
-``w.repeat([1, B, 1, 1])``, a column of ones appended to h, ``matmul``, ``/ sqrt(n_in + 1)``, ReLU (bnn_vi.py:36-48) --
-is ONE kernel each way (``zhusuan.particle_linear``, PL1 of include/zs_hip.h); ``layer='bmm'`` is round 2's batched-GEMM
-formulation (cat + bmm + div + relu), ``layer='materialize'`` reproduces the reference's op sequence.
+likelihood with ``multiplier`` = training-set size.  The particle-batched network -- in the reference, per layer,
+``w.repeat([1, B, 1, 1])``, a column of ones appended to h, ``matmul``, ``/ sqrt(n_in + 1)``, ReLU (bnn_vi.py:27-48) --
+runs ALL its layers as ONE kernel each way with ``layer='fused'`` (default: ``zhusuan.particle_mlp``, PM1 of include/zs_hip.h)
+and one kernel per layer and direction with ``layer='per_layer'`` (``zhusuan.particle_linear``, PL1); ``layer='bmm'`` is round 2's
+batched-GEMM formulation (cat + bmm + div + relu), ``layer='materialize'`` reproduces the reference's op sequence.
 """
 import argparse
 import math
@@ -25,8 +26,8 @@ class Net(BayesianNet):
         self.n_particles = n_particles
         self.multiplier = multiplier
         self.layer = layer or ('materialize' if materialize else 'fused')
-        if self.layer not in ('fused', 'bmm', 'materialize'):
-            raise ValueError("layer: 'fused', 'bmm' or 'materialize'")
+        if self.layer not in ('fused', 'per_layer', 'bmm', 'materialize'):
+            raise ValueError("layer: 'fused', 'per_layer', 'bmm' or 'materialize'")
         self.y_logstd = torch.nn.Parameter(torch.zeros([1], dtype=torch.float32))
         self._priors = None
         self._ones = {}
@@ -42,7 +43,8 @@ class Net(BayesianNet):
         self.observe(observed)
         x = self.observed['x']
         K = self.n_particles
-        h = x if self.layer == 'fused' else x.unsqueeze(0).expand(K, *x.shape)      # (the reference repeats x K times, :27)
+        h = x if self.layer in ('fused', 'per_layer') else x.unsqueeze(0).expand(K, *x.shape)      # (the reference repeats x K times, :27)
+        ws = []
         batch_size = x.shape[0]
         priors = self._prior_params()
         n_layers = len(self.layer_sizes) - 1
@@ -50,7 +52,10 @@ class Net(BayesianNet):
             w = self.normal(name='w' + str(i), mean=priors[i][0], std=priors[i][1], group_ndims=2,
                             n_samples=K, reduce_mean_dims=[0])
             last = i == n_layers - 1
-            if self.layer == 'fused':
+            if self.layer == 'fused':                 # the whole network below, in one launch (PM1)
+                ws.append(w)
+                continue
+            if self.layer == 'per_layer':             # one launch per layer (PL1)
                 h = zhusuan.particle_linear(h, w, relu=not last)
                 continue
             key = (tuple(h.shape[:-1]), h.device, h.dtype)
@@ -66,9 +71,11 @@ class Net(BayesianNet):
                 h = torch.bmm(h, w.transpose(1, 2)) / scale
             if not last:
                 h = torch.relu(h)
+        if self.layer == 'fused':
+            h = zhusuan.particle_mlp(x, ws)
         y_mean = torch.squeeze(h, 2)
         y = self.observed['y']
-        if self.layer == 'fused':
+        if self.layer in ('fused', 'per_layer'):
             # sqrt(mean((y - mean(y_mean, 0))^2)) (bnn_vi.py:84-87) as one launch
             self.cache['rmse'] = zhusuan.particle_rmse(y_mean, y)
         else:

@@ -17,5 +17,5 @@ from .utils import *
 from ._rng import inject_epsilon, DeviceRNG, device_rng, reference_rng
 from .graph import GraphedStep, GraphedStages
 from .framework.stochastic_tensor import skip_discarded_draws
-from .layers import particle_linear, particle_rmse, Linear, Sequential
+from .layers import particle_linear, particle_mlp, particle_rmse, Linear, Sequential
 from . import optim

@@ -64,12 +64,17 @@ ADAM_MAX_TENSORS = 32      # ZS_ADAM_MAX_TENSORS of include/zs_hip.h
 LJ_MAX_TERMS, LJ_WORKSPACE = 8, 8192
 LJ_ROWS, LJ_NORMAL, LJ_NORMAL_LOGSTD, LJ_BERNOULLI, LJ_BERNOULLI_LOGITS = 0, 1, 2, 3, 4
 MS_MAX_TERMS = 8
+PM_MAX_LAYERS = 4
 
 
 class LJTerm(ctypes.Structure):
     _fields_ = [("family", ctypes.c_int32), ("reserved", ctypes.c_int32), ("n", _i64),
                 ("x", _p), ("px", _i64), ("a", _p), ("pa", _i64), ("b", _p), ("pb", _i64),
                 ("coef", ctypes.c_double), ("gx", _p), ("ga", _p), ("gb", _p)]
+
+
+class PMLayer(ctypes.Structure):          # struct zs_pm_layer
+    _fields_ = [("w", _p), ("out", _p), ("gw", _p), ("n_in", _i64), ("n_out", _i64)]
 
 
 class MSTerm(ctypes.Structure):
@@ -93,6 +98,10 @@ PROTOTYPES.update({
     "zs_column_sum_f32": [_p, _p, _i64, _i64, _p, _i64, _p, _i64, _p],
     # g, y, act, gpre, gbias, rows, cols, workspace, workspace_len, tickets, n_tickets, stream
     "zs_dense_act_bwd_f32": [_p, _p, _int, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _p],
+    # x, x_stride_k, layers (host table), n_layers, K, B, stream
+    "zs_particle_mlp_f32": [_p, _i64, _p, _int, _i64, _i64, _p],
+    # x, x_stride_k, layers, n_layers, gout, gx, K, B, workspace, workspace_len, tickets, stream
+    "zs_particle_mlp_bwd_f32": [_p, _i64, _p, _int, _p, _p, _i64, _i64, _p, _i64, _p, _p],
     # pred, y, out, K, B, workspace (double), workspace_len, ticket, stream
     "zs_particle_rmse_f32": [_p, _p, _p, _i64, _i64, _p, _i64, _p, _p],
     # h, h_stride_k, w, out, gout, gh, gw, K, B, n_in, n_out, relu, workspace, workspace_len, tickets, stream

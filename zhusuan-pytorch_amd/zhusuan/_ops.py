@@ -968,6 +968,66 @@ class ParticleLinear(torch.autograd.Function):
         return gh, (gw if need_w else None), None
 
 
+class ParticleMLP(torch.autograd.Function):
+    """PM1: a chain of PL1 layers (ReLU after every layer but the last) -- the BNN caller's whole network
+    (examples/bayesian_neural_nets/bnn_vi.py:27-48) -- as ONE launch forward and ONE backward.  ``x``: [B, n_0] (shared by the
+    particles) or [K, B, n_0]; ``ws[l]``: [K, n_{l+1}, n_l + 1].  Returns the last layer's output [K, B, n_L]; bit-identical to
+    ``ParticleLinear`` applied layer by layer."""
+
+    @staticmethod
+    def forward(ctx, x, *ws):
+        _hip.require_device(x, *ws)
+        sfx = _sfx(x, *ws)
+        L = len(ws)
+        K = ws[0].shape[0]
+        shared = x.dim() == 2
+        B = x.shape[-2]
+        sizes = [ws[0].shape[2] - 1] + [w.shape[1] for w in ws]
+        ok = x.shape[-1] == sizes[0] and (shared or (x.dim() == 3 and x.shape[0] == K))
+        for l, w in enumerate(ws):
+            ok = ok and w.dim() == 3 and w.shape[0] == K and w.shape[2] == sizes[l] + 1
+        if not ok:
+            raise RuntimeError("particle_mlp: x %s does not match the weights %s" % (tuple(x.shape), [tuple(w.shape) for w in ws]))
+        x = x.contiguous()
+        ws = [w.contiguous() for w in ws]
+        outs = [torch.empty((K, B, sizes[l + 1]), dtype=x.dtype, device=x.device) for l in range(L)]
+        table = (_hip.PMLayer * L)()
+        for l in range(L):
+            table[l].w, table[l].out, table[l].gw = _hip.ptr(ws[l]), _hip.ptr(outs[l]), None
+            table[l].n_in, table[l].n_out = sizes[l], sizes[l + 1]
+        _hip.lib().call("zs_particle_mlp" + sfx, _hip.ptr(x), 0 if shared else B * sizes[0], ctypes.byref(table), L, K, B,
+                        _hip.stream_for(x))
+        ctx.meta = (K, B, sizes, shared)
+        ctx.save_for_backward(x, *ws, *outs)
+        ctx.mark_non_differentiable(*outs[:-1])
+        return outs[-1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        K, B, sizes, shared = ctx.meta
+        L = len(sizes) - 1
+        saved = ctx.saved_tensors
+        x, ws, outs = saved[0], saved[1:1 + L], saved[1 + L:]
+        need_x = ctx.needs_input_grad[0]
+        if not any(ctx.needs_input_grad):
+            return (None,) * (1 + L)
+        gout = gout.contiguous()
+        gx = torch.empty((K, B, sizes[0]), dtype=x.dtype, device=x.device) if need_x else None
+        gws = [torch.empty_like(w) for w in ws]
+        slab = sum(sizes[l + 1] * (sizes[l] + 1) + 3 for l in range(L))
+        part = torch.empty(K * ((B + 15) // 16) * slab, dtype=x.dtype, device=x.device)          # tile partials of every layer's gw
+        tickets = _pl_tickets(x.device, K)
+        table = (_hip.PMLayer * L)()
+        for l in range(L):
+            table[l].w, table[l].out, table[l].gw = _hip.ptr(ws[l]), _hip.ptr(outs[l]), _hip.ptr(gws[l])
+            table[l].n_in, table[l].n_out = sizes[l], sizes[l + 1]
+        _hip.lib().call("zs_particle_mlp_bwd" + _sfx(x), _hip.ptr(x), 0 if shared else B * sizes[0], ctypes.byref(table), L,
+                        _hip.ptr(gout), _hip.ptr(gx), K, B, _hip.ptr(part), part.numel(), _hip.ptr(tickets), _hip.stream_for(x))
+        if need_x and shared:
+            gx = gx.sum(0)
+        return (gx,) + tuple(g if ctx.needs_input_grad[1 + l] else None for l, g in enumerate(gws))
+
+
 def column_sum(x2d):
     """CS1: ``x2d.sum(0)`` of a contiguous [rows, cols] matrix in one launch, deterministic (include/zs_hip.h)."""
     _hip.require_device(x2d)

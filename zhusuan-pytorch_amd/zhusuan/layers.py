@@ -9,7 +9,7 @@ import torch
 
 from . import _ops
 
-__all__ = ['particle_linear', 'particle_rmse', 'Linear', 'Sequential']
+__all__ = ['particle_linear', 'particle_mlp', 'particle_rmse', 'Linear', 'Sequential']
 
 
 def _fits_lds(n_in, n_out, itemsize):
@@ -43,6 +43,43 @@ def particle_linear(h, w, relu=False):
         h = h.unsqueeze(0).expand(K, *h.shape)
     out = (torch.bmm(h, w[:, :, :n_in].transpose(1, 2)) + w[:, :, n_in].unsqueeze(1)) / (float(n_in + 1) ** 0.5)
     return torch.relu(out) if relu else out
+
+
+def _fits_lds_mlp(sizes, itemsize):
+    """PM1's admission rule (pm_build, csrc/zs_layers.hip): all layers' weights, the tiles of every layer's input and two
+    gradient / activation tiles of the widest layer within 60 KB of LDS, at most 4 layers."""
+    L = len(sizes) - 1
+    if not (1 <= L <= 4) or any(not (1 <= sizes[l] <= 255 and 1 <= sizes[l + 1] <= 256) for l in range(L)):
+        return False
+    lim = 15360 * 4 // itemsize
+    pad4 = lambda v: (v + 3) & ~3
+    odd = lambda v: v | 1
+    maxw = max(sizes)
+    fwd = 2 * pad4(64 * maxw) + sum(pad4(sizes[l + 1] * odd(sizes[l] + 1)) for l in range(L))
+    bwd = 2 * pad4(64 * maxw) + sum(pad4(64 * sizes[l]) for l in range(L)) + sum(pad4(sizes[l + 1] * (sizes[l] + 1)) for l in range(L))
+    return max(fwd, bwd) <= lim
+
+
+def particle_mlp(x, weights):
+    """The BNN caller's network (examples/bayesian_neural_nets/bnn_vi.py:27-48): ``h = x``; for every layer
+    ``h = ([h, 1] @ w[k].T) / sqrt(n_in + 1)``, ReLU after every layer but the last.
+
+    :param x: inputs ``[B, n_0]`` (shared by the particles) or ``[K, B, n_0]``.
+    :param weights: one ``[K, n_out, n_in + 1]`` tensor per layer.
+    :return: ``[K, B, n_L]``.
+
+    Networks of up to four layers that fit a workgroup's LDS run as ONE kernel forward and one backward (PM1); anything else
+    as a chain of ``particle_linear`` calls (the same values bit for bit)."""
+    weights = list(weights)
+    if not weights:
+        raise ValueError("particle_mlp: at least one layer")
+    sizes = [weights[0].shape[2] - 1] + [w.shape[1] for w in weights]
+    if len(weights) > 1 and _fits_lds_mlp(sizes, weights[0].element_size()):
+        return _ops.ParticleMLP.apply(x, *weights)
+    h = x
+    for l, w in enumerate(weights):
+        h = particle_linear(h, w, relu=l < len(weights) - 1)
+    return h
 
 
 def particle_rmse(pred, y):
