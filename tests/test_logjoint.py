@@ -827,9 +827,15 @@ def test_c_oracle_particle_mlp(orc, orc64):
 @pytest.mark.gpu
 @pytest.mark.parametrize("sizes,K,B,shared", PM_NETS)
 def test_hip_particle_mlp(hip, hip64, sizes, K, B, shared):
+    from zhusuan.layers import _fits_lds_mlp
     _pm_check(hip, hip, sizes, K, B, shared, 3e-6)
-    if K * B <= 6000:
-        _pm_check(hip64, hip64, sizes, K, B, shared, 1e-13)
+    if _fits_lds_mlp(sizes, 8):
+        if K * B <= 6000:
+            _pm_check(hip64, hip64, sizes, K, B, shared, 1e-13)
+    else:                                                    # twice the bytes per element: this network does not fit the LDS
+        x, ws, _ = _pm_inputs(sizes, K, B, shared, 1)
+        with pytest.raises(RuntimeError, match="code -2"):
+            hip64.pm(x, ws)
 
 
 @pytest.mark.gpu
