@@ -1069,6 +1069,7 @@ def _cs_scratch(dev, dtype, cols):
 
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2          # ZS_ACT_* of include/zs_hip.h
+_ADDMM_RELU = getattr(torch, '_addmm_activation', None)      # bias + ReLU epilogue of the GEMM (a private torch entry point: optional)
 
 
 def dense_act_bwd(g2d, y2d, act):
@@ -1098,8 +1099,8 @@ class DenseLayer(torch.autograd.Function):
     def forward(ctx, x, w, b, act=ACT_NONE):
         ctx.has_bias = b is not None
         ctx.act = act
-        if act == ACT_RELU and b is not None and x.dim() >= 1 and x.shape[-1] == w.shape[1] and b.dim() == 1:
-            y = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]), w.t()).reshape(*x.shape[:-1], w.shape[0])
+        if act == ACT_RELU and b is not None and x.dim() >= 1 and x.shape[-1] == w.shape[1] and b.dim() == 1 and _ADDMM_RELU is not None:
+            y = _ADDMM_RELU(b, x.reshape(-1, x.shape[-1]), w.t()).reshape(*x.shape[:-1], w.shape[0])
         else:
             y = torch.nn.functional.linear(x, w, b)
             if act == ACT_RELU:
