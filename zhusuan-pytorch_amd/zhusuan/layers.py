@@ -120,7 +120,8 @@ class Linear(torch.nn.Linear):
 
 class Sequential(torch.nn.Sequential):
     """``torch.nn.Sequential`` (same children, same indices, same parameter names, slicing included) that runs every
-    ``zhusuan.Linear`` followed by an ``nn.ReLU`` / ``nn.Sigmoid`` as one fused layer."""
+    ``zhusuan.Linear`` followed by an ``nn.ReLU`` / ``nn.Sigmoid`` as one fused layer.  (The activation module of such a pair
+    is not called: forward hooks registered on it do not fire.  Use ``torch.nn.Sequential`` where that matters.)"""
 
     def forward(self, x):
         mods = list(self)
