@@ -998,8 +998,7 @@ class ParticleMLP(torch.autograd.Function):
         _hip.lib().call("zs_particle_mlp" + sfx, _hip.ptr(x), 0 if shared else B * sizes[0], ctypes.byref(table), L, K, B,
                         _hip.stream_for(x))
         ctx.meta = (K, B, sizes, shared)
-        ctx.save_for_backward(x, *ws, *outs)
-        ctx.mark_non_differentiable(*outs[:-1])
+        ctx.save_for_backward(x, *ws, *outs)          # (the hidden activations are intermediates: saved, not returned)
         return outs[-1]
 
     @staticmethod
