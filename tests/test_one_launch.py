@@ -359,6 +359,13 @@ def test_zhusuan_sequential_fuses_linear_with_its_activation(dev):
     np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
     with pytest.raises(ValueError, match="activation"):
         zs.Linear(3, 3, activation='tanh')
+    # precisions without kernels take torch's ops (same numbers as torch.nn's modules), with autograd
+    if dev.type == "cuda":
+        half = zs.Sequential(zs.Linear(19, 6), torch.nn.ReLU()).to(dev).to(torch.bfloat16)
+        xh = torch.randn(9, 19, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        with launches() as names:
+            half(xh).sum().backward()
+        assert names == [] and xh.grad is not None and half[0].bias.grad is not None
     mixed = zs.Sequential(zs.Linear(19, 6), torch.nn.Tanh(), torch.nn.Linear(6, 4), torch.nn.ReLU()).to(dev)
     with launches() as names:
         mixed(xa).sum().backward()

@@ -112,10 +112,12 @@ class Linear(torch.nn.Linear):
 
     def forward(self, x, activation='own'):
         act = self.activation if activation == 'own' else activation
-        if x.requires_grad or self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad):
+        kernels = self.weight.dtype in (torch.float32, torch.float64) and x.dtype == self.weight.dtype and \
+            not torch.is_autocast_enabled()          # (other precisions: torch's own ops, same results as torch.nn's modules)
+        if kernels and (x.requires_grad or self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad)):
             return _ops.DenseLayer.apply(x, self.weight, self.bias, _ACTS[act])
         y = torch.nn.functional.linear(x, self.weight, self.bias)
-        return y if act is None else (torch.relu_(y) if act == 'relu' else torch.sigmoid_(y))
+        return y if act is None else (torch.relu(y) if act == 'relu' else torch.sigmoid(y))
 
 
 class Sequential(torch.nn.Sequential):
