@@ -410,3 +410,28 @@ def test_particle_mlp_is_the_layer_chain_in_one_launch(dev):
         zs.particle_mlp(torch.zeros(3, 4, device=dev), [torch.zeros(2, 5, 5, device=dev), torch.zeros(2, 2, 7, device=dev)])
     with pytest.raises(ValueError, match="at least one layer"):
         zs.particle_mlp(torch.zeros(3, 4, device=dev), [])
+
+
+def test_layer_functions_accept_deferred_node_values(dev):
+    """Inside zhusuan.skip_discarded_draws() a variational net's node values are LazyDraw handles; the layer functions of this
+    package draw them like any torch function would."""
+    class Q(BayesianNet):
+        def __init__(self):
+            super().__init__()
+            self.mu = torch.nn.Parameter(torch.zeros(3, 5, 4))
+            self.fc = zs.Linear(4, 2)
+
+        def forward(self, observed):
+            self.observe(observed)
+            w = self.normal(name="w", mean=self.mu, std=torch.ones_like(self.mu), group_ndims=2, reduce_mean_dims=None)
+            self.cache["is_lazy"] = isinstance(w, LazyDraw)
+            self.cache["a"] = zs.particle_linear(torch.ones(6, 3, device=self.mu.device), w, relu=True)
+            self.cache["b"] = zs.particle_mlp(torch.ones(6, 3, device=self.mu.device), [w, w[:, :2, :].contiguous().repeat(1, 1, 2)[:, :, :6]])
+            self.cache["c"] = self.fc(w)
+            self.cache["d"] = zs.particle_rmse(self.cache["a"][:, :, 0], torch.zeros(6, device=self.mu.device))
+            return self
+    q = Q().to(dev)
+    with zs.skip_discarded_draws(), zs.framework.stochastic_tensor.deferred_node_values():
+        q({})
+    assert q.cache["is_lazy"] and q.cache["a"].shape == (3, 6, 5) and q.cache["b"].shape == (3, 6, 2)
+    assert q.cache["c"].shape == (3, 5, 2) and q.cache["d"].dim() == 0

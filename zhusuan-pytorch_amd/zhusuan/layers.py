@@ -8,6 +8,7 @@ and one backward; nothing is repeated or concatenated.
 import torch
 
 from . import _ops
+from .framework.stochastic_tensor import _materialize
 
 __all__ = ['particle_linear', 'particle_mlp', 'particle_rmse', 'Linear', 'Sequential']
 
@@ -35,6 +36,7 @@ def particle_linear(h, w, relu=False):
     Layers that do not fit a workgroup's LDS (n_in > 255, n_out > 256, or more than about 15 000 fp32 weights +
     tile elements) take the equivalent batched-GEMM formulation through torch.
     """
+    h, w = _materialize((h, w))          # (node values deferred by zhusuan.skip_discarded_draws)
     K, n_out, n_in1 = w.shape
     n_in = n_in1 - 1
     if _fits_lds(n_in, n_out, w.element_size()):
@@ -70,7 +72,8 @@ def particle_mlp(x, weights):
 
     Networks of up to four layers that fit a workgroup's LDS run as ONE kernel forward and one backward (PM1); anything else
     as a chain of ``particle_linear`` calls (the same values bit for bit)."""
-    weights = list(weights)
+    weights = list(_materialize(tuple(weights)))
+    x = _materialize(x)
     if not weights:
         raise ValueError("particle_mlp: at least one layer")
     sizes = [weights[0].shape[2] - 1] + [w.shape[1] for w in weights]
@@ -86,7 +89,7 @@ def particle_rmse(pred, y):
     """``sqrt(mean((y - pred.mean(0)) ** 2))``: the error of the particle-mean prediction ``pred`` [K, B] against ``y`` [B], the
     diagnostic the BNN caller evaluates in every forward pass (examples/bayesian_neural_nets/bnn_vi.py:84-87: five torch
     launches), as one kernel (PR1).  Returned without autograd history."""
-    return _ops.particle_rmse(pred, y)
+    return _ops.particle_rmse(*_materialize((pred, y)))
 
 
 _ACTS = {None: _ops.ACT_NONE, 'relu': _ops.ACT_RELU, 'sigmoid': _ops.ACT_SIGMOID}
@@ -112,6 +115,7 @@ class Linear(torch.nn.Linear):
 
     def forward(self, x, activation='own'):
         act = self.activation if activation == 'own' else activation
+        x = _materialize(x)                  # (a node value deferred by zhusuan.skip_discarded_draws)
         kernels = self.weight.dtype in (torch.float32, torch.float64) and x.dtype == self.weight.dtype and \
             not torch.is_autocast_enabled()          # (other precisions: torch's own ops, same results as torch.nn's modules)
         if kernels and (x.requires_grad or self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad)):
