@@ -734,9 +734,14 @@ int column_sum(const T* x, T* out, int64_t rows, int64_t cols, T* workspace, int
   const int ncol_tile = v4 ? 256 : 64;
   const int64_t ctiles = (cols + ncol_tile - 1) / ncol_tile;
   // row chunks: enough workgroups to fill the chip (~512), at least 32 rows each, at most CS_MAX_CHUNKS per column tile
-  int64_t nchunks = (512 + ctiles - 1) / ctiles;
-  if (nchunks > CS_MAX_CHUNKS) nchunks = CS_MAX_CHUNKS;
-  if (nchunks > (rows + 31) / 32) nchunks = (rows + 31) / 32;
+  // (experiments only, zs_common.h.  More, smaller chunks do not pay: the last arrival's reduction grows with them -- CS1 at
+  // [12 800, 500]: 128 / 256 / 512 chunks per column tile = 8.1 / 14.4 / 19.2 us, AB1 17.9 / 23.0 / 27.5 us)
+  static const int wgs_env = env_knob("ZS_CS_WGS", 0), chunks_env = env_knob("ZS_CS_CHUNKS", 0), minrows_env = env_knob("ZS_CS_MINROWS", 0);
+  const int64_t want_wgs = wgs_env > 0 ? wgs_env : 512, max_chunks = chunks_env > 0 ? chunks_env : CS_MAX_CHUNKS;
+  const int64_t min_rows = minrows_env > 0 ? minrows_env : 32;
+  int64_t nchunks = (want_wgs + ctiles - 1) / ctiles;
+  if (nchunks > max_chunks) nchunks = max_chunks;
+  if (nchunks > (rows + min_rows - 1) / min_rows) nchunks = (rows + min_rows - 1) / min_rows;
   if (nchunks < 1) nchunks = 1;
   int64_t rpc = (rows + nchunks - 1) / nchunks;
   rpc = (rpc + 3) / 4 * 4;                               // whole groups of four rows (one per wavefront)
