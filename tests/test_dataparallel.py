@@ -371,10 +371,10 @@ def test_staged_buckets_two_ranks_match_the_single_bucket(tmp_path, estimator):
     np.testing.assert_allclose(s0["flat"].numpy(), flat.numpy(), rtol=2e-4, atol=2e-6)
 
 
-def test_staged_update_with_flat_adam_matches_full_batch_adam(tmp_path):
-    """Three staged 2-rank steps whose update reads the all-reduced SUMS with grad_scale = 1/world (no scaling pass over the
-    buckets) train exactly like torch.optim.Adam on the full minibatch in one process."""
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_staged_update_with_flat_adam_matches_full_batch_adam(tmp_path, world):
+    """Three staged 2-rank (4-rank) steps whose update reads the all-reduced SUMS with grad_scale = 1/world (no scaling pass
+    over the buckets) train exactly like torch.optim.Adam on the full minibatch in one process."""
     port = _free_port()
     mp.spawn(_worker_staged_update, args=(world, port, "vimco", str(tmp_path)), nprocs=world, join=True)
     u0, u1 = torch.load(str(tmp_path / "u0.pt")), torch.load(str(tmp_path / "u1.pt"))
@@ -384,8 +384,11 @@ def test_staged_update_with_flat_adam_matches_full_batch_adam(tmp_path):
     losses, params = _run_shard_staged_update(0, 1, "vimco")
     from zhusuan import _hip
     host_backend.uninstall()
-    np.testing.assert_allclose(u0["losses"], losses, rtol=5e-6)
+    # (the first step's objective is the plain shard mean; later steps see parameters that went through Adam's normalisation of
+    # near-zero gradients, where the order of the shard sums shows)
+    np.testing.assert_allclose(u0["losses"][0], losses[0], rtol=5e-6)
+    np.testing.assert_allclose(u0["losses"], losses, rtol=5e-6 if world == 2 else 5e-5)
     for a, b in zip(u0["params"], params):
         # Adam normalises every gradient by its own magnitude: where a gradient is ~0 the shard-sum's rounding decides the
         # update's size, so the allowance is a fraction of a step (lr = 1e-2), not of the parameter
-        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-4, atol=2e-4 if world == 2 else 6e-4)
