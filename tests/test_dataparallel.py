@@ -388,6 +388,7 @@ def test_staged_update_with_flat_adam_matches_full_batch_adam(tmp_path, world):
     # near-zero gradients, where the order of the shard sums shows)
     np.testing.assert_allclose(u0["losses"][0], losses[0], rtol=5e-6)
     np.testing.assert_allclose(u0["losses"], losses, rtol=5e-6 if world == 2 else 5e-5)
+    outliers = total = 0
     for a, b in zip(u0["params"], params):
         # Adam normalises every gradient by its own magnitude: where a gradient is ~0 the shard-sum's rounding decides the
         # update's size, so the allowance is a fraction of a step (lr = 1e-2), not of the parameter
@@ -397,4 +398,7 @@ def test_staged_update_with_flat_adam_matches_full_batch_adam(tmp_path, world):
             # four shard sums: a handful of elements whose gradient is exactly zero up to rounding get the rounding's SIGN
             # normalised to a full step (Adam: m / sqrt(v) = +-1) -- at most steps * lr apart, and rare
             d = (a - b).abs()
-            assert float((d > 6e-4 + 2e-4 * b.abs()).float().mean()) < 1e-3 and float(d.max()) <= 3 * 1e-2 + 1e-6
+            outliers += int((d > 6e-4 + 2e-4 * b.abs()).sum())
+            total += d.numel()
+            assert float(d.max()) <= 3 * 1e-2 + 1e-6
+    assert outliers <= 1e-3 * max(total, 1), (outliers, total)
