@@ -418,7 +418,9 @@ int zs_logjoint_scalar_bwd_f32(const zs_lj_term* terms, int n_terms, const float
  * zs_normal_sample_logprob / _bwd (same formulas, same Philox stream: term t draws with call id  base + terms[t].offset,
  * group = flat index / 4), meant for the launch-bound small shapes (a wavefront per row; use K1 for a single large node).
  * `terms` is a HOST array.  rng_state / rng_used: as for K1, shared by all terms ({seed, base}).
- * Backward: gz / glp (either may be NULL) -> gmu, gsigma per term (reparameterised nodes: normal.py:104-105).
+ * Backward: gz / glp (either may be NULL) -> gmu, gsigma per term (reparameterised nodes: normal.py:104-105); gz2 (may be
+ * NULL): a second gradient w.r.t. the same sample, added to gz element by element (a draw that feeds the model AND its own
+ * prior term collects two gradients; autograd would add them with a launch of its own).
  * -------------------------------------------------------------------------*/
 #define ZS_MS_MAX_TERMS 8
 typedef struct zs_ms_term {
@@ -431,6 +433,7 @@ typedef struct zs_ms_term {
   const void* gz; const void* glp;                     /* backward only */
   int64_t glp_stride_k, glp_stride_r;
   void* gmu; void* gsigma;
+  const void* gz2;                                     /* backward only, optional */
 } zs_ms_term;
 int zs_normal_sample_logprob_multi_f32(const zs_ms_term* terms, int n_terms, uint64_t seed, const uint64_t* rng_state,
                                        uint64_t* rng_used, void* stream);

@@ -137,6 +137,9 @@ class Raw(object):
             e.K, e.M, e.D = K, M, D
             e.offset, e.sigma_is_logstd = nd.get("offset", 0), nd.get("ls", 0)
             e.gz = gz.data_ptr() if gz is not None else None
+            gz2 = self.t(nd.get("gz2"))
+            e.gz2 = gz2.data_ptr() if gz2 is not None else None
+            keep.append(gz2)
             e.glp = glp.data_ptr() if glp is not None else None
             e.glp_stride_k, e.glp_stride_r = R, 1
             e.gmu, e.gsigma = gmu.data_ptr(), gs.data_ptr()
@@ -477,6 +480,12 @@ def test_c_oracle_multi_sampler_is_k1_per_node(orc, orc64):
             tol = 1e-9 if raw.dtype == torch.float64 else 2e-4
             np.testing.assert_allclose(gmu, gz.sum(0), rtol=tol, atol=tol)
             np.testing.assert_allclose(gs, b * sg - gl if nd["ls"] else b - gl / sg, rtol=tol, atol=tol * 10)
+        # two gradients w.r.t. one sample (gz + gz2, either may be missing) == their sum handed over as gz
+        split = [dict(nd, gz=(None if i == 1 else 0.25 * nd["gz"]), gz2=(nd["gz"] if i == 1 else 0.75 * nd["gz"])) for i, nd in enumerate(nodes)]
+        for (gmu, gs), (gmu2, gs2) in zip(out, raw.ms_bwd(split, seed=1, rs=st)):
+            tol = 1e-12 if raw.dtype == torch.float64 else 3e-6
+            np.testing.assert_allclose(gmu2, gmu, rtol=tol, atol=tol * 10)
+            np.testing.assert_allclose(gs2, gs, rtol=tol, atol=tol * 10)
 
 
 def _pl_reference(h, w, relu):
@@ -596,6 +605,10 @@ def test_hip_multi_sampler(hip, orc, hip64, orc64):
                 nd["gz"] = rng.standard_normal(nd["K"] * nd["mu"].size)
                 nd["glp"] = rng.standard_normal(nd["K"] * (nd["mu"].size // nd["D"]))
             for (ga, sa), (gb, sb), nd in zip(h.ms_bwd(nodes, rs=st_h), o.ms_bwd(nodes, rs=st_o), nodes):
+                np.testing.assert_allclose(ga, gb, rtol=1e-5, atol=1e-5)
+                np.testing.assert_allclose(sa, sb, rtol=2e-4, atol=2e-4 * max(np.abs(sb).max(), 1) if sb.size else 0)
+            split = [dict(nd, gz=(None if i == 1 else 0.25 * nd["gz"]), gz2=(nd["gz"] if i == 1 else 0.75 * nd["gz"])) for i, nd in enumerate(nodes)]
+            for (ga, sa), (gb, sb) in zip(h.ms_bwd(split, rs=st_h), o.ms_bwd(split, rs=st_o)):
                 np.testing.assert_allclose(ga, gb, rtol=1e-5, atol=1e-5)
                 np.testing.assert_allclose(sa, sb, rtol=2e-4, atol=2e-4 * max(np.abs(sb).max(), 1) if sb.size else 0)
 

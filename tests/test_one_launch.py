@@ -61,6 +61,10 @@ def test_bnn_step_is_one_launch_per_phase_and_equals_the_reference_op_sequence(d
     assert names[:n_fwd] == ["zs_normal_sample_logprob"] * 2 + ["zs_normal_sample_logprob_multi", "zs_particle_mlp", "zs_particle_rmse",
                              "zs_logjoint_scalar"]
     assert names[n_fwd:] == ["zs_logjoint_scalar_bwd", "zs_particle_mlp_bwd", "zs_normal_sample_logprob_multi_bwd"]
+    # the prior terms read the weight samples through the sampler's alias outputs (indices 4, 5; z: 0, 2; log q: 1, 3),
+    # so that their gradient and the network's meet INSIDE the sampler's backward kernel, not in an autograd accumulation launch
+    sampler_inputs = sorted(i for f, i in loss.grad_fn.next_functions if f is not None and "NormalSampleLogProbMulti" in type(f).__name__)
+    assert sampler_inputs == [4, 5]                   # (the log q rows arrive through a view)
     rmse = float(model.generator.cache["rmse"])
     # one launch per layer (PL1): the same numbers bit for bit
     pl_model, _, _ = _bnn(dev, "per_layer")

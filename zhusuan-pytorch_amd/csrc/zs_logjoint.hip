@@ -546,7 +546,7 @@ struct MSTerm {
   int ls;
   int wpr;                    // forward: wavefronts per row (1, 2 or 4: a row's Philox groups in ONE round of lanes)
   int64_t wave0;              // forward: first wavefront of this term (a multiple of 4: rows never straddle workgroups)
-  const T *gz, *glp;
+  const T *gz, *gz2, *glp;
   int64_t gsk, gsr;
   T *gmu, *gsigma;
   int ks;                     // backward: particle slices per parameter element (power of two <= 16)
@@ -661,8 +661,10 @@ __global__ __launch_bounds__(256) void k_normal_sample_multi_bwd(const MSArgs<T>
   T a = (T)0, b = (T)0, g = (T)0;
   for (int64_t k = ks; k < t.K; k += KS) {
     const int64_t i = k * t.M + mc;
-    if (t.gz) {
-      const T gzv = t.gz[i];
+    if (t.gz || t.gz2) {
+      // two gradient tensors for one sample (the draw used by the model AND by its own prior / log-joint term): added here
+      // instead of by an autograd accumulation launch in front of this kernel
+      const T gzv = (t.gz ? t.gz[i] : (T)0) + (t.gz2 ? t.gz2[i] : (T)0);
       const T e = t.eps ? t.eps[i] : (T)f4_get(philox_normal4((uint64_t)(i >> 2), call, seed), (int)(i & 3));
       a += gzv;
       b += gzv * e;
@@ -714,7 +716,7 @@ int ms_build(const zs_ms_term* terms, int n_terms, bool backward, MSArgs<T>& A, 
       waves += (wv + 3) / 4 * 4;
     } else {
       if (!s.sigma || !s.gmu || !s.gsigma) return ZS_EINVAL;
-      t.gz = (const T*)s.gz; t.glp = (const T*)s.glp; t.gsk = s.glp_stride_k; t.gsr = s.glp_stride_r;
+      t.gz = (const T*)s.gz; t.gz2 = (const T*)s.gz2; t.glp = (const T*)s.glp; t.gsk = s.glp_stride_k; t.gsr = s.glp_stride_r;
       t.gmu = (T*)s.gmu; t.gsigma = (T*)s.gsigma;
       int ks = 1;
       while (ks < 16 && ks < s.K) ks *= 2;

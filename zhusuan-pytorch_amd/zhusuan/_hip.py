@@ -81,7 +81,7 @@ class MSTerm(ctypes.Structure):
     _fields_ = [("mu", _p), ("sigma", _p), ("eps", _p), ("z", _p), ("lp", _p),
                 ("K", _i64), ("M", _i64), ("D", _i64), ("lp_stride_k", _i64), ("lp_stride_r", _i64),
                 ("offset", _u64), ("sigma_is_logstd", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("gz", _p), ("glp", _p), ("glp_stride_k", _i64), ("glp_stride_r", _i64), ("gmu", _p), ("gsigma", _p)]
+                ("gz", _p), ("glp", _p), ("glp_stride_k", _i64), ("glp_stride_r", _i64), ("gmu", _p), ("gsigma", _p), ("gz2", _p)]
 
 
 PROTOTYPES.update({

@@ -836,7 +836,10 @@ class LogJointScalar(torch.autograd.Function):
 class NormalSampleLogProbMulti(torch.autograd.Function):
     """MS1: K1 (z = mu + sigma * eps and its row-summed log-density) for SEVERAL reparameterised Normal nodes in one
     launch, their backward in one more.  ``meta`` = per node ``(K, has_k_axis, n_fold, is_logstd, call)``; ``tensors`` =
-    ``(mu, sigma, eps)`` per node (eps None: in-kernel Philox with call id base + call).  Returns (z_0, lp_0, z_1, lp_1, ...).
+    ``(mu, sigma, eps)`` per node (eps None: in-kernel Philox with call id base + call).  Returns (z_0, lp_0, z_1, lp_1, ...,
+    alias_0, alias_1, ...): ``alias_i`` is ``z_i`` once more (the same memory) as a separate output -- a consumer that reads the
+    sample through it (the log-joint's prior term) sends its gradient to a slot of its own, and the backward kernel adds the
+    two slots while it reads them, where autograd would have launched an accumulation in front of it.
     Replaces the per-latent re-read of ELBO.forward (zhusuan/variational/elbo.py:122) for models with more than one latent
     node (the BNN's weight matrices, examples/bayesian_neural_nets/bnn_vi.py:83-93)."""
 
@@ -880,7 +883,7 @@ class NormalSampleLogProbMulti(torch.autograd.Function):
         ctx.rng_state = used if used is not None else rng_state
         ctx.save_for_backward(*[t for t in tensors if t is not None])
         ctx.present = [t is not None for t in tensors]
-        return tuple(outs)
+        return tuple(outs) + tuple(outs[2 * i].view_as(outs[2 * i]) for i in range(nt))
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -908,6 +911,11 @@ class NormalSampleLogProbMulti(torch.autograd.Function):
                 gz = gz.contiguous()
                 keep.append(gz)
                 tm.gz = gz.data_ptr()
+            gz2 = gouts[2 * nt + i]
+            if gz2 is not None:
+                gz2 = gz2.contiguous()
+                keep.append(gz2)
+                tm.gz2 = gz2.data_ptr()
             if glp is not None and M > 0:
                 glp, gsk, gsr = _kr_view(glp, Kk, R)
                 keep.append(glp)

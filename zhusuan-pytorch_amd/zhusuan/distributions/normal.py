@@ -149,6 +149,9 @@ class Normal(Distribution):
             raise RuntimeError("Normal.log_prob(None) needs a cached sample: call sample() first")
         if self._fused is not None and self._fused[0] is x and self._fused[2] == n_fold:
             return None
+        # a sample drawn by the multi-node sampler carries itself once more as a separate autograd output: reading it through
+        # that one sends this term's gradient to its own slot of the sampler's backward (no accumulation launch)
+        x = getattr(x, '_zs_grad_alias', x)
         x = torch.as_tensor(x, dtype=self._dtype).to(self._mean.device)
         full = value_shape(x.shape, self._mean.dim(), self._mean.shape, self._scale_operand().shape)
         px, Px = _ops.periodic_operand(x, full)

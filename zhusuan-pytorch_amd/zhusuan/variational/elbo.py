@@ -81,6 +81,7 @@ def draw_latents(nodes_q):
     outs = _ops.NormalSampleLogProbMulti.apply(tuple(meta), seed, rng_state, *tensors)
     for i, (node, n_fold) in enumerate(plans):
         z, lp = outs[2 * i], outs[2 * i + 1]
+        z._zs_grad_alias = outs[2 * len(plans) + i]      # (the same sample as a second output: see NormalSampleLogProbMulti)
         node.dist._adopt_draw(z, lp, n_fold)
         values[node.name] = z
     for name in names[idx[-1] + 1:]:
