@@ -806,7 +806,7 @@ __global__ __launch_bounds__(PR_BLOCK) void k_particle_rmse(const T* __restrict_
                                                             int64_t K, int64_t B, double* __restrict__ ws, unsigned* __restrict__ ticket) {
   __shared__ double sh[PR_BLOCK / 64];
   __shared__ bool last;
-  const T invK = (T)1 / (T)K;
+  const T Kf = (T)K;
   double acc = 0.0;
   for (int64_t b = (int64_t)blockIdx.x * PR_BLOCK + threadIdx.x; b < B; b += (int64_t)gridDim.x * PR_BLOCK) {
     T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(PR_BLOCK) void k_particle_rmse(const T* __restrict_
       s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
     for (; k < K; ++k) s0 += pred[k * B + b];
-    const T d = y[b] - ((s0 + s1) + (s2 + s3)) * invK;
+    const T d = y[b] - ((s0 + s1) + (s2 + s3)) / Kf;         // torch.mean: the sum divided by K
     acc += (double)d * (double)d;
   }
   acc = wave_sum_d(acc);
@@ -857,7 +857,7 @@ template <typename T>
 int particle_rmse(const T* pred, const T* y, T* out, int64_t K, int64_t B, double* workspace, int64_t workspace_len, uint32_t* ticket,
                   void* stream) {
   if (K < 0 || B < 0 || !out) return ZS_EINVAL;
-  // (K == 0 or B == 0: torch's mean of nothing is NaN; the kernel's 0 * (1 / 0) and 0 / 0 produce it)
+  // (K == 0 or B == 0: torch's mean of nothing is NaN; the kernel's 0 / 0 produces it)
   if (B > 0 && (!y || (K > 0 && !pred))) return ZS_EINVAL;
   int64_t nb = B <= PR_ONE_BLOCK_MAX ? 1 : (B + PR_BLOCK - 1) / PR_BLOCK;
   if (nb > PR_MAX_BLOCKS) nb = PR_MAX_BLOCKS;
