@@ -120,9 +120,12 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--flat-adam', action='store_true',
                     help="zhusuan.optim.FlatAdam: torch.optim.Adam's update as one kernel launch")
+    ap.add_argument('--layer', default='fused', choices=['fused', 'per_layer', 'bmm', 'materialize'],
+                    help="the particle-batched network: one kernel each way (PM1), one per layer (PL1), round 2's batched GEMMs, "
+                         "or the reference's op sequence")
     args = ap.parse_args()
     device = torch.device('cuda')
-    model = build(n_particles=args.particles, device=device)
+    model = build(n_particles=args.particles, device=device, layer=args.layer)
     if args.flat_adam:
         import zhusuan
         opt = zhusuan.optim.FlatAdam(model.parameters(), lr=1e-3)

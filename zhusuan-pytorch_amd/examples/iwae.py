@@ -118,9 +118,11 @@ def main():
     ap.add_argument('--flat-adam', action='store_true',
                     help="zhusuan.optim.FlatAdam: torch.optim.Adam's update as one kernel launch")
     ap.add_argument('--fused-logits', action='store_true')
+    ap.add_argument('--dense', default='torch', choices=['torch', 'zhusuan', 'fused'],
+                    help="the MLPs' modules: torch.nn's (as the reference), zhusuan.Linear, or zhusuan.Linear in zhusuan.Sequential")
     args = ap.parse_args()
     device = torch.device('cuda')
-    model = build(args.particles, args.estimator, device=device, fused_logits=args.fused_logits)
+    model = build(args.particles, args.estimator, device=device, fused_logits=args.fused_logits, dense=args.dense)
     if args.flat_adam:
         import zhusuan
         opt = zhusuan.optim.FlatAdam(model.parameters(), lr=args.lr)
