@@ -206,7 +206,10 @@ def test_training_reduces_loss(dev):
                                                          "--fused-logits"]),
                                       ("examples.bnn_vi", ["--steps", "60"]),
                                       ("examples.vae_mnist", ["--batch", "32", "--steps", "60", "--flat-adam"]),
-                                      ("examples.bnn_vi", ["--steps", "60", "--flat-adam"])])
+                                      ("examples.bnn_vi", ["--steps", "60", "--flat-adam"]),
+                                      ("examples.vae_mnist", ["--batch", "32", "--steps", "60", "--flat-adam", "--dense", "fused"]),
+                                      ("examples.iwae", ["--batch", "16", "--particles", "8", "--steps", "60", "--dense", "fused"]),
+                                      ("examples.bnn_vi", ["--steps", "60", "--layer", "per_layer"])])
 def test_example_scripts_run(mod, args):
     """The counterparts of the reference's example scripts run as programs on the GPU (synthetic data)."""
     import subprocess
