@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""Randomised differential run of the HOT-PATH kernels through the C ABI -- K1 (fused Normal sample + log-density, given eps and
+in-kernel Philox) and its backward, K2 (Normal log-density of a value, every broadcast period) and its backwards, K3 (Bernoulli
+log-mass, probs and logits) and its backward, K4 (importance-weighted reduction, sgvb and vimco), log-mean-exp, K5 (Bernoulli
+sampler), Philox -- libzs_hip.so on the GPU against the C oracle on the host, random shapes, for a given number of seconds.  Uses
+the raw-call helpers of tests/test_cabi.py and its tolerances.  Exit code 1 at the first mismatch.
+
+  python tools/fuzz_hotpath.py [seconds=120] [seed=0]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+
+from zhusuan import _hip
+from conftest import host_kernel_library
+from test_cabi import Raw
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.RandomState(seed)
+hip = Raw(_hip.KernelLibrary(_hip.LIB_PATH), "cuda:0")
+orc = Raw(host_kernel_library(), "cpu")
+counts = {}
+
+
+def close(a, b, rtol, atol, what, shape):
+    if not np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True):
+        d = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))
+        print("MISMATCH %s at %s: max abs diff %.3e (atol %.1e, rtol %.1e)" % (what, shape, np.nanmax(d), atol, rtol), flush=True)
+        sys.exit(1)
+
+
+def dim(hi, small=0.3):
+    return int(rng.randint(1, (min(hi, 9) if rng.rand() < small else hi) + 1))
+
+
+def shape3():
+    K, R, D = dim(64), dim(300), (dim(64) if rng.rand() < 0.6 else dim(800))
+    while K * R * D > 400000:
+        R = max(R // 2, 1)
+    return K, R, D
+
+
+def case_k1():
+    K, R, D = shape3()
+    M, ls, kfast = R * D, int(rng.rand() < 0.4), bool(rng.rand() < 0.5)
+    mu = rng.standard_normal(M).astype(np.float32)
+    sg = (rng.uniform(-0.5, 0.3, M) if ls else rng.uniform(0.5, 1.5, M)).astype(np.float32)
+    shape = (K, R, D, ls, kfast)
+    if rng.rand() < 0.5:                      # eps given: z bit-exact (two roundings, like the reference)
+        eps = rng.standard_normal(K * M).astype(np.float32)
+        a, b = hip.normal_sample(mu, sg, eps, K, D, kfast=kfast, ls=ls), orc.normal_sample(mu, sg, eps, K, D, kfast=kfast, ls=ls)
+        if ls:                                # sigma = exp(log-std): the device's expf against glibc's (1 ulp)
+            close(a["z"], b["z"], 3e-7, 3e-7 * max(np.abs(b["z"]).max(), 1), "K1 z (eps given, log-std)", shape)
+        elif not np.array_equal(a["z"], b["z"]):
+            print("MISMATCH K1 z (eps given) not bit-exact at %s" % (shape,), flush=True)
+            sys.exit(1)
+    else:                                     # in-kernel Philox: device sin / cos / log against libm
+        eps = None
+        s, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+        a = hip.normal_sample(mu, sg, None, K, D, seed=s, off=off, kfast=kfast, ls=ls)
+        b = orc.normal_sample(mu, sg, None, K, D, seed=s, off=off, kfast=kfast, ls=ls)
+        close(a["z"], b["z"], 0, 3e-5 * max(np.abs(b["z"]).max(), 1), "K1 z (Philox)", shape)
+    close(a["lp"], b["lp"], 3e-5, 3e-4 * max(D, 1) ** 0.5, "K1 lp", shape)
+    gz, glp = rng.standard_normal(K * M).astype(np.float32), rng.standard_normal(K * R).astype(np.float32)
+    if eps is not None:
+        ga, gb = hip.normal_sample_bwd(sg, eps, gz, glp, K, D, ls=ls), orc.normal_sample_bwd(sg, eps, gz, glp, K, D, ls=ls)
+        for k in ("gmu", "gsigma"):
+            close(ga[k], gb[k], 2e-4, 2e-4 * max(np.abs(gb[k]).max(), 1), "K1 bwd " + k, shape)
+
+
+def case_k2():
+    K, R, D = shape3()
+    N, ls = K * R * D, int(rng.rand() < 0.4)
+    per = lambda: [1, D, R * D, N][int(rng.randint(4))] if rng.rand() < 0.8 else R * D
+    px, pm, ps = (N if rng.rand() < 0.7 else R * D), per(), per()
+    x, mu = rng.standard_normal(px).astype(np.float32), rng.standard_normal(pm).astype(np.float32)
+    sg = (rng.uniform(-0.5, 0.3, ps) if ls else rng.uniform(0.5, 1.5, ps)).astype(np.float32)
+    shape = (K, R, D, px, pm, ps, ls)
+    kfast = bool(rng.rand() < 0.5)
+    a, b = hip.normal_lp(x, mu, sg, K, R, D, kfast=kfast, ls=ls), orc.normal_lp(x, mu, sg, K, R, D, kfast=kfast, ls=ls)
+    close(a["lp"], b["lp"], 3e-5, 3e-4 * max(D, 1) ** 0.5, "K2 lp", shape)
+    glp = rng.standard_normal(K * R).astype(np.float32)
+    ga, gb = hip.normal_lp_bwd(x, mu, sg, glp, K, R, D, ls=ls), orc.normal_lp_bwd(x, mu, sg, glp, K, R, D, ls=ls)
+    for k in ("gx", "gmu", "gsigma"):
+        close(ga[k], gb[k], 2e-4, 2e-4 * max(np.abs(gb[k]).max(), 1), "K2 bwd " + k, shape)
+    if px == N and pm == R * D and ps == R * D:
+        want_gx = bool(rng.rand() < 0.5)
+        ga = hip.normal_lp_bwd_ksum(x, mu, sg, glp, K, R, D, want_gx=want_gx, ls=ls)
+        gb = orc.normal_lp_bwd_ksum(x, mu, sg, glp, K, R, D, want_gx=want_gx, ls=ls)
+        for k in gb:
+            close(ga[k], gb[k], 3e-4, 3e-4 * max(np.abs(gb[k]).max(), 1), "K2 bwd-ksum " + k, shape)
+
+
+def case_k3():
+    K, R, D = shape3()
+    logits, kfast = bool(rng.rand() < 0.4), bool(rng.rand() < 0.5)
+    N = K * R * D
+    # (logits within +-6: beyond, log(1 - sigmoid(l) + 1e-8) amplifies the last bit of the fp32 sigmoid -- 6e-8 against 1 - p -- by
+    # orders of magnitude, in the reference's own arithmetic as much as here)
+    p = (np.clip(2.0 * rng.standard_normal(N), -6, 6) if logits else rng.uniform(0, 1, N)).astype(np.float32)
+    if not logits and N > 4:
+        p[rng.randint(N, size=3)] = [0.0, 1.0, 1e-9]                     # the edges the +1e-8 exists for
+    xr = R if rng.rand() < 0.6 else K * R
+    x = (rng.uniform(0, 1, xr * D) < 0.5).astype(np.float32) if rng.rand() < 0.7 else rng.uniform(0, 1, xr * D).astype(np.float32)
+    shape = (K, R, D, xr, logits, kfast)
+    want_p = bool(logits and rng.rand() < 0.5)
+    a = hip.bern_lp(p, x, K, R, D, logits=logits, kfast=kfast, want_p=want_p)
+    b = orc.bern_lp(p, x, K, R, D, logits=logits, kfast=kfast, want_p=want_p)
+    close(a["lp"], b["lp"], 3e-5, (1e-4 if logits else 3e-5) * D, "K3 lp", shape)
+    if want_p:
+        close(a["p"], b["p"], 3e-6, 3e-7, "K3 probs_out", shape)
+    glp = rng.standard_normal(K * R).astype(np.float32)
+    ga, gb = hip.bern_lp_bwd(p, x, glp, K, R, D, logits=logits), orc.bern_lp_bwd(p, x, glp, K, R, D, logits=logits)
+    close(ga["gp"], gb["gp"], 1e-4 if logits else 3e-5, 3e-5 * max(np.abs(gb["gp"]).max(), 1), "K3 bwd", shape)
+
+
+def case_k4():
+    B, K = dim(3000), (dim(64) if rng.rand() < 0.7 else dim(1200))
+    K = max(K, 2)
+    spread = [1.0, 5.0, 30.0][int(rng.randint(3))]
+    logp, logq = (spread * rng.standard_normal((B, K))).astype(np.float32), rng.standard_normal((B, K)).astype(np.float32)
+    est = int(rng.randint(2))
+    a, b = hip.iw(logp, logq, est), orc.iw(logp, logq, est)
+    shape = (B, K, spread, est)
+    for k in ("cost", "bound"):
+        close(a[k], b[k], 3e-5, 3e-4 * max(np.abs(b[k]).max(), 1) * 1e-1, "K4 " + k, shape)
+    for k in ("cp", "cq"):
+        close(a[k], b[k], 1e-3, 2e-5 * max(np.abs(b[k]).max(), 1), "K4 " + k, shape)
+    close(hip.lme(logp), orc.lme(logp), 3e-6, 3e-6 * max(np.abs(logp).max(), 1), "LME", shape)
+
+
+def case_rng():
+    n, s, off = dim(200000), int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+    close(hip.philox(n, s, off), orc.philox(n, s, off), 0, 3e-5, "Philox normal", (n, s, off))
+    P = dim(5000)
+    p = rng.uniform(0, 1, P).astype(np.float32)
+    nn = P * dim(20)
+    if not np.array_equal(hip.bern_sample(p, nn, s, off), orc.bern_sample(p, nn, s, off)):
+        print("MISMATCH K5 Bernoulli sample at %s" % ((P, nn, s, off),), flush=True)
+        sys.exit(1)
+
+
+cases = [case_k1, case_k2, case_k3, case_k4, case_rng]
+t0 = time.time()
+while time.time() - t0 < budget:
+    c = cases[int(rng.randint(len(cases)))]
+    c()
+    counts[c.__name__] = counts.get(c.__name__, 0) + 1
+print("fuzz_hotpath: %.0f s, seed %d, no mismatch: %s" % (time.time() - t0, seed, counts))
