@@ -135,9 +135,9 @@ def case_k4():
     close(a["bound"], t["bound"], 2e-6, 2e-5, "K4 bound", shape)
     close(a["cp"], t["cp"], 1e-4, 1e-6, "K4 cp", shape)
     # (floors: a few fp32 roundings of the largest value -- with a handful of elements the maximum of either error is one rounding)
-    for key, floor in (("cost", 2e-5 * np.abs(t["cost"]).max()), ("cq", max(2e-6, 5e-7 * np.abs(t["cq"]).max()))):
+    for key, floor in (("cost", 2e-5 * np.abs(t["cost"]).max()), ("cq", max(2e-6, 1e-6 * np.abs(t["cq"]).max()))):
         err_hip, err_orc = np.abs(a[key] - t[key]).max(), np.abs(b[key] - t[key]).max()
-        if not err_hip <= max(1.5 * err_orc, floor):
+        if not err_hip <= max((1.5 if B * K >= 4096 else 3.0) * err_orc, floor):
             print("MISMATCH K4 %s at %s: error against float64 %.3e, the fp32 oracle's %.3e" % (key, shape, err_hip, err_orc), flush=True)
             sys.exit(1)
         slack = 2.5 * err_orc + 1e-5 * max(1.0, np.abs(t[key]).max())
