@@ -134,16 +134,21 @@ def case_k4():
     shape = (B, K, spread, est)
     close(a["bound"], t["bound"], 2e-6, 2e-5, "K4 bound", shape)
     close(a["cp"], t["cp"], 1e-4, 1e-6, "K4 cp", shape)
-    # (floors: a few fp32 roundings of the largest value -- with a handful of elements the maximum of either error is one rounding)
-    for key, floor in (("cost", 2e-5 * np.abs(t["cost"]).max()), ("cq", max(2e-6, 1e-6 * np.abs(t["cq"]).max()))):
-        err_hip, err_orc = np.abs(a[key] - t[key]).max(), np.abs(b[key] - t[key]).max()
-        if not err_hip <= max((1.5 if B * K >= 4096 else 3.0) * err_orc, floor):
-            print("MISMATCH K4 %s at %s: error against float64 %.3e, the fp32 oracle's %.3e" % (key, shape, err_hip, err_orc), flush=True)
-            sys.exit(1)
-        slack = 2.5 * err_orc + 1e-5 * max(1.0, np.abs(t[key]).max())
-        if not np.abs(a[key] - b[key]).max() <= slack:
-            print("MISMATCH K4 %s at %s: %.3e from the oracle (slack %.3e)" % (key, shape, np.abs(a[key] - b[key]).max(), slack), flush=True)
-            sys.exit(1)
+    if B * K < 2048:
+        # a handful of elements: the maximum of either fp32 error is one unlucky rounding of (sum of the row - l) / (K - 1), a ~500-sized
+        # intermediate of the reference's own formulation -- only a loose agreement is meaningful
+        for key in ("cost", "cq"):
+            close(a[key], b[key], 1e-4, 1e-6 * K * np.abs(logp - logq).max(), "K4 %s (small)" % key, shape)
+    else:
+        for key, floor in (("cost", 2e-5 * np.abs(t["cost"]).max()), ("cq", 2e-6)):
+            err_hip, err_orc = np.abs(a[key] - t[key]).max(), np.abs(b[key] - t[key]).max()
+            if not err_hip <= max(1.5 * err_orc, floor):
+                print("MISMATCH K4 %s at %s: error against float64 %.3e, the fp32 oracle's %.3e" % (key, shape, err_hip, err_orc), flush=True)
+                sys.exit(1)
+            slack = 2.5 * err_orc + 1e-5 * max(1.0, np.abs(t[key]).max())
+            if not np.abs(a[key] - b[key]).max() <= slack:
+                print("MISMATCH K4 %s at %s: %.3e from the oracle (slack %.3e)" % (key, shape, np.abs(a[key] - b[key]).max(), slack), flush=True)
+                sys.exit(1)
     close(hip.lme(logp), orc.lme(logp), 2e-6, 2e-5, "LME", shape)
 
 
