@@ -274,8 +274,17 @@ ZS_HD Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) {
 // 2^-24: there m + 0.5 needs 25 bits, the top 256 words rounded up to exactly 1.0 and a Logistic draw log(u) - log(1 - u)
 // became +inf about once in 1.7e7 draws (found by the host-side sanitizer / reference test of this header,
 // tests/host_math/zs_host_math.hip).
+// On the device the same value in TWO instructions instead of three (the generators are bound by instruction issue): the upper 23
+// bits become the mantissa of a float in [1, 2) (v_alignbit_b32, as in angle_rev below) and 1 - 2^-24 is subtracted --
+// (1 + m * 2^-23) - (1 - 2^-24) = (2m + 1) * 2^-24 is representable, so the subtraction is exact and the result bit-identical to
+// the fma form for all 2^23 mantissas (the device streams are compared with the oracle's bit for bit: tests/test_locscale.py
+// test_hip_uniform_sample, tests/test_cabi.py Bernoulli sampler).
 ZS_HD float u01(uint32_t v) {
+#if ZS_ON_DEVICE
+  return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, v, 9)) - 0.99999994039535522461f;
+#else
   return __builtin_fmaf((float)(v >> 9), 1.1920928955078125e-07f, 5.9604644775390625e-08f);
+#endif
 }
 
 // Angle of a Box-Muller pair, in revolutions, from one Philox word: the word's upper 23 bits become the mantissa of a

@@ -131,7 +131,10 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
           if (HAS_LP) {
             if (DIST == D_NORMAL) {
               const float d0 = zz.x - m.x, d1 = zz.y - m.y, d2 = zz.z - m.z, d3 = zz.w - m.w;
-              *stp = rowc - (hp[0] * (d0 * d0) + hp[1] * (d1 * d1) + hp[2] * (d2 * d2) + hp[3] * (d3 * d3));
+              // two packed chains (v_pk_mul_f32 + v_pk_fma_f32) and one add instead of four products and three adds: the loop is
+              // bound by instruction issue
+              const float t0 = fmaf(hp[2], d2 * d2, hp[0] * (d0 * d0)), t1 = fmaf(hp[3], d3 * d3, hp[1] * (d1 * d1));
+              *stp = rowc - (t0 + t1);
             } else {
               *stp = rowc + dens;
             }
