@@ -328,7 +328,7 @@ def cpu_baseline(name="c3", budget_s=8.0, one_thread_budget_s=5.0, max_steps=40)
 # ------------------------------------------------------------------------------------------------ timing helpers
 def timed_trials(step, steps, world, dev, min_seconds=MIN_TIMED_SECONDS, max_trials=200):
     """Trials of exactly `steps` steps, each bracketed by synchronize + barrier and reduced with MAX over the ranks;
-    enough trials to cover `min_seconds` (every rank derives the same count from the first, rank-reduced, trial).
+    at least three and as many as it takes to cover `min_seconds`.
     Returns (list of elapsed seconds per trial, last loss)."""
     def one():
         torch.cuda.synchronize()
@@ -347,10 +347,10 @@ def timed_trials(step, steps, world, dev, min_seconds=MIN_TIMED_SECONDS, max_tri
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, last
-    first, last = one()
-    n = int(min(max_trials, max(3, np.ceil(min_seconds / max(first, 1e-6)))))
-    trials = [first]
-    for _ in range(n - 1):
+    trials = []
+    last = None
+    # (every rank sees the same, rank-reduced, elapsed times, so every rank stops after the same trial)
+    while len(trials) < max_trials and (len(trials) < 3 or sum(trials) < min_seconds):
         el, last = one()
         trials.append(el)
     return trials, last
