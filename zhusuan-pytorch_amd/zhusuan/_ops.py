@@ -883,7 +883,9 @@ class NormalSampleLogProbMulti(torch.autograd.Function):
         ctx.rng_state = used if used is not None else rng_state
         ctx.save_for_backward(*[t for t in tensors if t is not None])
         ctx.present = [t is not None for t in tensors]
-        return tuple(outs) + tuple(outs[2 * i].view_as(outs[2 * i]) for i in range(nt))
+        # (detach(): the same storage without a view relationship -- a view would keep its base alive, and the base keeps the alias
+        # in an attribute: a reference cycle that only the garbage collector frees)
+        return tuple(outs) + tuple(outs[2 * i].detach() for i in range(nt))
 
     @staticmethod
     def backward(ctx, *gouts):
