@@ -134,8 +134,8 @@ def case_k4():
     shape = (B, K, spread, est)
     close(a["bound"], t["bound"], 2e-6, 2e-5, "K4 bound", shape)
     close(a["cp"], t["cp"], 1e-4, 1e-6, "K4 cp", shape)
-    if B * K < 2048:
-        # a handful of elements: the maximum of either fp32 error is one unlucky rounding of (sum of the row - l) / (K - 1), a ~500-sized
+    if B * K < 2048 or B < 64:
+        # a handful of elements or of rows: the maximum of either fp32 error is one unlucky rounding of (sum of the row - l) / (K - 1), a ~500-sized
         # intermediate of the reference's own formulation -- only a loose agreement is meaningful
         for key in ("cost", "cq"):
             close(a[key], b[key], 1e-4, 3e-6 * K * np.abs(logp - logq).max(), "K4 %s (small)" % key, shape)
