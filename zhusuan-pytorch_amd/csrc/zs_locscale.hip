@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256) void k_logistic_sample_bwd(const T* __restrict
     int64_t r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = (m0 + j) / D;
-    for (int64_t k = slice; k < K; k += 4) {
+    const int64_t ks = __builtin_amdgcn_readfirstlane(slice);      // wave-uniform: the particle loop runs on scalar counters
+    for (int64_t k = ks; k < K; k += 4) {
       const int64_t i0 = k * M + m0;
       T grow = (T)0;
       if (SAME_ROW && glp) grow = glp[k * gsk + r[0] * gsr];

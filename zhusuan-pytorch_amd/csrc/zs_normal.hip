@@ -301,33 +301,40 @@ __global__ __launch_bounds__(64 * NS) void k_normal_sample_bwd(
   const bool on = m4 < M4;
   float4 am = make_float4(0.f, 0.f, 0.f, 0.f), as = am;
   float gl = 0.f;
-  if (on && slice < K) {
+  // The slice index is the same for the whole wavefront: with it in a scalar register the particle loop runs on scalar
+  // counters, and the three streams (gz, eps, glp) and the Philox group index advance by ONE 64-bit add each per particle --
+  // the index arithmetic of the per-lane form (k * M4 + m4 and kn * gsk + r * gsr with 64-bit multiplies, the clamp of the
+  // prefetch index, the loop predicate) was 28 of the loop's 95 VALU instructions, and the kernel is bound by instruction issue.
+  const int64_t ks = __builtin_amdgcn_readfirstlane(slice);
+  if (on && ks < K) {
     const int64_t r = (int64_t)((uint64_t)m4 >> 31 ? m4 / D4 : (int64_t)((uint32_t)m4 / (uint32_t)D4));
     // rolling prefetch: the loads of particle k + NS are in flight while the draw of particle k is regenerated (which
     // operands exist is compiled in: a branch between two loads would make the second wait for the first)
     float4 gn = make_float4(0.f, 0.f, 0.f, 0.f), en = gn;
     float gln = 0.f;
-    {
-      const int64_t g0 = (int64_t)slice * M4 + m4;
-      if (HAS_GZ) gn = gz[g0];
-      if (HAS_GZ && HAS_EPS) en = eps[g0];
-      if (HAS_GLP) gln = glp[(int64_t)slice * gsk + r * gsr];
-    }
-    for (int64_t k = slice; k < K; k += NS) {
-      const int64_t g = k * M4 + m4;
+    const float4* __restrict__ gzp = HAS_GZ ? gz + (ks * M4 + m4) : nullptr;
+    const float4* __restrict__ epp = (HAS_GZ && HAS_EPS) ? eps + (ks * M4 + m4) : nullptr;
+    const float* __restrict__ glpp = HAS_GLP ? glp + (ks * gsk + r * gsr) : nullptr;
+    uint64_t g = (uint64_t)(ks * M4 + m4);                 // Philox group of (particle k, this lane)
+    if (HAS_GZ) gn = *gzp;
+    if (HAS_GZ && HAS_EPS) en = *epp;
+    if (HAS_GLP) gln = *glpp;
+    const int64_t zstep = (int64_t)NS * M4, lstep = (int64_t)NS * gsk;
+    for (int64_t k = ks; k < K; k += NS) {                  // uniform: scalar registers
       const float4 gv = gn;
       float4 e = en;
       gl += gln;
-      const int64_t kn = k + NS < K ? k + NS : k;          // last iteration: a harmless re-read
-      const int64_t gnx = kn * M4 + m4;
-      if (HAS_GZ) gn = gz[gnx];
-      if (HAS_GZ && HAS_EPS) en = eps[gnx];
-      if (HAS_GLP) gln = glp[kn * gsk + r * gsr];
+      const bool more = k + NS < K;                         // last iteration: a harmless re-read of the same particle
+      const int64_t zs = more ? zstep : 0, ls2 = more ? lstep : 0;
+      if (HAS_GZ) { gzp += zs; gn = *gzp; }
+      if (HAS_GZ && HAS_EPS) { epp += zs; en = *epp; }
+      if (HAS_GLP) { glpp += ls2; gln = *glpp; }
       if (HAS_GZ) {
-        if (!HAS_EPS) e = philox_normal4((uint64_t)g, call, seed);
+        if (!HAS_EPS) e = philox_normal4(g, call, seed);
         am.x += gv.x; am.y += gv.y; am.z += gv.z; am.w += gv.w;
         as.x += gv.x * e.x; as.y += gv.y * e.y; as.z += gv.z * e.z; as.w += gv.w * e.w;
       }
+      g += (uint64_t)zstep;
     }
   }
   red_a[slice][lane] = am;

@@ -464,15 +464,23 @@ __global__ __launch_bounds__(64 * NS) void k_logprob_bwd_ksum(
       inv[j] = (DIST == D_NORMAL && ls) ? 1.0f : 1.0f / sv[j];     // d/d logstd = sigma * d/d sigma
     }
     float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t k = slice; k < K; k += NS) {      // (unrolling by 4 was measured: 76 -> 67 % at 1 M rows, registers)
-      const int64_t i4 = k * M4 + m4;
-      const float g = glp[k * gsk + r * gsr];
-      const float4 xv = x[i4];
+    // the slice index is wave-uniform: scalar loop counter, and the three streams advance by one 64-bit add each per particle
+    // (instead of k * M4 + m4 and k * gsk + r * gsr with 64-bit multiplies per lane)
+    const int64_t ks = __builtin_amdgcn_readfirstlane(slice);
+    const float4* __restrict__ xp = x + (ks * M4 + m4);
+    float4* __restrict__ gxp = gx ? gx + (ks * M4 + m4) : nullptr;
+    const float* __restrict__ glpp = glp + (ks * gsk + r * gsr);
+    const int64_t zstep = (int64_t)NS * M4, lstep = (int64_t)NS * gsk;
+    for (int64_t k = ks; k < K; k += NS) {         // (unrolling by 4 was measured: 76 -> 67 % at 1 M rows, registers)
+      const float g = *glpp;
+      const float4 xv = *xp;
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
       float t[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) ksum_elem<DIST>(g, xs[j], mv[j], pr[j], inv[j], t[j], a[j], b[j]);
-      if (gx) gx[i4] = make_float4(t[0], t[1], t[2], t[3]);
+      if (gx) { *gxp = make_float4(t[0], t[1], t[2], t[3]); gxp += zstep; }
+      xp += zstep;
+      glpp += lstep;
     }
     am = make_float4(a[0], a[1], a[2], a[3]);
     as = make_float4(b[0], b[1], b[2], b[3]);
