@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 11
+#define ZS_ABI_VERSION 12
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -198,6 +198,55 @@ int zs_iw_objective_f32(const float* logp_a, int64_t ld_a, const float* logp_b, 
                         float* cost_b, float* bound_b, float* coef, float* mean_cost,
                         float* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
 
+
+/* ---------------------------------------------------------------------------
+ * IW1  The GENERATOR SIDE of the importance-weighted objective in one launch: the Bernoulli likelihood's row sums (K3), the
+ * log-density of the latent value under a Normal prior (K2), the addition of the generator's log-joint terms, the
+ * subtraction of log q and the whole of K4b.  Replaces the per-node loop of ImportanceWeightedObjective.log_joint /
+ * .forward (zhusuan/variational/importance_weighted_objective.py:66-100) over Normal._log_prob (normal.py:109-126) and
+ * Bernoulli._log_prob (bernoulli.py:84-95) plus .sgvb / .vimco (:102-191) for the IWAE caller
+ * (examples/variational_autoencoder/iwae.py:49-81):
+ *
+ *   lp_x[r, k]  = sum_d  x*log(p + 1e-8) + (1 - x)*log((1 - p) + 1e-8)         p [K, R, D] (probabilities, or logits with
+ *                                                                              from_logits != 0: p = sigmoid(logit) as K3);
+ *                                                                              x periodic with Px = R*D (shared by the
+ *                                                                              particles) or K*R*D
+ *   lp_z[r, k]  = sum_d  log N(z[k, r, d] | pmu, psigma)                        optional (z == NULL: no such term); z [K, R, Dz];
+ *                                                                              pmu / psigma with period 1 or R*Dz
+ *   log_w[r, k] = ((rows_a[r, k] + lp_z[r, k]) + lp_x[r, k]) - logq[r, k]       rows_a optional: ready-made K-fastest rows of
+ *                                                                              further generator nodes; absent terms are
+ *                                                                              left out of the sum (the reference adds the
+ *                                                                              nodes left to right)
+ * and then exactly zs_iw_objective on log_w: cost_b, bound_b, coef [2, R, K] (scaled by 1/R when want_mean), mean_cost.
+ * K-fastest [R, K] outputs: lp_x (required), lp_z (optional; the float64 twin requires it when z is given).  cost_b is
+ * required; mean_cost (want_mean) is the deterministic batch mean: every workgroup adds its cost in fixed point to the 64-bit
+ * word `acc` (one zero-initialised device word, handed back at zero; integer addition does not depend on the order of
+ * arrival), resolution 2^-21 per datapoint at R = 256, NaN when some cost is non-finite or >= 2^24 (2^20 beyond R = 4096).
+ * Returns ZS_ENOTSUP outside the fused kernel's domain (K <= 64, R <= 32768, D % 4 == 0, 256 <= D <= 1024, Dz % 4 == 0,
+ * Dz <= 256, 16-byte aligned operands): the caller then composes K2 / K3 / K4b itself.
+ * -------------------------------------------------------------------------*/
+int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, const float* x, int64_t Px,
+                                  int64_t K, int64_t R, int64_t D,
+                                  const float* z, const float* pmu, int64_t Pm, const float* psigma, int64_t Ps,
+                                  int64_t Dz, int psigma_is_logstd,
+                                  const float* rows_a, int64_t ld_a, const float* logq, int64_t ld_q,
+                                  int estimator, int want_mean,
+                                  float* lp_x, float* lp_z, float* cost_b, float* bound_b, float* coef, float* mean_cost,
+                                  uint64_t* acc, void* stream);
+
+/* Backward of IW1.  The incoming gradient of the objective stays a DEVICE value: gout[r * gout_stride] (gout_stride = 0: the
+ * 0-d gradient of the batch mean; 1: one value per datapoint) multiplies the coefficient rows inside the kernels, so no
+ * pass over the [2, R, K] coefficient buffer is launched:
+ *   gp[k, r, d]      = coef[0][r, k] * gout[r] * d lp_x / d p          (as zs_bernoulli_logprob_bwd; logits form with from_logits)
+ * and, when the variational node is handed in (zq != NULL: a non-reparameterised Normal draw zq [K, R, Dq] with parameters
+ * qmu, qsigma [R, Dq]; normal.py:102,112-116), the gradient of -sum log q terms w.r.t. its parameters
+ *   gqmu[r, d], gqsigma[r, d] = sum_k coef[1][r, k] * gout[r] * d log N(zq[k, r, d] | qmu, qsigma) / d (qmu, qsigma)
+ * (as zs_normal_logprob_bwd_ksum).  gp may be NULL (nothing flows into the decoder). */
+int zs_bernoulli_iw_objective_bwd_f32(const float* p, int from_logits, const float* x, int64_t Px,
+                                      int64_t K, int64_t R, int64_t D,
+                                      const float* coef, const float* gout, int64_t gout_stride, float* gp,
+                                      const float* zq, const float* qmu, const float* qsigma, int64_t Dq,
+                                      int qsigma_is_logstd, float* gqmu, float* gqsigma, void* stream);
 
 /* out[b] = log_mean_exp_k(x[b*ld + k])  (zhusuan/utils.py:6-21, K-fastest rows) */
 int zs_log_mean_exp_f32(const float* x, int64_t ld, int64_t B, int64_t K, float* out, void* stream);
@@ -543,6 +592,8 @@ int zs_bernoulli_logits_logprob_bwd_f64(const double* logits, const double* x, i
 int zs_bernoulli_sample_f64(const double* p, int64_t Pp, double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 int zs_iw_reduce_f64(const double* logp, int64_t ld_p, const double* logq, int64_t ld_q, int64_t B, int64_t K, int estimator, double* cost_b, double* bound_b, double* coef_p, double* coef_q, void* stream);
 int zs_iw_objective_f64(const double* logp_a, int64_t ld_a, const double* logp_b, int64_t ld_b, const double* logq, int64_t ld_q, int64_t B, int64_t K, int estimator, int want_mean, double* cost_b, double* bound_b, double* coef, double* mean_cost, double* workspace, int64_t workspace_len, uint32_t* ticket, void* stream);
+int zs_bernoulli_iw_objective_f64(const double* p, int from_logits, const double* x, int64_t Px, int64_t K, int64_t R, int64_t D, const double* z, const double* pmu, int64_t Pm, const double* psigma, int64_t Ps, int64_t Dz, int psigma_is_logstd, const double* rows_a, int64_t ld_a, const double* logq, int64_t ld_q, int estimator, int want_mean, double* lp_x, double* lp_z, double* cost_b, double* bound_b, double* coef, double* mean_cost, uint64_t* acc, void* stream);
+int zs_bernoulli_iw_objective_bwd_f64(const double* p, int from_logits, const double* x, int64_t Px, int64_t K, int64_t R, int64_t D, const double* coef, const double* gout, int64_t gout_stride, double* gp, const double* zq, const double* qmu, const double* qsigma, int64_t Dq, int qsigma_is_logstd, double* gqmu, double* gqsigma, void* stream);
 int zs_log_mean_exp_f64(const double* x, int64_t ld, int64_t B, int64_t K, double* out, void* stream);
 int zs_philox_normal_f64(double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);
 int zs_logistic_sample_logprob_f64(const double* loc, const double* scale, const double* u, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, uint64_t* rng_used, void* stream);

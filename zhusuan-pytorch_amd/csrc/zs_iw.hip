@@ -79,31 +79,7 @@ __global__ __launch_bounds__(256) void k_iw_reduce_wave(
       if (ext.logp_b) lp += lb;                                   // (a + b) - q, rounded like the reference's add
       l = lp - lq;
     }
-    IwRow r;
-    r.m1 = wave_max(l);
-    const unsigned long long hit = __ballot(on && l == r.m1);
-    r.jstar = hit ? (int)__ffsll((long long)hit) - 1 : 0;
-    r.m2 = wave_max((on && lane != r.jstar) ? l : -INFINITY);
-    const float e = on ? expf(l - r.m1) : 0.f;
-    r.S = wave_sum(e);
-    r.sumL = wave_sum(on ? l : 0.f);
-    r.S2 = 0.f;
-    if (estimator == ZS_IW_VIMCO) r.S2 = wave_sum((on && lane != r.jstar) ? expf(l - r.m2) : 0.f);
-    r.logS = logf(r.S);
-    r.invK = 1.0f / (float)K;
-    r.invKm1 = K > 1 ? 1.0f / (float)(K - 1) : 0.f;
-    float wt = 0.f, ct = 0.f, cq = 0.f;
-    if (on) iw_particle(r, l, lq, lane, estimator, wt, ct, cq);
-    const float cost = wave_sum(ct);
-    my_cost += cost;
-    if (on) {
-      if (coef_p) coef_p[b * K + lane] = -wt * ext.scale;
-      if (coef_q) coef_q[b * K + lane] = cq * ext.scale;
-    }
-    if (lane == 0) {
-      if (cost_b) cost_b[b] = cost;
-      if (bound_b) bound_b[b] = logf(r.S * r.invK) + r.m1;  // log(mean(exp(x - max))) + max, utils.py:18
-    }
+    my_cost += iw_wave_row(l, lq, on, lane, K, estimator, ext.scale, b, cost_b, bound_b, coef_p, coef_q);
   }
   if (ext.mean_cost) {
     if (lane == 0) wave_cost[threadIdx.x >> 6] = my_cost;
@@ -514,7 +490,7 @@ const char* const kKernelNames[zs::KID_COUNT] = {
     "zs_logistic_logprob_bwd_ksum_f32", "zs_logjoint_scalar_f32", "zs_logjoint_scalar_bwd_f32",
     "zs_normal_sample_logprob_multi_f32", "zs_normal_sample_logprob_multi_bwd_f32", "zs_particle_linear_f32",
     "zs_particle_linear_bwd_f32", "zs_column_sum_f32", "zs_dense_act_bwd_f32", "zs_particle_rmse_f32", "zs_particle_mlp_f32",
-    "zs_particle_mlp_bwd_f32"};
+    "zs_particle_mlp_bwd_f32", "zs_bernoulli_iw_objective_f32", "zs_bernoulli_iw_objective_bwd_f32"};
 void prof_clear(ProfState& s) {
   for (int k = 0; k < zs::KID_COUNT; ++k) {
     for (auto& p : s.ev[k]) {

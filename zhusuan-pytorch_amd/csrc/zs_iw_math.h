@@ -70,5 +70,39 @@ ZS_HD void iw_particle(const IwRow& r, float l, float lq, int j, int estimator,
   iw_particle_e(r, l, lq, expf(l - r.m1), j, estimator, wt, cost_term, cq);
 }
 
+// One datapoint on one wavefront, lane = particle (K <= 64): the row scalars by butterflies, then the per-particle terms
+// (the body of k_iw_reduce_wave; also the tail of the fused generator-side objective, zs_iwfused.hip).  `l` = log w of this
+// lane's particle (-inf on lanes >= K), `lq` its log q.  Writes the two coefficient rows (scaled) and, from lane 0, the
+// per-datapoint cost / bound when the pointers are given; returns the datapoint's cost (uniform across the wave).
+__device__ __forceinline__ float iw_wave_row(float l, float lq, bool on, int lane, int K, int estimator, float scale,
+                                             int64_t b, float* __restrict__ cost_b, float* __restrict__ bound_b,
+                                             float* __restrict__ coef_p, float* __restrict__ coef_q) {
+  IwRow r;
+  r.m1 = wave_max(l);
+  const unsigned long long hit = __ballot(on && l == r.m1);
+  r.jstar = hit ? (int)__ffsll((long long)hit) - 1 : 0;
+  r.m2 = wave_max((on && lane != r.jstar) ? l : -INFINITY);
+  const float e = on ? expf(l - r.m1) : 0.f;
+  r.S = wave_sum(e);
+  r.sumL = wave_sum(on ? l : 0.f);
+  r.S2 = 0.f;
+  if (estimator == ZS_IW_VIMCO) r.S2 = wave_sum((on && lane != r.jstar) ? expf(l - r.m2) : 0.f);
+  r.logS = logf(r.S);
+  r.invK = 1.0f / (float)K;
+  r.invKm1 = K > 1 ? 1.0f / (float)(K - 1) : 0.f;
+  float wt = 0.f, ct = 0.f, cq = 0.f;
+  if (on) iw_particle(r, l, lq, lane, estimator, wt, ct, cq);
+  const float cost = wave_sum(ct);
+  if (on) {
+    if (coef_p) coef_p[b * K + lane] = -wt * scale;
+    if (coef_q) coef_q[b * K + lane] = cq * scale;
+  }
+  if (lane == 0) {
+    if (cost_b) cost_b[b] = cost;
+    if (bound_b) bound_b[b] = logf(r.S * r.invK) + r.m1;  // log(mean(exp(x - max))) + max, utils.py:18
+  }
+  return cost;
+}
+
 
 }  // namespace zs

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64 * NS) void k_logprob_bwd_ksum(
     const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
     const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float4* __restrict__ gx, float4* __restrict__ gmu, float4* __restrict__ gsigma,
-    int64_t K, int64_t M4, int D4, bool ls) {
+    int64_t K, int64_t M4, int D4, bool ls, const float* __restrict__ gscale, int64_t gss) {
   __shared__ float4 red[2][NS][64];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int64_t m4 = (int64_t)blockIdx.x * 64 + lane;
@@ -470,9 +470,11 @@ __global__ __launch_bounds__(64 * NS) void k_logprob_bwd_ksum(
     const float4* __restrict__ xp = x + (ks * M4 + m4);
     float4* __restrict__ gxp = gx ? gx + (ks * M4 + m4) : nullptr;
     const float* __restrict__ glpp = glp + (ks * gsk + r * gsr);
+    // optional scale of the row gradients (the objective's incoming gradient: one device scalar, gss = 0, or one per row r)
+    const float gs = gscale ? gscale[r * gss] : 1.0f;
     const int64_t zstep = (int64_t)NS * M4, lstep = (int64_t)NS * gsk;
     for (int64_t k = ks; k < K; k += NS) {         // (unrolling by 4 was measured: 76 -> 67 % at 1 M rows, registers)
-      const float g = *glpp;
+      const float g = gscale ? *glpp * gs : *glpp;
       const float4 xv = *xp;
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
       float t[4];
@@ -507,15 +509,16 @@ __global__ __launch_bounds__(256) void k_logprob_bwd_ksum_serial(
     const float* __restrict__ x, const float* __restrict__ mu, const float* __restrict__ sigma,
     const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float* __restrict__ gx, float* __restrict__ gmu, float* __restrict__ gsigma,
-    int64_t K, int64_t M, int64_t D, bool ls) {
+    int64_t K, int64_t M, int64_t D, bool ls, const float* __restrict__ gscale, int64_t gss) {
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = m / D;
+    const float gs = gscale ? gscale[r * gss] : 1.0f;
     const float s = sigma_of(sigma[m], ls), mm = mu[m];
     const float inv = (DIST == D_NORMAL && ls) ? 1.0f : 1.0f / s;
     const float prec = DIST == D_NORMAL ? exp2_fast(-2.0f * log2_fast(s)) : 0.f;
     float a = 0.f, b = 0.f;
     for (int64_t k = 0; k < K; ++k) {
-      const float g = glp[k * gsk + r * gsr];
+      const float g = gscale ? glp[k * gsk + r * gsr] * gs : glp[k * gsk + r * gsr];
       float t;
       ksum_elem<DIST>(g, x[k * M + m], mm, prec, inv, t, a, b);
       if (gx) gx[k * M + m] = t;
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(256) void k_logprob_bwd_ksum_serial(
 template <int DIST>
 inline void launch_logprob_bwd_ksum(int kid, const float* x, const float* mu, const float* sigma, const float* glp, int64_t gsk,
                                     int64_t gsr, float* gx, float* gmu, float* gsigma, int64_t K, int64_t R, int64_t D, bool ls,
-                                    hipStream_t st) {
+                                    hipStream_t st, const float* gscale = nullptr, int64_t gss = 0) {
   const int64_t M = R * D;
   const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(mu) && aligned16(sigma) && (!gx || aligned16(gx)) &&
                    (!gmu || aligned16(gmu)) && (!gsigma || aligned16(gsigma));
@@ -539,14 +542,14 @@ inline void launch_logprob_bwd_ksum(int kid, const float* x, const float* mu, co
     if ((M4 + 63) / 64 < 256 && K >= 16)
       ZS_LAUNCH(kid, (k_logprob_bwd_ksum<DIST, 16>), dim3((unsigned)((M4 + 63) / 64)), dim3(1024), st, (const float4*)x,
                 (const float4*)mu, (const float4*)sigma, glp, gsk, gsr, (float4*)gx, (float4*)gmu, (float4*)gsigma, K, M4,
-                (int)(D / 4), ls);
+                (int)(D / 4), ls, gscale, gss);
     else
       ZS_LAUNCH(kid, (k_logprob_bwd_ksum<DIST, 4>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), st, (const float4*)x,
                 (const float4*)mu, (const float4*)sigma, glp, gsk, gsr, (float4*)gx, (float4*)gmu, (float4*)gsigma, K, M4,
-                (int)(D / 4), ls);
+                (int)(D / 4), ls, gscale, gss);
   } else {
     ZS_LAUNCH(kid, (k_logprob_bwd_ksum_serial<DIST>), dim3(grid_for(M, 256)), dim3(256), st, x, mu, sigma, glp, gsk, gsr, gx, gmu,
-              gsigma, K, M, D, ls);
+              gsigma, K, M, D, ls, gscale, gss);
   }
 }
 

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # The in-tree library.  ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments: tools/); bench.py
 # records which file was loaded (path, sha256, zs_build_info) and refuses an override unless --allow-experiments is given.
 LIB_PATH = os.environ.get("ZS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -52,6 +52,12 @@ PROTOTYPES = {
     "zs_reinforce_f32": [_p, _p, _p, _i64, _i64, _int, _int, ctypes.c_double, _p, _p, _p, _p, _p, _p, _i64, _p, _p],
     # the whole importance-weighted objective in one launch
     "zs_iw_objective_f32": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _i64, _p, _p],
+    # IW1: p, from_logits, x, Px, K, R, D, z, pmu, Pm, psigma, Ps, Dz, psigma_is_logstd, rows_a, ld_a, logq, ld_q, estimator,
+    # want_mean, lp_x, lp_z, cost_b, bound_b, coef, mean_cost, acc, stream
+    "zs_bernoulli_iw_objective_f32": [_p, _int, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _i64, _int, _p, _i64, _p, _i64,
+                                      _int, _int, _p, _p, _p, _p, _p, _p, _p, _p],
+    # p, from_logits, x, Px, K, R, D, coef, gout, gout_stride, gp, zq, qmu, qsigma, Dq, qsigma_is_logstd, gqmu, gqsigma, stream
+    "zs_bernoulli_iw_objective_bwd_f32": [_p, _int, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _int, _p, _p, _p],
     # scalar ELBO epilogue: six (rows, n, coef) slots, out, coef_out, stream
     "zs_scalar_objective_f32": [_p, _i64, ctypes.c_double] * 6 + [_p, _p, _p],
     # Adam update: param_ptrs, grad_ptrs, starts (host arrays), n_tensors, exp_avg, exp_avg_sq, steps, ticket, n, lr, beta1,

@@ -169,14 +169,23 @@ class NormalLogProb(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, glp):
-        K, R, D, (Px, Pm, Ps), ls = ctx.meta
+        K, R, D, periods, ls = ctx.meta
         x, mu, sigma = ctx.saved_tensors
+        need = ctx.needs_input_grad[:3]
+        if K * R * D == 0 or not any(need):
+            return (None,) * 8
+        return _normal_logprob_grads(x, mu, sigma, glp, K, R, D, periods, ls, need) + (None,) * 5
+
+
+def _normal_logprob_grads(x, mu, sigma, glp, K, R, D, periods, ls, need):
+    """(gx, gmu, gsigma) of the row-summed Normal log-density for row gradients `glp` (K2's backward: the K-summed kernel
+    when the parameters are [R, D] repeated over the particles, else element-wise partials folded over the periods)."""
+    if True:
+        Px, Pm, Ps = periods
+        need_x, need_mu, need_sigma = need
         sfx = _sfx(x)
-        need_x, need_mu, need_sigma = ctx.needs_input_grad[:3]
         N = K * R * D
         lib = _hip.lib()
-        if N == 0 or not (need_x or need_mu or need_sigma):
-            return (None,) * 8
         glp, gsk, gsr = _kr_view(glp, K, R)
         st = _hip.stream_for(x)
         gx = gmu = gsigma = None
@@ -203,8 +212,7 @@ class NormalLogProb(torch.autograd.Function):
                     f = f.view(N // P, P).sum(0)
                 return f.view(like.shape)
             gx, gmu, gsigma = fold(fx, Px, x), fold(fm, Pm, mu), fold(fs, Ps, sigma)
-        return (gx if need_x else None, gmu if need_mu else None, gsigma if need_sigma else None,
-                None, None, None, None, None)
+        return (gx if need_x else None, gmu if need_mu else None, gsigma if need_sigma else None)
 
 
 class BernoulliLogProb(torch.autograd.Function):
@@ -295,12 +303,16 @@ class IWReduce(torch.autograd.Function):
 
 
 _SCRATCH = {}     # (device, stream | 'capture', kind) -> tuple of tensors
+_SCRATCH_RETIRED = []   # capture sets that a larger one has replaced: kept alive, see _scratch
 
 
 def _scratch(device, kind, fits, make):
     """Scratch of the kernels that combine per-workgroup partial results in-kernel (workspaces, zero-initialised ticket words
     that the kernels hand back at zero): one set per (device, STREAM, kind).  Launches on one stream are ordered, so they
     share it; objectives evaluated concurrently on different streams of a device each get their own.
+
+    A set that turns out too small is replaced by a bigger one; a replaced CAPTURE set is kept alive forever
+    (``_SCRATCH_RETIRED``): graphs captured before the growth keep replaying on the old one.
 
     While a hipGraph is being captured nothing may be cached that lives in the graph's private memory pool (it would dangle
     once the graph is destroyed), and allocating + zero-filling a fresh set per call would put a fill launch in front of
@@ -321,6 +333,10 @@ def _scratch(device, kind, fits, make):
     if device.type == "cuda":
         c = _SCRATCH.get(ckey)
         if c is None or not fits(c):
+            if c is not None:
+                # a hipGraph captured earlier has this set's workspace and ticket pointers baked in: it must stay allocated
+                # (and its tickets at zero) for as long as that graph may be replayed -- never hand it back to the allocator
+                _SCRATCH_RETIRED.append(c)
             _SCRATCH[ckey] = make()
     return sc
 
@@ -387,6 +403,109 @@ class IWObjective(torch.autograd.Function):
         gp = gc[0]
         return (gp if ctx.needs_input_grad[0] else None, gp if (ctx.has_b and ctx.needs_input_grad[1]) else None,
                 gc[1] if ctx.needs_input_grad[2] else None, None, None)
+
+
+def _iw1_accumulator(device):
+    """The zero-initialised 64-bit word of IW1's one-atomic batch mean (handed back at zero by the kernel; see _scratch)."""
+    return _scratch(device, "iw1", lambda sc: True, lambda: (torch.zeros(2, dtype=torch.int64, device=device),))[0]
+
+
+IW1_MAX_DATAPOINTS = 384
+
+
+def iw1_supported(K, B, X, dtype, *tensors):
+    """The fused kernel's domain (include/zs_hip.h, IW1): a workgroup per datapoint, lane = particle in its tail, rows read
+    16 bytes per lane."""
+    if dtype == torch.float64:
+        return True                      # (the float64 twin composes plain kernels: any shape)
+    # (B: one workgroup per datapoint and one resident workgroup per CU -- beyond ~1.5 workgroups per CU the wave-per-row grid of
+    # K3 plus K2 and K4b is the faster form: B = 512, K = 50: 29 against 25 us, profiles/r04_iw1_timing.txt; the entry point itself
+    # takes up to 32 768 datapoints)
+    return K <= 64 and B <= IW1_MAX_DATAPOINTS and X % 4 == 0 and 256 <= X <= 1024 and all(t.data_ptr() % 16 == 0 for t in tensors)
+
+
+def iw1_term_supported(Dz, dtype, *tensors):
+    """Whether a Normal node of a [K, B, Dz] value can ride in IW1's launch as a term (else it enters as ready-made rows)."""
+    if dtype == torch.float64:
+        return True
+    return Dz % 4 == 0 and 4 <= Dz <= 256 and all(t.numel() == 1 or t.data_ptr() % 16 == 0 for t in tensors)
+
+
+class BernoulliIWObjective(torch.autograd.Function):
+    """IW1: the generator side of the importance-weighted objective in ONE launch -- the Bernoulli likelihood's row sums over
+    p [K, B, X] (K3), the Normal log-density of the latent value z [K, B, Dz] (K2, optional), the left-to-right sum of the
+    generator's terms (plus ready-made rows of further nodes), minus log q, and K4b (per-datapoint IWAE / VIMCO costs, their
+    batch mean, both coefficient matrices).  Replaces the per-node loop of ImportanceWeightedObjective.forward
+    (zhusuan/variational/importance_weighted_objective.py:66-100) for the IWAE caller.
+
+    Backward is ONE call: the Bernoulli gradient with the row gradients coef * g formed inside the kernel (no multiply launch),
+    and, when the variational node (a non-reparameterised Normal draw ``qz`` with parameters ``qmu``, ``qsigma``) is handed
+    in, the K-summed gradient of log q w.r.t. those parameters (what K1's backward would have launched); ``logq`` is then
+    passed detached.  ``meta`` = (from_logits, Px, Pm, Ps, prior_is_logstd, estimator, want_mean, q_is_logstd).
+    Returns (cost, bound_b)."""
+
+    @staticmethod
+    def forward(ctx, p, x, z, pmu, psigma, rows_a, logq, qmu, qsigma, qz, meta):
+        ctx.set_materialize_grads(False)
+        from_logits, Px, Pm, Ps, p_ls, estimator, want_mean, q_ls = meta
+        _hip.require_device(p, x, z, pmu, psigma, rows_a, logq, qmu, qsigma, qz)
+        sfx = _sfx(p, x, z, pmu, psigma, rows_a, logq, qmu, qsigma, qz)
+        K, B, X = p.shape
+        dt, dev = p.dtype, p.device
+        q2, ld_q = _rows_for_iw(logq, K)
+        a2, ld_a = (None, K) if rows_a is None else _rows_for_iw(rows_a, K)
+        Dz = z.shape[-1] if z is not None else 1
+        out = torch.empty((4 if z is not None else 3, B, K), dtype=dt, device=dev)       # coef [2, B, K], lp_x, lp_z
+        vecs = torch.empty((2, B), dtype=dt, device=dev)                                  # per-datapoint costs, bounds
+        cost_b, bound = vecs[0], vecs[1]
+        cost = torch.empty((), dtype=dt, device=dev) if want_mean else cost_b
+        acc = _iw1_accumulator(dev) if want_mean else None
+        _hip.lib().call("zs_bernoulli_iw_objective" + sfx, _hip.ptr(p), 1 if from_logits else 0, _hip.ptr(x), Px, K, B, X,
+                        _hip.ptr(z), _hip.ptr(pmu), Pm, _hip.ptr(psigma), Ps, Dz, 1 if p_ls else 0,
+                        _hip.ptr(a2), ld_a, _hip.ptr(q2), ld_q, estimator, 1 if want_mean else 0,
+                        _hip.ptr(out[2]), _hip.ptr(out[3]) if z is not None else None,
+                        _hip.ptr(cost_b), _hip.ptr(bound), _hip.ptr(out), _hip.ptr(cost) if want_mean else None,
+                        _hip.ptr(acc), _hip.stream_for(p))
+        ctx.meta = meta
+        ctx.fold_q = qz is not None
+        ctx.save_for_backward(p, x, z, pmu, psigma, out, qmu, qsigma, qz)
+        ctx.mark_non_differentiable(bound)
+        return cost, bound
+
+    @staticmethod
+    def backward(ctx, g_cost, g_bound):
+        if g_cost is None:
+            return (None,) * 11
+        from_logits, Px, Pm, Ps, p_ls, estimator, want_mean, q_ls = ctx.meta
+        p, x, z, pmu, psigma, out, qmu, qsigma, qz = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("zhusuan (MI355X build): gradient w.r.t. the Bernoulli observation is not built")
+        K, B, X = p.shape
+        coef = out[:2]
+        g = g_cost.contiguous()
+        need = ctx.needs_input_grad
+        gp = torch.empty_like(p) if need[0] else None
+        fold = ctx.fold_q and (need[7] or need[8])
+        gqmu = torch.empty_like(qmu) if fold else None
+        gqsigma = torch.empty_like(qsigma) if fold else None
+        if gp is not None or fold:
+            _hip.lib().call("zs_bernoulli_iw_objective_bwd" + _sfx(p), _hip.ptr(p), 1 if from_logits else 0, _hip.ptr(x), Px, K, B, X,
+                            _hip.ptr(coef), _hip.ptr(g), 0 if want_mean else 1, _hip.ptr(gp),
+                            _hip.ptr(qz) if fold else None, _hip.ptr(qmu) if fold else None, _hip.ptr(qsigma) if fold else None,
+                            qz.shape[-1] if fold else 1, 1 if q_ls else 0, _hip.ptr(gqmu), _hip.ptr(gqsigma), _hip.stream_for(p))
+        gz = gpm = gps = ga = gq = None
+        # the rarer consumers take the row gradients as a tensor (one multiply, as K4b's backward)
+        if need[2] or need[3] or need[4] or need[5] or need[6]:
+            gc = coef * (g if want_mean else g.reshape(1, -1, 1))                 # [2, B, K]
+            if need[5]:
+                ga = gc[0]                                                        # (rows_a and logq are [B, K] matrices)
+            if need[6]:
+                gq = gc[1]
+            if z is not None and (need[2] or need[3] or need[4]):
+                Dz = z.shape[-1]
+                gz, gpm, gps = _normal_logprob_grads(z, pmu, psigma, gc[0].t(), K, B, Dz, (K * B * Dz, Pm, Ps), 1 if p_ls else 0,
+                                                     (need[2], need[3], need[4]))
+        return gp, None, gz, gpm, gps, ga, gq, (gqmu if need[7] else None), (gqsigma if need[8] else None), None, None
 
 
 MAX_TERMS = 6      # ZS_MAX_TERMS of include/zs_hip.h

@@ -7,6 +7,8 @@ from ..framework.stochastic_tensor import StochasticTensor
 from .. import _ops
 from .elbo import latent_value, draw_latents, run_variational
 from .._shapes import broadcast_shapes
+from ..distributions.bernoulli import Bernoulli
+from ..distributions.normal import Normal
 
 __all__ = ['ImportanceWeightedObjective']
 
@@ -69,6 +71,9 @@ class ImportanceWeightedObjective(nn.Module):
             # a subclass overrides one of the reference's hooks: keep calling them like the reference does (:97-100)
             logpxz, logqz = self.log_joint(nodes_p), self.log_joint(nodes_q)
             return self.sgvb(logpxz, logqz, reduce_mean) if self.estimator == 'sgvb' else self.vimco(logpxz, logqz, reduce_mean)
+        fused = self._generator_side_in_one_launch(nodes_p, nodes_q, reduce_mean)
+        if fused is not None:
+            return fused
         terms_p = [nodes_p[n].log_prob() for n in nodes_p.keys()]
         logqz = self.log_joint(nodes_q)
         head = None
@@ -77,6 +82,62 @@ class ImportanceWeightedObjective(nn.Module):
         if head is None:
             return self._objective(terms_p[0], None, logqz, reduce_mean)
         return self._objective(head, terms_p[-1], logqz, reduce_mean)
+
+    def _generator_side_in_one_launch(self, nodes_p, nodes_q, reduce_mean):
+        """IW1 (``_ops.BernoulliIWObjective``): when the generator's LAST node is a Bernoulli likelihood over [K, B, X] whose
+        log-probability reduces to [K, B] -- the IWAE caller, examples/variational_autoencoder/iwae.py:49-81 -- its row sums,
+        the log-density of the latent under a Normal prior node, the sum of the generator's terms, the subtraction of log q,
+        the K-particle reductions and the batch mean are ONE launch instead of the per-node loop (:66-100) + K4b; the backward
+        is one call as well, which also takes over the gradient of a non-reparameterised Normal q node.  Returns None when
+        the layout is anything else (the per-node path then runs)."""
+        if self._axis != 0 or not nodes_p or not nodes_q:
+            return None
+        vimco = self.estimator == 'vimco'
+        names = list(nodes_p.keys())
+        last = nodes_p[names[-1]]
+        plan = _bernoulli_rows_plan(last)
+        if plan is None:
+            return None
+        par, x, Px, from_logits, (K, B, X) = plan
+        if (vimco and K < 2) or not _ops.iw1_supported(K, B, X, par.dtype, par, x):
+            return None
+        # the other generator nodes: ONE Normal node of the latent value becomes a term of the launch; anything else enters as
+        # ready-made rows from its own kernel (added left to right like log_joint, :66-77)
+        z = pmu = psigma = None
+        Pm = Ps = 1
+        p_ls = False
+        rows_a = None
+        others = names[:-1]
+        if others:
+            term = _normal_rows_plan(nodes_p[others[-1]], K, B)
+            if term is not None:
+                z, pmu, psigma, Pm, Ps, p_ls = term
+                others = others[:-1]
+            for n in others:
+                lp = nodes_p[n].log_prob()
+                if tuple(lp.shape) != (K, B):
+                    return None
+                rows_a = lp if rows_a is None else rows_a + lp
+        logqz = self.log_joint(nodes_q)
+        if not isinstance(logqz, torch.Tensor) or tuple(logqz.shape) != (K, B) or logqz.dtype != par.dtype or logqz.device != par.device:
+            return None
+        if rows_a is not None and (rows_a.dtype != par.dtype or rows_a.device != par.device):
+            return None
+        # a single non-reparameterised Normal q node whose fused log-density is log q: IW1's backward forms its parameter
+        # gradients itself (log q then enters detached; the sampler's own backward is not needed)
+        qmu = qsigma = qz = None
+        q_ls = False
+        if len(nodes_q) == 1:
+            fold = _foldable_q_node(next(iter(nodes_q.values())), logqz, K, B)
+            if fold is not None:
+                qmu, qsigma, qz, q_ls = fold
+                logqz = logqz.detach()
+        want_mean = True if vimco else bool(reduce_mean)          # vimco always returns the batch mean (:191)
+        meta = (from_logits, Px, Pm, Ps, p_ls, _ops.ZS_IW_VIMCO if vimco else _ops.ZS_IW_SGVB, want_mean, q_ls)
+        cost, bound_b = _ops.BernoulliIWObjective.apply(par, x, z, pmu, psigma, None if rows_a is None else rows_a.t(), logqz.t(),
+                                                        qmu, qsigma, qz, meta)
+        self.last_iw_bound = bound_b
+        return cost
 
     def _rows(self, tensors, vimco=False):
         """The given log-joint tensors as K-fastest [B, K] matrices plus K and the shape of the non-particle axes.
@@ -141,3 +202,97 @@ class ImportanceWeightedObjective(nn.Module):
     def vimco(self, logpxz, logqz, reduce_mean=True):
         """importance_weighted_objective.py:134-191.  Always returns the batch mean, like the reference."""
         return self._objective(logpxz, None, logqz, reduce_mean, 'vimco')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Layout checks of the one-launch generator side (IW1).  Each returns None when the node is not of the simple layout the
+# fused kernel covers; nothing is launched by asking.
+# ---------------------------------------------------------------------------------------------------------------------
+def _plain_rows_node(node, cls):
+    """The node's distribution when it is exactly a `cls` node whose log_prob is a plain trailing sum (no mean, no multiplier)."""
+    dist = getattr(node, 'dist', None)
+    if type(dist) is not cls or not isinstance(node, StochasticTensor):
+        return None
+    if node._multiplier or node._reduce_mean_dims:
+        return None
+    return dist
+
+
+def _bernoulli_rows_plan(node):
+    """(parameter [K, B, X], observation, its period, from_logits, (K, B, X)) of a Bernoulli node whose log_prob is [K, B]."""
+    dist = _plain_rows_node(node, Bernoulli)
+    if dist is None:
+        return None
+    par = dist._param()
+    x = dist.sample_cache
+    if not isinstance(x, torch.Tensor) or par.dim() != 3 or par.dtype not in (torch.float32, torch.float64):
+        return None
+    K, B, X = par.shape
+    try:
+        full, nd, mean_dims, sum_dims, extra = node._reduction_plan()
+    except (RuntimeError, IndexError):
+        return None
+    if tuple(full) != (K, B, X) or nd - extra != 2 or dist.group_ndims + extra != 1 or mean_dims or any(d < nd - extra for d in sum_dims):
+        return None
+    if K * B * X == 0 or x.dtype != par.dtype or x.device != par.device:
+        return None
+    if tuple(x.shape) == (B, X):
+        Px = B * X
+    elif tuple(x.shape) == (K, B, X):
+        Px = K * B * X
+    else:
+        return None
+    return par.contiguous(), x.contiguous(), Px, dist._from_logits, (K, B, X)
+
+
+def _normal_rows_plan(node, K, B):
+    """(value [K, B, Dz], mean, scale operand, their periods, scale_is_logstd) of a Normal node of a given [K, B, Dz] value
+    whose log_prob is [K, B] and whose parameters are [B, Dz] (repeated over the particles) or scalars."""
+    dist = _plain_rows_node(node, Normal)
+    if dist is None:
+        return None
+    z = dist.sample_cache
+    if not isinstance(z, torch.Tensor) or z.dim() != 3 or tuple(z.shape[:2]) != (K, B):
+        return None
+    if dist._fused is not None and dist._fused[0] is z:
+        return None                      # the node drew this value itself: its fused log-density exists already (rows)
+    Dz = z.shape[2]
+    try:
+        full, nd, mean_dims, sum_dims, extra = node._reduction_plan()
+    except (RuntimeError, IndexError):
+        return None
+    if tuple(full) != (K, B, Dz) or nd - extra != 2 or dist.group_ndims + extra != 1 or mean_dims or any(d < nd - extra for d in sum_dims):
+        return None
+    mean, scale = dist._mean, dist._scale_operand()
+    ops = []
+    for t in (mean, scale):
+        if t.dtype != z.dtype or t.device != z.device:
+            return None
+        if t.numel() == 1 and B * Dz != 1:
+            ops.append((t.reshape(1), 1))
+        elif tuple(t.shape) == (B, Dz) or tuple(t.shape) == (1, B, Dz):
+            ops.append((t.contiguous(), B * Dz))
+        else:
+            return None
+    z = z.contiguous()
+    if Dz == 0 or not _ops.iw1_term_supported(Dz, z.dtype, z, ops[0][0], ops[1][0]):
+        return None
+    return z, ops[0][0], ops[1][0], ops[0][1], ops[1][1], dist._logstd_given is not None
+
+
+def _foldable_q_node(node, logqz, K, B):
+    """(mean, scale operand, draw, scale_is_logstd) when `logqz` IS the fused log-density of this non-reparameterised Normal
+    node's current draw z [K, B, Dq] with parameters [B, Dq]: then d(-objective)/d(mean, scale) is a K-summed function of
+    (z, mean, scale) and the objective's coefficients, which IW1's backward evaluates itself (normal.py:102,112-116)."""
+    dist = _plain_rows_node(node, Normal)
+    if dist is None or dist.is_reparameterized or dist._fused is None:
+        return None
+    z, lp, n_fold = dist._fused
+    if lp is not logqz or z is not dist.sample_cache or z.dim() != 3 or tuple(z.shape[:2]) != (K, B) or n_fold != 1:
+        return None
+    mean, scale = dist._mean, dist._scale_operand()
+    if tuple(mean.shape) != tuple(z.shape[1:]) or tuple(scale.shape) != tuple(z.shape[1:]):
+        return None
+    if not (mean.requires_grad or scale.requires_grad):
+        return None
+    return mean.contiguous(), scale.contiguous(), z.detach().contiguous(), dist._logstd_given is not None
