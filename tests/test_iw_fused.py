@@ -248,8 +248,14 @@ def test_hip_iw1_backward(hip, orc, K, R, D, Dq, logits, x_full, q_ls):
     for gout in (np.float32([1.0]), np.float32([-0.37]), rng.standard_normal(R).astype(np.float32)):
         got = iw1_bwd(hip, p, x, K, R, D, coef, gout, logits, zq, qmu, qsg, q_ls)
         base = composed_bwd(hip, p, x, K, R, D, coef, gout, logits, zq, qmu, qsg, q_ls)     # same kernels, product formed on the host
-        for key in ("gp", "gqmu", "gqsigma"):
-            np.testing.assert_array_equal(got[key], base[key], err_msg=key)
+        if K * R <= 32768 and D % 4 == 0 and 256 <= D <= 1024:
+            np.testing.assert_array_equal(got["gp"], base["gp"])      # the merged launch's Bernoulli role IS K3's wave-per-row backward
+        else:
+            np.testing.assert_allclose(got["gp"], base["gp"], rtol=1e-6, atol=1e-30)
+        for key in ("gqmu", "gqsigma"):                                # (4 instead of 16 K-slices per workgroup: another order of summation)
+            np.testing.assert_allclose(got[key], base[key], rtol=2e-5, atol=2e-6 * np.abs(base[key]).max(), err_msg=key)
+        only_p = iw1_bwd(hip, p, x, K, R, D, coef, gout, logits)       # the Bernoulli gradient alone takes K3's own launch
+        np.testing.assert_array_equal(only_p["gp"], base["gp"])
         if K * R * D <= 2_000_000:
             ref = iw1_bwd(orc, p, x, K, R, D, coef, gout, logits, zq, qmu, qsg, q_ls)
             np.testing.assert_allclose(got["gp"], ref["gp"], rtol=2e-5, atol=1e-6 * np.abs(ref["gp"]).max())

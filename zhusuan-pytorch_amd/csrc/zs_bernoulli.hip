@@ -398,6 +398,68 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_longrow2d(
   }
 }
 
+// IW1's backward as ONE launch with two independent roles (no hand-off between them): plane y = 0 of the grid is the K-summed
+// gradient of log q w.r.t. the variational node's parameters (K2's backward-ksum, 4 K-slices per workgroup: its dependent rounds
+// of loads hide under the stream below -- it is dispatched first), planes y = 1 .. K are K3's backward, one wave per row with
+// the row's coordinates taken from the block indices.  Both take their row gradients as coef[.][r, k] * gout[r * gss].
+template <bool LOGITS, bool NT>
+__global__ __launch_bounds__(256) void k_iw1_bwd(
+    const float4* __restrict__ p, const float4* __restrict__ x, int x_full, const float* __restrict__ coef,
+    const float* __restrict__ gout, int64_t gss, float4* __restrict__ gp, int64_t K, int64_t R, int D4,
+    const float4* __restrict__ zq, const float4* __restrict__ qmu, const float4* __restrict__ qsigma, float4* __restrict__ gqmu,
+    float4* __restrict__ gqsigma, int64_t Mq4, int Dq4, bool q_ls) {
+  if (blockIdx.y == 0) {
+    if ((int64_t)blockIdx.x * 64 < Mq4)
+      logprob_bwd_ksum_body<D_NORMAL, 4>(blockIdx.x, zq, qmu, qsigma, coef + R * K, 1, K, nullptr, gqmu, gqsigma, K, Mq4, Dq4, q_ls,
+                                         gout, gss);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t k = blockIdx.y - 1;
+  if (r >= R) return;
+  const int64_t row = k * R + r;
+  const float4* __restrict__ prow = p + row * D4;
+  const float4* __restrict__ xrow = x + (x_full ? row : r) * D4;
+  float4* __restrict__ grow = gp + row * D4;
+  float4 pv[4], xv[4];
+  bool ok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = lane + 64 * u;
+    ok[u] = c < D4;
+    if (ok[u]) {
+      pv[u] = prow[c];
+      xv[u] = xrow[c];
+    }
+  }
+  const float g = coef[r * K + k] * gout[r * gss];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (ok[u]) {
+      float4 o;
+      if (LOGITS) {
+        const float a = sigmoid_fast(pv[u].x), b = sigmoid_fast(pv[u].y), c = sigmoid_fast(pv[u].z), d = sigmoid_fast(pv[u].w);
+        o.x = g * bern_dp(a, xv[u].x) * a * (1.0f - a);
+        o.y = g * bern_dp(b, xv[u].y) * b * (1.0f - b);
+        o.z = g * bern_dp(c, xv[u].z) * c * (1.0f - c);
+        o.w = g * bern_dp(d, xv[u].w) * d * (1.0f - d);
+      } else {
+        o.x = g * bern_dp(pv[u].x, xv[u].x);
+        o.y = g * bern_dp(pv[u].y, xv[u].y);
+        o.z = g * bern_dp(pv[u].z, xv[u].z);
+        o.w = g * bern_dp(pv[u].w, xv[u].w);
+      }
+      if (NT) {
+        const zs_f4v v = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<zs_f4v*>(&grow[lane + 64 * u]));
+      } else {
+        grow[lane + 64 * u] = o;
+      }
+    }
+  }
+}
+
 // K3 backward for big problems with a shared observation (same tiling as k_bern_logprob_xreuse): the wave keeps
 // x[b, :] in registers, streams JC particle rows of p past it and writes the gradient rows, non-temporally when
 // the tensor cannot stay in the Infinity Cache.
@@ -800,6 +862,25 @@ extern "C" int zs_bernoulli_iw_objective_bwd_f32(const float* p, int from_logits
   if (R == 0) return 0;
   if (!coef || !gout) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  // both gradients wanted and both roles on their 16-byte paths: ONE launch
+  if (gp && zq && qmu && qsigma && gqmu && gqsigma && Dq >= 1 && p && x && (D % 4) == 0 && D >= 256 && D <= 1024 && K <= 65534 &&
+      K * R <= 32768 && (Px == R * D || Px == K * R * D) && aligned16(p) && aligned16(x) && aligned16(gp) && (Dq % 4) == 0 &&
+      aligned16(zq) && aligned16(qmu) && aligned16(qsigma) && aligned16(gqmu) && aligned16(gqsigma)) {
+    const int64_t Mq4 = R * Dq / 4;
+    const int64_t bx_rows = (R + 3) / 4, bx_q = (Mq4 + 63) / 64;
+    const dim3 grid((unsigned)(bx_rows > bx_q ? bx_rows : bx_q), (unsigned)(K + 1));
+    const int x_full = (Px == K * R * D && Px != R * D) ? 1 : 0;
+    const bool nt = (double)K * (double)R * (double)D * 4.0 > 268435456.0;
+#define ZS_LAUNCH_IW1B(L, T)                                                                                                 \
+  ZS_LAUNCH(KID_BERN_IW_OBJECTIVE_BWD, (k_iw1_bwd<L, T>), grid, dim3(256), st, (const float4*)p, (const float4*)x, x_full, coef, \
+            gout, gout_stride, (float4*)gp, K, R, (int)(D / 4), (const float4*)zq, (const float4*)qmu, (const float4*)qsigma,    \
+            (float4*)gqmu, (float4*)gqsigma, Mq4, (int)(Dq / 4), qsigma_is_logstd != 0)
+    if (from_logits) { if (nt) ZS_LAUNCH_IW1B(true, true); else ZS_LAUNCH_IW1B(true, false); }
+    else             { if (nt) ZS_LAUNCH_IW1B(false, true); else ZS_LAUNCH_IW1B(false, false); }
+#undef ZS_LAUNCH_IW1B
+    ZS_CHECK_LAUNCH();
+    return 0;
+  }
   if (gp) {
     const int rc = from_logits ? launch_bwd<true>(p, x, Px, coef, 1, K, gp, K, R, D, st, gout, gout_stride)
                                : launch_bwd<false>(p, x, Px, coef, 1, K, gp, K, R, D, st, gout, gout_stride);

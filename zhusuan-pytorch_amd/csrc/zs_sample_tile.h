@@ -441,15 +441,16 @@ __device__ __forceinline__ void ksum_elem(float g, float xv, float mv, float c, 
   }
 }
 
+// (the body as a device function of the workgroup's index: also one ROLE of IW1's merged backward launch, zs_bernoulli.hip)
 template <int DIST, int NS>
-__global__ __launch_bounds__(64 * NS) void k_logprob_bwd_ksum(
-    const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
+__device__ __forceinline__ void logprob_bwd_ksum_body(
+    int64_t block, const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
     const float* __restrict__ glp, int64_t gsk, int64_t gsr,
     float4* __restrict__ gx, float4* __restrict__ gmu, float4* __restrict__ gsigma,
     int64_t K, int64_t M4, int D4, bool ls, const float* __restrict__ gscale, int64_t gss) {
   __shared__ float4 red[2][NS][64];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int64_t m4 = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t m4 = block * 64 + lane;
   const bool on = m4 < M4;
   float4 am = make_float4(0.f, 0.f, 0.f, 0.f), as = am;
   if (on) {
@@ -501,6 +502,15 @@ __global__ __launch_bounds__(64 * NS) void k_logprob_bwd_ksum(
     if (gmu) gmu[m4] = a;
     if (gsigma) gsigma[m4] = b;
   }
+}
+
+template <int DIST, int NS>
+__global__ __launch_bounds__(64 * NS) void k_logprob_bwd_ksum(
+    const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
+    const float* __restrict__ glp, int64_t gsk, int64_t gsr,
+    float4* __restrict__ gx, float4* __restrict__ gmu, float4* __restrict__ gsigma,
+    int64_t K, int64_t M4, int D4, bool ls, const float* __restrict__ gscale, int64_t gss) {
+  logprob_bwd_ksum_body<DIST, NS>(blockIdx.x, x, mu, sigma, glp, gsk, gsr, gx, gmu, gsigma, K, M4, D4, ls, gscale, gss);
 }
 
 // rows that are not a multiple of four elements, or unaligned operands: a thread per parameter element
