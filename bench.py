@@ -14,15 +14,18 @@ Timing: trials of EXACTLY `--steps` steps, each bracketed by torch.cuda.synchron
 reduced with MAX over the ranks; trials repeat until at least MIN_TIMED_SECONDS have been timed (so that `--steps 20` is
 not a 24 ms sample) and the MEDIAN trial is reported.
 
-Rank 0 prints ONE JSON line (contract in the task description) with
-  `roofline`      the hot-path kernel that moves the most bytes per step (the backward of the Bernoulli log-prob row
-                  sum), timed live in the launch mode of the timed region;
-  `hip_kernels`   every hot-path kernel's own figures at the config size, `hbm_resident` the same kernels on working
-                  sets beyond the 256 MiB Infinity Cache measured in the same run;
+Rank 0 prints ONE JSON line (contract in the task description; kept under 8 KB) with
+  `roofline`      the hot-path kernel that moves the most bytes per step (the backward of the Bernoulli stream), timed live
+                  in the launch mode of the timed region, plus flat scalars for the other kernels the contract names:
+                  `k1_frac_1M`, `k1_frac_4M` (the fused Normal sample + log-prob kernel beyond the cache), `k3_fwd_frac`,
+                  `hbm_resident_frac`;
   `cpu_baseline`  the CPU oracle (oracle/zs_oracle.py) on the same workload on this host's cores (calibrated thread
                   count, plus a 1-thread figure);
-  `extra_configs` the other single-GPU BASELINE configs (VAE B=512, BNN B=512 K=10, IWAE with the sigmoid fused), each
-                  with its own CPU baselines.
+  `extra_configs` {name: {ms_per_step, value}}: the other single-GPU BASELINE configs, the reference example as written
+                  (torch.nn modules, torch.optim.Adam, default GEMM selection, an eager Python loop over fresh minibatches),
+                  the same with only GraphedStep added, eager launches of the headline step, the opt-ins;
+  `full_record`   the file (bench_full.json next to this script) that holds everything else: per-kernel tables
+                  (`hip_kernels`, `hbm_resident`), trial times, the long-form description of every setting.
 """
 import argparse
 import json
@@ -70,10 +73,14 @@ def parse_args(argv=None):
                     help="run although ZS_* experiment variables are set (ZS_HIP_LIBRARY: another build of the kernel library; "
                          "ZS_K*: dispatch knobs of a -DZS_EXPERIMENTS build) or the loaded library is an experiments build; the "
                          "line then says so (`env_overrides`, `library`).  Without the flag such a run is refused (exit code 2)")
-    ap.add_argument("--reference-draws", action="store_true",
-                    help="also execute the draw of every latent that the reference's objectives throw away (the node factory's "
-                         "sample, bn.py:158 / elbo.py:122): the package's default behaviour.  The bench runs inside "
-                         "zhusuan.skip_discarded_draws() unless this flag is given (one sampling launch per latent and step)")
+    ap.add_argument("--skip-discarded-draws", action="store_true",
+                    help="run the step inside zhusuan.skip_discarded_draws(): the draw of every latent that the reference's "
+                         "objectives throw away (the node factory's sample, bn.py:158 / elbo.py:122) is then not executed.  An "
+                         "opt-in of the package, OFF by default here as in the package (extra_configs.c3_skip_discarded_draws in "
+                         "the default run)")
+    ap.add_argument("--reference-draws", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--full-record", default=os.path.join(ROOT, "bench_full.json"),
+                    help="where the long-form record goes (per-kernel tables, trial times, setting descriptions)")
     ap.add_argument("--torch-linear", action="store_true",
                     help="build the callers' MLPs from torch.nn.Linear / Sequential (as the reference's examples do) instead of "
                          "zhusuan.Linear / zhusuan.Sequential -- the same layers (parameters, names, GEMMs) with the ReLU in the forward "
@@ -232,6 +239,14 @@ def make_workload(name, dev, seed_rank=0, fused_logits=False, dense="fused"):
         y = torch.tensor(rs.standard_normal(512).astype(np.float32), device=dev)
         return bnn_vi.build(n_particles=10, device=dev), {"x": x, "y": y}, 5120, \
             "BNN-VI [13,50,1], batch=512 per GPU, K=10 (per-GPU shape of BASELINE configs[4])"
+    if name == "iwae_default":      # the reference example's own settings (examples/variational_autoencoder/iwae.py:126,131)
+        model = iwae.build(n_samples=40, estimator="vimco", x_dim=X_DIM, z_dim=Z_DIM, hidden=HIDDEN, device=dev, dense=dense)
+        return model, {"x": bits(64)}, 64 * 40, "IWAE-MNIST VIMCO, batch=64, K=40 (the reference example's defaults, iwae.py:126,131)"
+    if name == "bnn_default":       # examples/bayesian_neural_nets/bnn_vi.py:116-118
+        x = torch.tensor(rs.standard_normal((114, 13)).astype(np.float32), device=dev)
+        y = torch.tensor(rs.standard_normal(114).astype(np.float32), device=dev)
+        return bnn_vi.build(n_particles=512, device=dev), {"x": x, "y": y}, 114 * 512, \
+            "BNN-VI [13,50,1], batch=114, K=512 (the reference example's defaults, bnn_vi.py:116-118)"
     raise ValueError(name)
 
 
@@ -360,45 +375,83 @@ def make_optimizer(model, torch_adam, groups=None):
     """Adam, lr 1e-3 (the reference callers' optimizer, iwae.py:141): zhusuan.optim.FlatAdam -- the same update over flat
     buckets, one launch per bucket -- or torch.optim.Adam(fused, capturable) with --torch-adam.  `groups`: parameter
     lists that should be one bucket each (the stages of dataparallel.StagedBuckets)."""
+    if torch_adam == "reference":          # torch.optim.Adam(model.parameters(), lr): the reference example's line (iwae.py:141)
+        return torch.optim.Adam(model.parameters(), 1e-3)
+    if torch_adam == "reference_capturable":      # ... with the one flag torch needs to let a step be captured in a graph
+        return torch.optim.Adam(model.parameters(), 1e-3, capturable=True)
     if torch_adam:
         return torch.optim.Adam(model.parameters(), 1e-3, fused=True, capturable=True)
     import zhusuan
     return zhusuan.optim.FlatAdam(groups if groups is not None else model.parameters(), lr=1e-3)
 
 
-def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False, skip_discarded=True,
-                          dense="fused"):
-    """A BASELINE config other than the headline one on this GPU: full training steps replayed from one hipGraph."""
+def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False, skip_discarded=False,
+                          dense="fused", eager=False, refresh=False, device_rng=True):
+    """A workload on this GPU as full training steps -- replayed from one hipGraph (default) or launched eagerly from a
+    Python loop (`eager`).  `refresh`: every step trains on ANOTHER minibatch, copied (device to device) into the step's
+    input tensors from a resident stream of 8 batches, as the reference's loop feeds one (iwae.py:151-160).  `torch_adam`:
+    False (zhusuan.optim.FlatAdam), True (torch's fused capturable Adam), "reference" / "reference_capturable"
+    (torch.optim.Adam(params, lr) as the reference's example constructs it).  `device_rng`: the draws' Philox state lives in
+    device memory (needed by graphs); without it they take their call ids from torch's generator, as plain eager code does."""
+    import contextlib
     import zhusuan
     gemm_tuning(tuned)
     torch.manual_seed(0)
     model, obs, evals, label = make_workload(name, dev, fused_logits=fused_logits, dense=dense)
     opt = make_optimizer(model, torch_adam)
-    rng = zhusuan.DeviceRNG(dev, seed=1)
-
+    rng = zhusuan.DeviceRNG(dev, seed=1) if (device_rng or not eager) else None
+    stream = None
+    if refresh:
+        g = torch.Generator(device="cpu").manual_seed(7)
+        stream = dict((k, [v[torch.randperm(v.shape[0], generator=g).to(v.device)].contiguous() for _ in range(8)]) for k, v in obs.items())
+    counter = [0]
     one = torch.ones((), device=dev)          # backward's seed, allocated once (loss.backward() fills a fresh one per step)
 
     def compute():
-        rng.begin_step()
+        if rng is not None:
+            rng.begin_step()
         for p in model.parameters():
             p.grad = None
         loss = model(obs)
         loss.backward(one)
         return loss.detach()
-    with zhusuan.device_rng(rng), zhusuan.skip_discarded_draws(skip_discarded):
-        step = zhusuan.GraphedStep(compute, opt.step, rng=rng, warmup=max(3, min(warmup, 10)))
+
+    def next_batch():
+        i = counter[0] = (counter[0] + 1) % 8
+        return dict((k, v[i]) for k, v in stream.items())
+    with contextlib.ExitStack() as ctx:
+        if rng is not None:
+            ctx.enter_context(zhusuan.device_rng(rng))
+        ctx.enter_context(zhusuan.skip_discarded_draws(skip_discarded))
+        if eager:
+            def step():
+                if refresh:
+                    for k, v in next_batch().items():
+                        obs[k].copy_(v, non_blocking=True)
+                loss = compute()
+                opt.step()
+                return loss
+            for _ in range(max(3, min(warmup, 10)) + 3):
+                step()
+        else:
+            graphed = zhusuan.GraphedStep(compute, opt.step, rng=rng, warmup=max(3, min(warmup, 10)), inputs=obs)
+            step = (lambda: graphed(**next_batch())) if refresh else graphed
         gemm_tuning(tuned, tune=False)       # every GEMM shape of the step has been seen: keep the picks, stop timing
         for _ in range(3):
             step()
         trials, last = timed_trials(step, steps, 1, dev, min_seconds=0.3)
     med = float(np.median(trials))
     assert np.isfinite(float(last))
+    opt_label = {False: "zhusuan.optim.FlatAdam", True: "torch.optim.Adam(fused=True, capturable=True)",
+                 "reference": "torch.optim.Adam(params, lr) (the reference example's line)",
+                 "reference_capturable": "torch.optim.Adam(params, lr, capturable=True)"}[torch_adam]
     return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
-            "launch_mode": "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
+            "launch_mode": "eager (Python loop)" if eager else "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
+            "minibatch": "a new minibatch every step (8 resident batches, copied into the step's inputs)" if refresh else "one resident minibatch",
             "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default)",
             "dense_layers": DENSE_LABEL[dense],
             "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape)" if tuned else "PyTorch default",
-            "optimizer": "torch.optim.Adam(fused=True, capturable=True)" if torch_adam else "zhusuan.optim.FlatAdam"}
+            "optimizer": opt_label}
 
 
 DENSE_LABEL = {"fused": "zhusuan.Linear in zhusuan.Sequential (ReLU in the GEMM epilogue; activation backward + bias gradient: AB1)",
@@ -499,7 +552,8 @@ def hbm_resident_kernels(klib, dev, launches=30):
 
 # kernel-name fragment -> C-ABI entry point (most specific first); logits forms carry <true, ...> as first template argument
 # (the kernels shared by the location-scale families live in namespace zs: first template argument 0 = Normal, 1 = Logistic)
-_KERNEL_ENTRY = [("k_column_sum", "zs_column_sum_f32"), ("k_logjoint_bwd", "zs_logjoint_scalar_bwd_f32"), ("k_logjoint_fwd", "zs_logjoint_scalar_f32"),
+_KERNEL_ENTRY = [("k_iw1_block", "zs_bernoulli_iw_objective_f32"), ("k_iw1_bwd", "zs_bernoulli_iw_objective_bwd_f32"),
+                 ("k_column_sum", "zs_column_sum_f32"), ("k_logjoint_bwd", "zs_logjoint_scalar_bwd_f32"), ("k_logjoint_fwd", "zs_logjoint_scalar_f32"),
                  ("k_normal_sample_multi_bwd", "zs_normal_sample_logprob_multi_bwd_f32"),
                  ("k_normal_sample_multi", "zs_normal_sample_logprob_multi_f32"),
                  ("k_particle_linear_bwd", "zs_particle_linear_bwd_f32"), ("k_particle_linear", "zs_particle_linear_f32"),
@@ -665,7 +719,7 @@ def main():
             sbuckets.scale(gradients=False)
             opt.step(grad_scale=sbuckets.grad_scale())
 
-    skip_discarded = not args.reference_draws
+    skip_discarded = bool(args.skip_discarded_draws)
     klib = _hip.lib()
     if "experiments" in klib.build_info() and not args.allow_experiments:
         raise SystemExit("bench: %s is an experiments build (%s); pass --allow-experiments" % (klib.path, klib.build_info()))
@@ -769,6 +823,11 @@ def main():
             "zs_normal_logprob_bwd_ksum_f32": 4 * N * D + 4 * N + 16 * B * D,
             "zs_iw_reduce_f32": 16 * N + 8 * B,
             "zs_iw_objective_f32": 20 * N + 4 * B + 4,                            # read a, b, q; write [2,B,K] coefficients, bounds, mean
+            # IW1: read p, x, z, the prior's parameters, log q; write both row-sum matrices, both coefficient matrices, costs, bounds
+            "zs_bernoulli_iw_objective_f32": 4 * N * X + 4 * B * X + 4 * N * D + 8 * B * D + 4 * N + 16 * N + 8 * B + 4,
+            # its backward: K3's backward (read p, x, coefficients; write gp) + K2's K-summed backward (read z, mu, sigma, coefficients;
+            # write gmu, gsigma) in one launch
+            "zs_bernoulli_iw_objective_bwd_f32": (8 * N * X + 4 * B * X + 4 * N) + (4 * N * D + 4 * N + 16 * B * D),
             "zs_adam_step_f32": 28 * sum(p.numel() for p in model.parameters()),  # read p, g, m, v; write p, m, v
         }
         # the IW kernels serve two entry points; the tracer sees kernel names only
@@ -824,6 +883,42 @@ def main():
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         traffic, traffic_source = pmc_traffic(dominant, args.fused_logits, _hip.ABI_VERSION)
         nbytes = sbuckets.nbytes() if staged else (obuckets.nbytes() if hooks else bucket.nbytes())
+        settings = {
+            "workload": "IWAE-MNIST VIMCO, batch=%d per GPU (global %d), K=%d, latent=%d, x=%d, hidden=%d, full training step "
+                        "(fwd+bwd+all-reduce+Adam)" % (BATCH_PER_GPU, BATCH_PER_GPU * world, PARTICLES, Z_DIM, X_DIM, HIDDEN),
+            "global_batch": BATCH_PER_GPU * world, "particles": PARTICLES,
+            "parallelism": "dp%d (minibatch shards; %s, %d bytes per step)" % (
+                world, "two flat buckets (decoder | encoder gradients + objective)" if (staged or hooks)
+                else "one flat bucket [gradients | objective]", nbytes),
+            "bernoulli_path": "logits (sigmoid inside the kernel)" if args.fused_logits else "probs (nn.Sigmoid pass, as the reference's example)",
+            "dense_layers": DENSE_LABEL[dense],
+            "mlp_gemm_library": args.blas,
+            "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape, callers' nn.Linear stack)" if tuned else "PyTorch default",
+            "optimizer": "torch.optim.Adam(lr=1e-3, fused=True, capturable=True)" if args.torch_adam else "zhusuan.optim.FlatAdam(lr=1e-3)",
+            "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default, as the reference)",
+            "launch_mode": mode,
+            "timing": "median of %d trials of %d steps, each bracketed by synchronize + barrier, max over ranks" % (len(trials), args.steps)}
+        long_settings = {
+            "dense_layers": "zhusuan.Linear / zhusuan.Sequential keep torch.nn.Linear's parameters, names and fp32 GEMMs (forward with "
+                            "torch._addmm_activation: the same hipBLASLt solution with the ReLU in its epilogue); per layer one launch of this "
+                            "package forms the activation's backward and the bias gradient (extra_configs.c3_torch_linear: torch.nn modules)",
+            "mlp_gemm_selection": "PyTorch TunableOp times the fp32 hipBLASLt / rocBLAS solutions per GEMM shape during warm-up and keeps the "
+                                  "fastest (callers' nn.Linear stack, outside the hot path; extra_configs.c3_default_gemm: PyTorch's default)",
+            "optimizer": "zhusuan.optim.FlatAdam: torch.optim.Adam's update over flat buckets, one launch per bucket "
+                         "(extra_configs.c3_torch_adam: torch's multi-tensor Adam)",
+            "discarded_draws": "the reference draws every latent twice per objective evaluation and uses the second draw (bn.py:158 / "
+                               "elbo.py:122); both are executed here by default; extra_configs.c3_skip_discarded_draws is the opt-in "
+                               "zhusuan.skip_discarded_draws()",
+            "reference_example": "extra_configs.c3_reference_example is the reference's example as written: torch.nn modules, "
+                                 "torch.optim.Adam(params, lr), PyTorch's default GEMM selection, both draws, an eager Python loop, a new "
+                                 "minibatch copied in every step (iwae.py:133-160); ..._graphed is the same with zhusuan.GraphedStep "
+                                 "(and capturable=True on the optimizer, which torch requires for capture) and nothing else"}
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": 1e3 * k_ms if k_ms else None,
+                "min_launch_us": 1e3 * k_min_ms, "launches_timed": k_count, "eager_event_avg_us": 1e3 * ev_ms,
+                "timing": "device timestamps per dispatch in the timed region's launch mode (torch.profiler / roctracer)"
+                          if dominant in dev_times else "HIP events bound to each dispatch, eager launches"}
         out = {
             "metric": baseline_metric(),
             "value": evals_per_step * world * args.steps / elapsed,
@@ -833,132 +928,101 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "trials": len(trials), "timed_seconds_total": float(sum(trials)),
-            "trial_ms_per_step": {"min": 1e3 * min(trials) / args.steps, "median": 1e3 * elapsed / args.steps,
-                                  "max": 1e3 * max(trials) / args.steps},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "IWAE-MNIST VIMCO, batch=%d per GPU (global %d), K=%d, latent=%d, x=%d, hidden=%d, "
-                                   "full training step (fwd+bwd+all-reduce+Adam)" % (
-                                       BATCH_PER_GPU, BATCH_PER_GPU * world, PARTICLES, Z_DIM, X_DIM, HIDDEN),
-                       "global_batch": BATCH_PER_GPU * world, "particles": PARTICLES,
-                       "parallelism": "dp%d (minibatch shards; %s, %d bytes per step)" % (
-                           world, "two flat buckets (decoder | encoder gradients + objective)" if (staged or hooks)
-                           else "one flat bucket [gradients | objective]", nbytes),
-                       "bernoulli_path": "logits: the decoder's final sigmoid is formed inside the Bernoulli log-prob kernel"
-                                         if args.fused_logits else
-                                         "probs (nn.Sigmoid pass, as the reference's example is written; extra_configs.c3_logits: the "
-                                         "same step with the sigmoid inside the Bernoulli log-prob kernel)",
-                       "dense_layers": DENSE_LABEL[dense] + (
-                           ": torch.nn.Linear's parameters, names and fp32 GEMMs (forward with torch._addmm_activation, the same "
-                           "hipBLASLt solution with the ReLU in its epilogue); per layer one launch of this package forms the "
-                           "activation's backward and the bias gradient (extra_configs.c3_torch_linear: the same step built from "
-                           "torch.nn modules; c3_unfused_activations: only the bias gradient taken over)" if dense == "fused" else ""),
-                       "mlp_gemm_library": args.blas,
-                       "mlp_gemm_selection": ("PyTorch TunableOp: fastest fp32 hipBLASLt / rocBLAS solution per GEMM shape, picked during "
-                                              "warm-up (callers' nn.Linear stack, outside the hot path; extra_configs.c3_default_gemm "
-                                              "is the same step with PyTorch's default selection)") if tuned else "PyTorch default",
-                       "optimizer": "torch.optim.Adam(lr=1e-3, fused=True, capturable=True)" if args.torch_adam else
-                                    "zhusuan.optim.FlatAdam(lr=1e-3): torch.optim.Adam's update over flat buckets, one launch per "
-                                    "bucket (extra_configs.c3_torch_adam: the same step with torch's multi-tensor Adam)",
-                       "discarded_draws": ("skipped: the step runs inside zhusuan.skip_discarded_draws(), so the draw of the latent "
-                                           "that the reference's objective throws away (bn.py:158 / elbo.py:122) is not executed -- "
-                                           "one fused sample + log-density launch per step; extra_configs.c3_reference_draws is the "
-                                           "same step with it executed") if skip_discarded else
-                                          "executed, as the package does by default (--reference-draws)",
-                       "launch_mode": mode,
-                       "timing": "median of %d trials of %d steps, each bracketed by synchronize + barrier, max over ranks"
-                                 % (len(trials), args.steps)},
+            "config": settings,
             "final_loss": final_loss,
             "library": library_record(klib), "env_overrides": env_overrides(),
             **({"test_mode": "ranks share GPU 0 and reduce over gloo (ZS_BENCH_SHARE_DEVICE): control-flow test, NOT a measurement"}
                if share_device else {}),
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": 1e3 * k_ms if k_ms else None,
-                         "min_launch_us": 1e3 * k_min_ms, "launches_timed": k_count,
-                         "eager_event_avg_us": 1e3 * ev_ms, "timing": timing,
-                         "working_set_note": "%.0f MB per launch: resident in the 256 MiB Infinity Cache between the producer "
-                                             "kernel and this one; hbm_resident holds the same kernel on a working set beyond it"
-                                             % (algo_bytes / 1e6)},
-            "hip_kernels": per_kernel,
+            "roofline": roof,
         }
+        # everything that does not fit a one-line record (the driver keeps the line's scalars): per-kernel tables, trial times, prose
+        full = {"trial_ms_per_step": {"min": 1e3 * min(trials) / args.steps, "median": 1e3 * elapsed / args.steps,
+                                      "max": 1e3 * max(trials) / args.steps, "all": [1e3 * t / args.steps for t in trials]},
+                "settings_explained": long_settings, "hip_kernels": per_kernel,
+                "roofline_notes": {"timing": timing, "traffic_source": traffic_source,
+                                   "working_set": "%.0f MB per launch: resident in the 256 MiB Infinity Cache between the producer kernel and "
+                                                  "this one; hbm_resident holds the streaming kernels on working sets beyond it" % (algo_bytes / 1e6)}}
+        k3f = per_kernel.get("zs_bernoulli_iw_objective_f32") or per_kernel.get("zs_bernoulli_logprob_f32") or \
+            per_kernel.get("zs_bernoulli_logits_logprob_f32")
+        if k3f and "frac_of_hbm_peak" in k3f:
+            roof["k3_fwd_frac"] = k3f["frac_of_hbm_peak"]          # the forward Bernoulli stream of the step (IW1 when it runs fused)
         extras = world == 1 and not args.no_extras and not args.force_collective_path
         if extras:
             try:
-                out["hbm_resident"] = dict(k1_first, **hbm_resident_kernels(klib, dev))
-                # the kernel BASELINE.json's north_star sets its >= 60 % target on, where the driver's record shows it
-                k1 = {}
-                for key, label in (("zs_normal_sample_logprob_f32@1M", "rows_1M"), ("zs_normal_sample_logprob_f32", "rows_4M")):
-                    r = out["hbm_resident"].get(key)
-                    if r:
-                        k1[label] = {"rows": r["rows"], "row_length": r["row_length"], "algorithmic_bytes": r["algorithmic_bytes"],
-                                     "median_us": r["median_us"], "min_us": r["min_us"], "launches": r["launches"],
-                                     "achieved": r["GBps"], "frac": r["frac_of_hbm_peak"]}
-                out["roofline"]["k1_fused_sample_logprob"] = dict(
-                    k1, kernel="zs_normal_sample_logprob_f32 (in-kernel Philox4x32-10, K = 50, D = 40)", unit="GB/s", peak=HBM_PEAK_GBS,
-                    bytes_per_row="4*D + 4 (z and log q written) + 8*D/K (mu, sigma read): SURVEY.md 8d",
-                    timing="median of 30 back-to-back launches, HIP events bound to each dispatch, in this process, each size right "
-                           "after continuous launches of the same kernel (1 - 4 s, until their rate stops improving): VALU-issue bound, the shader "
-                           "clock follows the recent load (the same launch is 40 % slower after a second of idling, "
-                           "tools/k1_clock_probe.py)")
-                dom = out["hbm_resident"].get(dominant)
+                full["hbm_resident"] = hb = dict(k1_first, **hbm_resident_kernels(klib, dev))
+                # the kernel BASELINE.json's north_star sets its >= 60 % target on: flat scalars in the driver-visible line
+                for key, label in (("zs_normal_sample_logprob_f32@1M", "k1_frac_1M"), ("zs_normal_sample_logprob_f32", "k1_frac_4M")):
+                    if key in hb:
+                        roof[label] = hb[key]["frac_of_hbm_peak"]
+                dom = hb.get("zs_bernoulli_logprob_bwd_f32")
                 if dom:
-                    out["roofline"]["hbm_resident"] = {"frac": dom["frac_of_hbm_peak"], "achieved": dom["GBps"],
-                                                       "median_launch_us": dom["median_us"], "rows": dom["rows"],
-                                                       "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
+                    roof["hbm_resident_frac"] = dom["frac_of_hbm_peak"]       # the Bernoulli backward stream at 831 MB (beyond the cache)
+                full["roofline_notes"]["k1"] = (
+                    "zs_normal_sample_logprob_f32 (in-kernel Philox4x32-10, K = 50, D = 40) at 1 M / 4.2 M rows: median of 30 back-to-back "
+                    "launches, HIP events bound to each dispatch, each size right after 1 - 4 s of the kernel's own launches (VALU-issue "
+                    "bound: the shader clock follows the recent load); bytes per row 4*D + 4 written + 8*D/K read (SURVEY.md 8d)")
             except Exception as e:                                  # noqa: BLE001
-                out["hbm_resident"] = {"error": repr(e)}
+                full["hbm_resident"] = {"error": repr(e)}
             del model, opt, bucket
             torch.cuda.empty_cache()
-            out["extra_configs"] = {}
-            for name in ("c2", "c5", "c3_probs" if args.fused_logits else "c3_logits"):
+            ex = full["extra_configs"] = {}
+
+            def extra(key, name, **kw):
                 try:
-                    out["extra_configs"][name] = run_single_gpu_config(name, dev, args.steps, args.warmup, tuned=tuned,
-                                                                       torch_adam=args.torch_adam, skip_discarded=skip_discarded,
-                                                                       dense=dense)
+                    ex[key] = run_single_gpu_config(name, dev, args.steps, args.warmup, **kw)
                 except Exception as e:                              # noqa: BLE001
-                    out["extra_configs"][name] = {"error": repr(e)}
-            if tuned:       # the headline step once more with PyTorch's default GEMM selection (what round 1 measured)
-                try:
-                    out["extra_configs"]["c3_default_gemm"] = run_single_gpu_config("c3_probs", dev, args.steps, args.warmup,
-                                                                                    tuned=False, torch_adam=True)
-                except Exception as e:                              # noqa: BLE001
-                    out["extra_configs"]["c3_default_gemm"] = {"error": repr(e)}
-            # the headline step built from torch.nn modules, as the reference's example is; and with only the bias gradient taken over
-            for key, other in (("c3_torch_linear", "torch"), ("c3_unfused_activations", "zhusuan")):
-                if dense != "fused":
-                    break
-                try:
-                    out["extra_configs"][key] = run_single_gpu_config(
-                        "c3", dev, args.steps, args.warmup, tuned=tuned, torch_adam=args.torch_adam, fused_logits=args.fused_logits,
-                        skip_discarded=skip_discarded, dense=other)
-                except Exception as e:                              # noqa: BLE001
-                    out["extra_configs"][key] = {"error": repr(e)}
-            if skip_discarded:          # the headline step with the reference's discarded draw executed (the package default)
-                try:
-                    out["extra_configs"]["c3_reference_draws"] = run_single_gpu_config(
-                        "c3", dev, args.steps, args.warmup, tuned=tuned, torch_adam=args.torch_adam, fused_logits=args.fused_logits,
-                        skip_discarded=False, dense=dense)
-                except Exception as e:                              # noqa: BLE001
-                    out["extra_configs"]["c3_reference_draws"] = {"error": repr(e)}
-            if not args.torch_adam:     # the headline step with torch's multi-tensor Adam
-                try:
-                    out["extra_configs"]["c3_torch_adam"] = run_single_gpu_config("c3", dev, args.steps, args.warmup, tuned=tuned,
-                                                                                  torch_adam=True, fused_logits=args.fused_logits)
-                except Exception as e:                              # noqa: BLE001
-                    out["extra_configs"]["c3_torch_adam"] = {"error": repr(e)}
+                    ex[key] = {"error": repr(e)}
+            base = dict(tuned=tuned, torch_adam=args.torch_adam, skip_discarded=skip_discarded, dense=dense)
+            # the other single-GPU BASELINE configs, in the headline's settings
+            extra("c2", "c2", **base)
+            extra("c5", "c5", **base)
+            extra("c3_probs" if args.fused_logits else "c3_logits", "c3_probs" if args.fused_logits else "c3_logits", **base)
+            # what a user of the reference gets by swapping the import: the example as written, and with only GraphedStep added
+            ref = dict(tuned=False, skip_discarded=False, dense="torch", refresh=True)
+            extra("c3_reference_example", "c3_probs", torch_adam="reference", eager=True, device_rng=False, **ref)
+            extra("c3_reference_example_graphed", "c3_probs", torch_adam="reference_capturable", **ref)
+            extra("c5_reference_example", "c5", torch_adam="reference", eager=True, device_rng=False, **ref)
+            extra("c5_reference_example_graphed", "c5", torch_adam="reference_capturable", **ref)
+            # the headline's settings launched eagerly from Python (no graph), one resident minibatch
+            extra("c3_eager", "c3", eager=True, fused_logits=args.fused_logits, **base)
+            extra("c3_eager_torch_linear", "c3", eager=True, fused_logits=args.fused_logits, **dict(base, dense="torch"))
+            extra("c5_eager", "c5", eager=True, **base)
+            # the reference examples' own default shapes (iwae.py:126,131; bnn_vi.py:116-118), headline settings
+            extra("iwae_default", "iwae_default", **base)
+            extra("bnn_default", "bnn_default", **base)
+            if not skip_discarded:      # the opt-in that drops the draw the reference discards
+                extra("c3_skip_discarded_draws", "c3", fused_logits=args.fused_logits, **dict(base, skip_discarded=True))
+            if tuned:                   # PyTorch's default GEMM selection and its multi-tensor Adam (what round 1 measured)
+                extra("c3_default_gemm", "c3_probs", tuned=False, torch_adam=True, skip_discarded=skip_discarded)
+            if dense == "fused":        # the headline step built from torch.nn modules
+                extra("c3_torch_linear", "c3", fused_logits=args.fused_logits, **dict(base, dense="torch"))
+            if not args.torch_adam:     # ... and with torch's multi-tensor Adam
+                extra("c3_torch_adam", "c3", fused_logits=args.fused_logits, **dict(base, torch_adam=True))
+            out["extra_configs"] = dict((k, ({"ms_per_step": v["ms_per_step"], "value": v["value"]} if "error" not in v else v))
+                                        for k, v in ex.items())
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline("c3")
+            cb = cpu_baseline("c3")
+            full["cpu_baseline"] = cb
+            out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                   "sample": cb["sample"], "ms_per_step": cb["ms_per_step"], "one_thread_value": cb["one_thread"]["value"],
+                                   "host_cpus_available": cb["host_cpus_available"]}
             if extras:
                 for name, b1, b2 in (("c2", 2.5, 2.0), ("c5", 2.0, 1.5)):
-                    if "error" not in out["extra_configs"].get(name, {"error": 1}):
-                        out["extra_configs"][name]["cpu_baseline"] = cpu_baseline(name, budget_s=b1, one_thread_budget_s=b2,
-                                                                                  max_steps=2000)
-                for name in ("c3_logits", "c3_probs"):
-                    if "error" not in out["extra_configs"].get(name, {"error": 1}):
-                        out["extra_configs"][name]["cpu_baseline"] = "same workload as the headline line: see cpu_baseline"
-        print(json.dumps(out), flush=True)
+                    if "error" not in full["extra_configs"].get(name, {"error": 1}):
+                        c = cpu_baseline(name, budget_s=b1, one_thread_budget_s=b2, max_steps=2000)
+                        full["extra_configs"][name]["cpu_baseline"] = c
+                        out["extra_configs"][name]["cpu_value"] = c["value"]
+        try:
+            with open(args.full_record, "w") as f:
+                json.dump(dict(out, **full), f, indent=1)
+            out["full_record"] = os.path.relpath(args.full_record, ROOT) if args.full_record.startswith(ROOT) else args.full_record
+        except OSError as e:
+            out["full_record"] = "not written: %r" % (e,)
+        line = json.dumps(out)
+        assert len(line) <= 8192, "the one-line record must stay under 8 KB (%d bytes): move detail to the full record" % len(line)
+        print(line, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -50,25 +50,41 @@ def test_shipped_library_reads_no_environment():
     assert "getenv" not in out, "libzs_hip.so imports getenv: built with -DZS_EXPERIMENTS?"
 
 
-def _run_bench(*extra):
+def _run_bench(*extra, full=False):
     env = dict(os.environ)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("MASTER_PORT", "29533")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3"] + list(extra),
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    full_path = os.path.join(ROOT, "gpurun_out", "bench_full_test.json")
+    os.makedirs(os.path.dirname(full_path), exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--full-record", full_path]
+                       + list(extra), cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    assert len(lines[0]) <= 8192, "the one-line record must stay under 8 KB (the driver keeps a tail of stdout): %d" % len(lines[0])
+    rec = json.loads(lines[0])
+    if full:
+        return rec, json.load(open(full_path))
+    return rec
+
+
+def test_record_is_flat_where_the_driver_reads_it():
+    """The driver keeps the SCALARS of `roofline` (nested dicts do not survive into its parsed record): the fractions the
+    contract names are flat keys, and the bulky tables go to the full record, not into the line (VERDICT r03 missing 4)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ("k1_frac_1M", "k1_frac_4M", "hbm_resident_frac", "k3_fwd_frac"):
+        assert 'roof["%s"]' % key in src or '"%s"' % key in src, key
+    assert "assert len(line) <= 8192" in src and '"full_record"' in src
+    assert 'out["hip_kernels"]' not in src and '"hip_kernels": per_kernel' in src          # per-kernel table: full record only
 
 
 @pytest.mark.gpu
 def test_bench_line_single_rank():
-    rec = _run_bench()
+    rec, full = _run_bench(full=True)
     for key in REQUIRED:
         assert key in rec, key
     cpu = rec["cpu_baseline"]
-    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"] and cpu["one_thread_value"] > 0
     assert rec["n_gpus"] == 1 and rec["steps"] == 6 and rec["warmup"] == 3
     assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["vs_baseline"] is None
     assert rec["dtype"] == "f32" or rec["dtype"] == "fp32"
@@ -76,45 +92,54 @@ def test_bench_line_single_rank():
     roof = rec["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-6
+    assert all(not isinstance(v, (dict, list)) for v in roof.values()), "roofline must hold scalars only"
     assert "workload" in rec["config"] and "model" not in rec["config"] and "test_mode" not in rec
     assert rec["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     # a 6-step trial is ~7 ms: the timed region is repeated until it covers at least half a second, median reported
     assert rec["trials"] >= 3 and rec["timed_seconds_total"] >= 0.45
-    k1 = roof["k1_fused_sample_logprob"]          # the north-star kernel's own fraction, in the driver-visible record
-    for label in ("rows_1M", "rows_4M"):
-        assert k1[label]["rows"] > 1000000 and 0.2 < k1[label]["frac"] <= 1.0
-        assert abs(k1[label]["frac"] - k1[label]["achieved"] / 8000.0) < 1e-9
-    assert rec["config"]["discarded_draws"].startswith("skipped") and "c3_reference_draws" in rec["extra_configs"]
+    # the north-star kernel's own fraction (beyond the cache), the forward Bernoulli stream and the HBM-resident backward: flat
+    for key in ("k1_frac_1M", "k1_frac_4M", "hbm_resident_frac", "k3_fwd_frac"):
+        assert 0.2 < roof[key] <= 1.0, (key, roof.get(key))
+    # THE HEADLINE IS THE PACKAGE DEFAULT: both draws of every latent executed, as the reference does
+    assert rec["config"]["discarded_draws"].startswith("executed") and "c3_skip_discarded_draws" in rec["extra_configs"]
     assert rec["config"]["dense_layers"].startswith("zhusuan.Linear in zhusuan.Sequential")
-    ab1 = rec["hip_kernels"]["zs_dense_act_bwd_f32"]            # caller-side layer kernels: bytes of all their launches, from the calls
+    # the step's generator side is ONE launch each way (IW1): its backward is the kernel that moves the most bytes
+    assert rec["config"]["bernoulli_path"].startswith("probs") and roof["kernel"] == "zs_bernoulli_iw_objective_bwd_f32"
+    hk = full["hip_kernels"]
+    assert hk["zs_bernoulli_iw_objective_f32"]["launches_per_step"] == 1 and hk["zs_bernoulli_iw_objective_bwd_f32"]["launches_per_step"] == 1
+    assert hk["zs_normal_sample_logprob_f32"]["launches_per_step"] == 2          # the discarded draw and the used one
+    for gone in ("zs_bernoulli_logprob_f32", "zs_normal_logprob_f32", "zs_iw_objective_f32", "zs_normal_logprob_bwd_ksum_f32"):
+        assert gone not in hk, gone
+    ab1 = hk["zs_dense_act_bwd_f32"]            # caller-side layer kernels: bytes of all their launches, from the calls
     assert ab1["launches_per_step"] == 5 and ab1["algorithmic_bytes_per_step"] == 12 * (12800 * (2 * 500 + 784) + 256 * 2 * 500) + 4 * (4 * 500 + 784)
-    assert 0.1 < ab1["frac_of_hbm_peak"] < 1.0 and "glue" in ab1["role"]
-    for key in ("c3_torch_linear", "c3_unfused_activations"):      # the same step from torch.nn modules / with torch's activation passes
-        assert rec["extra_configs"][key]["value"] > 1e5 and "torch.nn" in rec["extra_configs"][key]["dense_layers"]
     lib = rec["library"]
     assert lib["abi"] == 12 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
     assert lib["path"].endswith("lib/libzs_hip.so") and rec["env_overrides"] == {}
-    assert rec["trial_ms_per_step"]["min"] <= rec["ms_per_step"] <= rec["trial_ms_per_step"]["max"]
-    assert roof["traffic_source"] is None or roof["traffic_source"]["measured_in_this_run"] is False
-    # the same kernels on working sets beyond the Infinity Cache, measured in this run
-    hb = rec["hbm_resident"]
+    assert full["trial_ms_per_step"]["min"] <= rec["ms_per_step"] <= full["trial_ms_per_step"]["max"]
+    # the same kernels on working sets beyond the Infinity Cache, measured in this run (full record)
+    hb = full["hbm_resident"]
     for k in ("zs_bernoulli_logprob_f32", "zs_bernoulli_logprob_bwd_f32", "zs_bernoulli_logits_logprob_f32",
               "zs_bernoulli_logits_logprob_bwd_f32", "zs_normal_sample_logprob_f32"):
         assert hb[k]["algorithmic_bytes"] > 256 * 2 ** 20 and 0.2 < hb[k]["frac_of_hbm_peak"] < 1.0
-    assert 0.2 < roof["hbm_resident"]["frac"] < 1.0
-    # the other single-GPU configs, each with its CPU baselines (calibrated thread count and one thread)
-    for name in ("c2", "c5", "c3_logits"):
-        ex = rec["extra_configs"][name]
-        assert ex["value"] > 1e5 and ex["ms_per_step"] > 0 and ex["launch_mode"] == "hipgraph", ex
+    # the other configs: compact in the line ({ms_per_step, value}), long form in the full record
+    ex, fx = rec["extra_configs"], full["extra_configs"]
+    for name in ("c2", "c5", "c3_logits", "iwae_default", "bnn_default", "c3_skip_discarded_draws", "c3_torch_linear", "c3_torch_adam",
+                 "c3_default_gemm", "c3_reference_example", "c3_reference_example_graphed", "c5_reference_example",
+                 "c5_reference_example_graphed", "c3_eager", "c3_eager_torch_linear", "c5_eager"):
+        assert ex[name]["value"] > 1e4 and ex[name]["ms_per_step"] > 0 and set(ex[name]) <= {"ms_per_step", "value", "cpu_value"}, (name, ex[name])
+        assert np.isfinite(fx[name]["final_loss"])
+    # the reference example as written: torch.nn modules, torch.optim.Adam(params, lr), default GEMMs, both draws, eager, fresh batches
+    r0 = fx["c3_reference_example"]
+    assert r0["launch_mode"].startswith("eager") and "torch.nn.Linear" in r0["dense_layers"] and "reference example" in r0["optimizer"]
+    assert r0["mlp_gemm_selection"] == "PyTorch default" and r0["discarded_draws"].startswith("executed") and "new minibatch" in r0["minibatch"]
+    r1 = fx["c3_reference_example_graphed"]
+    assert r1["launch_mode"] == "hipgraph" and "capturable" in r1["optimizer"] and "new minibatch" in r1["minibatch"]
+    assert ex["c3_reference_example_graphed"]["ms_per_step"] < ex["c3_reference_example"]["ms_per_step"]
     for name in ("c2", "c5"):
-        cb = rec["extra_configs"][name]["cpu_baseline"]
-        assert cb["value"] > 0 and cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0
-    assert cpu["one_thread"]["cores"] == 1 and cpu["one_thread"]["value"] > 0
-    # the update: one launch over the flat bucket by default, torch's multi-tensor Adam beside it
-    assert rec["config"]["bernoulli_path"].startswith("probs") and roof["kernel"] == "zs_bernoulli_logprob_bwd_f32"
-    assert "FlatAdam" in rec["config"]["optimizer"] and "torch.optim.Adam" in rec["extra_configs"]["c3_torch_adam"]["optimizer"]
-    assert rec["extra_configs"]["c3_torch_adam"]["value"] > 1e5
-    assert np.isfinite(rec["extra_configs"]["c3_torch_adam"]["final_loss"]) and np.isfinite(rec["final_loss"])
+        cb = fx[name]["cpu_baseline"]
+        assert cb["value"] > 0 and cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0 and ex[name]["cpu_value"] == cb["value"]
+    assert "FlatAdam" in rec["config"]["optimizer"] and "torch.optim.Adam" in fx["c3_torch_adam"]["optimizer"]
+    assert np.isfinite(rec["final_loss"]) and rec["full_record"]
 
 
 @pytest.mark.gpu
@@ -122,7 +147,7 @@ def test_bench_line_with_torch_adam():
     """The step with torch's optimizer (as round 1 ran it)."""
     rec = _run_bench("--no-cpu-baseline", "--no-extras", "--torch-adam")
     assert rec["value"] > 1e5 and rec["config"]["optimizer"].startswith("torch.optim.Adam")
-    assert rec["config"]["bernoulli_path"].startswith("probs") and rec["roofline"]["kernel"] == "zs_bernoulli_logprob_bwd_f32"
+    assert rec["config"]["bernoulli_path"].startswith("probs") and rec["roofline"]["kernel"] == "zs_bernoulli_iw_objective_bwd_f32"
 
 
 @pytest.mark.gpu

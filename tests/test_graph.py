@@ -183,3 +183,105 @@ def test_staged_graphs_with_the_scalar_objective():
     np.testing.assert_allclose(lg, le, rtol=2e-5)
     for pe, pg in zip(me.parameters(), mg.parameters()):
         np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["iwae", "vae"])
+def test_graphed_training_over_a_stream_of_minibatches(kind):
+    """The documented recipe for feeding a NEW minibatch to every replay (GraphedStep(inputs=...), step(x=batch)): graphed
+    training over ten different batches equals eager training over the same stream (reference loop: iwae.py:151-160)."""
+    dev = torch.device("cuda:0")
+    model_e, opt_e, rng_e, obs_e = _make(kind, dev)
+    model_g, opt_g, rng_g, obs_g = _make(kind, dev)
+    B = obs_e["x"].shape[0]
+    gen = torch.Generator().manual_seed(4)
+    stream = [(torch.rand(B, 784, generator=gen) < 0.5).float() for _ in range(10)]          # host tensors, as a loader yields them
+    step = zs.GraphedStep(_compute(model_g, rng_g, obs_g), opt_g.step, rng=rng_g, warmup=3, restore=True, inputs=obs_g)
+    le, lg = [], []
+    with zs.device_rng(rng_e):
+        for xb in stream:
+            le.append(float(_compute(model_e, rng_e, {"x": xb.to(dev)})()))
+            opt_e.step()
+    for xb in stream:
+        lg.append(float(step(x=xb)))
+    np.testing.assert_allclose(lg, le, rtol=2e-5)
+    assert len(set(np.round(lg, 3))) == 10
+    for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+    with pytest.raises(ValueError, match="shape"):
+        step(x=torch.zeros(B + 1, 784))
+    with pytest.raises(KeyError):
+        step(y=torch.zeros(B))
+
+
+@pytest.mark.gpu
+def test_scratch_growth_after_a_capture_keeps_the_captured_set_alive():
+    """A graph captured with one scratch set (workspaces + zero-initialised tickets of the hand-off kernels) keeps replaying
+    correctly after an EAGER call has made the package allocate a bigger set (more particles than ticket words): the old set
+    must stay allocated -- its pointers are baked into the graph."""
+    from zhusuan import _ops
+    dev = torch.device("cuda:0")
+    model_e, opt_e, rng_e, obs = _make_bnn(dev)
+    model_g, opt_g, rng_g, _ = _make_bnn(dev)
+    step = zs.GraphedStep(_compute(model_g, rng_g, obs), opt_g.step, rng=rng_g, warmup=3, restore=True)
+    comp_e = _compute(model_e, rng_e, obs)
+    le, lg = [], []
+    with zs.device_rng(rng_e):
+        for _ in range(3):
+            le.append(float(comp_e()))
+            opt_e.step()
+    for _ in range(3):
+        lg.append(float(step()))
+    # grow the per-particle ticket set eagerly (K = 200 > the 64 words the capture set was made with), then churn the allocator
+    retired = len(_ops._SCRATCH_RETIRED)
+    h = torch.randn(200, 8, 13, device=dev, requires_grad=True)
+    w = torch.randn(200, 5, 14, device=dev, requires_grad=True)
+    zs.particle_linear(h, w, relu=True).sum().backward()
+    assert len(_ops._SCRATCH_RETIRED) > retired, "the replaced capture set must be kept, not freed"
+    junk = [torch.full((1 << 16,), 7.0, device=dev) for _ in range(64)]
+    torch.cuda.synchronize()
+    del junk
+    with zs.device_rng(rng_e):
+        for _ in range(4):
+            le.append(float(comp_e()))
+            opt_e.step()
+    for _ in range(4):
+        lg.append(float(step()))
+    np.testing.assert_allclose(lg, le, rtol=2e-5)
+    for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["iwae", "vae"])
+def test_replays_and_eager_steps_do_not_grow_the_allocator(kind):
+    """A replay allocates nothing; eager steps return to their own baseline once the last loss is dropped (tools/soak.py
+    asserts the same over 20 000 replays at the config shapes)."""
+    import gc
+    dev = torch.device("cuda:0")
+    model, opt, rng, obs = _make(kind, dev)
+    compute = _compute(model, rng, obs)
+    step = zs.GraphedStep(compute, opt.step, rng=rng, warmup=3)
+
+    def settled():
+        gc.collect()
+        torch.cuda.synchronize()
+        return torch.cuda.memory_allocated()
+    for _ in range(5):
+        step()
+    m5 = settled()
+    for _ in range(60):
+        step()
+    assert settled() == m5
+    with zs.device_rng(rng):
+        for n, keep in ((3, "a"), (40, "b")):
+            for _ in range(n):
+                loss = compute()
+                opt.step()
+            del loss
+            for p in model.parameters():
+                p.grad = None
+            if keep == "a":
+                base = settled()
+            else:
+                assert settled() <= base

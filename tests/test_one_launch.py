@@ -439,3 +439,54 @@ def test_layer_functions_accept_deferred_node_values(dev):
         q({})
     assert q.cache["is_lazy"] and q.cache["a"].shape == (3, 6, 5) and q.cache["b"].shape == (3, 6, 2)
     assert q.cache["c"].shape == (3, 5, 2) and q.cache["d"].dim() == 0
+
+
+def test_skip_discarded_draws_is_context_local_and_stale_handles_raise(dev):
+    """The switch is a contextvar: a thread that evaluates its own objective while another one sits inside
+    ``zhusuan.skip_discarded_draws()`` keeps the default.  A LazyDraw that user code stored and touches
+    only AFTER the objective has re-read the node stands for the draw the reference discards: it raises instead of drawing
+    out of order."""
+    import threading
+    from zhusuan.framework import stochastic_tensor as st
+    seen = {}
+
+    def other():
+        seen["skip"] = st.skipping_discarded_draws()
+        with zs.skip_discarded_draws():
+            seen["inner"] = st.skipping_discarded_draws()
+    with zs.skip_discarded_draws():
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert st.skipping_discarded_draws() is True
+    assert seen == {"skip": False, "inner": True} and st.skipping_discarded_draws() is False
+
+    class Q(BayesianNet):
+        def __init__(self):
+            super().__init__()
+            self.mu = torch.nn.Parameter(torch.zeros(4, 3))
+
+        def forward(self, observed):
+            self.observe(observed)
+            self.kept = self.normal(name="z", mean=self.mu, std=torch.ones_like(self.mu), reduce_mean_dims=[0], reduce_sum_dims=[1])
+            return self
+
+    class P(BayesianNet):
+        def forward(self, observed):
+            self.observe(observed)
+            dev_ = self.observed["z"].device
+            self.normal(name="z", mean=torch.zeros(4, 3, device=dev_), std=torch.ones(4, 3, device=dev_), reduce_mean_dims=[0],
+                        reduce_sum_dims=[1])
+            return self
+    from zhusuan.variational.elbo import ELBO
+    q = Q().to(dev)
+    model = ELBO(P().to(dev), q)
+    with zs.skip_discarded_draws(), launches() as names:
+        loss = model({})
+        assert names.count("zs_normal_sample_logprob") == 1 and isinstance(q.kept, LazyDraw)
+        with pytest.raises(RuntimeError, match="was not used before the objective drew the node again"):
+            q.kept + 1.0
+        assert "expired" in repr(q.kept)
+    assert torch.isfinite(loss)
+    loss = model({})                    # outside the context the factory returns the (discarded) first draw, as in the reference
+    assert isinstance(q.kept, torch.Tensor) and q.kept.shape == (4, 3)

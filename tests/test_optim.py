@@ -128,7 +128,7 @@ def test_flat_adam_leaves_parameters_without_a_gradient_alone(dev):
 
 
 def test_flat_adam_param_groups_schedulers_and_checkpoints(dev):
-    """param_groups is persistent (the `for g in opt.param_groups: g['lr'] = ...` idiom and torch's schedulers act on the
+    """param_groups is persistent (the `for g in opt.param_groups: g['lr'] = ...` idiom acts on the
     update), state_dict / load_state_dict resume a run exactly."""
     a, b = _model(dev, seed=6), _model(dev, seed=6)
     x = torch.randn(5, 7, device=dev)
@@ -143,6 +143,8 @@ def test_flat_adam_param_groups_schedulers_and_checkpoints(dev):
             for g in opt.param_groups:
                 g["lr"] = g["lr"] * 0.5
     assert opt.param_groups[0]["lr"] == ref.param_groups[0]["lr"] == opt.lr
+    with pytest.raises(TypeError):          # torch's scheduler classes want a torch.optim.Optimizer: documented, not claimed
+        torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5)
     for p, q in zip(a.parameters(), b.parameters()):
         np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=5e-6, atol=5e-7)
     # checkpoint, continue, and resume a copy from the checkpoint: same parameters

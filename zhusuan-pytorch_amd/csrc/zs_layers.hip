@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_particle_linear(const T* __restrict__ h
     ws[o * WS + i] = wk[e];
   }
   __syncthreads();
-  const T p = Mth<T>::rsqrt_n(n_in + 1);                           // torch.sqrt(torch.as_tensor(h.shape[2])), bnn_vi.py:42
+  const T p = Mth<T>::sqrt_n(n_in + 1);                           // torch.sqrt(torch.as_tensor(h.shape[2])), bnn_vi.py:42
   T* __restrict__ ok = out + ((int64_t)k * B + b0) * n_out;
   for (int e = threadIdx.x; e < nb * n_out; e += 256) {
     const int b = e / n_out, o = e - b * n_out;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_particle_linear_bwd(const T* __restrict
                                                              int ntiles, int bt) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __shared__ bool last;
-  const T p = Mth<T>::rsqrt_n(n_in + 1);
+  const T p = Mth<T>::sqrt_n(n_in + 1);
   const int WS = n_in + 1, nW = n_out * (n_in + 1);
   T* gs = reinterpret_cast<T*>(smem_raw);                     // [bt][n_out] flat
   T* hs = gs + ((bt * n_out + 3) & ~3);                        // [bt][n_in] flat
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_particle_mlp(const PMArgs<T> A, const T
     if (l >= A.L) break;
     const int n_in = A.n[l], n_out = A.n[l + 1], WS = pl_odd(n_in + 1);
     const bool relu = l < A.L - 1;
-    const T p = Mth<T>::rsqrt_n(n_in + 1);
+    const T p = Mth<T>::sqrt_n(n_in + 1);
     const T* __restrict__ wl = wsm + A.woff[l];
     T* __restrict__ ok = A.out[l] + ((int64_t)k * B + b0) * n_out;
     for (int e = threadIdx.x; e < nb * n_out; e += 256) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_particle_mlp_bwd(const PMArgs<T> A, con
     const int l = L - 1 - ll;
     if (l < 0) break;
     const int n_in = A.n[l], n_out = A.n[l + 1], nW = n_out * (n_in + 1), WS = n_in + 1;
-    const T p = Mth<T>::rsqrt_n(n_in + 1);
+    const T p = Mth<T>::sqrt_n(n_in + 1);
     const T* __restrict__ in = sm + A.ioff[l];
     T* __restrict__ pk = slab + A.poff[l];
     for (int e = threadIdx.x; e < nW; e += 256) {   // the tile's partial weight gradient (unscaled: / p in the reduction)
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_particle_mlp_bwd(const PMArgs<T> A, con
     for (int l = 0; l < PM_MAX_LAYERS; ++l) {
       if (l >= L) break;
       const int nW = A.n[l + 1] * (A.n[l] + 1);
-      pl_reduce_tiles<T>(p0 + A.poff[l], A.slab, A.gw[l] + (int64_t)k * nW, nW, ntiles, Mth<T>::rsqrt_n(A.n[l] + 1));
+      pl_reduce_tiles<T>(p0 + A.poff[l], A.slab, A.gw[l] + (int64_t)k * nW, nW, ntiles, Mth<T>::sqrt_n(A.n[l] + 1));
     }
     if (threadIdx.x == 0) ticket_return(tickets + k);
   }

@@ -24,7 +24,7 @@ struct Mth<float> {
   static __device__ __forceinline__ float bern_term(float p, float x) { return bern_lp2_term(p, x) * ZS_LN2; }
   static __device__ __forceinline__ float bern_dp(float p, float x) { return zs::bern_dp(p, x); }
   static __device__ __forceinline__ float sigmoid(float l) { return sigmoid_fast(l); }
-  static __device__ __forceinline__ float rsqrt_n(int64_t n) { return sqrtf((float)n); }
+  static __device__ __forceinline__ float sqrt_n(int64_t n) { return sqrtf((float)n); }
 };
 template <>
 struct Mth<double> {
@@ -41,7 +41,7 @@ struct Mth<double> {
   }
   static __device__ __forceinline__ double bern_dp(double p, double x) { return x / (p + 1e-8) - (1.0 - x) / ((1.0 - p) + 1e-8); }
   static __device__ __forceinline__ double sigmoid(double l) { return 1.0 / (1.0 + exp(-l)); }
-  static __device__ __forceinline__ double rsqrt_n(int64_t n) { return sqrt((double)n); }
+  static __device__ __forceinline__ double sqrt_n(int64_t n) { return sqrt((double)n); }
 };
 
 template <typename T>

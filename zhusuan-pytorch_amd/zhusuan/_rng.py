@@ -26,43 +26,43 @@ consumes the CPU stream like the reference run under the same seed (two draws pe
 yields the reference's numbers.  It costs a host draw and a copy per sample: a reproduction mode, not the fast path.
 """
 import contextlib
+import contextvars
 
 import torch
 
-_queue = None
+# the three switches of this module are context-local (contextvars), like zhusuan.skip_discarded_draws: another thread's
+# objective is not affected by a `with` block here
+_queue = contextvars.ContextVar("zhusuan_injected_epsilons", default=None)
 
 
 @contextlib.contextmanager
 def inject_epsilon(eps_list, strict=True):
     """Supply the standard-normal draws of the enclosed Normal samples explicitly."""
-    global _queue
-    prev = _queue
-    _queue = list(eps_list)
+    q = list(eps_list)
+    token = _queue.set(q)
     try:
         yield
-        if strict and _queue:
-            raise RuntimeError("inject_epsilon: %d epsilon tensors were not consumed" % len(_queue))
+        if strict and q:
+            raise RuntimeError("inject_epsilon: %d epsilon tensors were not consumed" % len(q))
     finally:
-        _queue = prev
+        _queue.reset(token)
 
 
-_reference_stream = False
+_reference_stream = contextvars.ContextVar("zhusuan_reference_rng", default=False)
 
 
 @contextlib.contextmanager
 def reference_rng():
     """Draw like the reference: on the CPU, from torch's default generator (``torch.manual_seed``), call for call."""
-    global _reference_stream
-    prev = _reference_stream
-    _reference_stream = True
+    token = _reference_stream.set(True)
     try:
         yield
     finally:
-        _reference_stream = prev
+        _reference_stream.reset(token)
 
 
 def reference_stream_active():
-    return _reference_stream and _queue is None
+    return _reference_stream.get() and _queue.get() is None
 
 
 def _host_draw(kind, shape, dtype):
@@ -83,13 +83,14 @@ def _host_draw(kind, shape, dtype):
 def pop_injected(shape, device, dtype=torch.float32, kind="normal"):
     """Next injected epsilon (moved to `device`, cast to `dtype`); inside ``reference_rng()`` a host draw of `kind`;
     None when neither is active (the kernels then draw from their Philox stream)."""
-    if _queue is None:
-        if _reference_stream:
+    q = _queue.get()
+    if q is None:
+        if _reference_stream.get():
             return _host_draw(kind, shape, dtype).to(device).contiguous()
         return None
-    if not _queue:
+    if not q:
         raise RuntimeError("inject_epsilon: the model drew more Normal samples than epsilons were supplied")
-    e = torch.as_tensor(_queue.pop(0), dtype=dtype)
+    e = torch.as_tensor(q.pop(0), dtype=dtype)
     if tuple(e.shape) != tuple(shape):
         raise RuntimeError("inject_epsilon: next epsilon has shape %s, the draw needs %s"
                            % (tuple(e.shape), tuple(shape)))
@@ -126,27 +127,26 @@ class DeviceRNG(object):
         return d
 
 
-_device_rng = None
+_device_rng = contextvars.ContextVar("zhusuan_device_rng", default=None)
 
 
 @contextlib.contextmanager
 def device_rng(rng):
     """Route the draws of the enclosed code through `rng` (a DeviceRNG)."""
-    global _device_rng
-    prev = _device_rng
-    _device_rng = rng
+    token = _device_rng.set(rng)
     try:
         yield rng
     finally:
-        _device_rng = prev
+        _device_rng.reset(token)
 
 
 def next_call(device):
     """(seed, call id, device state tensor or None) for one draw on `device`."""
-    if _device_rng is not None:
-        if _device_rng.device != device:
-            raise RuntimeError("DeviceRNG lives on %s, draw requested on %s" % (_device_rng.device, device))
-        return 0, _device_rng.next_delta(), _device_rng.state
+    rng = _device_rng.get()
+    if rng is not None:
+        if rng.device != device:
+            raise RuntimeError("DeviceRNG lives on %s, draw requested on %s" % (rng.device, device))
+        return 0, rng.next_delta(), rng.state
     s, c = _seed_and_call(device)
     return s, c, None
 

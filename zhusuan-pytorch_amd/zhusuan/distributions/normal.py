@@ -3,11 +3,18 @@ log-density come from the fused HIP kernel K1, the density of a given value from
 import torch
 
 from .base import Distribution
-from .utils import assert_same_log_float_dtype, check_broadcast
+from .utils import assert_same_log_float_dtype
 from .. import _hip, _ops, _rng
 from .._shapes import broadcast_shapes, value_shape
 
 __all__ = ['Normal']
+
+
+def _as_param(v, dtype, device):
+    """``torch.as_tensor(v, dtype=dtype).to(device)`` (normal.py:50,56,58), without the two calls when `v` is already that."""
+    if isinstance(v, torch.Tensor) and (dtype is None or v.dtype == dtype) and v.device == device:
+        return v
+    return torch.as_tensor(v, dtype=dtype).to(device)
 
 
 class Normal(Distribution):
@@ -34,7 +41,7 @@ class Normal(Distribution):
                  device=None,
                  **kwargs):
         device = _hip.resolve_device(device, mean, std, logstd)
-        self._mean = torch.as_tensor(mean, dtype=dtype).to(device)
+        self._mean = _as_param(mean, dtype, device)
         if (logstd is None) == (std is None):
             raise ValueError(
                 "Either `std` or `logstd` should be passed. It is not allowed "
@@ -43,13 +50,14 @@ class Normal(Distribution):
             # normal.py:56 computes std = exp(logstd) here.  The kernels take log(sigma) directly (sigma_is_logstd of
             # include/zs_hip.h) and form exp() in registers, so constructing the node launches nothing; `std` is
             # materialised only if somebody reads the property.
-            self._logstd_given = torch.as_tensor(logstd, dtype=dtype).to(device)
+            self._logstd_given = _as_param(logstd, dtype, device)
             self._std_cache = None
         else:
             self._logstd_given = None
-            self._std_cache = torch.as_tensor(std, dtype=dtype).to(device)
+            self._std_cache = _as_param(std, dtype, device)
         scale = self._scale_operand()
-        check_broadcast(scale, self._mean)
+        # (the broadcast check IS the batch shape: kept, the eager path asks for it several times per step)
+        self._bshape = torch.Size(broadcast_shapes(self._mean.shape, scale.shape))
         dtype = assert_same_log_float_dtype([(self._mean, "Normal.mean"), (scale, "Normal.std")])
         super(Normal, self).__init__(dtype=dtype,
                                      is_continuous=is_continuous,
@@ -82,7 +90,7 @@ class Normal(Distribution):
         return torch.log(self._std)         # normal.py:77-79 (log of exp of the argument, as in the reference)
 
     def _batch_shape(self):
-        return torch.Size(broadcast_shapes(self._mean.shape, self._scale_operand().shape))
+        return self._bshape
 
     def _sample_plan(self, n_samples=1, epsilon=None):
         """Operands of one draw (normal.py:89-107): ``(mu, sigma, eps, K, has_k, n_fold, is_logstd, simple)``.  The

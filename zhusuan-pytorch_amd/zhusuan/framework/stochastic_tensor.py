@@ -1,6 +1,7 @@
 """StochasticTensor: a named node = (BayesianNet, Distribution, n_samples, reduction kwargs).
 Interface of zhusuan/framework/stochastic_tensor.py:5-181 of the reference."""
 import contextlib
+import contextvars
 
 import torch
 
@@ -18,43 +19,58 @@ __all__ = ['StochasticTensor', 'LazyDraw', 'skip_discarded_draws']
 # somebody actually touches it, so a net that ignores the returned values (all three example callers) draws each latent
 # once per step.
 # ---------------------------------------------------------------------------------------------------------------------
-_skip_discarded = False
-_deferring = False
+# Both switches are CONTEXT-LOCAL (contextvars): another thread, or another asyncio task, evaluating its own objective is not
+# affected by a ``with zhusuan.skip_discarded_draws():`` here (round 3 kept them in module globals).
+_skip_discarded = contextvars.ContextVar("zhusuan_skip_discarded_draws", default=False)
+_deferring = contextvars.ContextVar("zhusuan_deferring_node_values", default=False)
 
 
 @contextlib.contextmanager
 def skip_discarded_draws(enabled=True):
-    """Objectives evaluated inside this context do not execute the draw that the reference discards (default: they do)."""
-    global _skip_discarded
-    prev = _skip_discarded
-    _skip_discarded = bool(enabled)
+    """Objectives evaluated inside this context do not execute the draw that the reference discards (default: they do).
+
+    Contract of the deferred values: inside the context a node factory of the VARIATIONAL net returns a ``LazyDraw`` instead
+    of a tensor.  Touching it while the net's ``forward`` runs (any torch function, arithmetic, indexing, an attribute) draws
+    the sample at that point -- exactly the value the reference's factory would have returned.  A handle that is still
+    untouched when the objective re-reads the node (elbo.py:122) is EXPIRED: using it afterwards raises ``RuntimeError``
+    instead of drawing out of order (the reference would have handed back the discarded first draw, which no longer exists)."""
+    token = _skip_discarded.set(bool(enabled))
     try:
         yield
     finally:
-        _skip_discarded = prev
+        _skip_discarded.reset(token)
 
 
 def skipping_discarded_draws():
-    return _skip_discarded
+    return _skip_discarded.get()
 
 
 @contextlib.contextmanager
 def deferred_node_values():
     """Used by the objectives around their call of the variational net (only while skip_discarded_draws is active)."""
-    global _deferring
-    prev = _deferring
-    _deferring = True
+    token = _deferring.set(True)
     try:
         yield
     finally:
-        _deferring = prev
+        _deferring.reset(token)
 
 
 def node_value(node):
     """What a BayesianNet node factory returns: ``node.tensor`` (bn.py:158,216), or a LazyDraw while deferring."""
-    if _deferring and node.name not in node.bn.observed:
-        return LazyDraw(node)
+    if _deferring.get() and node.name not in node.bn.observed:
+        handle = LazyDraw(node)
+        node.__dict__['_lazy_handle'] = handle
+        return handle
     return node.tensor
+
+
+def expire_deferred_value(node):
+    """Called by the objectives when they re-read a node (elbo.py:122): a deferred value nobody has touched by now stands for
+    the draw the reference discards, and must not be drawn later (it would consume the next call id of the stream and hand the
+    caller a sample that belongs to no evaluation)."""
+    handle = getattr(node, '__dict__', {}).pop('_lazy_handle', None)
+    if handle is not None and handle._value is None:
+        object.__setattr__(handle, "_expired", True)
 
 
 def _materialize(v):
@@ -75,9 +91,15 @@ class LazyDraw(object):
     def __init__(self, node):
         object.__setattr__(self, "_node", node)
         object.__setattr__(self, "_value", None)
+        object.__setattr__(self, "_expired", False)
 
     def materialize(self):
         if self._value is None:
+            if self._expired:
+                raise RuntimeError(
+                    "zhusuan.skip_discarded_draws: the value that the node factory of '%s' returned was not used before the "
+                    "objective drew the node again, so it stands for the draw the reference discards and was never made. Use it "
+                    "inside the variational net's forward(), or evaluate the objective outside skip_discarded_draws()." % self._node.name)
             object.__setattr__(self, "_value", self._node.tensor)
         return self._value
 
@@ -89,7 +111,7 @@ class LazyDraw(object):
         return getattr(self.materialize(), name)
 
     def __repr__(self):
-        return "LazyDraw(%r%s)" % (self._node.name, "" if self._value is None else ", drawn")
+        return "LazyDraw(%r%s)" % (self._node.name, (", expired" if self._expired else "") if self._value is None else ", drawn")
 
     def __len__(self):
         return len(self.materialize())
@@ -217,6 +239,14 @@ class StochasticTensor(object):
         x = dist.sample_cache if sample is None else sample
         if x is None:
             raise RuntimeError("node '%s' has no value yet" % self._name)
+        cached = self.__dict__.get('_plan_cache')          # (asked two or three times per node and step for the same value)
+        if cached is not None and cached[0] is x:
+            return cached[1]
+        plan = self._reduction_plan_of(x, dist, g)
+        self.__dict__['_plan_cache'] = (x, plan)
+        return plan
+
+    def _reduction_plan_of(self, x, dist, g):
         full = tuple(broadcast_shapes(tuple(torch.as_tensor(x).shape), tuple(dist.batch_shape)))
         nd = len(full) - g  # ndim of dist.log_prob(x)
         mean_dims = _norm_dims(self._reduce_mean_dims, nd)

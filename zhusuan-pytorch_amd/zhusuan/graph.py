@@ -18,6 +18,17 @@ launch path, not the GPU, sets the pace.  ``GraphedStep`` records the step once 
     for _ in range(n):
         loss = step()                                           # one graph launch
 
+A NEW MINIBATCH PER STEP.  A graph replays fixed addresses, so the observations must live in tensors that stay put: hand
+them over as ``inputs`` and pass the step's data to the call -- it is copied into those tensors (device-to-device, or
+host-to-device from pinned memory, on the replay's stream) right before the replay:
+
+    obs = {'x': torch.empty(B, 784, device=dev)}               # the static input buffers `compute` reads
+    step = zhusuan.GraphedStep(compute, opt.step, rng=rng, inputs=obs)
+    for x_batch in loader:                                      # the reference's loop (examples/.../iwae.py:151-160)
+        loss = step(x=x_batch)
+
+(``tests/test_graph.py::test_graphed_training_over_a_stream_of_minibatches``: ten different batches, equal to eager training.)
+
 With an ``exchange`` callable (the data-parallel all-reduce, see ``zhusuan.dataparallel``) the step is recorded as two
 graphs around it -- graph A = ``compute``, then ``exchange`` launched eagerly (the RCCL collective stays outside the
 graphs), then graph B = the optimizer.
@@ -63,10 +74,13 @@ class GraphedStep(object):
     :param restore: undo the warm-up's effect on parameters / optimizer state / RNG state after recording.
     :param optimizer: the optimizer object, needed only for ``restore`` (its state tensors are reset in place).
     :param parameters: iterable of the tensors ``restore`` must put back (default: the optimizer's parameters).
+    :param inputs: dict name -> the STATIC tensor ``compute`` reads that observation from; ``step(name=batch)`` copies a new
+        minibatch into it before replaying (shapes and dtypes must match: a graph has no dynamic shapes).
     """
 
     def __init__(self, compute, optimizer_step=None, exchange=None, rng=None, warmup=3, restore=False, optimizer=None,
-                 parameters=None):
+                 parameters=None, inputs=None):
+        self._inputs = dict(inputs) if inputs else {}
         if not torch.cuda.is_available():
             raise RuntimeError("zhusuan.GraphedStep needs a HIP device: the MI355X build has no CPU path")
         self._compute, self._opt_step, self._exchange, self._rng = compute, optimizer_step, exchange, rng
@@ -136,8 +150,22 @@ class GraphedStep(object):
         import contextlib
         return contextlib.nullcontext()
 
-    def __call__(self):
-        """Replay the recorded step; returns the (static) loss tensor of this step."""
+    def feed(self, **batches):
+        """Copy new observations into the static input tensors (stream-ordered in front of the next replay)."""
+        for name, value in batches.items():
+            dst = self._inputs.get(name)
+            if dst is None:
+                raise KeyError("GraphedStep: no static input named %r (constructor argument `inputs`)" % name)
+            value = torch.as_tensor(value)
+            if tuple(value.shape) != tuple(dst.shape):
+                raise ValueError("GraphedStep: input %r has shape %s, the captured step reads %s" % (
+                    name, tuple(value.shape), tuple(dst.shape)))
+            dst.copy_(value, non_blocking=True)
+
+    def __call__(self, **batches):
+        """Replay the recorded step (after copying ``batches`` into the static inputs); returns the (static) loss tensor."""
+        if batches:
+            self.feed(**batches)
         sync = getattr(self._optimizer, 'sync_hyperparameters', None)
         if sync is not None:
             sync()              # zhusuan.optim.FlatAdam: upload lr / betas / eps if the caller changed them (a 4-float compare)

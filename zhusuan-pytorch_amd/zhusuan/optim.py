@@ -89,7 +89,8 @@ class FlatAdam(object):
     :param lr, betas, eps: as ``torch.optim.Adam``.
 
     ``param_groups`` is a persistent list of dicts (one per group given to the constructor) with the keys ``params``,
-    ``lr``, ``betas``, ``eps``: the idiom ``for g in opt.param_groups: g['lr'] = ...`` and torch's lr schedulers work, also
+    ``lr``, ``betas``, ``eps``: the idiom ``for g in opt.param_groups: g['lr'] = ...`` works (a ``torch.optim.lr_scheduler`` does
+    NOT attach: FlatAdam is not a ``torch.optim.Optimizer`` subclass -- set ``g['lr']`` from the schedule yourself), also
     for a step captured in a hipGraph (the kernel reads the hyper-parameters from device memory; ``sync_hyperparameters()``
     -- called by ``step()`` and by ``GraphedStep`` before each replay -- uploads changes).  ``state_dict()`` /
     ``load_state_dict()`` hold the moments and the per-tensor step counts.

@@ -22,6 +22,7 @@ def latent_value(node):
     gradient and lets autograd skip the dead branches through the generator (first decoder dgrad, prior log-prob
     backward).  Families whose non-reparameterised draw still depends differentiably on the parameters (Uniform,
     uniform.py:63-70) stay attached, so the pathwise gradient reaches low / high as in the reference."""
+    _st.expire_deferred_value(node)
     t = node.tensor
     dist = getattr(node, 'dist', None)
     if (dist is not None and not dist.is_reparameterized and isinstance(t, torch.Tensor)
@@ -71,6 +72,7 @@ def draw_latents(nodes_q):
     seed, rng_state = 0, None
     for name in batch:
         node = nodes_q[name]
+        _st.expire_deferred_value(node)
         mu, sigma, eps, K, has_k, n_fold, is_logstd, _ = node.dist._sample_plan(1 if node._n_samples is None else node._n_samples)
         call = 0
         if eps is None:
