@@ -98,7 +98,7 @@ def test_bench_line_single_rank():
     # a 6-step trial is ~7 ms: the timed region is repeated until it covers at least half a second, median reported
     assert rec["trials"] >= 3 and rec["timed_seconds_total"] >= 0.45
     # the north-star kernel's own fraction (beyond the cache), the forward Bernoulli stream and the HBM-resident backward: flat
-    for key in ("k1_frac_1M", "k1_frac_4M", "hbm_resident_frac", "k3_fwd_frac"):
+    for key in ("k1_frac_1M", "k1_frac_4M", "hbm_resident_frac", "k3_fwd_frac", "iw1_fwd_frac"):
         assert 0.2 < roof[key] <= 1.0, (key, roof.get(key))
     # THE HEADLINE IS THE PACKAGE DEFAULT: both draws of every latent executed, as the reference does
     assert rec["config"]["discarded_draws"].startswith("executed") and "c3_skip_discarded_draws" in rec["extra_configs"]
@@ -218,4 +218,28 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
     assert ("hipgraph x3" in rec["config"]["launch_mode"]) == (extra == [])
     assert "NOT a measurement" in rec["test_mode"]
     assert abs(rec["value"] - 2 * 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
+    assert "graph capture failed" not in r.stderr, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_sharing_one_gpu_over_gloo():
+    """The driver's N = 8 command line end to end on a one-GPU box: 8 ranks (torch.distributed.run) on GPU 0 over gloo --
+    per-rank shards and Philox streams, the staged buckets (three hipGraphs per rank around two eagerly launched
+    collectives), max-over-ranks timing, ONE JSON line from rank 0 with n_gpus = n_ranks_seen = 8.  A control-flow test
+    (RCCL refuses two ranks on one device): no 2 / 4 / 8-GPU NUMBER exists until the driver runs one."""
+    env = dict(os.environ)
+    env["ZS_BENCH_SHARE_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "3",
+           "--no-cpu-baseline", "--no-gemm-tuning"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["n_ranks_seen"] == 8 and rec["scaling"] == "weak" and "gloo" in rec["collective_library"]
+    assert "hipgraph x3" in rec["config"]["launch_mode"] and rec["config"]["global_batch"] == 2048
+    assert "dp8" in rec["config"]["parallelism"] and "two flat buckets" in rec["config"]["parallelism"]
+    assert abs(rec["value"] - 8 * 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
+    assert "NOT a measurement" in rec["test_mode"] and np.isfinite(rec["final_loss"])
     assert "graph capture failed" not in r.stderr, r.stderr[-2000:]

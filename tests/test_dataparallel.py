@@ -402,3 +402,83 @@ def test_staged_update_with_flat_adam_matches_full_batch_adam(tmp_path, world):
             total += d.numel()
             assert float(d.max()) <= 3 * 1e-2 + 1e-6
     assert outliers <= 1e-3 * max(total, 1), (outliers, total)
+
+
+# ------------------------------------------------------------------ 8 ranks against the global-batch golden of BASELINE config 4
+def _worker_c4(rank, world, port, out_dir):
+    """Rank `rank` of 8: rows [256 r, 256 (r + 1)) of the B = 2048 minibatch of config 4 (IWAE-VIMCO, K = 50, hidden 500) with the
+    matching slices of the golden's epsilon draws, per-rank model replica (rank 0's weights broadcast), staged buckets: decoder
+    gradients all-reduced while the encoder's backward runs, then the 1/world mean."""
+    for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zhusuan as zs
+        from zhusuan import dataparallel
+        from examples import iwae
+        host_backend.install(host_kernel_library())
+        Bg, Kg = 2048, 50
+        model = iwae.build(n_samples=Kg, estimator="vimco", hidden=500, device=torch.device("cpu"))
+        H.load_params_into(model, (2000 + Bg + Kg) if rank == 0 else 1)       # replicas differ until the broadcast
+        dataparallel.broadcast_parameters(model, src=0)
+        x, e1, e2 = H.iwae_data(Bg, Kg)
+        per = Bg // world
+        sl = slice(rank * per, (rank + 1) * per)
+        xs = dataparallel.shard_rows(torch.tensor(x), rank, world)
+        assert torch.equal(xs, torch.tensor(x[sl]))
+        sb = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()])
+        sb.zero()
+        with zs.inject_epsilon([e1[:, sl], e2[:, sl]]):
+            loss = model({"x": xs})
+        sb.backward_stage(loss, 0)
+        sb.launch(0)
+        sb.backward_stage(loss, 1)
+        sb.launch(1)
+        sb.wait()
+        sb.scale()
+        bound = model.last_iw_bound.detach().mean().reshape(1).clone()
+        dist.all_reduce(bound)
+        out = {"loss": float(sb.loss()), "bound": float(bound) / world, "n_ranks": dist.get_world_size(),
+               "bound_rows": model.last_iw_bound.detach().clone()}
+        if rank in (0, world - 1):
+            out["grads"] = dict((n, p.grad.detach().clone()) for n, p in model.named_parameters())
+        torch.save(out, os.path.join(out_dir, "c4_%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_reproduces_the_global_batch_golden_of_config_4(tmp_path):
+    """BASELINE config 4 as it is meant to run -- 8 ranks x 256 rows, one all-reduce of [gradients | objective] -- against
+    the golden that the real reference produced for the WHOLE B = 2048 minibatch in one process (g_iwae_vimco_c4g): the mean
+    of the 8 shard means is the global mean.  CPU, gloo, C oracle as the kernel library; every rank ends up with
+    the same averaged gradients."""
+    from conftest import load_golden
+    from test_end_to_end import _check_grads
+    world = 8
+    port = _free_port()
+    mp.spawn(_worker_c4, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(str(tmp_path / ("c4_%d.pt" % r))) for r in range(world)]
+    g = load_golden("g_iwae_vimco_c4g")
+    assert all(o["n_ranks"] == 8 for o in outs)
+    assert len({o["loss"] for o in outs}) == 1 and len({o["bound"] for o in outs}) == 1       # all-reduced: identical everywhere
+    assert abs(outs[0]["loss"] - float(g["loss"])) <= 5e-5 * abs(float(g["loss"]))
+    assert abs(outs[0]["bound"] - float(g["iw_bound"])) <= 2e-5 * abs(float(g["iw_bound"]))
+    bound = torch.cat([o["bound_rows"] for o in outs]).numpy()                                 # rank order = row order
+    np.testing.assert_allclose(bound[::16], g["bound_b_every16"], rtol=2e-5, atol=2e-4)
+    for n in outs[0]["grads"]:
+        assert torch.equal(outs[0]["grads"][n], outs[-1]["grads"][n])
+
+    class Holder(object):            # _check_grads walks named_parameters() with .grad
+        def __init__(self, grads):
+            self._g = grads
+
+        def named_parameters(self):
+            for n, v in self._g.items():
+                p = torch.nn.Parameter(torch.zeros_like(v))
+                p.grad = v
+                yield n, p
+    assert _check_grads(g, Holder(outs[0]["grads"]), rtol_norm=1e-3) > 1000

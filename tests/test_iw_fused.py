@@ -325,3 +325,40 @@ def test_fused_generator_side_equals_the_per_node_path(dev, estimator, fused_log
         np.testing.assert_allclose(fused_vec[0], plain_vec[0], rtol=2e-6)
         for a, b in zip(fused_vec[1], plain_vec[1]):
             np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4 * max(np.abs(b).max(), 1e-30))   # (VIMCO's signal amplifies the rows' last-bit differences)
+
+
+def test_staged_backward_launches_only_the_side_each_stage_needs(dev, monkeypatch):
+    """dataparallel.StagedBuckets runs backward once per stage (decoder parameters, then encoder parameters) on a retained
+    graph.  IW1's backward node lies on both paths; told the targets of the pass it launches the Bernoulli side in stage 0 and
+    the log q side in stage 1 -- not both in both -- and the gradients equal the single-pass ones."""
+    import zhusuan as zs
+    from zhusuan import dataparallel, _hip as hipmod
+    from examples import iwae
+    import helpers as H
+    B, K = 6, 5
+    model = iwae.build(n_samples=K, estimator="vimco", hidden=16, device=dev)
+    H.load_params_into(model, 31)
+    x, e1, e2 = H.iwae_data(B, K)
+    xt = torch.tensor(x, device=dev)
+    with zs.inject_epsilon([e1, e2]):
+        loss = model({"x": xt})
+    loss.backward()
+    ref = [p.grad.detach().clone() for p in model.parameters()]
+    sb = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()])
+    sb.zero()
+    with zs.inject_epsilon([e1, e2]):
+        loss = model({"x": xt})
+    klib = hipmod.lib()
+    real, calls = klib.call, []
+
+    def spy(name, *a):
+        if name.startswith("zs_bernoulli_iw_objective_bwd"):
+            calls.append((a[10] is not None, a[11] is not None))          # (gp wanted, q side wanted)
+        return real(name, *a)
+    monkeypatch.setattr(klib, "call", spy)
+    sb.backward_stage(loss, 0)
+    assert calls == [(True, False)]
+    sb.backward_stage(loss, 1)
+    assert calls == [(True, False), (False, True)]
+    for p, r in zip(model.parameters(), ref):
+        np.testing.assert_allclose(p.grad.detach().cpu().numpy(), r.cpu().numpy(), rtol=1e-6, atol=1e-9)

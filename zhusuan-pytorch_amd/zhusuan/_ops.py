@@ -405,6 +405,52 @@ class IWObjective(torch.autograd.Function):
                 gc[1] if ctx.needs_input_grad[2] else None, None, None)
 
 
+# ------------------------------------------------------------------------------------------------
+# A backward pass restricted to some parameters (``torch.autograd.backward(loss, inputs=params)``: the stages of
+# dataparallel.StagedBuckets) still runs every node that lies on a path to them, and a node cannot see which of ITS inputs the
+# pass is after.  IW1's backward serves two sides (the decoder through p, the variational parameters through log q): told the
+# targets of the pass, it launches only the side(s) that lead there instead of both in every stage.  A module global, not a
+# contextvar: the autograd engine runs Python backward functions of GPU tensors on its own thread.
+# ------------------------------------------------------------------------------------------------
+_GRAD_TARGETS = None
+
+
+class grad_targets(object):
+    """``with grad_targets(params): torch.autograd.backward(loss, inputs=params)``."""
+
+    def __init__(self, params):
+        self._ids = frozenset(id(p) for p in params)
+
+    def __enter__(self):
+        global _GRAD_TARGETS
+        self._prev, _GRAD_TARGETS = _GRAD_TARGETS, self._ids
+        return self
+
+    def __exit__(self, *exc):
+        global _GRAD_TARGETS
+        _GRAD_TARGETS = self._prev
+        return False
+
+
+def _leads_to_targets(t, targets):
+    """Whether the autograd graph above tensor `t` reaches one of the leaf tensors whose ids are in `targets`."""
+    if t is None or not t.requires_grad:
+        return False
+    if t.grad_fn is None:
+        return id(t) in targets
+    seen, stack = set(), [t.grad_fn]
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        var = getattr(fn, "variable", None)           # AccumulateGrad
+        if var is not None and id(var) in targets:
+            return True
+        stack.extend(nf for nf, _ in fn.next_functions)
+    return False
+
+
 def _iw1_accumulator(device):
     """The zero-initialised 64-bit word of IW1's one-atomic batch mean (handed back at zero by the kernel; see _scratch)."""
     return _scratch(device, "iw1", lambda sc: True, lambda: (torch.zeros(2, dtype=torch.int64, device=device),))[0]
@@ -468,6 +514,8 @@ class BernoulliIWObjective(torch.autograd.Function):
                         _hip.ptr(acc), _hip.stream_for(p))
         ctx.meta = meta
         ctx.fold_q = qz is not None
+        # (for passes restricted to some parameters: which side leads where is a property of the graph ABOVE the inputs)
+        ctx.sides = (p, qmu, qsigma)
         ctx.save_for_backward(p, x, z, pmu, psigma, out, qmu, qsigma, qz)
         ctx.mark_non_differentiable(bound)
         return cost, bound
@@ -483,7 +531,12 @@ class BernoulliIWObjective(torch.autograd.Function):
         K, B, X = p.shape
         coef = out[:2]
         g = g_cost.contiguous()
-        need = ctx.needs_input_grad
+        need = list(ctx.needs_input_grad)
+        if _GRAD_TARGETS is not None:          # a pass restricted to some parameters: only the side(s) that lead to them
+            tp, tqm, tqs = ctx.sides
+            need[0] = need[0] and _leads_to_targets(tp, _GRAD_TARGETS)
+            need[7] = need[7] and _leads_to_targets(tqm, _GRAD_TARGETS)
+            need[8] = need[8] and _leads_to_targets(tqs, _GRAD_TARGETS)
         gp = torch.empty_like(p) if need[0] else None
         fold = ctx.fold_q and (need[7] or need[8])
         gqmu = torch.empty_like(qmu) if fold else None

@@ -8,6 +8,8 @@ path: samples, log-probs and the K-particle reductions of a datapoint never leav
 import torch
 import torch.distributed as dist
 
+from . import _ops
+
 
 def _bucket_dtype(params):
     """The one dtype of a flat gradient bucket: the parameters' (float32 in every benchmark config; float64 models work
@@ -268,7 +270,8 @@ class StagedBuckets(object):
             # step's gradients onto it would feed world-times-too-large stale values into the next all-reduce
             raise RuntimeError("zhusuan.dataparallel.StagedBuckets: the buckets hold last step's all-reduced SUM "
                                "(scale(gradients=False)); call zero() before the next backward")
-        torch.autograd.backward(loss, inputs=st["params"], retain_graph=not last)
+        with _ops.grad_targets(st["params"]):          # (kernels that serve several sides launch only this stage's)
+            torch.autograd.backward(loss, inputs=st["params"], retain_graph=not last)
         _fill_flat(st["flat"], st["params"], st["views"], [loss] if i == 0 else [])
         for p, v in zip(st["params"], st["views"]):
             p.grad = v
