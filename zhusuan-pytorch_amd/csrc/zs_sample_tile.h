@@ -321,7 +321,19 @@ __device__ __forceinline__ float krep_terms(const float4 xv, const float4 m, con
   return acc;
 }
 
-template <int DIST>
+// value rows read with the non-temporal hint (the once-read stream of a problem beyond the Infinity Cache)
+template <bool NTL>
+__device__ __forceinline__ float4 ld_value4(const float4* __restrict__ q) {
+  if (NTL) {
+    const zs_f4v v = __builtin_nontemporal_load(reinterpret_cast<const zs_f4v*>(q));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *q;
+}
+
+// U value rows in flight per wave (2: the config sizes; 4: problems beyond the cache, where a wave's 2 x 960 bytes in flight
+// left the CU with 60 KB outstanding), NTL: non-temporal loads of the value stream.
+template <int DIST, int U, bool NTL>
 __global__ __launch_bounds__(256) void k_logprob_krep(
     const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma,
     float* __restrict__ lp, int64_t K, int64_t R, int D4, int G, int rpw, int p2, int64_t kchunk,
@@ -339,12 +351,13 @@ __global__ __launch_bounds__(256) void k_logprob_krep(
     divmod(t, row_tiles, kt, rt);
     const int64_t r = rt * rpw + rw;
     const bool on = lane_on && r < R;
-    const int64_t m4 = r * D4 + lig;
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), s = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (on) {
-      m = mu[m4];
-      s = sigma_of(sigma[m4], ls);
-    }
+    // every lane loads unconditionally (no exec-mask change between two loads); an idle lane re-reads the address of the wave's
+    // LAST active row (same cache lines as its neighbours: one request -- clamping to element 0 made every wave of the launch
+    // hit one line, 72 -> 64 % at 1 M rows), and its result is dropped
+    const int64_t rc = r < R ? (lane_on ? r : rt * rpw + (rpw - 1 < R - 1 - rt * rpw ? rpw - 1 : R - 1 - rt * rpw)) : R - 1;
+    const int64_t m4 = rc * D4 + (lane_on ? lig : 0);
+    const float4 m = mu[m4];
+    const float4 s = sigma_of(sigma[m4], ls);
     float rowc = 0.f, c[4];
     {
       const float sv[4] = {s.x, s.y, s.z, s.w};
@@ -369,26 +382,21 @@ __global__ __launch_bounds__(256) void k_logprob_krep(
     const int64_t k0 = kt * kchunk;
     const int64_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
     int64_t g = k0 * M4 + m4;
-    float* __restrict__ lpp = lp + (k0 * sk + r * sr);
+    float* __restrict__ lpp = lp + (k0 * sk + rc * sr);
     int64_t k = k0;
-    for (; k + 1 < k1; k += 2, g += 2 * M4, lpp += 2 * sk) {   // two value rows in flight
-      float4 xa = m, xb = m;
-      if (on) {
-        xa = x[g];
-        xb = x[g + M4];
-      }
-      float acca = rowc - krep_terms<DIST>(xa, m, c);
-      float accb = rowc - krep_terms<DIST>(xb, m, c);
-      acca = group_sum_down(acca, lig, G, p2);
-      accb = group_sum_down(accb, lig, G, p2);
-      if (on && lig == 0) {
-        lpp[0] = acca;
-        lpp[sk] = accb;
+    for (; k + U - 1 < k1; k += U, g += U * M4, lpp += U * sk) {   // U value rows in flight
+      float4 xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) xv[u] = ld_value4<NTL>(x + g + u * M4);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float acc = rowc - krep_terms<DIST>(xv[u], m, c);
+        acc = group_sum_down(acc, lig, G, p2);
+        if (on && lig == 0) lpp[u * sk] = acc;
       }
     }
     for (; k < k1; ++k, g += M4, lpp += sk) {
-      float4 xa = m;
-      if (on) xa = x[g];
+      const float4 xa = ld_value4<NTL>(x + g);
       float acca = rowc - krep_terms<DIST>(xa, m, c);
       acca = group_sum_down(acca, lig, G, p2);
       if (on && lig == 0) lpp[0] = acca;
@@ -408,6 +416,8 @@ inline void launch_logprob_krep(int kid, const float* x, const float* mu, const 
   // that the dispatcher can even out the rounds (4.2 M rows: 57 -> 60-62 %).
   const int64_t slots = 256 * 32;
   int64_t kt = row_tiles > slots ? 4 : (row_tiles >= 2048 ? 1 : slots / row_tiles);   // >= 2 waves per SIMD: do not split
+  static const int kt_env = env_knob("ZS_K2_KT", 0);         // experiments only
+  if (kt_env > 0) kt = kt_env;
   if (kt < 1) kt = 1;
   if (kt > K) kt = K;
   int64_t kchunk = (K + kt - 1) / kt;
@@ -417,8 +427,24 @@ inline void launch_logprob_krep(int kid, const float* x, const float* mu, const 
   const int64_t kmin = kmin_env > 0 ? kmin_env : (row_tiles * ((K + 3) / 4) * 4 < slots ? 2 : 4);
   if (kchunk < kmin) kchunk = K < kmin ? K : kmin;
   const int64_t total = row_tiles * ((K + kchunk - 1) / kchunk);
-  ZS_LAUNCH(kid, (k_logprob_krep<DIST>), dim3(grid_for(total, 4, 1u << 22)), dim3(256), st, (const float4*)x,
-            (const float4*)mu, (const float4*)sigma, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr, ls);
+  // Rows in flight per wave and the load policy, measured at K = 50, D = 40 (profiles/r04_k2_variants.txt; fraction of 8 TB/s for
+  // U = 2 / 4 rows in flight, plain / non-temporal loads of the value stream):
+  //      rows      MB     U2 plain   U2 nt   U4 plain   U4 nt
+  //     131 k      22       42.1      39.2     44.8      42.1
+  //       1 M     179       63.3      49.7     70.5      55.2        <- inside the 256 MB Infinity Cache: the hint throws the reuse away
+  //       2 M     357       61.6      66.2     59.0      60.2
+  //     4.2 M     715       62.5      66.7     64.7      66.9        <- read once from HBM: the hint pays, the depth does not matter
+  // so: four rows in flight while the stream fits the cache (and the chunk has four rows), two rows + non-temporal loads beyond.
+  static const int u_env = env_knob("ZS_K2_U", 0), ntl_env = env_knob("ZS_K2_NTL", -1);      // experiments only
+  const bool big = (double)K * (double)R * (double)D4 * 16.0 > 268435456.0;
+  const int U = u_env > 0 ? u_env : ((!big && kchunk >= 4) ? 4 : 2);
+  const bool ntl = ntl_env >= 0 ? ntl_env != 0 : big;
+#define ZS_LAUNCH_KREP(UU, NN)                                                                                          \
+  ZS_LAUNCH(kid, (k_logprob_krep<DIST, UU, NN>), dim3(grid_for(total, 4, 1u << 22)), dim3(256), st, (const float4*)x, \
+            (const float4*)mu, (const float4*)sigma, lp, K, R, D4, rm.G, rm.rpw, rm.p2, kchunk, sk, sr, ls)
+  if (U >= 4) { if (ntl) ZS_LAUNCH_KREP(4, true); else ZS_LAUNCH_KREP(4, false); }
+  else        { if (ntl) ZS_LAUNCH_KREP(2, true); else ZS_LAUNCH_KREP(2, false); }
+#undef ZS_LAUNCH_KREP
 }
 
 // ------------------------------------------------------------------------------------
