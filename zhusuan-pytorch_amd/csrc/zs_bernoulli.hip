@@ -240,6 +240,13 @@ __global__ __launch_bounds__(256) void k_bern_logprob_xreuse(
               pv[v][u].w = sigmoid_fast(pv[v][u].w);
               if (WRITE_P) probs_out[row * D4 + lane + 64 * u] = pv[v][u];
             }
+#ifdef ZS_K3_LOGITS_PACKED             // timing experiment: packed fp32 terms in the logits form
+            if (LOGITS) {
+              zs_f2v t2 = {0.f, 0.f};
+              bern_piece_acc(pv[v][u], xv[u], make_float4(1.0f - xv[u].x, 1.0f - xv[u].y, 1.0f - xv[u].z, 1.0f - xv[u].w), t2);
+              acc += t2.x + t2.y;
+            } else
+#endif
             acc += bern_row_terms(pv[v][u], xv[u]);
           }
         }
@@ -375,19 +382,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_longrow2d(
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     if (ok[u]) {
-      float4 o;
-      if (LOGITS) {
-        const float a = sigmoid_fast(pv[u].x), b = sigmoid_fast(pv[u].y), c = sigmoid_fast(pv[u].z), d = sigmoid_fast(pv[u].w);
-        o.x = g * bern_dp(a, xv[u].x) * a * (1.0f - a);
-        o.y = g * bern_dp(b, xv[u].y) * b * (1.0f - b);
-        o.z = g * bern_dp(c, xv[u].z) * c * (1.0f - c);
-        o.w = g * bern_dp(d, xv[u].w) * d * (1.0f - d);
-      } else {
-        o.x = g * bern_dp(pv[u].x, xv[u].x);
-        o.y = g * bern_dp(pv[u].y, xv[u].y);
-        o.z = g * bern_dp(pv[u].z, xv[u].z);
-        o.w = g * bern_dp(pv[u].w, xv[u].w);
-      }
+      const float4 o = bern_piece_grad<LOGITS>(pv[u], xv[u], g);          // packed fp32 (zs_common.h)
       if (NT) {
         const zs_f4v v = {o.x, o.y, o.z, o.w};
         __builtin_nontemporal_store(v, reinterpret_cast<zs_f4v*>(&grow[lane + 64 * u]));
@@ -437,19 +432,7 @@ __global__ __launch_bounds__(256) void k_iw1_bwd(
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     if (ok[u]) {
-      float4 o;
-      if (LOGITS) {
-        const float a = sigmoid_fast(pv[u].x), b = sigmoid_fast(pv[u].y), c = sigmoid_fast(pv[u].z), d = sigmoid_fast(pv[u].w);
-        o.x = g * bern_dp(a, xv[u].x) * a * (1.0f - a);
-        o.y = g * bern_dp(b, xv[u].y) * b * (1.0f - b);
-        o.z = g * bern_dp(c, xv[u].z) * c * (1.0f - c);
-        o.w = g * bern_dp(d, xv[u].w) * d * (1.0f - d);
-      } else {
-        o.x = g * bern_dp(pv[u].x, xv[u].x);
-        o.y = g * bern_dp(pv[u].y, xv[u].y);
-        o.z = g * bern_dp(pv[u].z, xv[u].z);
-        o.w = g * bern_dp(pv[u].w, xv[u].w);
-      }
+      const float4 o = bern_piece_grad<LOGITS>(pv[u], xv[u], g);          // packed fp32 (zs_common.h)
       if (NT) {
         const zs_f4v v = {o.x, o.y, o.z, o.w};
         __builtin_nontemporal_store(v, reinterpret_cast<zs_f4v*>(&grow[lane + 64 * u]));
@@ -526,20 +509,7 @@ __global__ __launch_bounds__(256) void k_bern_logprob_bwd_xreuse(
       float4* __restrict__ grow = gp + row * D4;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        float4 o;
-        if (LOGITS) {
-          const float a = sigmoid_fast(pv[u].x), b = sigmoid_fast(pv[u].y), c = sigmoid_fast(pv[u].z),
-                      d = sigmoid_fast(pv[u].w);
-          o.x = g * bern_dp(a, xv[u].x) * a * (1.0f - a);
-          o.y = g * bern_dp(b, xv[u].y) * b * (1.0f - b);
-          o.z = g * bern_dp(c, xv[u].z) * c * (1.0f - c);
-          o.w = g * bern_dp(d, xv[u].w) * d * (1.0f - d);
-        } else {
-          o.x = g * bern_dp(pv[u].x, xv[u].x);
-          o.y = g * bern_dp(pv[u].y, xv[u].y);
-          o.z = g * bern_dp(pv[u].z, xv[u].z);
-          o.w = g * bern_dp(pv[u].w, xv[u].w);
-        }
+        const float4 o = bern_piece_grad<LOGITS>(pv[u], xv[u], g);        // packed fp32 (zs_common.h)
         if (ok[u]) {
           if (NT) {
             const zs_f4v vv = {o.x, o.y, o.z, o.w};

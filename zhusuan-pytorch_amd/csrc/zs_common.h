@@ -157,6 +157,33 @@ __device__ __forceinline__ void bern_piece_acc(const float4& p, const float4& x,
   acc += __builtin_elementwise_fma(o0, lb0, x0 * la0);
   acc += __builtin_elementwise_fma(o1, lb1, x1 * la1);
 }
+// Gradient of that term w.r.t. p for one 16-byte piece, times the row gradient g, in packed fp32 arithmetic:
+//   g * (x / (p + eps) - (1 - x) / ((1 - p) + eps))            [LOGITS: p = sigmoid(l), result times p (1 - p)]
+// 3.5 packed instructions + two reciprocals per element instead of ~9 + 2: K3's backward stalls on instruction issue for half
+// of its wave cycles (SQ_WAIT_INST_ANY 0.50 at 6.6 GB, 0.59 in IW1's merged backward; profiles/r04_pmc_*.json).
+template <bool LOGITS>
+__device__ __forceinline__ float4 bern_piece_grad(const float4& pl, const float4& x, float g) {
+  const zs_f2v eps = {ZS_BERN_EPS, ZS_BERN_EPS}, one = {1.0f, 1.0f}, gg = {g, g};
+  zs_f2v p0 = {pl.x, pl.y}, p1 = {pl.z, pl.w};
+  if (LOGITS) {
+    p0.x = rcp_fast(1.0f + exp_fast(-p0.x)); p0.y = rcp_fast(1.0f + exp_fast(-p0.y));
+    p1.x = rcp_fast(1.0f + exp_fast(-p1.x)); p1.y = rcp_fast(1.0f + exp_fast(-p1.y));
+  }
+  const zs_f2v q0 = one - p0, q1 = one - p1;
+  const zs_f2v a0 = p0 + eps, a1 = p1 + eps, b0 = q0 + eps, b1 = q1 + eps;
+  const zs_f2v ra0 = {rcp_fast(a0.x), rcp_fast(a0.y)}, ra1 = {rcp_fast(a1.x), rcp_fast(a1.y)};
+  const zs_f2v rb0 = {rcp_fast(b0.x), rcp_fast(b0.y)}, rb1 = {rcp_fast(b1.x), rcp_fast(b1.y)};
+  const zs_f2v x0 = {x.x, x.y}, x1 = {x.z, x.w};
+  zs_f2v t0 = __builtin_elementwise_fma(x0 - one, rb0, x0 * ra0);          // x ra - (1 - x) rb
+  zs_f2v t1 = __builtin_elementwise_fma(x1 - one, rb1, x1 * ra1);
+  t0 = gg * t0;
+  t1 = gg * t1;
+  if (LOGITS) {
+    t0 = t0 * p0 * q0;
+    t1 = t1 * p1 * q1;
+  }
+  return make_float4(t0.x, t0.y, t1.x, t1.y);
+}
 // torch.sigmoid: 1 / (1 + exp(-l)), bernoulli.py:50
 ZS_HD float sigmoid_fast(float l) { return rcp_fast(1.0f + exp_fast(-l)); }
 // d/dp of x*log(p+e) + (1-x)*log((1-p)+e)
