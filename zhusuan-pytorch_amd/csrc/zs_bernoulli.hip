@@ -240,14 +240,16 @@ __global__ __launch_bounds__(256) void k_bern_logprob_xreuse(
               pv[v][u].w = sigmoid_fast(pv[v][u].w);
               if (WRITE_P) probs_out[row * D4 + lane + 64 * u] = pv[v][u];
             }
-#ifdef ZS_K3_LOGITS_PACKED             // timing experiment: packed fp32 terms in the logits form
-            if (LOGITS) {
+            if (LOGITS && U == 1) {
+              // the logits form with one row in flight (rows < 400 000) is the one variant of this kernel that gains from packed
+              // fp32 terms: 131 k rows 57 -> 69 % of the roofline; with two rows in flight (1 M rows) it LOSES 3 points, the
+              // probs form is indifferent (profiles/r04_k3_logits_packed.txt)
               zs_f2v t2 = {0.f, 0.f};
               bern_piece_acc(pv[v][u], xv[u], make_float4(1.0f - xv[u].x, 1.0f - xv[u].y, 1.0f - xv[u].z, 1.0f - xv[u].w), t2);
               acc += t2.x + t2.y;
-            } else
-#endif
-            acc += bern_row_terms(pv[v][u], xv[u]);
+            } else {
+              acc += bern_row_terms(pv[v][u], xv[u]);
+            }
           }
         }
         acc = wave_sum(acc);
