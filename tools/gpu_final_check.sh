@@ -1,8 +1,8 @@
 # Round-end GPU verification: build + smoke, the gpu test-suite, the PMC traffic passes (first: the bench line quotes them), the
-# bench line and its rocprofv3 kernel-trace summary.  Run through gpurun from the repository root:  gpurun --timeout 2400 -- 'bash tools/gpu_final_check.sh r03'
+# bench line and its rocprofv3 kernel-trace summary.  Run through gpurun from the repository root:  gpurun --timeout 2400 -- 'bash tools/gpu_final_check.sh r04'
 cd "$(dirname "$0")/.." || exit 1
 ROOT=$(pwd)
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"
 timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -16
@@ -17,7 +17,8 @@ done
 cd "$ROOT" && python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE --out gpurun_out/${TAG}_pmc_traffic.json \
   --command "python3 bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-extras --no-gemm-tuning"
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json      # the bench line below quotes it (roofline.traffic)
-python bench.py --steps 200 --warmup 20 > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/bench_n1.err; echo "bench rc=$?"
+python bench.py --steps 200 --warmup 20 --full-record gpurun_out/${TAG}_bench_full.json > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/bench_n1.err; echo "bench rc=$?"
+python bench.py --steps 20 --warmup 5 --full-record gpurun_out/${TAG}_bench_full_driver_cmd.json > gpurun_out/${TAG}_bench_n1_driver_cmd.json 2>> gpurun_out/bench_n1.err; echo "bench (driver's command) rc=$?"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -o bench -- python3 "$ROOT/bench.py" --steps 200 --warmup 20 --no-cpu-baseline --no-extras > "$ROOT/gpurun_out/bench_prof.json" 2> "$ROOT/gpurun_out/bench_prof.err"; echo "rocprof rc=$?"
 rm -f "$ROOT/gpurun_out/prof/bench_kernel_trace.csv"     # 8 MB of per-dispatch rows; the stats file is the summary
