@@ -220,7 +220,7 @@ int zs_iw_objective_f32(const float* logp_a, int64_t ld_a, const float* logp_b, 
  * and then exactly zs_iw_objective on log_w: cost_b, bound_b, coef [2, R, K] (scaled by 1/R when want_mean), mean_cost.
  * K-fastest [R, K] outputs: lp_x (required), lp_z (optional; the float64 twin requires it when z is given).  cost_b is
  * required; mean_cost (want_mean) is the deterministic batch mean: every workgroup adds its cost in fixed point to the 64-bit
- * word `acc` (one zero-initialised device word, handed back at zero; integer addition does not depend on the order of
+ * words `acc` (17 zero-initialised device words -- a total and 16 shards --, handed back at zero; integer addition does not depend on the order of
  * arrival), resolution 2^-21 per datapoint at R = 256, NaN when some cost is non-finite or >= 2^24 (2^20 beyond R = 4096).
  * Returns ZS_ENOTSUP outside the fused kernel's domain (K <= 64, R <= 32768, D % 4 == 0, 256 <= D <= 1024, Dz % 4 == 0,
  * Dz <= 256, 16-byte aligned operands): the caller then composes K2 / K3 / K4b itself.

@@ -38,7 +38,7 @@ class Scratch(object):
     """The accumulator word of the batch mean, reused across launches like the package's per-stream scratch."""
 
     def __init__(self, raw, R):
-        self.acc = torch.zeros(2, dtype=torch.int64, device=raw.dev)
+        self.acc = torch.zeros(32, dtype=torch.int64, device=raw.dev)
 
 
 def iw1(raw, p, x, K, R, D, z, pmu, psg, ls, rows_a, logq, est, want_mean, logits, scratch=None):

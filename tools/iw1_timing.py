@@ -60,7 +60,7 @@ def main():
         logq = torch.randn(B * K, device=dev) - 45
         lpx, lpz = torch.empty(B * K, device=dev), torch.empty(B * K, device=dev)
         cost, bound, coef = torch.empty(1, device=dev), torch.empty(B, device=dev), torch.empty(2 * B * K, device=dev)
-        ws, tk = torch.empty(max(B, 4096), device=dev), torch.zeros(2, dtype=torch.int64, device=dev)
+        ws, tk = torch.empty(max(B, 4096), device=dev), torch.zeros(32, dtype=torch.int64, device=dev)
         costb = torch.empty(B, device=dev)
         tk1 = torch.zeros(1, dtype=torch.int32, device=dev)
         gp = torch.empty(N * X, device=dev)

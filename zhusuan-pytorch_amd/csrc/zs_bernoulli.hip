@@ -802,6 +802,7 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
   a.acc = (unsigned long long*)acc;
   a.cb = iw1_cb(R);
   a.bound_bits = a.cb <= 12 ? 24 : 20;
+  a.sharded = R >= 128 ? 1 : 0;                                    // (many workgroups: two-level batch mean, zs_iwfused.h; 64: one level is faster)
   const int rounds = (int)((K + 15) / 16);
   static const int nw_env = env_knob("ZS_IW1_NW", 0), var_env = env_knob("ZS_IW1_VARIANT", 0);     // experiments only
   a.variant = var_env;

@@ -64,8 +64,8 @@ struct Iw1Args {
   float* coef_q;      // [R, K]
   float scale;
   float* mean_cost;
-  unsigned long long* acc;   // the batch mean's accumulator word (see above); zero between launches
-  int cb, bound_bits;
+  unsigned long long* acc;   // the batch mean's accumulator words (see above): [0] the total, [1 .. 16] shards; zero between launches
+  int cb, bound_bits, sharded;
   float inv_B;
   int variant;        // timing experiments only (-DZS_EXPERIMENTS): 0 = the kernel as shipped
 };
@@ -78,27 +78,46 @@ __host__ __device__ __forceinline__ int iw1_cb(int64_t R) {
 }
 
 // ONE lane per workgroup: count this workgroup's cost; the lane that completes the sum writes the mean.
-__device__ __forceinline__ void iw1_add_cost(const Iw1Args& a, float cost) {
+// Two levels when there are many workgroups: 256 same-address atomics arriving together serialise in L2 (~11 ns each: 2.8 us,
+// MI355X_MICROARCH.md "dequeue"), so workgroup r adds to shard word 1 + (r mod 16) -- same layout, 16 arrivals each -- and the
+// workgroup that completes a shard moves the shard's (still biased) sum and its count to word 0.
+#define ZS_IW1_SHARDS 16
+__device__ __forceinline__ void iw1_finish(const Iw1Args& a, unsigned long long tot, int S, int bias_bits, int scale_bits) {
+  const long long sum = (long long)(tot & ((1ull << S) - 1ull)) - (long long)((unsigned long long)a.R << bias_bits);
+  float m = (float)((double)sum / (double)(1ull << scale_bits) * (double)a.inv_B);
+  if (tot >> 63) m = __uint_as_float(0x7fc00000u);
+  a.mean_cost[0] = m;
+  __hip_atomic_store(a.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // back to zero for the next launch
+}
+__device__ __forceinline__ void iw1_poison(unsigned long long* w) {
+  // rare path: raise the flag, and let it land before the contribution is counted
+  (void)__hip_atomic_fetch_or(w, 1ull << 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void iw1_add_cost(const Iw1Args& a, float cost, int64_t r) {
   const int S = 62 - a.cb, bias_bits = S - 1 - a.cb, scale_bits = bias_bits - a.bound_bits;
+  const unsigned long long mask = (1ull << S) - 1ull;
   long long fx = 0;
   const bool ok = fabsf(cost) < __uint_as_float((unsigned)(127 + a.bound_bits) << 23);       // false for NaN / inf as well
-  if (ok) {
-    fx = __double2ll_rn((double)cost * (double)(1ull << scale_bits));
-  } else {
-    // rare path: raise the flag, and let it land before this workgroup is counted
-    (void)__hip_atomic_fetch_or(a.acc, 1ull << 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  if (ok) fx = __double2ll_rn((double)cost * (double)(1ull << scale_bits));
   const unsigned long long add = (1ull << S) + (unsigned long long)((long long)(1ull << bias_bits) + fx);
-  const unsigned long long old = __hip_atomic_fetch_add(a.acc, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long tot = old + add;
-  if (((tot << 1) >> (S + 1)) == (unsigned long long)a.R) {        // every workgroup is in: this lane holds the total
-    const long long sum = (long long)(tot & ((1ull << S) - 1ull)) - (long long)((unsigned long long)a.R << bias_bits);
-    float m = (float)((double)sum / (double)(1ull << scale_bits) * (double)a.inv_B);
-    if (tot >> 63) m = __uint_as_float(0x7fc00000u);
-    a.mean_cost[0] = m;
-    __hip_atomic_store(a.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // back to zero for the next launch
+  if (!a.sharded) {
+    if (!ok) iw1_poison(a.acc);
+    const unsigned long long tot = __hip_atomic_fetch_add(a.acc, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+    if (((tot << 1) >> (S + 1)) == (unsigned long long)a.R) iw1_finish(a, tot, S, bias_bits, scale_bits);
+    return;
   }
+  const int shard = (int)(r & (ZS_IW1_SHARDS - 1));
+  const unsigned long long members = (unsigned long long)((a.R - shard + ZS_IW1_SHARDS - 1) / ZS_IW1_SHARDS);
+  unsigned long long* w = a.acc + 1 + shard;
+  if (!ok) iw1_poison(w);
+  const unsigned long long tot = __hip_atomic_fetch_add(w, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+  if (((tot << 1) >> (S + 1)) != members) return;
+  __hip_atomic_store(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // the shard word back to zero
+  if (tot >> 63) iw1_poison(a.acc);
+  const unsigned long long add2 = (members << S) + (tot & mask);                       // the shard's count and its biased sum
+  const unsigned long long tot2 = __hip_atomic_fetch_add(a.acc, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add2;
+  if (((tot2 << 1) >> (S + 1)) == (unsigned long long)a.R) iw1_finish(a, tot2, S, bias_bits, scale_bits);
 }
 
 // Workgroup r = datapoint r; NW = blockDim.x / 64 waves share out its K rows, wave w taking rows w, w + NW, ... -- at most
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(1024) void k_iw1_block(Iw1Args a) {
     if (has_z && a.lp_z) a.lp_z[r * K + lane] = nz;
   }
   const float cost = iw_wave_row(l, t_lq, on, lane, K, a.estimator, a.scale, r, a.cost_b, a.bound_b, a.coef_p, a.coef_q);
-  if (a.mean_cost && lane == 0) iw1_add_cost(a, cost);
+  if (a.mean_cost && lane == 0) iw1_add_cost(a, cost, r);
 }
 
 }  // namespace zs

@@ -452,8 +452,9 @@ def _leads_to_targets(t, targets):
 
 
 def _iw1_accumulator(device):
-    """The zero-initialised 64-bit word of IW1's one-atomic batch mean (handed back at zero by the kernel; see _scratch)."""
-    return _scratch(device, "iw1", lambda sc: True, lambda: (torch.zeros(2, dtype=torch.int64, device=device),))[0]
+    """The zero-initialised 64-bit words (a total + 16 shards) of IW1's fixed-point batch mean (handed back at zero by the
+    kernel; see _scratch)."""
+    return _scratch(device, "iw1", lambda sc: True, lambda: (torch.zeros(32, dtype=torch.int64, device=device),))[0]
 
 
 IW1_MAX_DATAPOINTS = 384
