@@ -2,7 +2,7 @@
 """Randomised differential run of the HOT-PATH kernels through the C ABI -- K1 (fused Normal sample + log-density, given eps and
 in-kernel Philox) and its backward, K2 (Normal log-density of a value, every broadcast period) and its backwards, K3 (Bernoulli
 log-mass, probs and logits) and its backward, K4 (importance-weighted reduction, sgvb and vimco), log-mean-exp, K5 (Bernoulli
-sampler), Philox -- libzs_hip.so on the GPU against the C oracle on the host, random shapes, for a given number of seconds.  Uses
+sampler), Philox, IW1 (the generator side of the importance-weighted objective in one launch, both directions) -- libzs_hip.so on the GPU against the C oracle on the host, random shapes, for a given number of seconds.  Uses
 the raw-call helpers of tests/test_cabi.py and its tolerances.  Exit code 1 at the first mismatch.
 
   python tools/fuzz_hotpath.py [seconds=120] [seed=0]
@@ -19,6 +19,7 @@ import numpy as np
 from zhusuan import _hip
 from conftest import host_kernel_library
 from test_cabi import Raw, _iw_truth_f64
+import test_iw_fused as iwf
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -163,7 +164,50 @@ def case_rng():
         sys.exit(1)
 
 
-cases = [case_k1, case_k2, case_k3, case_k4, case_rng]
+def case_iw1():
+    """IW1 over its whole domain (K 2..64, D a multiple of 4 in 256..1024, latent rows of whole 16-byte pieces): against the oracle, and --
+    fed its own row sums -- bit for bit K4b; the merged backward against the oracle."""
+    K, R, D = int(rng.randint(2, 65)), dim(300), 4 * int(rng.randint(64, 257))
+    while K * R * D > 1500000:
+        R = max(R // 2, 1)
+    Dz = 4 * int(rng.randint(1, 65 if rng.rand() < 0.2 else 12))
+    logits, x_full, pms, pss, ls = [bool(rng.rand() < q) for q in (0.4, 0.3, 0.4, 0.4, 0.3)]
+    with_z, with_rows = bool(rng.rand() < 0.8), bool(rng.rand() < 0.4)
+    est, want_mean = int(rng.randint(2)), bool(rng.rand() < 0.7)
+    f = lambda a: None if a is None else a.astype(np.float32)
+    p, x, z, pmu, psg, rows_a, logq = iwf._inputs(rng, K, R, D, Dz, logits, x_full, pms, pss, ls)
+    args = (f(p), f(x), K, R, D, f(z) if with_z else None, f(pmu) if with_z else None, f(psg) if with_z else None, ls,
+            f(rows_a) if with_rows else None, f(logq))
+    shape = (K, R, D, Dz, logits, x_full, pms, pss, ls, with_z, with_rows, est, want_mean)
+    got, ref = iwf.iw1(hip, *args, est, want_mean, logits), iwf.iw1(orc, *args, est, want_mean, logits)
+    close(got["lp_x"], ref["lp_x"], 2e-5, 1e-3, "IW1 lp_x", shape)
+    if with_z:
+        close(got["lp_z"], ref["lp_z"], 2e-5, 1e-3, "IW1 lp_z", shape)
+    close(got["bound"], ref["bound"], 2e-5, 1e-3, "IW1 bound", shape)
+    same = iwf.composed(hip, *args, est, want_mean, logits, lp_x=got["lp_x"], lp_z=got["lp_z"])
+    for key in ("cost", "bound", "coef"):
+        if not np.array_equal(got[key], same[key]):
+            print("MISMATCH IW1 %s differs from K4b on the same rows at %s" % (key, shape), flush=True)
+            sys.exit(1)
+    if want_mean:
+        exact = got["cost"].astype(np.float64).mean()
+        if not abs(got["mean"][0] - exact) <= 2e-6 * abs(exact):
+            print("MISMATCH IW1 batch mean %r against %r at %s" % (got["mean"][0], exact, shape), flush=True)
+            sys.exit(1)
+    coef = (rng.standard_normal((2, R, K)) / R).astype(np.float32)
+    gout = np.float32([rng.standard_normal()]) if rng.rand() < 0.5 else rng.standard_normal(R).astype(np.float32)
+    q_ls = bool(rng.rand() < 0.3)
+    qmu, qsg = f(rng.standard_normal((R, Dz)) * 0.3), f(rng.uniform(0.5, 1.5, size=(R, Dz)))
+    if q_ls:
+        qsg = np.log(qsg)
+    a = iwf.iw1_bwd(hip, f(p), f(x), K, R, D, coef, gout, logits, f(z), qmu, qsg, q_ls)
+    b = iwf.iw1_bwd(orc, f(p), f(x), K, R, D, coef, gout, logits, f(z), qmu, qsg, q_ls)
+    close(a["gp"], b["gp"], 1e-4 if logits else 3e-5, 3e-6 * max(np.abs(b["gp"]).max(), 1e-30), "IW1 bwd gp", shape)
+    for key in ("gqmu", "gqsigma"):
+        close(a[key], b[key], 2e-4, 2e-5 * max(np.abs(b[key]).max(), 1e-30), "IW1 bwd " + key, shape)
+
+
+cases = [case_k1, case_k2, case_k3, case_k4, case_rng, case_iw1]
 t0 = time.time()
 while time.time() - t0 < budget:
     c = cases[int(rng.randint(len(cases)))]
