@@ -6,7 +6,7 @@ TAG=${1:-r04}
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"
 timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -16
-timeout 600 python tools/soak.py 5000 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${TAG}_soak.txt; echo "soak rc=$?"; cat gpurun_out/${TAG}_soak.txt
+timeout 600 python tools/soak.py 5000 > gpurun_out/soak_raw.txt 2>/dev/null; echo "soak rc=$?"; grep -v amdgpu.ids gpurun_out/soak_raw.txt > gpurun_out/${TAG}_soak.txt; cat gpurun_out/${TAG}_soak.txt
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   # (--no-gemm-tuning: the counter passes are about the hot-path kernels; TunableOp's thousands of trial GEMMs would only bloat the CSVs)

@@ -8,9 +8,11 @@ replays + 300 eager steps each.  What it ASSERTS (exit code 1 otherwise):
               the SAME numbers after thousands of launches on one workspace as a fresh eager launch on another;
   hand-offs   every ticket / accumulator word of every scratch set and of the optimizer back at zero; Adam's per-tensor step
               counts advanced by exactly the number of steps;
-  allocator   torch.cuda.memory_allocated() after replay 300 == after replay N (a replay allocates nothing), and the eager
-              steps return to their own baseline once the last loss is dropped (round 3's "160 MB delta" of the IWAE line was
-              the live autograd graph of the last eager step: the tool measured before dropping it);
+  allocator   torch.cuda.memory_allocated() does not move across any window of N / 10 replays (measured from the end of one twin
+              evaluation to the start of the next: a replay allocates nothing; the twin's own eager step is kept out of the window --
+              its fresh gradient tensors land in cached blocks of slightly different sizes, +-0.7 MB from one evaluation to the
+              next), and the eager steps return to their own baseline once the last loss is dropped (round 3's "160 MB delta" of
+              the IWAE line was the live autograd graph of the last eager step: the tool measured before dropping it);
   finite loss.
 
   python tools/soak.py [N]
@@ -67,7 +69,7 @@ for kind in ("iwae", "vae", "bnn"):
     step = zhusuan.GraphedStep(compute, opt.step, rng=rng)
     l0 = float(step())
     steps0 = [b.step.clone() for b in opt.buckets]
-    worst, checks, mem300, last = 0.0, 0, None, None
+    worst, checks, window_start, replay_growth, last = 0.0, 0, None, 0, None
     t0 = time.perf_counter()
     for i in range(N):
         check = i % max(N // 10, 1) == 0
@@ -78,6 +80,8 @@ for kind in ("iwae", "vae", "bnn"):
                 rng_t.state.copy_(rng.state)
         last = step()
         if check:
+            if window_start is not None:
+                replay_growth = max(replay_growth, abs(settled() - window_start))
             with zhusuan.device_rng(rng_t):
                 lt = compute_t()
             torch.cuda.synchronize()
@@ -86,12 +90,11 @@ for kind in ("iwae", "vae", "bnn"):
                 a, b = pm.grad.double(), pt.grad.double()
                 err = max(err, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)))
             worst, checks = max(worst, err), checks + 1
-            del lt
-        if i == 300:
-            mem300 = settled()
+            del lt, a, b
+            window_start = settled()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    memN = settled()
+    replay_growth = max(replay_growth, abs(settled() - window_start))
     with zhusuan.device_rng(rng):          # eager steps too (allocator churn, the per-stream scratch sets)
         loss_e = compute()
         opt.step()
@@ -114,10 +117,10 @@ for kind in ("iwae", "vae", "bnn"):
             if t.dtype in (torch.int32, torch.int64):
                 scratch += int(t.abs().sum().item())
     values_ok = worst <= 2e-4          # (eager and replayed kernels are the same code: differences are summation order of atomics-free sums)
-    good = counted and not any(tickets) and scratch == 0 and bool(torch.isfinite(last)) and values_ok and memN == mem300 and mem_e1 <= mem_e0
+    good = counted and not any(tickets) and scratch == 0 and bool(torch.isfinite(last)) and values_ok and replay_growth == 0 and mem_e1 <= mem_e0
     ok = ok and good
     print("%-4s %s  loss %.2f -> %.2f  %.4f ms/step  Adam step counts advanced by %d: %s  optimizer tickets %s  scratch tickets (sum) %d  "
-          "replay == eager twin at %d checkpoints: worst rel. diff %.2e  allocator: replay 300 -> %d: %+d B, eager step 1 -> 300: %+d B" % (
-              kind, "OK  " if good else "FAIL", l0, float(last), 1e3 * dt / N, N + 300, counted, tickets, scratch, checks, worst, N,
-              memN - mem300, mem_e1 - mem_e0), flush=True)
+          "replay == eager twin at %d checkpoints: worst rel. diff %.2e  allocator: largest change over a window of %d replays: %d B, eager step 1 -> 300: %+d B" % (
+              kind, "OK  " if good else "FAIL", l0, float(last), 1e3 * dt / N, N + 300, counted, tickets, scratch, checks, worst, max(N // 10, 1),
+              replay_growth, mem_e1 - mem_e0), flush=True)
 sys.exit(0 if ok else 1)

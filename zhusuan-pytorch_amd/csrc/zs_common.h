@@ -146,6 +146,7 @@ ZS_HD float bern_lp2_term(float p, float x) {
 // per instruction), accumulated pairwise into `acc`: per element 2.5 full-rate instructions + the two logarithms instead of 7 + 2.
 // The kernels that give a workgroup a fixed share of the rows (IW1) are bound by exactly this arithmetic.  `omx` = 1 - x.
 typedef float zs_f2v __attribute__((ext_vector_type(2)));
+typedef float zs_f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void bern_piece_acc(const float4& p, const float4& x, const float4& omx, zs_f2v& acc) {
   const zs_f2v eps = {ZS_BERN_EPS, ZS_BERN_EPS}, one = {1.0f, 1.0f};
   const zs_f2v p0 = {p.x, p.y}, p1 = {p.z, p.w};

@@ -164,7 +164,10 @@ __global__ __launch_bounds__(1024) void k_iw1_block(Iw1Args a) {
   const float t_lq = a.logq[r * a.ld_q + tl], t_ra = arow[tl];                                  // (used by wave 0: lane = particle)
   float4 pv[ROUNDS][4], zv[ROUNDS];
   auto load_row = [&](int i) {
-    const int k = w + i * NW, kc = k < K ? k : w;                 // (a round beyond K re-reads the wave's first row)
+    // (a round beyond K re-reads the wave's first row -- at K = 50, 14 of a datapoint's 64 row slots: FETCH_SIZE shows 1.22 x the
+    //  algorithmic bytes, served by the Infinity Cache.  Two ways of not issuing those requests were measured, one 16-byte piece for
+    //  every lane and buffer loads with num_records = 0: both correct, both 14.4 -> 15.2-15.5 us at B = 256; profiles/r04_iw1_timing.txt)
+    const int k = w + i * NW, kc = k < K ? k : w;
     const int64_t row = (int64_t)kc * a.R + r;
     const float4* __restrict__ prow = a.p + row * D4;
 #pragma unroll

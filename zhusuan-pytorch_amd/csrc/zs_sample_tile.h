@@ -13,7 +13,6 @@
 namespace zs {
 
 enum { D_NORMAL = 0, D_LOGISTIC = 1, D_UNIFORM = 2 };
-typedef float zs_f4v __attribute__((ext_vector_type(4)));
 
 // round-to-nearest mul / add that the compiler may not contract into an FMA: the sample
 // z = mean + std * eps must round twice like the reference's separate mul and add
