@@ -23,7 +23,15 @@
  *     out[k * stride_k + r * stride_r] (strides in elements).  The objectives
  *     use the K-fastest layout stride_k = 1, stride_r = ld >= K so that the
  *     importance-weight reduction finds the K particles of one datapoint on
- *     the 64 lanes of one wavefront.
+ *     the 64 lanes of one wavefront;
+ *   - gfx950 ONLY, also where it is not spelled in C: the entry points that take a `ticket` / `tickets` / `acc` word combine
+ *     partial results of many workgroups in the last one to arrive.  The hand-off is NOT a release/acquire pair of the HIP
+ *     memory model (an agent-scope release per workgroup costs 1.7-6.5 us on this chip): partials are stored write-through
+ *     (sc1), the storing waves drain (s_waitcnt vmcnt(0)), one lane per workgroup adds to the ticket with a relaxed agent-scope
+ *     atomic and the last arrival reads with sc1 loads or behind one agent-scope acquire -- the form MI355X_MICROARCH.md lists as
+ *     measured for gfx950 (csrc/zs_onelaunch.h).  A port to another target has to re-validate it; here it is held by the
+ *     twice-on-one-workspace tests of every such kernel and by tools/soak.py (replayed step == eager twin after thousands of
+ *     launches).  IW1's batch mean is exempt: its 64-bit atomics carry the data themselves.
  */
 #ifndef ZS_HIP_H
 #define ZS_HIP_H
