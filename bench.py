@@ -386,19 +386,20 @@ def make_optimizer(model, torch_adam, groups=None):
 
 
 def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False, skip_discarded=False,
-                          dense="fused", eager=False, refresh=False, device_rng=True):
+                          dense="fused", eager=False, refresh=False, device_rng=True, forward_only=False):
     """A workload on this GPU as full training steps -- replayed from one hipGraph (default) or launched eagerly from a
     Python loop (`eager`).  `refresh`: every step trains on ANOTHER minibatch, copied (device to device) into the step's
     input tensors from a resident stream of 8 batches, as the reference's loop feeds one (iwae.py:151-160).  `torch_adam`:
     False (zhusuan.optim.FlatAdam), True (torch's fused capturable Adam), "reference" / "reference_capturable"
     (torch.optim.Adam(params, lr) as the reference's example constructs it).  `device_rng`: the draws' Philox state lives in
-    device memory (needed by graphs); without it they take their call ids from torch's generator, as plain eager code does."""
+    device memory (needed by graphs); without it they take their call ids from torch's generator, as plain eager code does.
+    `forward_only`: a "step" is ONE EVALUATION OF THE OBJECTIVE (no backward, no optimizer): SURVEY.md 8d's metric (i)."""
     import contextlib
     import zhusuan
     gemm_tuning(tuned)
     torch.manual_seed(0)
     model, obs, evals, label = make_workload(name, dev, fused_logits=fused_logits, dense=dense)
-    opt = make_optimizer(model, torch_adam)
+    opt = None if forward_only else make_optimizer(model, torch_adam)
     rng = zhusuan.DeviceRNG(dev, seed=1) if (device_rng or not eager) else None
     stream = None
     if refresh:
@@ -410,6 +411,9 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
     def compute():
         if rng is not None:
             rng.begin_step()
+        if forward_only:
+            with torch.no_grad():
+                return model(obs)
         for p in model.parameters():
             p.grad = None
         loss = model(obs)
@@ -429,12 +433,13 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
                     for k, v in next_batch().items():
                         obs[k].copy_(v, non_blocking=True)
                 loss = compute()
-                opt.step()
+                if opt is not None:
+                    opt.step()
                 return loss
             for _ in range(max(3, min(warmup, 10)) + 3):
                 step()
         else:
-            graphed = zhusuan.GraphedStep(compute, opt.step, rng=rng, warmup=max(3, min(warmup, 10)), inputs=obs)
+            graphed = zhusuan.GraphedStep(compute, None if opt is None else opt.step, rng=rng, warmup=max(3, min(warmup, 10)), inputs=obs)
             step = (lambda: graphed(**next_batch())) if refresh else graphed
         gemm_tuning(tuned, tune=False)       # every GEMM shape of the step has been seen: keep the picks, stop timing
         for _ in range(3):
@@ -445,6 +450,8 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
     opt_label = {False: "zhusuan.optim.FlatAdam", True: "torch.optim.Adam(fused=True, capturable=True)",
                  "reference": "torch.optim.Adam(params, lr) (the reference example's line)",
                  "reference_capturable": "torch.optim.Adam(params, lr, capturable=True)"}[torch_adam]
+    if forward_only:
+        opt_label = "none (objective evaluation only: forward under no_grad)"
     return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
             "launch_mode": "eager (Python loop)" if eager else "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
             "minibatch": "a new minibatch every step (8 resident batches, copied into the step's inputs)" if refresh else "one resident minibatch",
@@ -1006,6 +1013,8 @@ def main():
             # the reference examples' own default shapes (iwae.py:126,131; bnn_vi.py:116-118), headline settings
             extra("iwae_default", "iwae_default", **base)
             extra("bnn_default", "bnn_default", **base)
+            # the objective alone (SURVEY.md 8d metric (i)): forward under no_grad, no backward, no optimizer
+            extra("c3_forward_only", "c3", fused_logits=args.fused_logits, forward_only=True, **base)
             if not skip_discarded:      # the opt-in that drops the draw the reference discards
                 extra("c3_skip_discarded_draws", "c3", fused_logits=args.fused_logits, **dict(base, skip_discarded=True))
             if tuned:                   # PyTorch's default GEMM selection and its multi-tensor Adam (what round 1 measured)

@@ -125,7 +125,7 @@ def test_bench_line_single_rank():
     ex, fx = rec["extra_configs"], full["extra_configs"]
     for name in ("c2", "c5", "c3_logits", "iwae_default", "bnn_default", "c3_skip_discarded_draws", "c3_torch_linear", "c3_torch_adam",
                  "c3_default_gemm", "c3_reference_example", "c3_reference_example_graphed", "c5_reference_example",
-                 "c5_reference_example_graphed", "c3_eager", "c3_eager_torch_linear", "c5_eager"):
+                 "c5_reference_example_graphed", "c3_eager", "c3_eager_torch_linear", "c5_eager", "c3_forward_only"):
         assert ex[name]["value"] > 1e4 and ex[name]["ms_per_step"] > 0 and set(ex[name]) <= {"ms_per_step", "value", "cpu_value"}, (name, ex[name])
         assert np.isfinite(fx[name]["final_loss"])
     # the reference example as written: torch.nn modules, torch.optim.Adam(params, lr), default GEMMs, both draws, eager, fresh batches
