@@ -149,6 +149,9 @@ def test_hip_iw1_forward(hip, orc, case):
         with_z, with_rows = False, True             # ... and the caller's alternative: that node's rows from its own kernel
     for rep in range(2):
         p, x, z, pmu, psg, rows_a, logq = _inputs(rng, K, R, D, Dz, logits, x_full, pms, pss, ls)
+        if rep == 1:                               # fractional observations: the two-logarithm form (rows of bits take the one-logarithm form)
+            x = rng.uniform(size=x.shape)
+            x[: max(R // 2, 1)].reshape(-1)[::5] = 1.0
         f = lambda a: None if a is None else a.astype(np.float32)
         args = (f(p), f(x), K, R, D, f(z) if with_z else None, f(pmu) if with_z else None, f(psg) if with_z else None, ls,
                 f(rows_a) if with_rows else None, f(logq))

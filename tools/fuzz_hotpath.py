@@ -176,6 +176,10 @@ def case_iw1():
     est, want_mean = int(rng.randint(2)), bool(rng.rand() < 0.7)
     f = lambda a: None if a is None else a.astype(np.float32)
     p, x, z, pmu, psg, rows_a, logq = iwf._inputs(rng, K, R, D, Dz, logits, x_full, pms, pss, ls)
+    if rng.rand() < 0.3:                           # fractional observations in some rows (rows of bits take the one-logarithm form)
+        frac = rng.uniform(size=x.shape)
+        rows = rng.rand(*x.shape[:-1]) < 0.5
+        x = np.where(rows[..., None], frac, x)
     args = (f(p), f(x), K, R, D, f(z) if with_z else None, f(pmu) if with_z else None, f(psg) if with_z else None, ls,
             f(rows_a) if with_rows else None, f(logq))
     shape = (K, R, D, Dz, logits, x_full, pms, pss, ls, with_z, with_rows, est, want_mean)

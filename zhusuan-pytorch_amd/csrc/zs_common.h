@@ -158,6 +158,20 @@ __device__ __forceinline__ void bern_piece_acc(const float4& p, const float4& x,
   acc += __builtin_elementwise_fma(o0, lb0, x0 * la0);
   acc += __builtin_elementwise_fma(o1, lb1, x1 * la1);
 }
+// The same piece when every x of the row is exactly 0 or 1 (binarised observations: the examples' data): with s = 2x - 1 and
+// c = 1 - x the selected argument is fma(p, s, c) -- p for x = 1, 1 - p (rounded as above) for x = 0 -- and the term is ONE
+// logarithm: x * la + (1 - x) * lb has a factor exactly 1 and a factor exactly 0.  Bit-identical to bern_piece_acc for every p
+// whose two arguments are positive (any p in [0, 1]); for an invalid p (outside [-1e-8, 1 + 1e-8]) the general form returns NaN
+// through 0 * log(negative) where this one does not evaluate the other branch.
+__device__ __forceinline__ void bern_piece_acc_bits(const float4& p, const float4& s, zs_f2v& acc) {
+  const zs_f2v eps = {ZS_BERN_EPS, ZS_BERN_EPS}, half = {0.5f, 0.5f}, mhalf = {-0.5f, -0.5f};
+  const zs_f2v p0 = {p.x, p.y}, p1 = {p.z, p.w}, s0 = {s.x, s.y}, s1 = {s.z, s.w};
+  const zs_f2v c0 = __builtin_elementwise_fma(s0, mhalf, half), c1 = __builtin_elementwise_fma(s1, mhalf, half);     // 1 - x, exactly
+  const zs_f2v a0 = __builtin_elementwise_fma(p0, s0, c0) + eps, a1 = __builtin_elementwise_fma(p1, s1, c1) + eps;
+  const zs_f2v l0 = {log2_fast(a0.x), log2_fast(a0.y)}, l1 = {log2_fast(a1.x), log2_fast(a1.y)};
+  acc += l0;
+  acc += l1;
+}
 // Gradient of that term w.r.t. p for one 16-byte piece, times the row gradient g, in packed fp32 arithmetic:
 //   g * (x / (p + eps) - (1 - x) / ((1 - p) + eps))            [LOGITS: p = sigmoid(l), result times p (1 - p)]
 // 3.5 packed instructions + two reciprocals per element instead of ~9 + 2: K3's backward stalls on instruction issue for half

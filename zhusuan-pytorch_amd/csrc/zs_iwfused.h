@@ -129,6 +129,7 @@ template <bool LOGITS, int ROUNDS>
 __global__ __launch_bounds__(1024) void k_iw1_block(Iw1Args a) {
   __shared__ float s_lx[64], s_lz[64];
   __shared__ float4 s_x[256], s_omx[256];      // the observation row and 1 - x: shared by the datapoint's rows, read per round
+  __shared__ float4 s_sgn[256];                // 2x - 1 (used when every x of the row is 0 or 1: one logarithm per element)
   __shared__ float4 s_zm[64], s_zl[64], s_zp[64];      // the prior's mean, log sigma, sigma^-2 per 16-byte piece of the latent row
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
   const int64_t r = blockIdx.x;
@@ -187,14 +188,21 @@ __global__ __launch_bounds__(1024) void k_iw1_block(Iw1Args a) {
   const bool x_stager = !a.x_full && (int)threadIdx.x < D4, x_stager2 = !a.x_full && (int)(threadIdx.x + blockDim.x) < D4;
   const bool z_stager = has_z && w == NW - 1;
   auto one_minus = [](const float4& v) { return make_float4(1.0f - v.x, 1.0f - v.y, 1.0f - v.z, 1.0f - v.w); };
-  if (x_stager) { s_x[threadIdx.x] = x_stage; s_omx[threadIdx.x] = one_minus(x_stage); }
-  if (x_stager2) { s_x[threadIdx.x + blockDim.x] = x_stage2; s_omx[threadIdx.x + blockDim.x] = one_minus(x_stage2); }
+  auto is_bits = [](const float4& v) {
+    return (v.x == 0.0f || v.x == 1.0f) && (v.y == 0.0f || v.y == 1.0f) && (v.z == 0.0f || v.z == 1.0f) && (v.w == 0.0f || v.w == 1.0f);
+  };
+  auto stage = [&](int c, const float4& v) {
+    const float4 o = one_minus(v);
+    s_x[c] = v;
+    s_omx[c] = o;
+    s_sgn[c] = make_float4(v.x - o.x, v.y - o.y, v.z - o.z, v.w - o.w);
+    return is_bits(v);
+  };
+  bool bits = true;
+  if (x_stager) bits = stage(threadIdx.x, x_stage);
+  if (x_stager2) bits = stage(threadIdx.x + blockDim.x, x_stage2) && bits;
   if (!a.x_full)                       // (fewer than 4 waves and a row of more than 2 * blockDim pieces: the rest, plainly)
-    for (int c = threadIdx.x + 2 * blockDim.x; c < D4; c += blockDim.x) {
-      const float4 v = a.x[r * D4 + c];
-      s_x[c] = v;
-      s_omx[c] = one_minus(v);
-    }
+    for (int c = threadIdx.x + 2 * blockDim.x; c < D4; c += blockDim.x) bits = stage(c, a.x[r * D4 + c]) && bits;
   if (z_stager) {
     // the prior's parameters are the same for every row of the datapoint: one wave forms log sigma and sigma^-2 (normal.py:121-123)
     const float sv[4] = {ps4.x, ps4.y, ps4.z, ps4.w};
@@ -209,7 +217,11 @@ __global__ __launch_bounds__(1024) void k_iw1_block(Iw1Args a) {
     s_zl[lane] = make_float4(lg[0], lg[1], lg[2], lg[3]);
     s_zp[lane] = make_float4(pr[0], pr[1], pr[2], pr[3]);
   }
-  __syncthreads();
+  // (the barrier of the staging; also: is every x of this datapoint's row 0 or 1?  Workgroup-uniform.)
+  const bool xbits = __syncthreads_and((int)bits) != 0 && !a.x_full;
+  float4 sg[4];                                // 2x - 1 of the lane's four pieces, in registers for every row of the wave
+#pragma unroll
+  for (int u = 0; u < 4; ++u) sg[u] = s_sgn[col[u]];
   // ---- the rows
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i) {
@@ -236,7 +248,8 @@ __global__ __launch_bounds__(1024) void k_iw1_block(Iw1Args a) {
         q.w = sigmoid_fast(q.w);
       }
       zs_f2v t = {0.f, 0.f};
-      bern_piece_acc(q, xv, ov, t);
+      if (xbits) bern_piece_acc_bits(q, sg[u], t);
+      else bern_piece_acc(q, xv, ov, t);
       if (ok[u]) acc2 += t;
     }
     const float acc = wave_sum(acc2.x + acc2.y) * ZS_LN2;
