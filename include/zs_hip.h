@@ -230,6 +230,9 @@ int zs_iw_objective_f32(const float* logp_a, int64_t ld_a, const float* logp_b, 
  * required; mean_cost (want_mean) is the deterministic batch mean: every workgroup adds its cost in fixed point to the 64-bit
  * words `acc` (17 zero-initialised device words -- a total and 16 shards --, handed back at zero; integer addition does not depend on the order of
  * arrival), resolution 2^-21 per datapoint at R = 256, NaN when some cost is non-finite or >= 2^24 (2^20 beyond R = 4096).
+ * A datapoint whose shared observation row holds only exact 0s and 1s (binarised data) is evaluated with ONE logarithm per
+ * element -- log(fma(p, 2x - 1, 1 - x) + 1e-8), bit-identical to the two-term form for every p in [0, 1]; for an invalid p
+ * (outside [-1e-8, 1 + 1e-8]) the two-term form's NaN from 0 * log(negative) is not reproduced.
  * Returns ZS_ENOTSUP outside the fused kernel's domain (K <= 64, R <= 32768, D % 4 == 0, 256 <= D <= 1024, Dz % 4 == 0,
  * Dz <= 256, 16-byte aligned operands): the caller then composes K2 / K3 / K4b itself.
  * -------------------------------------------------------------------------*/
