@@ -17,7 +17,7 @@ run k2_4M k2 83886 "k_logprob_krep<0"
 run l2_4M l2 83886 "k_logprob_krep<1"
 run u2_4M u2 83886 "k_logprob_krep<2"
 run k3bwd_6GB k3_bwd 20971 "k_bern_logprob_bwd"
-run l1u_1M l1_u 20971 "k_sample_tile<1"
+run l1u_1M l1_u 20971 "k_wave_rows"
 run k3logits_c3 k3_logits 256 "k_bern_logprob"
 run k3logits_1M k3_logits 20971 "k_bern_logprob"
 run k3probs_c3 k3 256 "k_bern_logprob"
