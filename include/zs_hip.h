@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 12
+#define ZS_ABI_VERSION 13
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -94,6 +94,18 @@ int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const floa
                                  int64_t K, int64_t M, int64_t D,
                                  int64_t lp_stride_k, int64_t lp_stride_r,
                                  int sigma_is_logstd, uint64_t* rng_used, void* stream);
+
+/* K1 twice: two independent draws of K particles each with the Philox call ids `offset` and `offset + 1` -- what the
+ * reference's objectives do with every latent: the node factory draws (stochastic_tensor.py:115-127 through bn.py:158),
+ * the objective's re-read of node.tensor draws again (elbo.py:122, importance_weighted_objective.py:85) -- as ONE launch
+ * where the flat-plane kernel takes the shape (else as the two launches it stands for).  z [2 K, M]: particles [0, K) are
+ * the first draw; lp element (k, r) of draw j is written at lp[(j K + k) * lp_stride_k + r * lp_stride_r] (K-fastest
+ * [R, 2 K]: lp_stride_k = 1, lp_stride_r = 2 K).  Each half is bit for bit what zs_normal_sample_logprob_f32 writes for its
+ * call id (in-kernel Philox only); rng_used receives the first draw's ids (the second's are + 1). */
+int zs_normal_sample_logprob_pair_f32(const float* mu, const float* sigma, uint64_t seed, uint64_t offset,
+                                      const uint64_t* rng_state, float* z, float* lp, int64_t K, int64_t M, int64_t D,
+                                      int64_t lp_stride_k, int64_t lp_stride_r, int sigma_is_logstd, uint64_t* rng_used,
+                                      void* stream);
 
 /* Backward of K1 for a reparameterised node (normal.py:104-105):
  *   gmu[m]    = sum_k gz[k, m]
@@ -591,6 +603,7 @@ int zs_particle_rmse_f32(const float* pred, const float* y, float* out, int64_t 
  * identical argument meaning, double* instead of float*.  They are plain (untuned) kernels: none of the
  * benchmark configurations uses float64.  Draws widen the same Philox / Box-Muller fp32 stream.
  * -------------------------------------------------------------------------*/
+int zs_normal_sample_logprob_pair_f64(const double* mu, const double* sigma, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, int sigma_is_logstd, uint64_t* rng_used, void* stream);
 int zs_normal_sample_logprob_f64(const double* mu, const double* sigma, const double* eps, uint64_t seed, uint64_t offset, const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, int sigma_is_logstd, uint64_t* rng_used, void* stream);
 int zs_normal_sample_logprob_bwd_f64(const double* sigma, const double* eps, uint64_t seed, uint64_t offset, const uint64_t* rng_state, const double* gz, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gmu, double* gsigma, int64_t K, int64_t M, int64_t D, int sigma_is_logstd, void* stream);
 int zs_normal_logprob_f64(const double* x, int64_t Px, const double* mu, int64_t Pm, const double* sigma, int64_t Ps, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, int sigma_is_logstd, void* stream);

@@ -27,15 +27,15 @@ def declared_symbols():
 
 def test_header_symbols_exported_by_both_libraries():
     names = declared_symbols()
-    assert len(names) == 83 and set(_hip.PROTOTYPES) <= set(names)
+    assert len(names) == 85 and set(_hip.PROTOTYPES) <= set(names)
     hip = ctypes.CDLL(_hip.LIB_PATH)           # loads without a GPU; no compute call is made here
     orc = ctypes.CDLL(build_oracle_lib())
     for n in names:
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 12
-    assert "release (no environment knobs)" in k.build_info() and "ABI 12" in k.build_info()
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 13
+    assert "release (no environment knobs)" in k.build_info() and "ABI 13" in k.build_info()
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 
@@ -96,6 +96,16 @@ class Raw(object):
                   lp if want_lp else None, K, M, D, sk, sr, ls, used)
         lpn = lp.cpu().numpy()
         return dict(z=z.cpu().numpy(), lp=lpn.T if kfast else lpn)
+
+    def normal_sample_pair(self, mu, sigma, K, D, seed=0, off=0, rs=None, ls=0, used=None, want_lp=True):
+        """Two draws of K particles (call ids off, off + 1) through the pair entry point: z [2, K, M], lp [2, K, R] (from the K-fastest
+        [R, 2 K] matrix the call writes)."""
+        M = mu.size
+        R = M // D
+        z, lp = self.empty(2 * K, M), self.empty(R, 2 * K)
+        self.call("zs_normal_sample_logprob_pair_f32", self.t(mu), self.t(sigma), seed, off, rs, z, lp if want_lp else None, K, M, D,
+                  1, 2 * K, ls, used)
+        return dict(z=z.cpu().numpy().reshape(2, K, M), lp=lp.cpu().numpy().T.reshape(2, K, R))
 
     def normal_sample_bwd(self, sigma, eps, gz, glp, K, D, seed=0, off=0, rs=None, ls=0):
         M = sigma.size
@@ -295,6 +305,44 @@ def test_hip_normal_sample_and_backward(hip, orc, K, R, D, kfast):
          2e-4, 2e-4 * np.sqrt(K))
     _cmp(hip.normal_sample_bwd(sd, eps, gz, None, K, D), orc.normal_sample_bwd(sd, eps, gz, None, K, D), 1e-4, 1e-4)
     _cmp(hip.normal_sample_bwd(sd, None, None, glp, K, D, 77, 5), orc.normal_sample_bwd(sd, None, None, glp, K, D, 77, 5), 1e-4, 1e-4)
+
+
+PAIR_SHAPES = [(50, 256, 40), (1, 512, 40), (5, 8, 40), (40, 64, 40), (7, 33, 12), (3, 5, 7), (2, 1, 784), (64, 300, 16), (10, 50, 14)]
+
+
+def test_c_oracle_pair_draw_is_two_draws(orc):
+    rng = np.random.RandomState(3)
+    for K, R, D in PAIR_SHAPES[2:6]:
+        mu, sd = rng.standard_normal(R * D).astype(np.float32), np.exp(0.3 * rng.standard_normal(R * D)).astype(np.float32)
+        pair = orc.normal_sample_pair(mu, sd, K, D, seed=11, off=4)
+        for j in range(2):
+            one = orc.normal_sample(mu, sd, None, K, D, seed=11, off=4 + j, kfast=True)
+            assert np.array_equal(pair["z"][j], one["z"]) and np.array_equal(pair["lp"][j], one["lp"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,D", PAIR_SHAPES)
+def test_hip_pair_draw_is_bit_for_bit_two_draws(hip, orc, K, R, D):
+    """zs_normal_sample_logprob_pair: one launch (flat-plane shapes) or two (the rest) -- either way each half is exactly the single
+    draw with its call id: values, row sums, the published ids, with the state by value and in device memory, sigma and log sigma."""
+    rng = np.random.RandomState(K + R + D)
+    M = R * D
+    mu = rng.standard_normal(M).astype(np.float32)
+    sd = np.exp(0.5 * rng.standard_normal(M)).astype(np.float32)
+    for ls in (0, 1):
+        sg = np.log(sd) if ls else sd
+        for rs in (None, torch.tensor([77, 1000], dtype=torch.int64, device=hip.dev)):
+            used = torch.zeros(2, dtype=torch.int64, device=hip.dev)
+            pair = hip.normal_sample_pair(mu, sg, K, D, seed=77, off=5, rs=rs, ls=ls, used=used)
+            assert used.tolist() == [77, 5 + (1000 if rs is not None else 0)]
+            for j in range(2):
+                one = hip.normal_sample(mu, sg, None, K, D, seed=77, off=5 + j, kfast=True, rs=rs, ls=ls)
+                assert np.array_equal(pair["z"][j], one["z"]), (j, ls)
+                assert np.array_equal(pair["lp"][j], one["lp"]), (j, ls)
+    only_z = hip.normal_sample_pair(mu, sd, K, D, seed=77, off=5, want_lp=False)
+    assert np.array_equal(only_z["z"], hip.normal_sample_pair(mu, sd, K, D, seed=77, off=5)["z"])
+    ref = orc.normal_sample_pair(mu, sd, K, D, seed=77, off=5)
+    np.testing.assert_allclose(hip.normal_sample_pair(mu, sd, K, D, seed=77, off=5)["z"], ref["z"], rtol=0, atol=2e-5 * float(sd.max()) * 6)
 
 
 @pytest.mark.gpu

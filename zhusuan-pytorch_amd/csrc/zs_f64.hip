@@ -379,6 +379,17 @@ extern "C" int zs_normal_sample_logprob_f64(const double* mu, const double* sigm
   return 0;
 }
 
+extern "C" int zs_normal_sample_logprob_pair_f64(const double* mu, const double* sigma, uint64_t seed, uint64_t offset,
+                                                 const uint64_t* rng_state, double* z, double* lp, int64_t K, int64_t M,
+                                                 int64_t D, int64_t sk, int64_t sr, int sigma_is_logstd, uint64_t* rng_used,
+                                                 void* stream) {
+  const int rc = zs_normal_sample_logprob_f64(mu, sigma, nullptr, seed, offset, rng_state, z, lp, K, M, D, sk, sr, sigma_is_logstd,
+                                              rng_used, stream);
+  if (rc != 0 || M <= 0) return rc;
+  return zs_normal_sample_logprob_f64(mu, sigma, nullptr, seed, offset + 1, rng_state, z + K * M, lp ? lp + K * sk : nullptr, K, M, D,
+                                      sk, sr, sigma_is_logstd, nullptr, stream);
+}
+
 extern "C" int zs_normal_sample_logprob_bwd_f64(const double* sigma, const double* eps, uint64_t seed, uint64_t offset,
                                                 const uint64_t* rng_state, const double* gz, const double* glp, int64_t gsk,
                                                 int64_t gsr, double* gmu, double* gsigma, int64_t K, int64_t M, int64_t D,

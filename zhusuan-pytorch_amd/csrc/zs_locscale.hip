@@ -647,7 +647,7 @@ int logistic_sample(const T* loc, const T* scale, const T* u, uint64_t seed, uin
   ZS_LAUNCH_SMEM(KID_LOGISTIC_SAMPLE, (k_sample_tile<D_LOGISTIC, L, NTF>), dim3(g.grid), dim3(g.threads), g.smem, st,     \
                  (const float4*)loc, (const float4*)scale, seed, offset, rng_state, (float4*)z, lp, (uint32_t)K, R,      \
                  (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, false, rng_used,     \
-                 (float4*)nullptr, false)
+                 (float4*)nullptr, false, 0u)
         if (nt) { if (lp) ZS_LAUNCH_LTILE(true, true); else ZS_LAUNCH_LTILE(false, true); }
         else    { if (lp) ZS_LAUNCH_LTILE(true, false); else ZS_LAUNCH_LTILE(false, false); }
 #undef ZS_LAUNCH_LTILE
@@ -838,12 +838,12 @@ int uniform_sample(const T* low, int64_t Pl, const T* high, int64_t Ph, const T*
           ZS_LAUNCH_SMEM(KID_UNIFORM_SAMPLE, (k_sample_tile<D_UNIFORM, false, true>), dim3(g.grid), dim3(g.threads), 0, st,
                          (const float4*)low, (const float4*)high, seed, offset, rng_state, (float4*)out, (float*)nullptr, (uint32_t)K,
                          Pl / 4, 1u, (uint32_t)(Pl / 4), g.kchunk, g.KB, g.n_ptiles, g.total, (int64_t)0, (int64_t)0, false,
-                         (uint64_t*)nullptr, (float4*)cache, reparam != 0);
+                         (uint64_t*)nullptr, (float4*)cache, reparam != 0, 0u);
         else
           ZS_LAUNCH_SMEM(KID_UNIFORM_SAMPLE, (k_sample_tile<D_UNIFORM, false, false>), dim3(g.grid), dim3(g.threads), 0, st,
                          (const float4*)low, (const float4*)high, seed, offset, rng_state, (float4*)out, (float*)nullptr, (uint32_t)K,
                          Pl / 4, 1u, (uint32_t)(Pl / 4), g.kchunk, g.KB, g.n_ptiles, g.total, (int64_t)0, (int64_t)0, false,
-                         (uint64_t*)nullptr, (float4*)cache, reparam != 0);
+                         (uint64_t*)nullptr, (float4*)cache, reparam != 0, 0u);
         ZS_CHECK_LAUNCH();
         return 0;
       }

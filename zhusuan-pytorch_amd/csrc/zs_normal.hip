@@ -630,7 +630,7 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
   ZS_LAUNCH_SMEM(KID_NORMAL_SAMPLE, (k_sample_tile<D_NORMAL, L, T>), dim3(kt_.grid), dim3(kt_.threads), kt_.smem, st, \
                  m4, s4, seed, offset, rng_state, (float4*)z, lp, (uint32_t)K, R, (uint32_t)D4,                \
                  (uint32_t)(R * D4), kt_.kchunk, kt_.KB, kt_.n_ptiles, kt_.total, sk, sr, ls, rng_used,    \
-                 (float4*)nullptr, false)
+                 (float4*)nullptr, false, 0u)
       if (nt) { if (lp) ZS_LAUNCH_TILE(true, true); else ZS_LAUNCH_TILE(false, true); }
       else    { if (lp) ZS_LAUNCH_TILE(true, false); else ZS_LAUNCH_TILE(false, false); }
 #undef ZS_LAUNCH_TILE
@@ -692,6 +692,46 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
   }
   ZS_CHECK_LAUNCH();
   return 0;
+}
+
+
+// Two independent draws of K particles each (Philox call ids offset and offset + 1) -- what the objectives do with every
+// latent (stochastic_tensor.py:115-127, then elbo.py:122 / importance_weighted_objective.py:85) -- as ONE launch when the
+// flat-plane kernel takes the shape, else as the two launches it stands for.  Results are bit for bit those of two calls of
+// zs_normal_sample_logprob_f32: z [2 K, M] (first K particles: the first draw), lp element (k, r) of draw j at
+// lp[(j K + k) * sk + r * sr].
+extern "C" int zs_normal_sample_logprob_pair_f32(const float* mu, const float* sigma, uint64_t seed, uint64_t offset,
+                                                 const uint64_t* rng_state, float* z, float* lp, int64_t K, int64_t M,
+                                                 int64_t D, int64_t sk, int64_t sr, int sigma_is_logstd, uint64_t* rng_used,
+                                                 void* stream) {
+  const bool ls = sigma_is_logstd != 0;
+  if (K < 1 || M < 0 || D < 1 || (M % D) != 0) return ZS_EINVAL;
+  if (M == 0) return 0;
+  if (!mu || !sigma || !z) return ZS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t R = M / D;
+  if ((D % 4 == 0) && aligned16(mu) && aligned16(sigma) && aligned16(z) && 2 * K <= 0x7fffffff) {
+    const int D4 = (int)(D / 4);
+    const K1Tile kt_ = k1_tile(2 * K, R, D4, lp != nullptr);
+    if (kt_.ok) {
+      const bool nt = 2.0 * (double)K * (double)M * 4.0 > 268435456.0;
+#define ZS_LAUNCH_TILE2(L, T)                                                                                 \
+  ZS_LAUNCH_SMEM(KID_NORMAL_SAMPLE, (k_sample_tile<D_NORMAL, L, T>), dim3(kt_.grid), dim3(kt_.threads), kt_.smem, st, \
+                 (const float4*)mu, (const float4*)sigma, seed, offset, rng_state, (float4*)z, lp, (uint32_t)(2 * K), R,  \
+                 (uint32_t)D4, (uint32_t)(R * D4), kt_.kchunk, kt_.KB, kt_.n_ptiles, kt_.total, sk, sr, ls, rng_used,     \
+                 (float4*)nullptr, false, (uint32_t)K)
+      if (nt) { if (lp) ZS_LAUNCH_TILE2(true, true); else ZS_LAUNCH_TILE2(false, true); }
+      else    { if (lp) ZS_LAUNCH_TILE2(true, false); else ZS_LAUNCH_TILE2(false, false); }
+#undef ZS_LAUNCH_TILE2
+      ZS_CHECK_LAUNCH();
+      return 0;
+    }
+  }
+  int rc = zs_normal_sample_logprob_f32(mu, sigma, nullptr, seed, offset, rng_state, z, lp, K, M, D, sk, sr, sigma_is_logstd, rng_used,
+                                        stream);
+  if (rc != 0) return rc;
+  return zs_normal_sample_logprob_f32(mu, sigma, nullptr, seed, offset + 1, rng_state, z + K * M, lp ? lp + K * sk : nullptr, K, M, D,
+                                      sk, sr, sigma_is_logstd, nullptr, stream);
 }
 
 extern "C" int zs_normal_sample_logprob_bwd_f32(const float* sigma, const float* eps, uint64_t seed,

@@ -49,6 +49,10 @@ __device__ __forceinline__ void publish_rng(uint64_t* __restrict__ rng_used, uin
 // Row sums: each lane parks its partial per particle in LDS ([KB][TB+1], odd leading dimension: conflict-free both
 // ways); after KB particles the workgroup reads them back transposed, adds the D4 partials of a row and writes log q
 // coalesced along the particle axis of the K-fastest result.
+// Kp > 0: TWO INDEPENDENT DRAWS of Kp particles each in one launch (K = 2 Kp): particles [Kp, 2 Kp) are the draw with Philox call id
+// call + 1 and counters relative to their own first particle -- each half is bit for bit what a launch of its own would have
+// written (the objectives draw every latent twice, stochastic_tensor.py:115-127 + elbo.py:122; at the config sizes a launch costs
+// 4.7 us and the second half of this one 0.25).  A batch of particles never straddles Kp.
 // In-kernel Philox only: with eps handed in (the parity path) the kernel is memory-bound and the row-per-lane-group
 // kernel above, which needs no workgroup barrier, is the faster one (69 % against 65 % of the roofline at 4.2 M rows).
 // ------------------------------------------------------------------------------------
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
     const float4* __restrict__ mu, const float4* __restrict__ sigma,
     uint64_t seed, uint64_t call, const uint64_t* __restrict__ rs, float4* __restrict__ z, float* __restrict__ lp,
     uint32_t K, int64_t R, uint32_t D4, uint32_t M4, uint32_t kchunk, uint32_t KB, uint32_t n_ptiles, uint32_t total,
-    int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used, float4* __restrict__ z2, bool raw_draw) {
+    int64_t sk, int64_t sr, bool ls, uint64_t* __restrict__ rng_used, float4* __restrict__ z2, bool raw_draw, uint32_t Kp) {
   extern __shared__ float zs_k1_stage[];
   if (rs) { seed = rs[0]; call += rs[1]; }
   publish_rng(rng_used, seed, call);
@@ -94,8 +98,12 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
     const uint32_t k0 = kt * kchunk;
     const uint32_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
     const int64_t rbase = (int64_t)pt * rows_in_tile;
-    for (uint32_t kb0 = k0; kb0 < k1; kb0 += KB) {
-      const uint32_t kb = (k1 - kb0 < KB) ? (k1 - kb0) : KB;
+    uint32_t kb = 0;
+    for (uint32_t kb0 = k0; kb0 < k1; kb0 += kb) {
+      kb = (k1 - kb0 < KB) ? (k1 - kb0) : KB;
+      if (Kp && kb0 < Kp && kb0 + kb > Kp) kb = Kp - kb0;              // (two draws: a batch stays inside one of them)
+      const bool second = Kp && kb0 >= Kp;
+      const uint64_t callx = second ? call + 1 : call;
       if (on) {
         const uint64_t base = (uint64_t)kb0 * M4;                      // uniform
         // uniform base pointer per particle (scalar registers) + this lane's 32-bit byte offset: the stores need no
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
         char* __restrict__ zk2 = reinterpret_cast<char*>(z2 + base);   // second output (Uniform: the cached draw)
         const uint32_t lane_off = m4 * 16u;
         const uint64_t step = (uint64_t)M4 * 16u;
-        uint64_t g = base + m4;                                        // Philox group of (particle kb0, this lane)
+        uint64_t g = (second ? base - (uint64_t)Kp * M4 : base) + m4;  // Philox group of (particle kb0 of its draw, this lane)
         float* __restrict__ stp = zs_k1_stage + tid;
         // one particle: sample, store, density partial.  `e` = the standard draw, `dens` = what the draw itself contributes
         // to the log-density (Logistic: sum_j log u_j + log(1 - u_j); unused for Normal)
@@ -167,14 +175,14 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
           particle(make_float4((float)(uint32_t)g, 1.f, 2.f, 3.f), 0.f);
 #else
           if (DIST == D_NORMAL) {
-            particle(philox_normal4(g, call, seed), 0.f);
+            particle(philox_normal4(g, callx, seed), 0.f);
           } else if (DIST == D_UNIFORM) {
-            const Philox4 r = philox4x32_10(g, call, seed);
+            const Philox4 r = philox4x32_10(g, callx, seed);
             particle_uniform(make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w)));
           } else {
             // Logistic draw (logistic.py:64-66): eps = log u - log(1 - u); its own log-density -eps - 2 softplus(-eps)
             // is log u + log(1 - u): the two logarithms serve both
-            const Philox4 r = philox4x32_10(g, call, seed);
+            const Philox4 r = philox4x32_10(g, callx, seed);
             float4 e;
             float d0, d1, d2, d3;
             logistic_draw(u01(r.x), e.x, d0);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # The in-tree library.  ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments: tools/); bench.py
 # records which file was loaded (path, sha256, zs_build_info) and refuses an override unless --allow-experiments is given.
 LIB_PATH = os.environ.get("ZS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -26,6 +26,7 @@ _int = ctypes.c_int
 # name -> argtypes ; every function returns int (0 = ok) unless noted
 PROTOTYPES = {
     "zs_normal_sample_logprob_f32": [_p, _p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p, _p],
+    "zs_normal_sample_logprob_pair_f32": [_p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p, _p],
     "zs_normal_sample_logprob_bwd_f32": [_p, _p, _u64, _u64, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _int, _p],
     "zs_normal_logprob_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _p],
     "zs_normal_logprob_bwd_f32": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p],
