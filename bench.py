@@ -386,14 +386,15 @@ def make_optimizer(model, torch_adam, groups=None):
 
 
 def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False, skip_discarded=False,
-                          dense="fused", eager=False, refresh=False, device_rng=True, forward_only=False):
+                          dense="fused", eager=False, refresh=False, device_rng=True, forward_only=False, pair_draws=True):
     """A workload on this GPU as full training steps -- replayed from one hipGraph (default) or launched eagerly from a
     Python loop (`eager`).  `refresh`: every step trains on ANOTHER minibatch, copied (device to device) into the step's
     input tensors from a resident stream of 8 batches, as the reference's loop feeds one (iwae.py:151-160).  `torch_adam`:
     False (zhusuan.optim.FlatAdam), True (torch's fused capturable Adam), "reference" / "reference_capturable"
     (torch.optim.Adam(params, lr) as the reference's example constructs it).  `device_rng`: the draws' Philox state lives in
     device memory (needed by graphs); without it they take their call ids from torch's generator, as plain eager code does.
-    `forward_only`: a "step" is ONE EVALUATION OF THE OBJECTIVE (no backward, no optimizer): SURVEY.md 8d's metric (i)."""
+    `forward_only`: a "step" is ONE EVALUATION OF THE OBJECTIVE (no backward, no optimizer): SURVEY.md 8d's metric (i).
+    `pair_draws=False`: zhusuan.pair_draws(False) -- the two draws of a latent as two launches (the package pairs them by default)."""
     import contextlib
     import zhusuan
     gemm_tuning(tuned)
@@ -427,6 +428,7 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
         if rng is not None:
             ctx.enter_context(zhusuan.device_rng(rng))
         ctx.enter_context(zhusuan.skip_discarded_draws(skip_discarded))
+        ctx.enter_context(zhusuan.pair_draws(pair_draws))
         if eager:
             def step():
                 if refresh:
@@ -455,7 +457,8 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
     return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
             "launch_mode": "eager (Python loop)" if eager else "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
             "minibatch": "a new minibatch every step (8 resident batches, copied into the step's inputs)" if refresh else "one resident minibatch",
-            "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default)",
+            "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else (
+                "executed (the package default)" if pair_draws else "executed, one launch per draw (zhusuan.pair_draws(False))"),
             "dense_layers": DENSE_LABEL[dense],
             "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape)" if tuned else "PyTorch default",
             "optimizer": opt_label}
@@ -836,6 +839,7 @@ def main():
             "zs_bernoulli_logits_logprob_f32": 4 * N * X + 4 * B * X + 4 * N,
             "zs_bernoulli_logits_logprob_bwd_f32": 8 * N * X + 4 * B * X + 4 * N,
             "zs_normal_sample_logprob_f32": 4 * N * D + 4 * N + 8 * B * D,        # write z, log q; read mu, sigma
+            "zs_normal_sample_logprob_pair_f32": 2 * (4 * N * D + 4 * N) + 8 * B * D,     # both draws of the latent in one launch
             "zs_normal_logprob_f32": 4 * N * D + 4 * N + 8 * B * D,
             "zs_normal_logprob_bwd_ksum_f32": 4 * N * D + 4 * N + 16 * B * D,
             "zs_iw_reduce_f32": 16 * N + 8 * B,
@@ -851,6 +855,10 @@ def main():
         if "zs_iw_reduce_f32" in dev_times and klib.prof_query("zs_iw_objective_f32")["count"] and \
                 not klib.prof_query("zs_iw_reduce_f32")["count"]:
             dev_times["zs_iw_objective_f32"] = dev_times.pop("zs_iw_reduce_f32")
+        # ... and so does the flat-plane sampling kernel (one draw / both draws of a latent)
+        if "zs_normal_sample_logprob_f32" in dev_times and klib.prof_query("zs_normal_sample_logprob_pair_f32")["count"] and \
+                not klib.prof_query("zs_normal_sample_logprob_f32")["count"]:
+            dev_times["zs_normal_sample_logprob_pair_f32"] = dev_times.pop("zs_normal_sample_logprob_f32")
         per_kernel = {}
         for name in (n for n in _hip.PROTOTYPES if n.endswith("_f32")):     # the workload is fp32 throughout
             q = klib.prof_query(name)
@@ -912,7 +920,7 @@ def main():
             "mlp_gemm_library": args.blas,
             "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape, callers' nn.Linear stack)" if tuned else "PyTorch default",
             "optimizer": "torch.optim.Adam(lr=1e-3, fused=True, capturable=True)" if args.torch_adam else "zhusuan.optim.FlatAdam(lr=1e-3)",
-            "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default, as the reference)",
+            "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default, as the reference: both draws of the latent, in one launch)",
             "launch_mode": mode,
             "timing": "median of %d trials of %d steps, each bracketed by synchronize + barrier, max over ranks" % (len(trials), args.steps)}
         long_settings = {
@@ -1015,6 +1023,8 @@ def main():
             extra("bnn_default", "bnn_default", **base)
             # the objective alone (SURVEY.md 8d metric (i)): forward under no_grad, no backward, no optimizer
             extra("c3_forward_only", "c3", fused_logits=args.fused_logits, forward_only=True, **base)
+            # both draws of the latent as two launches (the package makes them in one where the sampling kernel takes the shape)
+            extra("c3_one_launch_per_draw", "c3", fused_logits=args.fused_logits, pair_draws=False, **base)
             if not skip_discarded:      # the opt-in that drops the draw the reference discards
                 extra("c3_skip_discarded_draws", "c3", fused_logits=args.fused_logits, **dict(base, skip_discarded=True))
             if tuned:                   # PyTorch's default GEMM selection and its multi-tensor Adam (what round 1 measured)

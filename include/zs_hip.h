@@ -95,6 +95,9 @@ int zs_normal_sample_logprob_f32(const float* mu, const float* sigma, const floa
                                  int64_t lp_stride_k, int64_t lp_stride_r,
                                  int sigma_is_logstd, uint64_t* rng_used, void* stream);
 
+/* 1 when zs_normal_sample_logprob_pair_f32 (below) serves (K, M, D) with ONE launch (given 16-byte aligned operands), else 0. */
+int zs_normal_sample_pair_one_launch(int64_t K, int64_t M, int64_t D, int want_lp);
+
 /* K1 twice: two independent draws of K particles each with the Philox call ids `offset` and `offset + 1` -- what the
  * reference's objectives do with every latent: the node factory draws (stochastic_tensor.py:115-127 through bn.py:158),
  * the objective's re-read of node.tensor draws again (elbo.py:122, importance_weighted_objective.py:85) -- as ONE launch

@@ -60,6 +60,22 @@ static void philox_normal4(uint64_t group, uint64_t call, uint64_t seed, float n
   n[3] = (float)(rb * sin(two_pi * t3));
 }
 int zs_abi_version(void) { return ZS_ABI_VERSION; }
+/* The shapes the HIP library's flat-plane sampling kernel takes for 2 K particles (csrc/zs_sample_tile.h, k1_tile): rows of whole
+ * 16-byte pieces, at most 64 of them, a workgroup of whole rows and whole waves within 1024 lanes.  Restated here so that the
+ * package's host back-end pairs draws exactly where the GPU does. */
+int zs_normal_sample_pair_one_launch(int64_t K, int64_t M, int64_t D, int want_lp) {
+  (void)want_lp;
+  if (K < 1 || M < 1 || D < 1 || (M % D) != 0 || (D % 4) != 0 || 2 * K > 0x7fffffff) return 0;
+  const int64_t D4 = D / 4, M4 = M / 4;
+  if (D4 > 64 || M4 >= ((int64_t)1 << 28)) return 0;
+  int64_t a = 64, b = D4;
+  while (b) { const int64_t t = a % b; a = b; b = t; }
+  const int64_t l = 64 / a * D4;
+  int64_t TB = l * ((256 + l - 1) / l);
+  if (TB > 1024) TB = l;
+  if (TB > 1024) return 0;
+  return ((M4 + TB - 1) / TB) * (2 * K) < ((int64_t)1 << 31);       /* (an upper bound of the kernel's item count) */
+}
 const char* zs_build_info(void) { return "libzs_oracle: plain-C CPU restatement (test infrastructure, host pointers)"; }
 const char* zs_error_string(int code) {
   if (code == 0) return "success";

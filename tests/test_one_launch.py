@@ -125,6 +125,100 @@ def test_skip_discarded_draws_draws_each_latent_once(dev):
     assert names.count("zs_normal_sample_logprob") == 2
 
 
+def _seed(dev, s):
+    if dev.type == "cuda":
+        torch.manual_seed(s)
+    else:
+        import host_backend
+        host_backend.manual_seed(s)
+
+
+def test_both_draws_of_a_latent_in_one_launch_equal_two_launches(dev):
+    """Default draws (no injected epsilons): an objective draws every latent twice (stochastic_tensor.py:115-127 + elbo.py:122 of
+    the reference).  Where the sampling kernel takes the shape both draws leave in ONE launch (zs_normal_sample_logprob_pair) with
+    the Philox call ids two launches use -- value and every gradient are bit for bit those of ``zhusuan.pair_draws(False)``, the
+    factory still returns a tensor (the FIRST draw), and the node ends up holding the second."""
+    cases = [("iwae-vimco", iwae.build(n_samples=5, estimator="vimco", hidden=32, device=dev), H.iwae_data(8, 5)[0]),
+             ("iwae-sgvb", iwae.build(n_samples=5, estimator="sgvb", hidden=32, device=dev), H.iwae_data(8, 5)[0]),
+             ("vae", vae_mnist.build(16, hidden=32, device=dev), H.vae_data(16)[0])]
+    for label, model, x in cases:
+        obs = {"x": torch.tensor(x, device=dev)}
+
+        def run(paired):
+            _seed(dev, 11)
+            with zs.pair_draws(paired), launches() as names:
+                loss = model(obs)
+                g = _grads(model, loss)
+            return names, float(loss.detach()), g, model.variational.nodes["z"].dist.sample_cache.detach().cpu().numpy()
+        n1, l1, g1, z1 = run(True)
+        n0, l0, g0, z0 = run(False)
+        assert n1.count("zs_normal_sample_logprob_pair") == 1 and n1.count("zs_normal_sample_logprob") == 0, (label, n1)
+        assert n0.count("zs_normal_sample_logprob_pair") == 0 and n0.count("zs_normal_sample_logprob") == 2, (label, n0)
+        assert l1 == l0 and np.array_equal(z1, z0), label
+        for a, b in zip(g1, g0):
+            assert np.array_equal(a, b), label
+        assert len(n1) == len(n0) - 1, (label, n1, n0)
+    # injected epsilons / the reference's host stream / an explicit epsilon: one launch per draw, as before
+    m, x = cases[0][1], cases[0][2]
+    _, e1, e2 = H.iwae_data(8, 5)
+    with launches() as names, zs.inject_epsilon([e1, e2]):
+        m({"x": torch.tensor(x, device=dev)})
+    assert names.count("zs_normal_sample_logprob") == 2 and names.count("zs_normal_sample_logprob_pair") == 0
+    # outside an objective nothing is drawn ahead
+    q = m.variational
+    with launches() as names:
+        q({"x": torch.tensor(x, device=dev)})
+    assert names.count("zs_normal_sample_logprob_pair") == 0 and names.count("zs_normal_sample_logprob") == 1
+    assert "_pending_draw" not in q.nodes["z"].dist.__dict__
+
+
+def test_paired_draws_in_a_net_that_reads_its_first_draw(dev):
+    """A hierarchical variational net uses the value its first factory returned: with paired draws that value is the first draw of
+    the pair (a plain tensor, available at once), the objective scores the second; the second latent's parameters -- computed from
+    the first's FIRST draw, as in the reference -- are those of both of ITS draws."""
+    class Q(BayesianNet):
+        def __init__(self):
+            super().__init__()
+            self.mu = torch.nn.Parameter(torch.zeros(6, 8))
+            self.seen = None
+
+        def forward(self, observed):
+            self.observe(observed)
+            z1 = self.normal("z1", mean=self.mu, std=torch.ones_like(self.mu.detach()), reduce_mean_dims=[0], reduce_sum_dims=[1])
+            self.seen = z1
+            self.normal("z2", mean=torch.tanh(z1) * 0.5, std=torch.ones_like(self.mu.detach()), reduce_mean_dims=[0], reduce_sum_dims=[1])
+            return self
+
+    class P(BayesianNet):
+        def __init__(self):
+            super().__init__()
+            self.s = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, observed):
+            self.observe(observed)
+            one = torch.ones(6, 8, device=self.s.device)
+            z1 = self.normal("z1", mean=0 * one, std=one, reduce_mean_dims=[0], reduce_sum_dims=[1])
+            z2 = self.normal("z2", mean=z1 * self.s, std=one, reduce_mean_dims=[0], reduce_sum_dims=[1])
+            self.normal("x", mean=z2, std=one, reduce_mean_dims=[0], reduce_sum_dims=[1])
+            return self
+    model = ELBO(P(), Q()).to(dev)
+    _seed(dev, 3)
+    with launches() as names:
+        loss = model({})
+        loss.backward()
+    q = model.variational
+    assert isinstance(q.seen, torch.Tensor) and not isinstance(q.seen, LazyDraw)
+    used = q.nodes["z1"].dist.sample_cache
+    assert used is not q.seen and not torch.equal(used, q.seen) and torch.isfinite(loss)
+    # (two pairs for the latents; the one single draw is the generator's own unobserved node x)
+    assert names.count("zs_normal_sample_logprob_pair") == 2 and names.count("zs_normal_sample_logprob") == 1, names
+    assert names.count("zs_normal_sample_logprob_multi") == 0             # (the second draws came with the first)
+    assert q.mu.grad is not None and torch.isfinite(q.mu.grad).all()
+    # the two draws of a pair are independent standard draws: same mean / unit scale statistics
+    d = (used - q.mu.detach()).flatten()
+    assert abs(float(d.mean())) < 1.5 and 0.2 < float(d.std()) < 3.0
+
+
 class _Hierarchical(BayesianNet):
     """q(z1) q(z2 | z1): the net's own code READS the value its first node factory returned."""
 

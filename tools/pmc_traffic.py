@@ -26,7 +26,7 @@ ALGO = {
     "zs_bernoulli_logprob_bwd_f32": 8 * N * X + 4 * B * X + 4 * N,
     "zs_bernoulli_logits_logprob_f32": 4 * N * X + 4 * B * X + 4 * N,
     "zs_bernoulli_logits_logprob_bwd_f32": 8 * N * X + 4 * B * X + 4 * N,
-    "zs_normal_sample_logprob_f32": 4 * N * D + 4 * N + 8 * B * D,
+    "zs_normal_sample_logprob_pair_f32": 2 * (4 * N * D + 4 * N) + 8 * B * D,      # both draws of the latent in one launch (the bench step)
     "zs_normal_logprob_f32": 4 * N * D + 4 * N + 8 * B * D,
     "zs_normal_logprob_bwd_ksum_f32": 4 * N * D + 4 * N + 16 * B * D,
     "zs_iw_objective_f32": 20 * N + 4 * B + 4,
@@ -38,9 +38,9 @@ ALGO = {
 # (the kernels shared by the location-scale families live in namespace zs: template argument 0 = Normal)
 FRAGS = [("k_iw1_block", "zs_bernoulli_iw_objective_f32"), ("k_iw1_bwd", "zs_bernoulli_iw_objective_bwd_f32"),
          ("k_bern_logprob_bwd", "zs_bernoulli%s_logprob_bwd_f32"), ("k_bern_logprob", "zs_bernoulli%s_logprob_f32"),
-         ("k_sample_tile<0", "zs_normal_sample_logprob_f32"), ("k_logprob_bwd_ksum<0", "zs_normal_logprob_bwd_ksum_f32"),
+         ("k_sample_tile<0", "zs_normal_sample_logprob_pair_f32"), ("k_logprob_bwd_ksum<0", "zs_normal_logprob_bwd_ksum_f32"),
          ("k_logprob_krep<0", "zs_normal_logprob_f32"), ("k_adam_step<float", "zs_adam_step_f32"),
-         ("k_normal_sample_bwd", None), ("k_normal_sample", "zs_normal_sample_logprob_f32"),
+         ("k_normal_sample_bwd", None), ("k_normal_sample", None),
          ("k_normal_logprob_bwd_ksum", "zs_normal_logprob_bwd_ksum_f32"), ("k_normal_logprob_bwd", None),
          ("k_normal_logprob", "zs_normal_logprob_f32"), ("k_iw_", "zs_iw_objective_f32")]
 

@@ -48,6 +48,7 @@ enum KernelId {
   KID_UNIFORM_SAMPLE, KID_UNIFORM_LOGPROB, KID_PHILOX_UNIFORM, KID_REINFORCE, KID_IW_OBJECTIVE, KID_SCALAR_OBJECTIVE, KID_ADAM, KID_LOGISTIC_LOGPROB_BWD_KSUM,
   KID_LOGJOINT, KID_LOGJOINT_BWD, KID_NORMAL_SAMPLE_MULTI, KID_NORMAL_SAMPLE_MULTI_BWD, KID_PARTICLE_LINEAR, KID_PARTICLE_LINEAR_BWD, KID_COLUMN_SUM,
   KID_DENSE_ACT_BWD, KID_PARTICLE_RMSE, KID_PARTICLE_MLP, KID_PARTICLE_MLP_BWD, KID_BERN_IW_OBJECTIVE, KID_BERN_IW_OBJECTIVE_BWD,
+  KID_NORMAL_SAMPLE_PAIR,
   KID_COUNT
 };
 bool prof_begin_launch(int kid, hipEvent_t* start, hipEvent_t* stop);  // defined in zs_iw.hip

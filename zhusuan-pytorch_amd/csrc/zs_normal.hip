@@ -695,6 +695,13 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
 }
 
 
+// Whether zs_normal_sample_logprob_pair_f32 is ONE launch for this shape (16-byte aligned operands assumed): callers that gain
+// nothing from two launches behind one call (a second draw that other kernels batch) ask first.
+extern "C" int zs_normal_sample_pair_one_launch(int64_t K, int64_t M, int64_t D, int want_lp) {
+  if (K < 1 || M < 1 || D < 1 || (M % D) != 0 || (D % 4) != 0 || 2 * K > 0x7fffffff) return 0;
+  return k1_tile(2 * K, M / D, (int)(D / 4), want_lp != 0).ok ? 1 : 0;
+}
+
 // Two independent draws of K particles each (Philox call ids offset and offset + 1) -- what the objectives do with every
 // latent (stochastic_tensor.py:115-127, then elbo.py:122 / importance_weighted_objective.py:85) -- as ONE launch when the
 // flat-plane kernel takes the shape, else as the two launches it stands for.  Results are bit for bit those of two calls of
@@ -716,7 +723,7 @@ extern "C" int zs_normal_sample_logprob_pair_f32(const float* mu, const float* s
     if (kt_.ok) {
       const bool nt = 2.0 * (double)K * (double)M * 4.0 > 268435456.0;
 #define ZS_LAUNCH_TILE2(L, T)                                                                                 \
-  ZS_LAUNCH_SMEM(KID_NORMAL_SAMPLE, (k_sample_tile<D_NORMAL, L, T>), dim3(kt_.grid), dim3(kt_.threads), kt_.smem, st, \
+  ZS_LAUNCH_SMEM(KID_NORMAL_SAMPLE_PAIR, (k_sample_tile<D_NORMAL, L, T>), dim3(kt_.grid), dim3(kt_.threads), kt_.smem, st, \
                  (const float4*)mu, (const float4*)sigma, seed, offset, rng_state, (float4*)z, lp, (uint32_t)(2 * K), R,  \
                  (uint32_t)D4, (uint32_t)(R * D4), kt_.kchunk, kt_.KB, kt_.n_ptiles, kt_.total, sk, sr, ls, rng_used,     \
                  (float4*)nullptr, false, (uint32_t)K)

@@ -14,7 +14,7 @@ __version__ = '0.0.1+mi355x'
 from . import distributions
 from . import framework
 from .utils import *
-from ._rng import inject_epsilon, DeviceRNG, device_rng, reference_rng
+from ._rng import inject_epsilon, DeviceRNG, device_rng, reference_rng, pair_draws
 from .graph import GraphedStep, GraphedStages
 from .framework.stochastic_tensor import skip_discarded_draws
 from .layers import particle_linear, particle_mlp, particle_rmse, Linear, Sequential

@@ -146,6 +146,8 @@ class KernelLibrary(object):
             fn.restype = _int
             fn.argtypes = argtypes
             self._fn[name] = fn
+        self.cdll.zs_normal_sample_pair_one_launch.restype = _int
+        self.cdll.zs_normal_sample_pair_one_launch.argtypes = [_i64, _i64, _i64, _int]
         self.cdll.zs_prof_enable.restype = _int
         self.cdll.zs_prof_enable.argtypes = [_int]
         self.cdll.zs_prof_kernel_id.restype = _int
@@ -189,6 +191,10 @@ class KernelLibrary(object):
         if rc != 0:
             raise RuntimeError("zs_prof_query failed with code %d" % rc)
         return {"total_ms": tot.value, "min_ms": mn.value, "max_ms": mx.value, "count": n.value}
+
+    def pair_draw_is_one_launch(self, K, M, D):
+        """Whether two draws of a latent ([K, M] each, rows of D) fit ONE launch of the sampling kernel (zs_normal_sample_logprob_pair)."""
+        return self.cdll.zs_normal_sample_pair_one_launch(K, M, D, 1) == 1
 
     def call(self, name, *args):
         rc = self._fn[name](*args)

@@ -141,6 +141,71 @@ class NormalSampleLogProb(torch.autograd.Function):
         return (gmu, gsigma) + (None,) * 10
 
 
+class NormalSampleLogProbPair(torch.autograd.Function):
+    """K1 twice in one launch: the TWO draws an objective makes of a latent -- the node factory's (stochastic_tensor.py:115-127 of
+    the reference, through bn.py:158) and the objective's re-read (elbo.py:122, importance_weighted_objective.py:85) -- with the
+    Philox call ids `call` and `call + 1`.  Returns (z1, lp1, z2, lp2): each pair is bit for bit what NormalSampleLogProb returns
+    for its call id.  In-kernel Philox only (no epsilon operand); backward treats each draw like NormalSampleLogProb's."""
+
+    @staticmethod
+    def forward(ctx, mu, sigma, seed, call, rng_state, K, has_k_axis, n_fold, reparam, is_logstd=False):
+        ctx.set_materialize_grads(False)
+        _hip.require_device(mu, sigma)
+        sfx = _sfx(mu, sigma)
+        shape = tuple(mu.shape)
+        M = mu.numel()
+        rest = shape[:len(shape) - n_fold]
+        D = _prod(shape[len(shape) - n_fold:])
+        R = _prod(rest)
+        lead = (K,) if has_k_axis else ()
+        zz = torch.empty((2,) + lead + shape, dtype=mu.dtype, device=mu.device)
+        if has_k_axis and K > 1:            # K-fastest rows [R, 2 K]: each draw's [R, K] block keeps unit stride along K
+            buf = torch.empty((R, 2 * K), dtype=mu.dtype, device=mu.device)
+            lps = [buf[:, j * K:(j + 1) * K].t().view(lead + rest) for j in range(2)]
+            sk, sr = 1, 2 * K
+        else:
+            buf = torch.empty((2 * K, R), dtype=mu.dtype, device=mu.device)
+            lps = [buf[j * K:(j + 1) * K].view(lead + rest) for j in range(2)]
+            sk, sr = R, 1
+        used = _rng_snapshot(rng_state, reparam)
+        _hip.lib().call("zs_normal_sample_logprob_pair" + sfx, _hip.ptr(mu), _hip.ptr(sigma), seed, call, _hip.ptr(rng_state),
+                        _hip.ptr(zz), _hip.ptr(buf), K, M, D, sk, sr, 1 if is_logstd else 0, _hip.ptr(used), _hip.stream_for(mu))
+        if used is not None:
+            rng_state, call = used, 0
+        ctx.meta = (seed, call, K, M, D, R, reparam, 1 if is_logstd else 0)
+        ctx.rng_state = rng_state
+        ctx.save_for_backward(mu, sigma, zz)
+        return zz[0], lps[0], zz[1], lps[1]
+
+    @staticmethod
+    def backward(ctx, gz1, glp1, gz2, glp2):
+        seed, call, K, M, D, R, reparam, ls = ctx.meta
+        mu, sigma, zz = ctx.saved_tensors
+        lib, sfx = _hip.lib(), _sfx(mu)
+        gmu = gsigma = None
+        for j, (gz, glp) in enumerate(((gz1, glp1), (gz2, glp2))):
+            if gz is None and glp is None:
+                continue
+            if not reparam and glp is None:           # torch.normal(mean, std): zero derivative through the sample itself
+                continue
+            a, b = torch.empty_like(mu), torch.empty_like(sigma)
+            gsk = gsr = 0
+            if glp is not None:
+                glp, gsk, gsr = _kr_view(glp, K, R)
+            if reparam:
+                if gz is not None:
+                    gz = gz.contiguous()
+                lib.call("zs_normal_sample_logprob_bwd" + sfx, _hip.ptr(sigma), None, seed, call + j, _hip.ptr(ctx.rng_state),
+                         _hip.ptr(gz), _hip.ptr(glp), gsk, gsr, _hip.ptr(a), _hip.ptr(b), K, M, D, ls, _hip.stream_for(mu))
+            else:
+                lib.call("zs_normal_logprob_bwd_ksum" + sfx, _hip.ptr(zz[j]), _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(glp), gsk, gsr,
+                         None, _hip.ptr(a), _hip.ptr(b), K, R, D, ls, _hip.stream_for(mu))
+            gmu, gsigma = (a, b) if gmu is None else (gmu + a, gsigma + b)
+        if gmu is None and not reparam and (gz1 is not None or gz2 is not None):
+            gmu, gsigma = torch.zeros_like(mu), torch.zeros_like(sigma)
+        return (gmu, gsigma) + (None,) * 8
+
+
 class NormalLogProb(torch.autograd.Function):
     """K2: row-summed Normal log-density of a given value with periodically broadcast operands.
     Operands arrive contiguous; `periods` = (Px, Pm, Ps) in elements of the full [*full_shape] problem."""

@@ -140,6 +140,44 @@ def device_rng(rng):
         _device_rng.reset(token)
 
 
+# Set by the objectives around their run of the variational net (variational/elbo.py:run_variational): every latent created in
+# there is drawn AGAIN by the objective's re-read of node.tensor (elbo.py:122 of the reference), so a Normal node may make
+# both draws in one launch and keep the second for that re-read (distributions/normal.py).  Context-local.
+_redraw_expected = contextvars.ContextVar("zhusuan_redraw_expected", default=False)
+_pair_draws = contextvars.ContextVar("zhusuan_pair_draws", default=True)
+
+
+@contextlib.contextmanager
+def expecting_redraw():
+    token = _redraw_expected.set(True)
+    try:
+        yield
+    finally:
+        _redraw_expected.reset(token)
+
+
+@contextlib.contextmanager
+def pair_draws(enabled=True):
+    """Whether a latent that an objective is about to draw twice makes both draws in ONE launch (default: yes, where the
+    sampling kernel takes the shape).  Both draws are executed either way and carry the Philox call ids they would have had
+    in two launches when the variational net has one latent; with several latents the ids are handed out per node (first and
+    second draw of a node are consecutive) instead of per pass.  ``with zhusuan.pair_draws(False):`` restores one launch per draw."""
+    token = _pair_draws.set(bool(enabled))
+    try:
+        yield
+    finally:
+        _pair_draws.reset(token)
+
+
+def pair_draw_wanted():
+    return _redraw_expected.get() and _pair_draws.get() and not _reference_stream.get() and _queue.get() is None
+
+
+def pair_draw_consumable():
+    """A pre-made second draw stands in for a fresh one only where a fresh one would have come from the same stream."""
+    return not _reference_stream.get() and _queue.get() is None
+
+
 def next_call(device):
     """(seed, call id, device state tensor or None) for one draw on `device`."""
     rng = _device_rng.get()

@@ -133,9 +133,28 @@ class Normal(Distribution):
 
     def _sample(self, n_samples=1, epsilon=None):
         """normal.py:89-107 through K1: the sample and its row-summed log-density in one launch."""
-        mu, sigma, eps, K, has_k, n_fold, is_logstd, _ = self._sample_plan(n_samples, epsilon)
+        pending = self.__dict__.pop('_pending_draw', None)
+        if pending is not None and epsilon is None and pending[0] == int(n_samples) and _rng.pair_draw_consumable():
+            # the second of the two draws made in one launch when the node was created (below): this IS the objective's re-read
+            self._adopt_draw(pending[1], pending[2], pending[3])
+            return pending[1]
+        mu, sigma, eps, K, has_k, n_fold, is_logstd, simple = self._sample_plan(n_samples, epsilon)
         seed = call = 0
         rng_state = None
+        if (eps is None and simple and _rng.pair_draw_wanted() and mu.dtype == torch.float32 and mu.numel() > 0
+                and mu.data_ptr() % 16 == 0 and sigma.data_ptr() % 16 == 0
+                and _hip.lib().pair_draw_is_one_launch(K if has_k else 1, mu.numel(), _ops._prod(tuple(mu.shape)[mu.dim() - n_fold:]))):
+            # an objective is running the variational net: it will draw this node again (elbo.py:122 of the reference).  Both
+            # draws in ONE launch, with the call ids two launches would have used; the second waits for the re-read.
+            seed, call, rng_state = _rng.next_call(mu.device)
+            _, call2, _ = _rng.next_call(mu.device)
+            if call2 != call + 1:
+                raise RuntimeError("zhusuan: the Philox call ids of two consecutive draws are not consecutive (%d, %d)" % (call, call2))
+            z, lp, z2, lp2 = _ops.NormalSampleLogProbPair.apply(mu, sigma, seed, call, rng_state, K if has_k else 1, has_k, n_fold,
+                                                                bool(self._is_reparameterized), is_logstd)
+            self._adopt_draw(z, lp, n_fold)
+            self.__dict__['_pending_draw'] = (int(n_samples), z2, lp2, n_fold)
+            return z
         if eps is None:
             seed, call, rng_state = _rng.next_call(mu.device)
         z, lp = _ops.NormalSampleLogProb.apply(mu, sigma, eps, seed, call, rng_state, K if has_k else 1, has_k, n_fold,

@@ -38,7 +38,10 @@ def run_variational(net, observed):
     if _st.skipping_discarded_draws():
         with _st.deferred_node_values():
             return net(observed)
-    return net(observed)
+    # default: both draws of every latent are executed, as in the reference -- where the sampling kernel takes the shape, in ONE
+    # launch at the node's creation (distributions/normal.py: the second draw waits for the re-read)
+    with _rng.expecting_redraw():
+        return net(observed)
 
 
 def draw_latents(nodes_q):
@@ -48,6 +51,8 @@ def draw_latents(nodes_q):
     other node draws by itself (``latent_value``).  Draw order, injected epsilons and Philox call ids are those of the
     node-by-node loop."""
     names = list(nodes_q.keys())
+    if any(getattr(getattr(v, 'dist', None), '__dict__', {}).get('_pending_draw') is not None for v in nodes_q.values()):
+        return {k: latent_value(v) for k, v in nodes_q.items()}        # (second draws made with the first: nothing to batch)
     batch = []
     for name in names:
         node = nodes_q[name]
