@@ -307,7 +307,8 @@ def test_hip_normal_sample_and_backward(hip, orc, K, R, D, kfast):
     _cmp(hip.normal_sample_bwd(sd, None, None, glp, K, D, 77, 5), orc.normal_sample_bwd(sd, None, None, glp, K, D, 77, 5), 1e-4, 1e-4)
 
 
-PAIR_SHAPES = [(50, 256, 40), (1, 512, 40), (5, 8, 40), (40, 64, 40), (7, 33, 12), (3, 5, 7), (2, 1, 784), (64, 300, 16), (10, 50, 14)]
+PAIR_SHAPES = [(50, 256, 40), (1, 512, 40), (5, 8, 40), (40, 64, 40), (7, 33, 12), (3, 5, 7), (2, 1, 784), (64, 300, 16), (10, 50, 14),
+               (10, 1, 700), (10, 1, 51), (5, 40, 100), (1, 3, 100), (33, 2, 4), (2, 2600, 52)]     # long rows, wave rows, small rows
 
 
 def test_c_oracle_pair_draw_is_two_draws(orc):
