@@ -113,9 +113,8 @@ def test_vae(dev, tag, B):
 @pytest.mark.parametrize("fused_logits", [False, True])
 def test_iwae(dev, est, tag, B, K, hidden, fused_logits):
     """small: every tensor; c3 (BASELINE config 3 = per-GPU shape of config 4): every log-importance-weight and its three
-    terms; c4g: the GLOBAL batch of config 4 (2048 x 50) in one process, scalars + gradient statistics + slices."""
-    if tag == "c4g" and (est != "vimco" or fused_logits):
-        pytest.skip("the global-batch golden exists for the benchmark's estimator and Bernoulli path only")
+    terms; c4g: the GLOBAL batch of config 4 (2048 x 50) in one process, scalars + gradient statistics + slices (both estimators, both
+    Bernoulli paths)."""
     if tag == "c4g" and dev.type == "cpu":
         pytest.skip("103 M-element Bernoulli stream through the serial C oracle: GPU only")
     g = load_golden("g_iwae_%s_%s" % (est, tag))
