@@ -2,7 +2,7 @@
 """Randomised differential run of the HOT-PATH kernels through the C ABI -- K1 (fused Normal sample + log-density, given eps and
 in-kernel Philox) and its backward, K2 (Normal log-density of a value, every broadcast period) and its backwards, K3 (Bernoulli
 log-mass, probs and logits) and its backward, K4 (importance-weighted reduction, sgvb and vimco), log-mean-exp, K5 (Bernoulli
-sampler), Philox, IW1 (the generator side of the importance-weighted objective in one launch, both directions) -- libzs_hip.so on the GPU against the C oracle on the host, random shapes, for a given number of seconds.  Uses
+sampler), Philox, the two-draws-in-one-launch mode of K1, IW1 (the generator side of the importance-weighted objective in one launch, both directions) -- libzs_hip.so on the GPU against the C oracle on the host, random shapes, for a given number of seconds.  Uses
 the raw-call helpers of tests/test_cabi.py and its tolerances.  Exit code 1 at the first mismatch.
 
   python tools/fuzz_hotpath.py [seconds=120] [seed=0]
@@ -73,6 +73,26 @@ def case_k1():
         ga, gb = hip.normal_sample_bwd(sg, eps, gz, glp, K, D, ls=ls), orc.normal_sample_bwd(sg, eps, gz, glp, K, D, ls=ls)
         for k in ("gmu", "gsigma"):
             close(ga[k], gb[k], 2e-4, 2e-4 * max(np.abs(gb[k]).max(), 1), "K1 bwd " + k, shape)
+
+
+def case_pair():
+    """Both draws of a latent in one call (zs_normal_sample_logprob_pair): each half bit for bit the single draw with its call id -- the
+    flat-plane kernel's two-draw mode on the shapes it takes, two launches on the rest."""
+    K = int(rng.randint(1, 65))
+    D = 4 * int(rng.randint(1, 33)) if rng.rand() < 0.8 else dim(60)
+    R = dim(600)
+    while K * R * D > 400000:
+        R = max(R // 2, 1)
+    M, ls = R * D, int(rng.rand() < 0.4)
+    mu = rng.standard_normal(M).astype(np.float32)
+    sg = (rng.uniform(-0.5, 0.3, M) if ls else rng.uniform(0.5, 1.5, M)).astype(np.float32)
+    s, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+    pair = hip.normal_sample_pair(mu, sg, K, D, seed=s, off=off, ls=ls)
+    for j in range(2):
+        one = hip.normal_sample(mu, sg, None, K, D, seed=s, off=off + j, kfast=True, ls=ls)
+        if not (np.array_equal(pair["z"][j], one["z"]) and np.array_equal(pair["lp"][j], one["lp"])):
+            print("MISMATCH pair draw %d differs from the single draw at %s" % (j, (K, R, D, ls, s, off)), flush=True)
+            sys.exit(1)
 
 
 def case_k2():
@@ -211,7 +231,7 @@ def case_iw1():
         close(a[key], b[key], 2e-4, 2e-5 * max(np.abs(b[key]).max(), 1e-30), "IW1 bwd " + key, shape)
 
 
-cases = [case_k1, case_k2, case_k3, case_k4, case_rng, case_iw1]
+cases = [case_k1, case_k2, case_k3, case_k4, case_rng, case_iw1, case_pair]
 t0 = time.time()
 while time.time() - t0 < budget:
     c = cases[int(rng.randint(len(cases)))]
