@@ -245,39 +245,38 @@ class NormalLogProb(torch.autograd.Function):
 def _normal_logprob_grads(x, mu, sigma, glp, K, R, D, periods, ls, need):
     """(gx, gmu, gsigma) of the row-summed Normal log-density for row gradients `glp` (K2's backward: the K-summed kernel
     when the parameters are [R, D] repeated over the particles, else element-wise partials folded over the periods)."""
-    if True:
-        Px, Pm, Ps = periods
-        need_x, need_mu, need_sigma = need
-        sfx = _sfx(x)
-        N = K * R * D
-        lib = _hip.lib()
-        glp, gsk, gsr = _kr_view(glp, K, R)
-        st = _hip.stream_for(x)
-        gx = gmu = gsigma = None
-        if K > 1 and Px == N and Pm == Ps == R * D:
-            # parameters [R, D] repeated over the K particles: reduce over K inside the kernel
-            gx = torch.empty_like(x) if need_x else None
-            gmu = torch.empty_like(mu)
-            gsigma = torch.empty_like(sigma)
-            lib.call("zs_normal_logprob_bwd_ksum" + sfx, _hip.ptr(x), _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(glp),
-                     gsk, gsr, _hip.ptr(gx), _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D, ls, st)
-        else:
-            def full():
-                return torch.empty(N, dtype=x.dtype, device=x.device)
-            fx = full() if need_x else None
-            fm = full() if need_mu else None
-            fs = full() if need_sigma else None
-            lib.call("zs_normal_logprob_bwd" + sfx, _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
-                     _hip.ptr(glp), gsk, gsr, _hip.ptr(fx), _hip.ptr(fm), _hip.ptr(fs), K, R, D, ls, st)
+    Px, Pm, Ps = periods
+    need_x, need_mu, need_sigma = need
+    sfx = _sfx(x)
+    N = K * R * D
+    lib = _hip.lib()
+    glp, gsk, gsr = _kr_view(glp, K, R)
+    st = _hip.stream_for(x)
+    gx = gmu = gsigma = None
+    if K > 1 and Px == N and Pm == Ps == R * D:
+        # parameters [R, D] repeated over the K particles: reduce over K inside the kernel
+        gx = torch.empty_like(x) if need_x else None
+        gmu = torch.empty_like(mu)
+        gsigma = torch.empty_like(sigma)
+        lib.call("zs_normal_logprob_bwd_ksum" + sfx, _hip.ptr(x), _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(glp),
+                 gsk, gsr, _hip.ptr(gx), _hip.ptr(gmu), _hip.ptr(gsigma), K, R, D, ls, st)
+    else:
+        def full():
+            return torch.empty(N, dtype=x.dtype, device=x.device)
+        fx = full() if need_x else None
+        fm = full() if need_mu else None
+        fs = full() if need_sigma else None
+        lib.call("zs_normal_logprob_bwd" + sfx, _hip.ptr(x), Px, _hip.ptr(mu), Pm, _hip.ptr(sigma), Ps,
+                 _hip.ptr(glp), gsk, gsr, _hip.ptr(fx), _hip.ptr(fm), _hip.ptr(fs), K, R, D, ls, st)
 
-            def fold(f, P, like):
-                if f is None:
-                    return None
-                if P != N:
-                    f = f.view(N // P, P).sum(0)
-                return f.view(like.shape)
-            gx, gmu, gsigma = fold(fx, Px, x), fold(fm, Pm, mu), fold(fs, Ps, sigma)
-        return (gx if need_x else None, gmu if need_mu else None, gsigma if need_sigma else None)
+        def fold(f, P, like):
+            if f is None:
+                return None
+            if P != N:
+                f = f.view(N // P, P).sum(0)
+            return f.view(like.shape)
+        gx, gmu, gsigma = fold(fx, Px, x), fold(fm, Pm, mu), fold(fs, Ps, sigma)
+    return (gx if need_x else None, gmu if need_mu else None, gsigma if need_sigma else None)
 
 
 class BernoulliLogProb(torch.autograd.Function):
