@@ -173,12 +173,7 @@ __global__ __launch_bounds__(1024) void k_iw1_block(Iw1Args a) {
     const float4* __restrict__ prow = a.p + row * D4;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-#ifdef ZS_IW1_PRED                     // timing experiment: predicated instead of clamped loads
-      pv[i][u] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
-      if (ok[u]) pv[i][u] = prow[lane + 64 * u];
-#else
       pv[i][u] = prow[col[u]];
-#endif
     }
     zv[i] = a.z[row * a.Dz4 + zc];
   };
@@ -228,7 +223,10 @@ __global__ __launch_bounds__(1024) void k_iw1_block(Iw1Args a) {
     asm volatile("" ::: "memory");                                // keep the program order of the loads below (and re-read LDS per round)
     if (i + 2 < ROUNDS) load_row(i + 2);
     const int k = w + i * NW;
-    if (k >= K || (a.variant == 3 && pv[i][0].x != 123.456f)) continue;      // wave-uniform (variant 3: timing experiment, no arithmetic)
+#ifdef ZS_EXPERIMENTS
+    if (a.variant == 3 && pv[i][0].x != 123.456f) continue;       // (timing experiment: the loads without the arithmetic)
+#endif
+    if (k >= K) continue;                                         // wave-uniform
     zs_f2v acc2 = {0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -266,7 +264,10 @@ __global__ __launch_bounds__(1024) void k_iw1_block(Iw1Args a) {
     }
   }
   __syncthreads();
-  if (w != 0 || a.variant == 2) return;
+#ifdef ZS_EXPERIMENTS
+  if (a.variant == 2) return;                                     // (timing experiment: no tail)
+#endif
+  if (w != 0) return;
   // ---- the tail: wave 0, lane = particle
   const bool on = lane < K;
   float l = -INFINITY;
