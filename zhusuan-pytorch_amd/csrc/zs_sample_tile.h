@@ -411,6 +411,76 @@ __global__ __launch_bounds__(256) void k_logprob_krep(
   }
 }
 
+// The same log-density on the flat-plane tiling of k_sample_tile (a workgroup owns TB consecutive float4 groups of the parameter plane =
+// whole rows; every lane busy; every load of a wave one contiguous 1 KB segment; four value rows requested before the first is
+// used; row sums through LDS, written coalesced along the particle axis).  For streams beyond the Infinity Cache.
+template <int DIST, bool NTL>
+__global__ __launch_bounds__(1024) void k_logprob_tile(
+    const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma, float* __restrict__ lp,
+    uint32_t K, int64_t R, uint32_t D4, uint32_t M4, uint32_t kchunk, uint32_t KB, uint32_t n_ptiles, uint32_t total,
+    int64_t sk, int64_t sr, bool ls) {
+  extern __shared__ float zs_k2_stage[];
+  const uint32_t TB = blockDim.x, LDW = TB + 1, tid = threadIdx.x;
+  const uint32_t rows_in_tile = TB / D4;
+  for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+    const uint32_t kt = t / n_ptiles, pt = t - kt * n_ptiles;
+    const uint32_t m4 = pt * TB + tid;
+    const bool on = m4 < M4;
+    const uint32_t m4c = on ? m4 : M4 - 1;                  // (idle lanes of the last tile re-read its last piece: loads stay unconditional)
+    const float4 m = mu[m4c];
+    const float4 s = sigma_of(sigma[m4c], ls);
+    float rowc = 0.f, c[4];
+    {
+      const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (DIST == D_UNIFORM) {
+          const float mv = j == 0 ? m.x : (j == 1 ? m.y : (j == 2 ? m.z : m.w));
+          rowc -= logf(sv[j] - mv);
+          c[j] = sv[j];
+          continue;
+        }
+        const float l2 = log2_fast(sv[j]);
+        if (DIST == D_NORMAL) {
+          rowc += ZS_NEG_HALF_LOG_2PI - l2 * ZS_LN2;
+          c[j] = 0.5f * exp2_fast(-2.0f * l2);
+        } else {
+          rowc -= l2 * ZS_LN2;
+          c[j] = 1.0f / sv[j];
+        }
+      }
+    }
+    const uint32_t k0 = kt * kchunk;
+    const uint32_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
+    const int64_t rbase = (int64_t)pt * rows_in_tile;
+    for (uint32_t kb0 = k0; kb0 < k1; kb0 += KB) {
+      const uint32_t kb = (k1 - kb0 < KB) ? (k1 - kb0) : KB;
+      const float4* __restrict__ xp = x + ((uint64_t)kb0 * M4 + m4c);
+      float* __restrict__ stp = zs_k2_stage + tid;
+      for (uint32_t kk = 0; kk < kb; kk += 4) {
+        float4 xv[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) xv[u] = ld_value4<NTL>(xp + (uint64_t)(kk + u < kb ? kk + u : kb - 1) * M4);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u)
+          if (kk + u < kb) stp[(kk + u) * LDW] = rowc - krep_terms<DIST>(xv[u], m, c);
+      }
+      __syncthreads();
+      const uint32_t nout = rows_in_tile * kb;
+      for (uint32_t o = tid; o < nout; o += TB) {
+        uint32_t q, kk;
+        if (kb == 16u) { q = o >> 4; kk = o & 15u; }
+        else { q = o / kb; kk = o - q * kb; }
+        const float* __restrict__ src = zs_k2_stage + kk * LDW + q * D4;
+        float sum = 0.f;
+        for (uint32_t j = 0; j < D4; ++j) sum += src[j];
+        if (rbase + q < R) lp[(int64_t)(kb0 + kk) * sk + (rbase + q) * sr] = sum;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int DIST>
 inline void launch_logprob_krep(int kid, const float* x, const float* mu, const float* sigma, float* lp, int64_t K, int64_t R,
                                 int D4, int64_t sk, int64_t sr, bool ls, hipStream_t st) {
@@ -442,6 +512,23 @@ inline void launch_logprob_krep(int kid, const float* x, const float* mu, const 
   //       2 M     357       61.6      66.2     59.0      60.2
   //     4.2 M     715       62.5      66.7     64.7      66.9        <- read once from HBM: the hint pays, the depth does not matter
   // so: four rows in flight while the stream fits the cache (and the chunk has four rows), two rows + non-temporal loads beyond.
+  // The flat-plane kernel where its tiling exists (rows of whole 16-byte pieces that fit a workgroup of whole waves): against the
+  // row-tile kernel below, one box, K = 50, D = 40 (profiles/r04_k2_variants.txt): 131 k rows 6.4 -> 5.2 us, 1 M rows K2 70 -> 76 %,
+  // L2 57 -> 73 %, U2 70 -> 75 %, 2 M rows 58 -> 64 %, 4.2 M rows 61 -> 64-69 % (non-temporal loads beyond the Infinity Cache).
+  static const int tile_env = env_knob("ZS_K2_TILE", -1);      // experiments only: 0 = the row-tile kernel, 1 / 2 = plain / non-temporal loads
+  if (tile_env != 0) {
+    const K1Tile g = k1_tile(K, R, D4, true);
+    if (g.ok) {
+      const bool stream_once = tile_env > 0 ? tile_env == 2 : (double)K * (double)R * (double)D4 * 16.0 > 268435456.0;
+      if (stream_once)
+        ZS_LAUNCH_SMEM(kid, (k_logprob_tile<DIST, true>), dim3(g.grid), dim3(g.threads), g.smem, st, (const float4*)x, (const float4*)mu,
+                       (const float4*)sigma, lp, (uint32_t)K, R, (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, ls);
+      else
+        ZS_LAUNCH_SMEM(kid, (k_logprob_tile<DIST, false>), dim3(g.grid), dim3(g.threads), g.smem, st, (const float4*)x, (const float4*)mu,
+                       (const float4*)sigma, lp, (uint32_t)K, R, (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, ls);
+      return;
+    }
+  }
   static const int u_env = env_knob("ZS_K2_U", 0), ntl_env = env_knob("ZS_K2_NTL", -1);      // experiments only
   const bool big = (double)K * (double)R * (double)D4 * 16.0 > 268435456.0;
   const int U = u_env > 0 ? u_env : ((!big && kchunk >= 4) ? 4 : 2);
