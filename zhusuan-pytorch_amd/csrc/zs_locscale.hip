@@ -635,6 +635,28 @@ int logistic_sample(const T* loc, const T* scale, const T* u, uint64_t seed, uin
   const size_t A = sizeof(T) * 4;
   const bool vec = (M & 3) == 0 && al(loc, A) && al(scale, A) && al(u, A) && al(z, A);
   if constexpr (std::is_same<T, float>::value) {
+    // u handed in (the parity route): the flat-plane given-stream kernel in its SAMPLE mode -- against the generic wave-tile path
+    // below: 131 k rows 47 -> 67 %, 1 M rows 53 -> 70-72 %, 4.2 M rows 53-58 -> 73 % of the roofline (>= 62)
+    static const int given_tile_env = env_knob("ZS_K1_GIVEN_TILE", 1);      // experiments only: 0 = the generic path
+    if (u && given_tile_env && vec && (D & 3) == 0) {
+      const int D4 = (int)(D / 4);
+      const int64_t R = M / D;
+      const K1Tile g = k1_tile(K, R, D4, true);
+      if (g.ok) {
+        hipStream_t st = (hipStream_t)stream;
+        const bool big = (double)K * (double)M * 8.0 > 268435456.0;
+        if (big)
+          ZS_LAUNCH_SMEM(KID_LOGISTIC_SAMPLE, (k_logprob_tile<D_LOGISTIC, true, true>), dim3(g.grid), dim3(g.threads), g.smem, st,
+                         (const float4*)u, (const float4*)loc, (const float4*)scale, lp, (uint32_t)K, R, (uint32_t)D4, (uint32_t)(R * D4),
+                         g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, false, (float4*)z);
+        else
+          ZS_LAUNCH_SMEM(KID_LOGISTIC_SAMPLE, (k_logprob_tile<D_LOGISTIC, false, true>), dim3(g.grid), dim3(g.threads), g.smem, st,
+                         (const float4*)u, (const float4*)loc, (const float4*)scale, lp, (uint32_t)K, R, (uint32_t)D4, (uint32_t)(R * D4),
+                         g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, false, (float4*)z);
+        ZS_CHECK_LAUNCH();
+        return 0;
+      }
+    }
     // in-kernel Philox, fp32, rows of up to 256 elements: the fused flat-plane kernel shared with Normal (zs_sample_tile.h)
     if (!u && vec && (D & 3) == 0) {
       const int D4 = (int)(D / 4);

@@ -622,6 +622,23 @@ extern "C" int zs_normal_sample_logprob_f32(const float* mu, const float* sigma,
   if (vec) {
     const int D4 = (int)(D / 4);
     const float4 *m4 = (const float4*)mu, *s4 = (const float4*)sigma, *e4 = (const float4*)eps;
+    // eps handed in (the parity route): the flat-plane given-stream kernel in its SAMPLE mode (zs_sample_tile.h) -- against the
+    // row-per-lane-group kernel below: 131 k rows 59 -> 68 %, 1 M rows 68 -> 70-71 %, 4.2 M rows 68 -> 73 % of the roofline
+    static const int given_tile_env = env_knob("ZS_K1_GIVEN_TILE", 1);      // experiments only: 0 = the row-per-lane-group kernel
+    if (eps && given_tile_env) {
+      const K1Tile g = k1_tile(K, R, D4, true);
+      if (g.ok) {
+        const bool big = (double)K * (double)M * 8.0 > 268435456.0;
+        if (big)
+          ZS_LAUNCH_SMEM(KID_NORMAL_SAMPLE, (k_logprob_tile<D_NORMAL, true, true>), dim3(g.grid), dim3(g.threads), g.smem, st, e4, m4, s4, lp, (uint32_t)K, R,
+                         (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, ls, (float4*)z);
+        else
+          ZS_LAUNCH_SMEM(KID_NORMAL_SAMPLE, (k_logprob_tile<D_NORMAL, false, true>), dim3(g.grid), dim3(g.threads), g.smem, st, e4, m4, s4, lp, (uint32_t)K, R,
+                         (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, ls, (float4*)z);
+        ZS_CHECK_LAUNCH();
+        return 0;
+      }
+    }
     const K1Tile kt_ = eps ? K1Tile() : k1_tile(K, R, D4, lp != nullptr);
     if (kt_.ok) {
       static const int nt_env = env_knob("ZS_K1_NT", -1);

@@ -414,11 +414,13 @@ __global__ __launch_bounds__(256) void k_logprob_krep(
 // The same log-density on the flat-plane tiling of k_sample_tile (a workgroup owns TB consecutive float4 groups of the parameter plane =
 // whole rows; every lane busy; every load of a wave one contiguous 1 KB segment; four value rows requested before the first is
 // used; row sums through LDS, written coalesced along the particle axis).  For streams beyond the Infinity Cache.
-template <int DIST, bool NTL>
+// SAMPLE: the given stream is the standard draw (Normal: eps; Logistic: u in (0, 1)) -- the parity route of K1 / L1 --: the sample
+// z = mu + sigma * e (two roundings, normal.py:105) is written as well and the density is that of the fresh sample.
+template <int DIST, bool NTL, bool SAMPLE = false>
 __global__ __launch_bounds__(1024) void k_logprob_tile(
     const float4* __restrict__ x, const float4* __restrict__ mu, const float4* __restrict__ sigma, float* __restrict__ lp,
     uint32_t K, int64_t R, uint32_t D4, uint32_t M4, uint32_t kchunk, uint32_t KB, uint32_t n_ptiles, uint32_t total,
-    int64_t sk, int64_t sr, bool ls) {
+    int64_t sk, int64_t sr, bool ls, float4* __restrict__ z) {
   extern __shared__ float zs_k2_stage[];
   const uint32_t TB = blockDim.x, LDW = TB + 1, tid = threadIdx.x;
   const uint32_t rows_in_tile = TB / D4;
@@ -462,8 +464,43 @@ __global__ __launch_bounds__(1024) void k_logprob_tile(
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) xv[u] = ld_value4<NTL>(xp + (uint64_t)(kk + u < kb ? kk + u : kb - 1) * M4);
 #pragma unroll
-        for (uint32_t u = 0; u < 4; ++u)
-          if (kk + u < kb) stp[(kk + u) * LDW] = rowc - krep_terms<DIST>(xv[u], m, c);
+        for (uint32_t u = 0; u < 4; ++u) {
+          if (kk + u >= kb) continue;
+          if (!SAMPLE) {
+            stp[(kk + u) * LDW] = rowc - krep_terms<DIST>(xv[u], m, c);
+          } else {
+            float4 e = xv[u];
+            float dens = 0.f;
+            if (DIST == D_LOGISTIC) {
+              float d0, d1, d2, d3;
+              logistic_draw(xv[u].x, e.x, d0);
+              logistic_draw(xv[u].y, e.y, d1);
+              logistic_draw(xv[u].z, e.z, d2);
+              logistic_draw(xv[u].w, e.w, d3);
+              dens = (d0 + d1) + (d2 + d3);
+            }
+            float4 zz;
+            zz.x = mul_add_2round(m.x, s.x, e.x);
+            zz.y = mul_add_2round(m.y, s.y, e.y);
+            zz.z = mul_add_2round(m.z, s.z, e.z);
+            zz.w = mul_add_2round(m.w, s.w, e.w);
+            if (on) {
+              float4* __restrict__ zp = z + ((uint64_t)(kb0 + kk + u) * M4 + m4);
+              if (NTL) {
+                const zs_f4v v = {zz.x, zz.y, zz.z, zz.w};
+                __builtin_nontemporal_store(v, reinterpret_cast<zs_f4v*>(zp));
+              } else {
+                *zp = zz;
+              }
+            }
+            if (DIST == D_NORMAL) {
+              const float d0 = zz.x - m.x, d1 = zz.y - m.y, d2 = zz.z - m.z, d3 = zz.w - m.w;
+              stp[(kk + u) * LDW] = rowc - (fmaf(c[2], d2 * d2, c[0] * (d0 * d0)) + fmaf(c[3], d3 * d3, c[1] * (d1 * d1)));
+            } else {
+              stp[(kk + u) * LDW] = rowc + dens;
+            }
+          }
+        }
       }
       __syncthreads();
       const uint32_t nout = rows_in_tile * kb;
@@ -474,7 +511,7 @@ __global__ __launch_bounds__(1024) void k_logprob_tile(
         const float* __restrict__ src = zs_k2_stage + kk * LDW + q * D4;
         float sum = 0.f;
         for (uint32_t j = 0; j < D4; ++j) sum += src[j];
-        if (rbase + q < R) lp[(int64_t)(kb0 + kk) * sk + (rbase + q) * sr] = sum;
+        if (lp && rbase + q < R) lp[(int64_t)(kb0 + kk) * sk + (rbase + q) * sr] = sum;
       }
       __syncthreads();
     }
@@ -522,10 +559,12 @@ inline void launch_logprob_krep(int kid, const float* x, const float* mu, const 
       const bool stream_once = tile_env > 0 ? tile_env == 2 : (double)K * (double)R * (double)D4 * 16.0 > 268435456.0;
       if (stream_once)
         ZS_LAUNCH_SMEM(kid, (k_logprob_tile<DIST, true>), dim3(g.grid), dim3(g.threads), g.smem, st, (const float4*)x, (const float4*)mu,
-                       (const float4*)sigma, lp, (uint32_t)K, R, (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, ls);
+                       (const float4*)sigma, lp, (uint32_t)K, R, (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, ls,
+                       (float4*)nullptr);
       else
         ZS_LAUNCH_SMEM(kid, (k_logprob_tile<DIST, false>), dim3(g.grid), dim3(g.threads), g.smem, st, (const float4*)x, (const float4*)mu,
-                       (const float4*)sigma, lp, (uint32_t)K, R, (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, ls);
+                       (const float4*)sigma, lp, (uint32_t)K, R, (uint32_t)D4, (uint32_t)(R * D4), g.kchunk, g.KB, g.n_ptiles, g.total, sk, sr, ls,
+                       (float4*)nullptr);
       return;
     }
   }
