@@ -14,10 +14,10 @@ run() {   # tag which B kernel-name-fragment
   rm -rf $R/gpurun_out/pmc_${tag}_sq $R/gpurun_out/pmc_${tag}_FETCH_SIZE $R/gpurun_out/pmc_${tag}_WRITE_SIZE
 }
 run k2_4M k2 83886 "k_logprob_tile<0"
-run l2_4M l2 83886 "k_logprob_tile<1"
+run l2_4M l2 83886 "k_logprob_tile<1, true, false>"
 run u2_4M u2 83886 "k_logprob_tile<2"
 run k3bwd_6GB k3_bwd 20971 "k_bern_logprob_bwd"
-run l1u_1M l1_u 20971 "k_wave_rows"
+run l1u_1M l1_u 20971 "k_logprob_tile<1, true, true>"
 run k3logits_c3 k3_logits 256 "k_bern_logprob"
 run k3logits_1M k3_logits 20971 "k_bern_logprob"
 run k3probs_c3 k3 256 "k_bern_logprob"
