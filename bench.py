@@ -90,6 +90,10 @@ def parse_args(argv=None):
     ap.add_argument("--unfused-activations", action="store_true",
                     help="zhusuan.Linear inside torch.nn.Sequential: only the bias gradient is this package's (CS1), the activations "
                          "are torch's passes (round 3's first setting; extra_configs.c3_unfused_activations in the default run)")
+    ap.add_argument("--strong-scaling", action="store_true",
+                    help="split config 4's GLOBAL batch of 2048 over the ranks (2048 / N datapoints per GPU; N must divide 2048) instead of "
+                         "256 per GPU: the line then says \"scaling\": \"strong\" (SURVEY.md 8d: 'also strong scaling B = 2048 total'). "
+                         "The default, and what the driver runs, is weak scaling")
     ap.add_argument("--torch-adam", action="store_true",
                     help="update with torch.optim.Adam(fused=True, capturable=True) instead of zhusuan.optim.FlatAdam "
                          "(the same update over flat buckets, one launch)")
@@ -639,6 +643,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if args.strong_scaling:
+        global BATCH_PER_GPU
+        if 2048 % world:
+            raise SystemExit("bench: --strong-scaling splits 2048 datapoints; %d ranks do not divide it" % world)
+        BATCH_PER_GPU = 2048 // world
     # test hook (tests/test_bench_contract.py): several ranks share GPU 0 and talk over gloo, so that the multi-rank
     # control flow (shards, buckets, staged graphs, max-over-ranks timing) can be exercised on a one-GPU box.  RCCL
     # refuses two ranks on one device, so this is never a measurement mode.
@@ -953,7 +962,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "trials": len(trials), "timed_seconds_total": float(sum(trials)),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong_scaling else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": settings,
             "final_loss": final_loss,
