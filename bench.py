@@ -33,6 +33,11 @@ import os
 import sys
 import time
 
+# dmabuf IPC only on this pool: RCCL (and any CUDA-tensor sharing across processes) fails with "hipIpcGetMemHandle: invalid
+# argument" without it.  Set here, before torch is imported, so that a rank started by ANY launcher (the driver's
+# `python -m torch.distributed.run ... bench.py --gpus N` as well as launch_ranks below) has it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
@@ -110,8 +115,7 @@ def launch_ranks(n_ranks, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env = dict(os.environ)                                # (carries HSA_ENABLE_IPC_MODE_LEGACY=0, set at the top of this file)
     env.setdefault("OMP_NUM_THREADS", "8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
@@ -120,7 +124,8 @@ def launch_ranks(n_ranks, argv):
 
 
 # ZS_* variables that are this script's own test hooks (reported, never refused); every other ZS_* variable is an experiment
-_BENCH_OWN_ENV = ("ZS_BENCH_SHARE_DEVICE", "ZS_BENCH_NO_TRACER")
+_BENCH_OWN_ENV = ("ZS_BENCH_SHARE_DEVICE", "ZS_BENCH_NO_TRACER", "ZS_BENCH_FAIL_CAPTURE_RANK", "ZS_BENCH_STALL_RANK",
+                  "ZS_BENCH_WATCHDOG_S")
 
 
 def env_overrides():
@@ -254,8 +259,22 @@ def make_workload(name, dev, seed_rank=0, fused_logits=False, dense="fused"):
     raise ValueError(name)
 
 
-def cpu_step_fn(name):
-    """One full training step (fwd + bwd + Adam) of the CPU oracle on workload `name`; returns (step, evals per step)."""
+def cpu_model_name():
+    """The host CPU's model string (/proc/cpuinfo), as SURVEY.md section 8d asks next to the CPU baseline."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
+def cpu_step_fn(name, optimizer=True):
+    """One training step of the CPU oracle on workload `name`: fwd + bwd + Adam, or (optimizer=False) fwd + bwd only -- what
+    BASELINE.md's table of the reference on the host cores times.  Returns (step, evals per step)."""
     from oracle import zs_oracle as O
     import helpers as H
     rng = np.random.RandomState(1234)
@@ -271,7 +290,8 @@ def cpu_step_fn(name):
             loss, _ = O.iwae_loss(p, x, eps, PARTICLES, "vimco")
             opt.zero_grad()
             loss.backward()
-            opt.step()
+            if optimizer:
+                opt.step()
         return step, BATCH_PER_GPU * PARTICLES
     if name == "c2":
         spec = H.vae_param_spec()
@@ -284,7 +304,8 @@ def cpu_step_fn(name):
             loss, _ = O.vae_loss(p, x, torch.randn(512, Z_DIM))
             opt.zero_grad()
             loss.backward()
-            opt.step()
+            if optimizer:
+                opt.step()
         return step, 512
     if name == "c5":
         wm, wl, yl = H.bnn_params(512, 10)
@@ -298,12 +319,13 @@ def cpu_step_fn(name):
             loss, _ = O.bnn_loss(wm, wl, yl, xb, yb, eps, 10)
             opt.zero_grad()
             loss.backward()
-            opt.step()
+            if optimizer:
+                opt.step()
         return step, 5120
     raise ValueError(name)
 
 
-def cpu_baseline(name="c3", budget_s=8.0, one_thread_budget_s=5.0, max_steps=40):
+def cpu_baseline(name="c3", budget_s=8.0, one_thread_budget_s=5.0, max_steps=40, fwd_bwd_budget_s=4.0):
     """The CPU oracle (torch-CPU restatement of the reference's op sequence, pinned to the reference by
     tests/test_oracle_golden.py) on workload `name`: forward + backward + Adam on this host's cores, at the fastest
     intra-op thread count (calibrated: all cores is often NOT the fastest -- on a 256-thread box the unfused elementwise
@@ -311,7 +333,7 @@ def cpu_baseline(name="c3", budget_s=8.0, one_thread_budget_s=5.0, max_steps=40)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     step, evals = cpu_step_fn(name)
 
-    def timed(budget):
+    def timed(budget, step=step):
         step()
         n, t0 = 0, time.perf_counter()
         while n < max_steps and (n < 2 or (time.perf_counter() - t0) < budget):
@@ -332,10 +354,17 @@ def cpu_baseline(name="c3", budget_s=8.0, one_thread_budget_s=5.0, max_steps=40)
     torch.set_num_threads(best[0])
     n, dt = timed(budget_s)
     rec = {"value": evals * n / dt, "unit": "ELBO-evals/s", "cores": torch.get_num_threads(), "kind": "port",
-           "ms_per_step": 1e3 * dt / n, "host_cpus_available": avail,
+           "ms_per_step": 1e3 * dt / n, "host_cpus_available": avail, "cpu_model": cpu_model_name(),
            "sample": "%d full training steps (fwd+bwd+Adam) of the same workload, torch-CPU fp32 oracle, %.1f s" % (n, dt),
            "includes": "objective forward + backward + torch.optim.Adam update, like the GPU step it stands beside (the CPU table "
                        "of SURVEY.md section 6 / BASELINE.md times forward + backward only: no optimizer)"}
+    if fwd_bwd_budget_s:
+        # forward + backward ONLY (no optimizer), same thread count: the quantity BASELINE.md's CPU table holds for the reference
+        # itself (35.2 k evals/s at C3 on the build container's 8 cores: iwae.py:157-160-style steps without the update)
+        fb_step, _ = cpu_step_fn(name, optimizer=False)
+        nf, dtf = timed(fwd_bwd_budget_s, fb_step)
+        rec["fwd_bwd_only"] = {"value": evals * nf / dtf, "unit": "ELBO-evals/s", "cores": torch.get_num_threads(),
+                               "ms_per_step": 1e3 * dtf / nf, "sample": "%d steps of forward + backward without the optimizer, %.1f s" % (nf, dtf)}
     torch.set_num_threads(1)
     n1, dt1 = timed(one_thread_budget_s)
     rec["one_thread"] = {"value": evals * n1 / dt1, "unit": "ELBO-evals/s", "cores": 1, "ms_per_step": 1e3 * dt1 / n1,
@@ -345,7 +374,7 @@ def cpu_baseline(name="c3", budget_s=8.0, one_thread_budget_s=5.0, max_steps=40)
 
 
 # ------------------------------------------------------------------------------------------------ timing helpers
-def timed_trials(step, steps, world, dev, min_seconds=MIN_TIMED_SECONDS, max_trials=200):
+def timed_trials(step, steps, world, dev, min_seconds=MIN_TIMED_SECONDS, max_trials=200, kick=None):
     """Trials of exactly `steps` steps, each bracketed by synchronize + barrier and reduced with MAX over the ranks;
     at least three and as many as it takes to cover `min_seconds`.
     Returns (list of elapsed seconds per trial, last loss)."""
@@ -370,6 +399,8 @@ def timed_trials(step, steps, world, dev, min_seconds=MIN_TIMED_SECONDS, max_tri
     last = None
     # (every rank sees the same, rank-reduced, elapsed times, so every rank stops after the same trial)
     while len(trials) < max_trials and (len(trials) < 3 or sum(trials) < min_seconds):
+        if kick is not None:
+            kick("timed trial %d" % len(trials))
         el, last = one()
         trials.append(el)
     return trials, last
@@ -611,6 +642,7 @@ def device_kernel_times(run_steps, n_steps):
     included), from the device timestamps of every dispatch collected in-process by torch.profiler (roctracer).
     HIP events cannot do this: neither hipExtLaunchKernelGGL's start/stop events nor event-record nodes survive stream
     capture (tools/graph_event_probe.hip).  Returns {} when the tracer is unavailable (e.g. rocprofv3 attached)."""
+    done = [False]
     try:
         from torch.profiler import profile, ProfilerActivity
         import warnings
@@ -618,6 +650,7 @@ def device_kernel_times(run_steps, n_steps):
             warnings.simplefilter("ignore")
             with profile(activities=[ProfilerActivity.CUDA]) as prof:
                 run_steps(n_steps)
+                done[0] = True
                 torch.cuda.synchronize()
             acc = {}
             for e in prof.events():
@@ -632,7 +665,97 @@ def device_kernel_times(run_steps, n_steps):
         return dict((k, {"avg_us": sum(v) / len(v), "min_us": min(v), "count": len(v)}) for k, v in acc.items())
     except Exception as e:                                          # noqa: BLE001
         sys.stderr.write("bench: in-process device tracing unavailable (%r); using HIP-event timing of eager launches\n" % (e,))
+        if not done[0]:
+            # with several ranks the steps hold collectives: this rank must run as many as its peers, tracer or not.  (A tracer
+            # that fails to START has run none; run_steps itself raising is a real error and propagates from here.)
+            run_steps(n_steps)
+            torch.cuda.synchronize()
         return {}
+
+
+COLLECTIVE_TIMEOUT_S = 180      # process-group timeout: rendezvous, and every collective under RCCL's watchdog
+
+
+class Watchdog(object):
+    """A multi-rank run must END, with a reason, whatever goes wrong on a node nobody can log in to.  Every stage of main()
+    calls kick(name); a daemon thread checks the time since the last kick and, past the limit, writes ONE line to stderr
+    (rank, stage, seconds) and leaves with os._exit(5) -- torch.distributed.run then tears the other ranks down.  Nothing is
+    re-exec'ed, nothing is retried.  (The process group's own timeout catches a collective that never completes under RCCL;
+    this catches everything else: a rank waiting in a barrier for a peer that died silently, a stuck capture, a wedged
+    host thread.)"""
+
+    def __init__(self, rank, limit_s):
+        import threading
+        self.rank, self.limit, self.stage, self.t = rank, float(limit_s), "start", time.monotonic()
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+        self._thread.start()
+
+    def kick(self, stage):
+        self.stage, self.t = stage, time.monotonic()
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        while not self._stop.wait(1.0):
+            waited = time.monotonic() - self.t
+            if waited > self.limit:
+                sys.stderr.write("bench: rank %d made no progress for %.0f s in stage '%s' (limit %.0f s): giving up, exit code 5\n"
+                                 % (self.rank, waited, self.stage, self.limit))
+                sys.stderr.flush()
+                os._exit(5)
+
+
+def fail(rank, what, exc=None):
+    """One line, non-zero exit (the launcher ends the other ranks); never re-exec, never continue half-configured."""
+    sys.stderr.write("bench: rank %d: %s%s\n" % (rank, what, (": %r" % (exc,)) if exc is not None else ""))
+    sys.stderr.flush()
+    raise SystemExit(3)
+
+
+def short(e, limit=150):
+    """An exception for the one-line record: type and the head of its message (the full text goes to stderr)."""
+    t = repr(e)
+    sys.stderr.write("bench: %s\n" % t[:4000])
+    return t if len(t) <= limit else t[:limit - 3] + "..."
+
+
+LINE_LIMIT = 8192
+
+
+def fit_line(out, limit=LINE_LIMIT):
+    """The one-line record, ALWAYS printed and always under `limit` bytes (the driver keeps a tail of stdout).  Error texts were
+    cut when they were recorded (`short`); if the line is still too long -- many failing extras -- the optional parts go, least
+    important first, and the line says which (`dropped_from_line`; the full record keeps everything).  Never an assertion:
+    the run that needs its diagnostics most is the one with failures in it."""
+    line = json.dumps(out)
+    if len(line) <= limit:
+        return line
+    out = dict(out)
+    dropped = []
+    ex = dict(out.get("extra_configs") or {})
+    order = sorted(ex, key=lambda k: ("error" not in ex[k], k))      # failed extras first (their text is in the full record)
+    while order and len(json.dumps(dict(out, extra_configs=ex, dropped_from_line=dropped))) > limit:
+        key = order.pop(0)
+        ex.pop(key)
+        dropped.append("extra_configs." + key)
+    out["extra_configs"] = ex
+    for key in ("env_overrides", "library", "cpu_baseline"):
+        out["dropped_from_line"] = dropped
+        if len(json.dumps(out)) <= limit:
+            break
+        if key in out:
+            out[key] = None if key == "cpu_baseline" else "see full_record"
+            dropped.append(key)
+    out["dropped_from_line"] = dropped
+    line = json.dumps(out)
+    if len(line) > limit:                      # the contract keys alone (cannot be reached with sane values)
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "full_record")
+        line = json.dumps(dict(((k, out.get(k)) for k in keep), config={"workload": str(out.get("config", {}).get("workload"))[:200]},
+                               roofline=None, cpu_baseline=None, dropped_from_line=["everything else"]))
+    return line
 
 
 def main():
@@ -657,11 +780,29 @@ def main():
         raise SystemExit("bench: rank %d needs GPU %d, this node exposes %d" % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    wd = Watchdog(rank, float(os.environ.get("ZS_BENCH_WATCHDOG_S", "600"))) if world > 1 else None
+    kick = wd.kick if wd is not None else (lambda stage: None)
     if world > 1 or (args.force_collective_path and "RANK" in os.environ):
-        if share_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        kick("init_process_group")
+        try:
+            if share_device:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
+            else:
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
+            # the first collective builds the communicator (RCCL: rings over xGMI, dmabuf IPC handles): do it HERE, where a
+            # failure has one obvious meaning, not inside the first training step
+            kick("first collective (communicator set-up)")
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                fail(rank, "the first all-reduce over %d ranks returned %r" % (world, probe.item()))
+        except SystemExit:
+            raise
+        except Exception as e:                                      # noqa: BLE001
+            fail(rank, "process group set-up failed (backend %s, %d ranks, HSA_ENABLE_IPC_MODE_LEGACY=%s)"
+                 % ("gloo" if share_device else "nccl", world, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")), e)
 
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library("cublaslt" if args.blas == "hipblaslt" else "cublas")
@@ -674,7 +815,7 @@ def main():
         try:
             k1_first = k1_resident(_hip.lib(), dev)
         except Exception as e:                                      # noqa: BLE001
-            k1_first = {"error": repr(e)}
+            k1_first = {"error": short(e)}
     torch.manual_seed(0)
     dense = "torch" if args.torch_linear else ("zhusuan" if args.unfused_activations else "fused")
     model, obs, evals_per_step, _ = make_workload("c3", dev, seed_rank=rank, fused_logits=args.fused_logits, dense=dense)
@@ -753,40 +894,91 @@ def main():
     if "experiments" in klib.build_info() and not args.allow_experiments:
         raise SystemExit("bench: %s is an experiments build (%s); pass --allow-experiments" % (klib.path, klib.build_info()))
     mode = "eager"
+    capture_note = None
+    # test hooks (tests/test_bench_contract.py): ONE rank's graph capture fails / ONE rank stops making progress
+    fail_capture_rank = int(os.environ.get("ZS_BENCH_FAIL_CAPTURE_RANK", "-1"))
+    stall_rank = int(os.environ.get("ZS_BENCH_STALL_RANK", "-1"))
+
+    def maybe_fail_capture():
+        if rank == fail_capture_rank and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("capture failure injected on rank %d (ZS_BENCH_FAIL_CAPTURE_RANK)" % rank)
+
+    def agree(ok):
+        return dataparallel.all_ranks_agree(ok, device=dev)
+
+    def eager_staged_step():
+        """the staged step without graphs: the SAME stages, hence the same two all-reduces, launched from Python"""
+        stage_forward_and_decoder_backward()
+        sbuckets.launch(0)
+        stage_encoder_backward()
+        sbuckets.launch(1)
+        sbuckets.wait()
+        stage_update()
+        return sbuckets.loss()
+
     with zhusuan.device_rng(rng), zhusuan.skip_discarded_draws(skip_discarded):
         step = step_body
         if args.no_graph:
-            for _ in range(args.warmup):
+            for i in range(args.warmup):
+                kick("eager warm-up step %d" % i)
                 step_body()
         else:
             # The launch-bound inner loop (~130 kernels, most of them a few microseconds) is replayed from hipGraphs
             # (warm-up on the capture stream, thread-local capture mode): ONE graph with a single rank; with a
             # collective, graphs around the eagerly launched RCCL calls.
+            #
+            # Several ranks decide TOGETHER whether they replay graphs: a rank that fell back to eager launches alone would
+            # still have to issue exactly its peers' collectives.  Both fallbacks do (the staged step's fallback runs the same
+            # stages eagerly: two all-reduces of the same two buckets; the one-bucket step's fallback is step_body: the same one
+            # all-reduce), and the decision itself is an all-reduce (MIN) every rank makes at the same points: after each
+            # capture attempt inside GraphedStages / once after GraphedStep's recording.  An exception anywhere ELSE (warm-up,
+            # out of memory) ends this rank with a one-line reason and a non-zero exit code; the launcher ends the others.
+            kick("graph warm-up and capture")
+            captured = True
             try:
                 if staged:
-                    stages = [("graph", stage_forward_and_decoder_backward), ("eager", lambda: sbuckets.launch(0)),
+                    def first_stage():
+                        maybe_fail_capture()
+                        return stage_forward_and_decoder_backward()
+                    stages = [("graph", first_stage), ("eager", lambda: sbuckets.launch(0)),
                               ("graph", stage_encoder_backward), ("eager", lambda: (sbuckets.launch(1), sbuckets.wait())),
                               ("graph", stage_update)]
-                    gs = zhusuan.GraphedStages(stages, rng=rng, warmup=max(args.warmup, 3))
+                    gs = zhusuan.GraphedStages(stages, rng=rng, warmup=max(args.warmup, 3), agree=agree if world > 1 else None)
+                    captured, capture_note = gs.captured, gs.capture_error
 
                     def step():
                         gs()
                         return sbuckets.loss()
                     mode = "hipgraph x3, all-reduce of the decoder's gradients overlapped with the encoder's backward"
                 else:
-                    step = zhusuan.GraphedStep(compute_part, opt.step, exchange=exchange_part if multi else None, rng=rng,
-                                               warmup=max(args.warmup, 3))
+                    def compute_graphed():
+                        maybe_fail_capture()
+                        return compute_part()
+                    step = gstep = zhusuan.GraphedStep(compute_graphed, opt.step, exchange=exchange_part if multi else None, rng=rng,
+                                                       warmup=max(args.warmup, 3), agree=agree if world > 1 else None)
+                    captured, capture_note = gstep.captured, gstep.capture_error
                     mode = "hipgraph x2 around an eager all-reduce" if multi else "hipgraph"
-                for _ in range(3):
-                    step()
-            except Exception as e:                      # noqa: BLE001  (report, fall back to eager launches)
-                sys.stderr.write("bench: graph capture failed (%r); running eager\n" % (e,))
+            except Exception as e:                      # noqa: BLE001
+                if world > 1:        # not at a meeting point: the peers may be inside a collective this rank will never join
+                    fail(rank, "graph warm-up failed outside a capture (stage '%s')" % (wd.stage if wd else "?"), e)
+                captured, capture_note = False, short(e)
                 torch.cuda.synchronize()
-                step, mode = step_body, "eager"
+            if not captured:
+                sys.stderr.write("bench: rank %d: graph capture gave way to eager launches on every rank (%s)\n"
+                                 % (rank, capture_note or "another rank's capture failed"))
+                step = eager_staged_step if staged else step_body
+                mode = ("eager (graph capture failed on a rank; all ranks fell back together), %s"
+                        % ("two staged all-reduces" if staged else "one all-reduce")) if multi else "eager"
+            for i in range(3):
+                kick("post-capture step %d" % i)
+                step()
         if hooks:
             mode = "eager, all-reduce overlapped with backward from autograd hooks (2 buckets)"
         gemm_tuning(tuned, tune=False)       # the warm-up has seen every GEMM shape of the step: keep the picks, stop timing
-        trials, last = timed_trials(step, args.steps, world, dev)
+        if rank == stall_rank:              # test hook: this rank stops here; its peers wait in the first trial's barrier
+            time.sleep(10 ** 6)
+        trials, last = timed_trials(step, args.steps, world, dev, kick=kick)
+        kick("per-kernel timing passes")
         elapsed = float(np.median(trials))
         final_loss = float(last)
         # per-kernel durations: the same steps launched eagerly with start/stop HIP events bound to each
@@ -837,6 +1029,23 @@ def main():
             run_steps(n_dev)
             dev_times = {}
         torch.cuda.synchronize()
+        # every replica started from rank 0's weights and applied the same averaged gradients: their parameters must be
+        # bit-identical after any number of steps.  A collective that summed the wrong buffers shows up here.
+        replicas = None
+        if world > 1 and dist.is_initialized():
+            kick("replica check")
+            with torch.no_grad():
+                flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double()
+                mine = torch.stack([flat.sum(), flat.abs().sum(), (flat * flat).sum()])
+            gathered = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            sums = torch.stack(gathered).cpu()
+            in_sync = bool((sums == sums[0:1]).all())
+            replicas = {"in_sync": in_sync, "ranks": world,
+                        "max_checksum_difference": float((sums - sums[0:1]).abs().max())}
+            if not in_sync:
+                sys.stderr.write("bench: rank %d: REPLICAS DIVERGED: per-rank parameter checksums %r\n" % (rank, sums.tolist()))
+    kick("record")
     assert np.isfinite(final_loss)
 
     if rank == 0:
@@ -958,6 +1167,7 @@ def main():
             "value": evals_per_step * world * args.steps / elapsed,
             "unit": "ELBO-evals/s",
             "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+            "replicas_in_sync": None if replicas is None else replicas["in_sync"],
             "collective_library": collective_library(share_device) if dist.is_initialized() else None,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -1002,7 +1212,7 @@ def main():
                     "launches, HIP events bound to each dispatch, each size right after 1 - 4 s of the kernel's own launches (VALU-issue "
                     "bound: the shader clock follows the recent load); bytes per row 4*D + 4 written + 8*D/K read (SURVEY.md 8d)")
             except Exception as e:                                  # noqa: BLE001
-                full["hbm_resident"] = {"error": repr(e)}
+                full["hbm_resident"] = {"error": short(e)}
             del model, opt, bucket
             torch.cuda.empty_cache()
             ex = full["extra_configs"] = {}
@@ -1011,7 +1221,7 @@ def main():
                 try:
                     ex[key] = run_single_gpu_config(name, dev, args.steps, args.warmup, **kw)
                 except Exception as e:                              # noqa: BLE001
-                    ex[key] = {"error": repr(e)}
+                    ex[key] = {"error": short(e)}
             base = dict(tuned=tuned, torch_adam=args.torch_adam, skip_discarded=skip_discarded, dense=dense)
             # the other single-GPU BASELINE configs, in the headline's settings
             extra("c2", "c2", **base)
@@ -1023,6 +1233,10 @@ def main():
             extra("c3_reference_example_graphed", "c3_probs", torch_adam="reference_capturable", **ref)
             extra("c5_reference_example", "c5", torch_adam="reference", eager=True, device_rng=False, **ref)
             extra("c5_reference_example_graphed", "c5", torch_adam="reference_capturable", **ref)
+            # the headline's settings on a NEW minibatch every replay (GraphedStep(inputs=...): a device-to-device copy of the
+            # next resident batch in front of each graph launch) -- the reference's loop never trains twice on one batch
+            # (iwae.py:151-160)
+            extra("c3_refresh", "c3", fused_logits=args.fused_logits, refresh=True, **base)
             # the headline's settings launched eagerly from Python (no graph), one resident minibatch
             extra("c3_eager", "c3", eager=True, fused_logits=args.fused_logits, **base)
             extra("c3_eager_torch_linear", "c3", eager=True, fused_logits=args.fused_logits, **dict(base, dense="torch"))
@@ -1044,16 +1258,20 @@ def main():
                 extra("c3_torch_adam", "c3", fused_logits=args.fused_logits, **dict(base, torch_adam=True))
             out["extra_configs"] = dict((k, ({"ms_per_step": v["ms_per_step"], "value": v["value"]} if "error" not in v else v))
                                         for k, v in ex.items())
+            if "error" not in ex.get("c3_refresh", {"error": 1}):
+                # how far a new minibatch per step is from the headline (same settings, same box, same run)
+                out["extra_configs"]["c3_refresh"]["vs_headline"] = ex["c3_refresh"]["value"] / out["value"]
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline("c3")
             full["cpu_baseline"] = cb
             out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                                    "sample": cb["sample"], "ms_per_step": cb["ms_per_step"], "one_thread_value": cb["one_thread"]["value"],
-                                   "host_cpus_available": cb["host_cpus_available"]}
+                                   "host_cpus_available": cb["host_cpus_available"], "cpu_model": cb["cpu_model"],
+                                   "fwd_bwd_only_value": cb.get("fwd_bwd_only", {}).get("value")}
             if extras:
                 for name, b1, b2 in (("c2", 2.5, 2.0), ("c5", 2.0, 1.5)):
                     if "error" not in full["extra_configs"].get(name, {"error": 1}):
-                        c = cpu_baseline(name, budget_s=b1, one_thread_budget_s=b2, max_steps=2000)
+                        c = cpu_baseline(name, budget_s=b1, one_thread_budget_s=b2, max_steps=2000, fwd_bwd_budget_s=0)
                         full["extra_configs"][name]["cpu_baseline"] = c
                         out["extra_configs"][name]["cpu_value"] = c["value"]
         try:
@@ -1062,11 +1280,13 @@ def main():
             out["full_record"] = os.path.relpath(args.full_record, ROOT) if args.full_record.startswith(ROOT) else args.full_record
         except OSError as e:
             out["full_record"] = "not written: %r" % (e,)
-        line = json.dumps(out)
-        assert len(line) <= 8192, "the one-line record must stay under 8 KB (%d bytes): move detail to the full record" % len(line)
-        print(line, flush=True)
+        print(fit_line(out), flush=True)
+    if wd is not None:
+        wd.kick("shutdown")
     if dist.is_initialized():
         dist.destroy_process_group()
+    if wd is not None:
+        wd.stop()
 
 
 if __name__ == "__main__":

@@ -74,8 +74,66 @@ def test_record_is_flat_where_the_driver_reads_it():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ("k1_frac_1M", "k1_frac_4M", "hbm_resident_frac", "k3_fwd_frac"):
         assert 'roof["%s"]' % key in src or '"%s"' % key in src, key
-    assert "assert len(line) <= 8192" in src and '"full_record"' in src
+    assert "print(fit_line(out), flush=True)" in src and "LINE_LIMIT = 8192" in src and '"full_record"' in src
     assert 'out["hip_kernels"]' not in src and '"hip_kernels": per_kernel' in src          # per-kernel table: full record only
+
+
+def _bench_module():
+    sys.path.insert(0, ROOT)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        import bench
+    finally:
+        sys.argv = argv
+    return bench
+
+
+def test_line_is_always_printed_and_always_fits():
+    """the 8 KB limit used to be an assertion AFTER all measurements -- a cascade of failing extras (each with an
+    unbounded repr) threw the whole record away.  Now: error texts are cut when recorded, and a line that is still too long
+    sheds optional parts (failed extras first) and says which."""
+    bench = _bench_module()
+    base = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "w"},
+            "roofline": {"frac": 0.5}, "cpu_baseline": {"value": 1.0}, "library": {"path": "p"}, "env_overrides": {}}
+    small = dict(base, extra_configs={"a": {"ms_per_step": 1.0, "value": 2.0}})
+    assert json.loads(bench.fit_line(small)) == small                        # nothing touched when it fits
+    ex = dict(("ok%d" % i, {"ms_per_step": 1.0, "value": 2.0}) for i in range(10))
+    ex.update(("bad%d" % i, {"error": "HIP out of memory " + "x" * 140}) for i in range(80))
+    line = bench.fit_line(dict(base, extra_configs=ex))
+    assert len(line) <= bench.LINE_LIMIT
+    rec = json.loads(line)
+    for key in REQUIRED:
+        assert key in rec, key
+    assert all(("ok%d" % i) in rec["extra_configs"] for i in range(10))      # the measured extras survive, failed ones go first
+    assert rec["dropped_from_line"] and all(d.startswith("extra_configs.bad") for d in rec["dropped_from_line"])
+    huge = dict(base, config={"workload": "w" * 20000})
+    rec = json.loads(bench.fit_line(huge))
+    assert len(json.dumps(rec)) <= bench.LINE_LIMIT and rec["metric"] == "m" and rec["value"] == 1.0
+    e = RuntimeError("y" * 5000)
+    assert len(bench.short(e)) <= 150
+
+
+def test_ranks_get_the_ipc_setting_and_a_bounded_rendezvous():
+    """VERDICT r04 item 1 (b, c): every rank process -- also one started by the driver's own torch.distributed.run -- sets
+    HSA_ENABLE_IPC_MODE_LEGACY=0 before torch is imported; the process group has a timeout; a failure exits with one line."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < src.index("import torch")
+    assert src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < src.index("def launch_ranks")
+    assert 'init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))' in src
+    assert "os.exec" not in src and "execv" not in src
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    r = subprocess.run([sys.executable, "-c", "import sys, os; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench; "
+                        "print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("0"), r.stdout + r.stderr
+
+
+def test_watchdog_ends_a_stuck_rank_with_one_line():
+    code = ("import sys, time; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench\n"
+            "w = bench.Watchdog(3, 2.0); w.kick('waiting for a peer'); time.sleep(30)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 5, (r.returncode, r.stderr[-500:])
+    assert "rank 3 made no progress" in r.stderr and "waiting for a peer" in r.stderr
 
 
 @pytest.mark.gpu
@@ -226,6 +284,7 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    assert rec["n_ranks_seen"] == 2 and "gloo" in rec["collective_library"] and rec["replicas_in_sync"] is True
     # default: three hipGraphs, the decoder-gradient all-reduce overlapping the encoder's backward; --no-overlap: two graphs
     # around one all-reduce; --no-graph --overlap-allreduce: eager launches, buckets leaving from autograd hooks
     assert ("overlapped" in rec["config"]["launch_mode"]) == (extra != ["--no-overlap"])
@@ -252,8 +311,55 @@ def test_bench_eight_ranks_sharing_one_gpu_over_gloo():
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 8 and rec["n_ranks_seen"] == 8 and rec["scaling"] == "weak" and "gloo" in rec["collective_library"]
+    assert rec["replicas_in_sync"] is True
     assert "hipgraph x3" in rec["config"]["launch_mode"] and rec["config"]["global_batch"] == 2048
     assert "dp8" in rec["config"]["parallelism"] and "two flat buckets" in rec["config"]["parallelism"]
     assert abs(rec["value"] - 8 * 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
     assert "NOT a measurement" in rec["test_mode"] and np.isfinite(rec["final_loss"])
     assert "graph capture failed" not in r.stderr, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--no-overlap"]])
+def test_one_ranks_failed_capture_takes_every_rank_to_eager_launches_together(extra):
+    """VERDICT r04 item 1 (a, d): rank 1's graph capture is made to fail.  The ranks meet (all-reduce MIN of "capture ok") and
+    fall back TOGETHER to the same stages launched eagerly -- the same collectives, so nobody waits for ever and nothing is
+    summed into the wrong buffer: the run ends normally, the line says so, and the replicas' parameters are bit-identical."""
+    env = dict(os.environ)
+    env["ZS_BENCH_SHARE_DEVICE"] = "1"
+    env["ZS_BENCH_FAIL_CAPTURE_RANK"] = "1"
+    env["ZS_BENCH_WATCHDOG_S"] = "300"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+           "--no-cpu-baseline", "--no-gemm-tuning"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_ranks_seen"] == 2 and rec["replicas_in_sync"] is True and np.isfinite(rec["final_loss"])
+    assert rec["config"]["launch_mode"].startswith("eager (graph capture failed on a rank; all ranks fell back together)")
+    assert ("two staged all-reduces" in rec["config"]["launch_mode"]) == (extra == [])
+    assert "capture failure injected on rank 1" in r.stderr          # rank 1 says why
+    assert r.stderr.count("gave way to eager launches on every rank") == 2        # ... and BOTH ranks changed mode
+    assert rec["env_overrides"].get("ZS_BENCH_FAIL_CAPTURE_RANK") == "1"
+
+
+@pytest.mark.gpu
+def test_a_rank_that_stops_ends_the_job_with_a_reason_instead_of_a_hang():
+    """Rank 1 stops making progress before the timed region.  Nobody can look at the node: the run must END, non-zero, with one
+    line naming the rank and the stage (the watchdog; under RCCL the process group's timeout does the same for a collective)."""
+    import time
+    env = dict(os.environ)
+    env["ZS_BENCH_SHARE_DEVICE"] = "1"
+    env["ZS_BENCH_STALL_RANK"] = "1"
+    env["ZS_BENCH_WATCHDOG_S"] = "25"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29553", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+           "--no-cpu-baseline", "--no-gemm-tuning"]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0
+    assert "made no progress" in r.stderr and "giving up, exit code 5" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]           # no line from a run that did not finish
+    assert time.time() - t0 < 600

@@ -482,3 +482,40 @@ def test_eight_rank_gloo_reproduces_the_global_batch_golden_of_config_4(tmp_path
                 p.grad = v
                 yield n, p
     assert _check_grads(g, Holder(outs[0]["grads"]), rtol_norm=1e-3) > 1000
+
+
+def _worker_agree(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "zhusuan-pytorch_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from zhusuan import dataparallel
+        # the protocol of zhusuan.GraphedStages(agree=...): after every capture attempt the ranks meet; rank 1's second "capture" fails
+        attempts = [(True, True), (True, False), (False, True), (True, True)]
+        votes = [dataparallel.all_ranks_agree(a[rank]) for a in attempts]
+        # ... and the stages launched eagerly afterwards issue the same collectives on both ranks (the fallback of bench.py)
+        loss, flat = _run_shard_staged(rank, world, "vimco")
+        torch.save({"votes": votes, "loss": loss, "flat": flat}, os.path.join(out_dir, "a%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_launch_mode_and_the_eager_fallback_stays_matched(tmp_path):
+    """a rank whose graph capture fails must not change the number or size of its collectives alone.  The
+    ranks vote (all-reduce MIN) at fixed points and fall back together; the fallback is the same two staged all-reduces."""
+    from zhusuan import dataparallel
+    assert dataparallel.all_ranks_agree(True) is True and dataparallel.all_ranks_agree(False) is False       # no process group
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_agree, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a0, a1 = torch.load(str(tmp_path / "a0.pt")), torch.load(str(tmp_path / "a1.pt"))
+    assert a0["votes"] == a1["votes"] == [True, False, False, True]
+    assert a0["loss"] == a1["loss"] and torch.equal(a0["flat"], a1["flat"])
+    loss, flat, _ = _run_shard(0, 1, "vimco")
+    host_backend.uninstall()
+    assert abs(a0["loss"] - loss) <= 2e-6 * abs(loss)
+    np.testing.assert_allclose(a0["flat"].numpy(), flat.numpy(), rtol=2e-4, atol=2e-6)

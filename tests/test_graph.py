@@ -285,3 +285,117 @@ def test_replays_and_eager_steps_do_not_grow_the_allocator(kind):
                 base = settled()
             else:
                 assert settled() <= base
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which_fails", [None, 0, 2])
+def test_a_failed_capture_with_agree_runs_the_same_stages_eagerly(which_fails):
+    """zhusuan.GraphedStages(agree=...) / GraphedStep(agree=...) (several ranks record the same step): `agree` is called once
+    after EVERY capture attempt, whatever happened; when it returns False (this rank's capture failed, or a peer's did) the
+    object gives its graphs up and runs the same stages eagerly -- same values as eager training, same eager stages in the
+    same order (the collectives of a multi-rank step), and no exception leaves the constructor."""
+    from zhusuan import dataparallel
+    dev = torch.device("cuda:0")
+
+    def make():
+        torch.manual_seed(3)
+        model = vae_mnist.build(32, hidden=64, device=dev, dense="zhusuan")
+        x = (torch.rand(32, 784, device=dev) < 0.5).float()
+        sb = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()])
+        opt = zs.optim.FlatAdam([list(model.generator.parameters()), list(model.variational.parameters())], lr=1e-3)
+        return model, {"x": x}, sb, opt, zs.DeviceRNG(dev, seed=9)
+
+    def stages(model, obs, sb, opt, rng, held, log, fail_at=None):
+        def boom(i):
+            if fail_at == i and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("injected capture failure in graph stage %d" % i)
+
+        def s1():
+            boom(0)
+            rng.begin_step()
+            sb.zero()
+            held["loss"] = model(obs)
+            sb.backward_stage(held["loss"], 0)
+            return held["loss"].detach()
+
+        def s2():
+            boom(1)
+            sb.backward_stage(held["loss"], 1)
+
+        def s3():
+            boom(2)
+            sb.scale(gradients=False)
+            opt.step(grad_scale=sb.grad_scale())
+        return [("graph", s1), ("eager", lambda: (log.append("c0"), sb.launch(0))), ("graph", s2),
+                ("eager", lambda: (log.append("c1"), sb.launch(1), sb.wait())), ("graph", s3)]
+    me, oe, sbe, ope, re_ = make()
+    mg, og, sbg, opg, rg = make()
+    votes, log_g, log_e = [], [], []
+
+    def agree(ok):
+        votes.append(ok)
+        return ok
+    gs = zs.GraphedStages(stages(mg, og, sbg, opg, rg, {}, log_g, fail_at=which_fails), rng=rg, warmup=3, restore=True,
+                          optimizer=opg, agree=agree)
+    if which_fails is None:
+        assert gs.captured and votes == [True, True, True] and len(gs.graphs) == 3
+    else:
+        assert not gs.captured and "injected capture failure" in gs.capture_error and gs.graphs == []
+        assert votes == [True] * (which_fails if which_fails < 2 else 2) + [False]      # nobody votes after the job fell back
+    del log_g[:]
+    eager = stages(me, oe, sbe, ope, re_, {}, log_e)
+    le, lg = [], []
+    with zs.device_rng(re_):
+        for _ in range(4):
+            first = None
+            for kind, fn in eager:
+                out = fn()
+                if kind == "graph" and first is None:
+                    first = out
+            le.append(float(first))
+    for _ in range(4):
+        lg.append(float(gs()))
+    np.testing.assert_allclose(lg, le, rtol=2e-5)
+    assert log_g == log_e == ["c0", "c1"] * 4                  # the eager stages (collectives) ran once per step, in order
+    for pe, pg in zip(me.parameters(), mg.parameters()):
+        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("peer_failed", [False, True])
+def test_graphed_step_with_agree_falls_back_when_any_rank_says_so(peer_failed):
+    dev = torch.device("cuda:0")
+    model_e, opt_e, rng_e, obs = _make("iwae", dev)
+    model_g, opt_g, rng_g, _ = _make("iwae", dev)
+    calls = []
+
+    def exchange(loss):
+        calls.append(1)
+        return loss
+    comp = _compute(model_g, rng_g, obs)
+
+    def compute():
+        if not peer_failed and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected capture failure")
+        return comp()
+    votes = []
+
+    def agree(ok):
+        votes.append(ok)
+        return ok and not peer_failed
+    step = zs.GraphedStep(compute, opt_g.step, exchange=exchange, rng=rng_g, warmup=3, restore=True, agree=agree)
+    assert votes == [peer_failed] and not step.captured and step.graphs == []
+    assert ("injected" in step.capture_error) == (not peer_failed)
+    calls.clear()
+    comp_e = _compute(model_e, rng_e, obs)
+    le, lg = [], []
+    with zs.device_rng(rng_e):
+        for _ in range(5):
+            le.append(float(comp_e()))
+            opt_e.step()
+    for _ in range(5):
+        lg.append(float(step()))
+    np.testing.assert_allclose(lg, le, rtol=2e-5)
+    assert len(calls) == 5
+    for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)

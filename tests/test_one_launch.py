@@ -219,6 +219,85 @@ def test_paired_draws_in_a_net_that_reads_its_first_draw(dev):
     assert abs(float(d.mean())) < 1.5 and 0.2 < float(d.std()) < 3.0
 
 
+@pytest.mark.parametrize("reparam", [True, False])
+def test_in_place_ops_on_a_latent_of_a_paired_draw(dev, reparam):
+    """both draws of a pair come out of ONE autograd Function.  Returned as views of shared bases they could
+    not be modified in place ("Output 0 of NormalSampleLogProbPairBackward is a view and is being modified inplace ... returns
+    multiple views"), which the single-draw path and the reference allow: a variational net that does z.mul_() / z += ... on
+    the value its factory returned must work with pair_draws on (the default) exactly as with pair_draws(False)."""
+    class Q(BayesianNet):
+        def __init__(self):
+            super().__init__()
+            self.mu = torch.nn.Parameter(torch.full((6, 8), 0.25))
+            self.ls = torch.nn.Parameter(torch.full((6, 8), -0.5))
+            self.two = False
+
+        def forward(self, observed):
+            self.observe(observed)
+            z1 = self.normal("z1", mean=self.mu, logstd=self.ls, is_reparameterized=reparam, reduce_mean_dims=[0], reduce_sum_dims=[1])
+            z1.mul_(0.5)                  # in place, on the first draw of the pair
+            z1 += 1.0
+            z1.clamp_(-3.0, 3.0)
+            if self.two:
+                self.normal("z2", mean=z1 * self.mu, std=torch.ones_like(self.mu.detach()), is_reparameterized=reparam,
+                            reduce_mean_dims=[0], reduce_sum_dims=[1])
+            return self
+
+    class P(BayesianNet):
+        def forward(self, observed):
+            self.observe(observed)
+            one = torch.ones(6, 8, device=observed["z1"].device if "z1" in observed else None)
+            z1 = self.normal("z1", mean=0 * one, std=one, reduce_mean_dims=[0], reduce_sum_dims=[1])
+            z2 = self.normal("z2", mean=z1, std=one, reduce_mean_dims=[0], reduce_sum_dims=[1]) if self.two else z1
+            self.normal("x", mean=z2, std=one, reduce_mean_dims=[0], reduce_sum_dims=[1])
+            return self
+    # a hierarchical net whose second latent is computed from the modified first draw: runs, finite gradients
+    model = ELBO(P(), Q(), estimator="sgvb").to(dev)
+    model.generator.two = model.variational.two = True
+    _seed(dev, 11)
+    with zs.pair_draws(True), launches() as names:
+        loss = model({"x": torch.zeros(6, 8, device=dev)})
+        loss.backward()
+    assert names.count("zs_normal_sample_logprob_pair") == 2 and torch.isfinite(loss) and torch.isfinite(model.variational.mu.grad).all()
+    # one latent: the pair's draws carry the call ids of two launches, so value and gradients equal pair_draws(False)
+    results = {}
+    for paired in (True, False):
+        model = ELBO(P(), Q(), estimator="sgvb").to(dev)
+        model.generator.two = model.variational.two = False
+        _seed(dev, 11)
+        with zs.pair_draws(paired), launches() as names:
+            loss = model({"x": torch.zeros(6, 8, device=dev)})
+            loss.backward()
+        assert (names.count("zs_normal_sample_logprob_pair") > 0) == paired, names
+        q = model.variational
+        results[paired] = (float(loss.detach()), q.mu.grad.detach().cpu().clone(), q.ls.grad.detach().cpu().clone())
+        assert torch.isfinite(loss) and torch.isfinite(q.mu.grad).all()
+    np.testing.assert_allclose(results[True][0], results[False][0], rtol=1e-6)
+    np.testing.assert_allclose(results[True][1].numpy(), results[False][1].numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(results[True][2].numpy(), results[False][2].numpy(), rtol=1e-5, atol=1e-7)
+    # the second draw of the pair (the one the objective scores) may be modified in place as well -- and, for a draw that is not
+    # reparameterised, autograd must NOTICE it (the K-summed backward needs the value): same contract as the single draw
+    mu = torch.full((6, 8), 0.25, device=dev, requires_grad=True)
+    sg = torch.ones(6, 8, device=dev)
+    with zs.pair_draws(True):
+        from zhusuan import _rng
+        with _rng.expecting_redraw():
+            d = zs.distributions.Normal(mean=mu, std=sg, is_reparameterized=reparam, group_ndims=1)     # (fused log-density)
+            first = d.sample(1)
+            assert "_pending_draw" in d.__dict__
+            second = d.sample(1)
+    assert first.data_ptr() != second.data_ptr() and first._base is None and second._base is None
+    lp = d.log_prob(second)
+    assert lp is d._fused[1] and lp._base is None
+    second.mul_(2.0)
+    if reparam:
+        (lp.sum() + second.sum()).backward()
+        assert torch.isfinite(mu.grad).all()
+    else:
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            lp.sum().backward()
+
+
 class _Hierarchical(BayesianNet):
     """q(z1) q(z2 | z1): the net's own code READS the value its first node factory returned."""
 

@@ -7,6 +7,7 @@ K particles of a datapoint stay contiguous for the importance-weight reduction (
 """
 import ctypes
 import math
+import weakref
 
 import torch
 
@@ -47,6 +48,21 @@ def _alloc_rows(K, has_k_axis, rest_shape, kfast, like):
     buf = torch.empty((K, R), dtype=like.dtype, device=like.device)
     view = buf.view(((K,) if has_k_axis else ()) + tuple(rest_shape))
     return buf, view, R, 1
+
+
+def _contiguous_strides(shape):
+    out, acc = [], 1
+    for n in reversed(tuple(shape)):
+        out.append(acc)
+        acc *= max(int(n), 1)
+    return tuple(reversed(out))
+
+
+def _own_tensor(base, offset, shape, strides):
+    """A tensor over part of `base`'s allocation that autograd does NOT see as a view of `base` (same memory, own version
+    counter, no `_base`): for kernels that write several results into one allocation."""
+    return torch.empty(0, dtype=base.dtype, device=base.device).set_(base.untyped_storage(), base.storage_offset() + offset,
+                                                                     tuple(shape), tuple(strides))
 
 
 def _kr_view(t, K, R):
@@ -158,14 +174,21 @@ class NormalSampleLogProbPair(torch.autograd.Function):
         D = _prod(shape[len(shape) - n_fold:])
         R = _prod(rest)
         lead = (K,) if has_k_axis else ()
+        # The kernel writes both draws into ONE allocation (z: [2, K, M]; rows: K-fastest [R, 2 K] or [2 K, R]).  The four outputs
+        # are handed to autograd as tensors of their OWN over disjoint parts of those allocations (Tensor.set_), not as views of
+        # two bases: several views of one base returned from one Function cannot be modified in place ("Output N of ... is a
+        # view and is being modified inplace ... returns multiple views"), and the reference allows z.mul_() /
+        # z.clamp_() / z += ... on a latent inside a variational net.
         zz = torch.empty((2,) + lead + shape, dtype=mu.dtype, device=mu.device)
+        zs_ = [_own_tensor(zz, j * K * M, lead + shape, _contiguous_strides(lead + shape)) for j in range(2)]
+        rstr = _contiguous_strides(rest)
         if has_k_axis and K > 1:            # K-fastest rows [R, 2 K]: each draw's [R, K] block keeps unit stride along K
             buf = torch.empty((R, 2 * K), dtype=mu.dtype, device=mu.device)
-            lps = [buf[:, j * K:(j + 1) * K].t().view(lead + rest) for j in range(2)]
+            lps = [_own_tensor(buf, j * K, lead + rest, (1,) + tuple(2 * K * t for t in rstr)) for j in range(2)]
             sk, sr = 1, 2 * K
         else:
             buf = torch.empty((2 * K, R), dtype=mu.dtype, device=mu.device)
-            lps = [buf[j * K:(j + 1) * K].view(lead + rest) for j in range(2)]
+            lps = [_own_tensor(buf, j * K * R, lead + rest, _contiguous_strides(lead + rest)) for j in range(2)]
             sk, sr = R, 1
         used = _rng_snapshot(rng_state, reparam)
         _hip.lib().call("zs_normal_sample_logprob_pair" + sfx, _hip.ptr(mu), _hip.ptr(sigma), seed, call, _hip.ptr(rng_state),
@@ -174,13 +197,22 @@ class NormalSampleLogProbPair(torch.autograd.Function):
             rng_state, call = used, 0
         ctx.meta = (seed, call, K, M, D, R, reparam, 1 if is_logstd else 0)
         ctx.rng_state = rng_state
-        ctx.save_for_backward(mu, sigma, zz)
-        return zz[0], lps[0], zz[1], lps[1]
+        if reparam:                 # backward regenerates epsilon: the draws themselves are not needed (and not kept alive)
+            ctx.save_for_backward(mu, sigma)
+        else:
+            # The K-summed backward of a draw that is not reparameterised needs the draw's VALUE.  Saving both outputs would make
+            # autograd check both whenever backward runs -- also the one nothing depends on (the factory's draw, which a net may
+            # well have modified in place).  So the allocation is saved, and each output's version is checked only when ITS
+            # gradient is formed (weak references: no cycle through the graph).
+            ctx.save_for_backward(mu, sigma, zz)
+            ctx.draw_refs = [(weakref.ref(t), t._version) for t in zs_]
+        return zs_[0], lps[0], zs_[1], lps[1]
 
     @staticmethod
     def backward(ctx, gz1, glp1, gz2, glp2):
         seed, call, K, M, D, R, reparam, ls = ctx.meta
-        mu, sigma, zz = ctx.saved_tensors
+        mu, sigma = ctx.saved_tensors[:2]
+        zz = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
         lib, sfx = _hip.lib(), _sfx(mu)
         gmu = gsigma = None
         for j, (gz, glp) in enumerate(((gz1, glp1), (gz2, glp2))):
@@ -198,6 +230,13 @@ class NormalSampleLogProbPair(torch.autograd.Function):
                 lib.call("zs_normal_sample_logprob_bwd" + sfx, _hip.ptr(sigma), None, seed, call + j, _hip.ptr(ctx.rng_state),
                          _hip.ptr(gz), _hip.ptr(glp), gsk, gsr, _hip.ptr(a), _hip.ptr(b), K, M, D, ls, _hip.stream_for(mu))
             else:
+                ref, version = ctx.draw_refs[j]
+                t = ref()
+                if t is not None and t._version != version:
+                    raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace "
+                                       "operation: draw %d of a paired Normal sample that is not reparameterised (its log-density's "
+                                       "gradient needs the value as drawn); is at version %d, expected version %d"
+                                       % (j + 1, t._version, version))
                 lib.call("zs_normal_logprob_bwd_ksum" + sfx, _hip.ptr(zz[j]), _hip.ptr(mu), _hip.ptr(sigma), _hip.ptr(glp), gsk, gsr,
                          None, _hip.ptr(a), _hip.ptr(b), K, R, D, ls, _hip.stream_for(mu))
             gmu, gsigma = (a, b) if gmu is None else (gmu + a, gsigma + b)

@@ -341,3 +341,18 @@ def broadcast_parameters(module, src=0, group=None):
             dist.broadcast(p.data, src=src, group=group)
         for b in module.buffers():
             dist.broadcast(b.data, src=src, group=group)
+
+
+def all_ranks_agree(ok, group=None, device=None):
+    """AND of ``ok`` over the ranks (all-reduce MIN of one integer): the meeting point where ranks decide TOGETHER between
+    two ways of running a step -- e.g. ``zhusuan.GraphedStages(..., agree=all_ranks_agree)``: hipGraph replay only if every
+    rank's capture succeeded.  A rank that changed its launch mode alone could issue another number or size of collectives
+    than its peers, and the job would hang.  Every rank must call it the same number of times.  With one rank (or no
+    process group) it returns ``bool(ok)``."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return bool(ok)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()) == 1)

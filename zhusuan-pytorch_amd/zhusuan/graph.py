@@ -74,13 +74,16 @@ class GraphedStep(object):
     :param restore: undo the warm-up's effect on parameters / optimizer state / RNG state after recording.
     :param optimizer: the optimizer object, needed only for ``restore`` (its state tensors are reset in place).
     :param parameters: iterable of the tensors ``restore`` must put back (default: the optimizer's parameters).
+    :param agree: several ranks: callable(ok) -> AND over the ranks (``zhusuan.dataparallel.all_ranks_agree``), called once
+        after the capture; if any rank's capture failed every rank runs the step eagerly (``captured`` False, ``capture_error``).
     :param inputs: dict name -> the STATIC tensor ``compute`` reads that observation from; ``step(name=batch)`` copies a new
         minibatch into it before replaying (shapes and dtypes must match: a graph has no dynamic shapes).
     """
 
     def __init__(self, compute, optimizer_step=None, exchange=None, rng=None, warmup=3, restore=False, optimizer=None,
-                 parameters=None, inputs=None):
+                 parameters=None, inputs=None, agree=None):
         self._inputs = dict(inputs) if inputs else {}
+        self.captured, self.capture_error = True, None
         if not torch.cuda.is_available():
             raise RuntimeError("zhusuan.GraphedStep needs a HIP device: the MI355X build has no CPU path")
         self._compute, self._opt_step, self._exchange, self._rng = compute, optimizer_step, exchange, rng
@@ -113,22 +116,40 @@ class GraphedStep(object):
                     eager_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            if self._exchange is None:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._static_loss = eager_step()
-                self.graphs = [g]
+
+            def record():
+                if self._exchange is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._static_loss = eager_step()
+                    self.graphs = [g]
+                else:
+                    ga = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                        self._static_loss = self._compute()
+                    self.graphs = [ga]
+                    if self._opt_step is not None:
+                        torch.cuda.synchronize()
+                        gb = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+                            self._opt_step()
+                        self.graphs.append(gb)
+            if agree is None:
+                record()
             else:
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                    self._static_loss = self._compute()
-                self.graphs = [ga]
-                if self._opt_step is not None:
-                    torch.cuda.synchronize()
-                    gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
-                        self._opt_step()
-                    self.graphs.append(gb)
+                # several ranks record the same step (no collective is issued while recording): they meet ONCE afterwards and
+                # replay graphs only if every rank's capture succeeded; otherwise every rank runs the step eagerly -- the same
+                # `exchange`, hence the same collectives, in either mode
+                ok = True
+                try:
+                    record()
+                except Exception as e:                # noqa: BLE001
+                    ok, self.capture_error = False, repr(e)
+                if not agree(ok):
+                    self.captured, self.graphs = False, []
+                    if self.capture_error is None:
+                        self.capture_error = "another rank's capture failed"
+            self._eager_step = eager_step
             torch.cuda.synchronize()
         if restore:
             with torch.no_grad():
@@ -169,6 +190,9 @@ class GraphedStep(object):
         sync = getattr(self._optimizer, 'sync_hyperparameters', None)
         if sync is not None:
             sync()              # zhusuan.optim.FlatAdam: upload lr / betas / eps if the caller changed them (a 4-float compare)
+        if not self.captured:
+            with self._rng_scope():
+                return self._eager_step()
         if self._exchange is None:
             self.graphs[0].replay()
             return self._static_loss
@@ -198,11 +222,17 @@ class GraphedStages(object):
     ``GraphedStep``; so is ``restore`` (with ``optimizer`` / ``parameters``): the warm-up passes are real training steps,
     and with ``restore=True`` parameters, optimizer state and the RNG state are put back after the last capture, so that
     constructing the object has no side effect on training.  The value returned by the FIRST graph stage is the step's
-    (static) loss tensor."""
+    (static) loss tensor.
 
-    def __init__(self, stages, rng=None, warmup=3, restore=False, optimizer=None, parameters=None):
+    ``agree``: with several ranks, a callable(ok: bool) -> bool that returns the AND of ``ok`` over the ranks (e.g.
+    ``zhusuan.dataparallel.all_ranks_agree``).  It is called once after every capture attempt; when any rank's capture
+    failed, every rank drops its graphs and the object runs the same stages eagerly from then on (``captured`` is False,
+    ``capture_error`` says why): the ranks issue the same collectives in either mode and cannot wait for each other."""
+
+    def __init__(self, stages, rng=None, warmup=3, restore=False, optimizer=None, parameters=None, agree=None):
         if not torch.cuda.is_available():
             raise RuntimeError("zhusuan.GraphedStages needs a HIP device: the MI355X build has no CPU path")
+        self.captured, self.capture_error = True, None
         kinds = [k for k, _ in stages]
         if not stages or any(k not in ("graph", "eager") for k in kinds) or "graph" not in kinds:
             raise ValueError("stages: a list of ('graph' | 'eager', callable) with at least one graph stage")
@@ -227,7 +257,9 @@ class GraphedStages(object):
                 out = fn()
                 if kind == "graph" and first is None:
                     first = out
+            self._static_loss = first
             return first
+        self._eager_pass = eager_pass
 
         with self._rng_scope():
             side = torch.cuda.Stream()
@@ -244,13 +276,34 @@ class GraphedStages(object):
                     self._plan.append(fn)
                     continue
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                    out = fn()
+                if agree is None:
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                        out = fn()
+                else:
+                    # Several ranks record the same step: a capture that fails on ONE rank must not let the others run on into
+                    # the next eager stage's collective (they would wait there for ever).  After every capture attempt the ranks
+                    # meet in `agree` -- the same number of calls on every rank, whatever happened -- and either all go on or
+                    # all give the graphs up and run the SAME stages eagerly (same collectives, same sizes, same order).
+                    ok, out = True, None
+                    try:
+                        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                            out = fn()
+                    except Exception as e:            # noqa: BLE001
+                        ok, self.capture_error = False, repr(e)
+                    if not agree(ok):
+                        self.captured = False
+                        if self.capture_error is None:
+                            self.capture_error = "another rank's capture failed"
+                        break
                 if pool is None:
                     pool = g.pool()
                     self._static_loss = out
                 self._plan.append(g)
                 torch.cuda.synchronize()
+            if not self.captured:
+                torch.cuda.synchronize()              # (collectives an earlier eager stage started have landed on every rank)
+                self._plan = [self._eager_pass]
+                self._static_loss = None
         self.graphs = [g for g in self._plan if isinstance(g, torch.cuda.CUDAGraph)]
         if restore:
             with torch.no_grad():
@@ -276,6 +329,9 @@ class GraphedStages(object):
         sync = getattr(self._optimizer, 'sync_hyperparameters', None)
         if sync is not None:
             sync()
+        if not self.captured:
+            with self._rng_scope():
+                return self._eager_pass()
         for item in self._plan:
             if isinstance(item, torch.cuda.CUDAGraph):
                 item.replay()
