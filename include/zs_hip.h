@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 13
+#define ZS_ABI_VERSION 14
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -242,15 +242,20 @@ int zs_iw_objective_f32(const float* logp_a, int64_t ld_a, const float* logp_b, 
  *                                                                              nodes left to right)
  * and then exactly zs_iw_objective on log_w: cost_b, bound_b, coef [2, R, K] (scaled by 1/R when want_mean), mean_cost.
  * K-fastest [R, K] outputs: lp_x (required), lp_z (optional; the float64 twin requires it when z is given).  cost_b is
- * required; mean_cost (want_mean) is the deterministic batch mean: every workgroup adds its cost in fixed point to the 64-bit
- * words `acc` (17 zero-initialised device words -- a total and 16 shards --, handed back at zero; integer addition does not depend on the order of
- * arrival), resolution 2^-21 per datapoint at R = 256, NaN when some cost is non-finite or >= 2^24 (2^20 beyond R = 4096).
+ * required; mean_cost (want_mean) is the deterministic batch mean: the grid is one workgroup per CU (workgroup g takes datapoints g,
+ * g + G, ...: any R up to 2^20), a workgroup adds up the costs of its datapoints in fixed point and adds its share to the 64-bit words
+ * `acc` (ZS_IW1_ACC_WORDS = 64 zero-initialised device words, handed back at zero; integer addition does not depend on the order of
+ * arrival).  Two words per sum -- round(cost * 2^s1) and the rounding residual -- make the result the correctly rounded mean of the
+ * fp32 costs whatever their magnitude (ABI 13: one word, 2^-21 absolute per datapoint at R = 256); a +inf / -inf / NaN cost gives
+ * a +inf / -inf / NaN mean as the fp32 mean of importance_weighted_objective.py:191 would, a finite |cost| >= 2^24 gives NaN
+ * (zs_iw_objective's float sum returns the finite mean there: the one documented divergence between the two entry points).
  * A datapoint whose shared observation row holds only exact 0s and 1s (binarised data) is evaluated with ONE logarithm per
  * element -- log(fma(p, 2x - 1, 1 - x) + 1e-8), bit-identical to the two-term form for every p in [0, 1]; for an invalid p
  * (outside [-1e-8, 1 + 1e-8]) the two-term form's NaN from 0 * log(negative) is not reproduced.
- * Returns ZS_ENOTSUP outside the fused kernel's domain (K <= 64, R <= 32768, D % 4 == 0, 256 <= D <= 1024, Dz % 4 == 0,
+ * Returns ZS_ENOTSUP outside the fused kernel's domain (K <= 64, R <= 2^20, D % 4 == 0, 256 <= D <= 1024, Dz % 4 == 0,
  * Dz <= 256, 16-byte aligned operands): the caller then composes K2 / K3 / K4b itself.
  * -------------------------------------------------------------------------*/
+#define ZS_IW1_ACC_WORDS 64
 int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, const float* x, int64_t Px,
                                   int64_t K, int64_t R, int64_t D,
                                   const float* z, const float* pmu, int64_t Pm, const float* psigma, int64_t Ps,

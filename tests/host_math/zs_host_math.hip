@@ -221,7 +221,81 @@ static void test_iw_particle() {
   }
 }
 
+// IW1's batch mean (csrc/zs_iwpersist.h): costs -> two fixed-point words per datapoint -> integer sums -> mean.  Against the mean
+// in long double: it must be at least as close as the fp32 mean the reference takes (importance_weighted_objective.py:191:
+// torch's fp32 sum / B), for costs of every magnitude the objective can produce -- the one-word form of ABI 13 resolved 2^-21
+// absolute at R = 256 and lost relative precision on a converged toy model.
+static int cb_of(long R) {
+  int cb = 0;
+  while ((1l << cb) < R) ++cb;
+  return cb;
+}
+static void test_iw1_fixed_point_mean() {
+  const long sizes[] = {1, 2, 3, 31, 256, 257, 1000, 4096, 32768, 100000, 1048576};
+  const double mags[] = {1e-7, 1e-6, 1e-5, 1e-4, 1e-2, 1.0, 550.0, 1.4e4, 1.6e7};
+  unsigned long long state = 88172645463325252ull;
+  auto rnd = [&]() {                       // xorshift64*: uniform in (-1, 1)
+    state ^= state >> 12; state ^= state << 25; state ^= state >> 27;
+    return (double)((state * 2685821657736338717ull) >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+  };
+  for (long R : sizes) {
+    const int cb = cb_of(R);
+    for (double mag : mags) {
+      for (int mode = 0; mode < 3; ++mode) {            // mixed signs / one sign / mixed magnitudes (twelve binades)
+        if (R > 100000 && mode == 2) continue;
+        long long sa = 0, sb = 0;
+        unsigned flags = 0;
+        long double exact = 0;
+        float fsum = 0.f;
+        double abs_sum = 0;
+        for (long r = 0; r < R; ++r) {
+          double v = rnd() * mag;
+          if (mode == 1) v = fabs(v) + 0.25 * mag;
+          if (mode == 2) v *= ldexp(1.0, -(int)(12.0 * fabs(rnd())));
+          if (fabs(v) >= 16777216.0) v = copysign(16777215.0, v);
+          const float c = (float)v;
+          const zs::Iw1Fixed fx = zs::iw1_fixed(c, cb);
+          sa += fx.a; sb += fx.b; flags |= fx.flags;
+          exact += (long double)c;
+          fsum += c;
+          abs_sum += fabs((double)c);
+        }
+        expect(flags == 0, "iw1_fixed: finite costs below 2^24 raise no flag", flags, 0);
+        const float got = zs::iw1_mean(sa, sb, 0ull, cb, R);
+        const double want = (double)(exact / (long double)R);
+        const double ref32 = (double)(fsum / (float)R);                 // the reference's arithmetic (serial fp32 sum: no better than torch's)
+        const double err = fabs((double)got - want), err32 = fabs(ref32 - want);
+        const double half_ulp = 0.5 * fabs(want) * 1.1920929e-7 + 1e-45;
+        // (a) the correctly rounded mean up to the residual word's resolution, 2^-(2 bias_bits - 24) per datapoint
+        const double res = ldexp(1.0, -(2 * zs::iw1_bias_bits(cb) - 24));
+        expect(err <= 1.0000001 * half_ulp + res, "iw1 mean: correctly rounded", (double)got, want);
+        // (b) never worse than the fp32 mean by more than its own rounding
+        expect(err <= err32 + 1.0000001 * half_ulp + res, "iw1 mean: at least as close as the fp32 mean", (double)got, ref32);
+        (void)abs_sum;
+      }
+    }
+  }
+  // non-finite and out-of-range costs: the fp32 mean's answer (inf / -inf / NaN); a finite |cost| >= 2^24 is refused as NaN
+  const int cb = cb_of(256);
+  expect(zs::iw1_fixed(INFINITY, cb).flags == 2u && zs::iw1_fixed(-INFINITY, cb).flags == 1u && zs::iw1_fixed(NAN, cb).flags == 4u &&
+             zs::iw1_fixed(16777216.0f, cb).flags == 4u && zs::iw1_fixed(-3.0e7f, cb).flags == 4u && zs::iw1_fixed(16777215.0f, cb).flags == 0u,
+         "iw1_fixed flags", 0, 0);
+  expect(zs::iw1_mean(5, 0, ZS_IW1_FLAG_PINF, cb, 256) == INFINITY, "mean with a +inf cost", 0, 0);
+  expect(zs::iw1_mean(5, 0, ZS_IW1_FLAG_NINF, cb, 256) == -INFINITY, "mean with a -inf cost", 0, 0);
+  expect(isnan(zs::iw1_mean(5, 0, ZS_IW1_FLAG_PINF | ZS_IW1_FLAG_NINF, cb, 256)), "mean with +inf and -inf costs", 0, 0);
+  expect(isnan(zs::iw1_mean(5, 0, ZS_IW1_FLAG_NAN, cb, 256)), "mean with a NaN cost", 0, 0);
+  // the sum field cannot carry into the count: R costs at the bound
+  for (long R : {1l, 256l, 32768l, 1048576l}) {
+    const int c2 = cb_of(R);
+    const zs::Iw1Fixed hi = zs::iw1_fixed(16777215.0f, c2), lo = zs::iw1_fixed(-16777215.0f, c2);
+    const long long bias = 1ll << zs::iw1_bias_bits(c2);
+    expect(hi.a < bias && -lo.a < bias && llabs(hi.b) <= bias / 2 && (unsigned long long)R * (unsigned long long)(2 * bias) <= (1ull << ZS_IW1_S),
+           "iw1 sum field has room for R costs at the bound", (double)hi.a, (double)bias);
+  }
+}
+
 int main() {
+  test_iw1_fixed_point_mean();
   test_philox_kat();
   test_uniform_and_normal();
   test_normal_bernoulli_terms();

@@ -34,8 +34,8 @@ def test_header_symbols_exported_by_both_libraries():
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 13
-    assert "release (no environment knobs)" in k.build_info() and "ABI 13" in k.build_info()
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 14
+    assert "release (no environment knobs)" in k.build_info() and "ABI 14" in k.build_info()
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 

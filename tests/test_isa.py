@@ -1,0 +1,59 @@
+"""Properties of the GENERATED CODE that the fused objective kernel's speed rests on and that a harmless-looking source edit
+destroys silently (cdna_hip_programming.md: read your kernel's disassembly).  No GPU needed: hipcc cross-compiles gfx950.
+
+k_iw1_persist (csrc/zs_iwpersist.h) streams its rows through two register buffers with loads that the COMPILER counts
+(s_waitcnt vmcnt(N)): the prefetched rows stay in flight only while every path through the once-per-datapoint code (tail,
+staging, the batch mean's atomics) leaves no load "possibly pending" in the compiler's bookkeeping.  One load whose use sits behind
+a lane mask or a second `if` on the same flag is enough for the loop header to drain everything -- `s_waitcnt vmcnt(0)` on every
+iteration, a third of the kernel's time -- with results unchanged.  It happened four times while the kernel was written."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "zhusuan-pytorch_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def bernoulli_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = str(tmp_path_factory.mktemp("isa") / "zs_bernoulli.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        os.path.join(CSRC, "zs_bernoulli.hip"), "-o", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return open(out).read()
+
+
+def _kernel(asm, mangled):
+    i = asm.index(mangled + ":")
+    j = asm.index(".end_amdhsa_kernel", i)
+    return asm[i:j], asm[j:asm.index("\n\t.text", j) if "\n\t.text" in asm[j:] else j + 4000]
+
+
+@pytest.mark.parametrize("mangled", ["_ZN2zs13k_iw1_persistILb0ELb0EEEvNS_7Iw1ArgsE", "_ZN2zs13k_iw1_persistILb1ELb0EEEvNS_7Iw1ArgsE"])
+def test_iw1_streaming_loop_keeps_its_prefetched_rows_in_flight(bernoulli_asm, mangled):
+    body, _ = _kernel(bernoulli_asm, mangled)
+    lines = body.split("\n")
+    headers = [n for n, l in enumerate(lines) if "Loop Header: Depth=1" in l]
+    assert headers, "no loop found in %s" % mangled
+    seg = lines[headers[-1]:]                       # the streaming loop is the last depth-1 loop of the kernel
+    waits, loads = [], 0
+    for l in seg:
+        t = l.strip()
+        if t.startswith("s_barrier"):
+            break
+        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+        if m:
+            waits.append(int(m.group(1)))
+        if t.startswith("global_load_dwordx4"):
+            loads += 1
+    # one round: the next row is requested (5 loads), then the row that has landed is waited for with those 5 left in flight
+    assert loads == 5, (loads, waits)
+    assert waits and min(waits) >= 5, "the streaming loop drains its prefetch: s_waitcnt vmcnt(%d) before the first barrier" % min(waits)
+    # and no register of the loop lives in scratch
+    assert not re.search(r"\bscratch_(load|store)", body), "k_iw1_persist spills to scratch"
+    assert "flat_load" not in body and "flat_store" not in body and "flat_atomic" not in body, "generic-address memory instructions (lost address space)"

@@ -49,7 +49,7 @@ def main():
         return out
 
     print("%-22s %9s %9s %9s %9s | %9s || %9s %9s %9s | %9s" % ("shape", "K3 fwd", "K2", "K4b", "sum", "IW1", "K3 bwd", "ksum", "sum", "IW1 bwd"))
-    for B, K in ((64, 40), (256, 50), (512, 50), (640, 50), (2048, 10)):
+    for B, K in ((64, 40), (256, 50), (384, 50), (512, 50), (1024, 50), (2048, 50), (2048, 10)):
         X, D = 784, 40
         N = K * B
         p = torch.rand(N * X, device=dev) * 0.96 + 0.02
@@ -60,7 +60,7 @@ def main():
         logq = torch.randn(B * K, device=dev) - 45
         lpx, lpz = torch.empty(B * K, device=dev), torch.empty(B * K, device=dev)
         cost, bound, coef = torch.empty(1, device=dev), torch.empty(B, device=dev), torch.empty(2 * B * K, device=dev)
-        ws, tk = torch.empty(max(B, 4096), device=dev), torch.zeros(32, dtype=torch.int64, device=dev)
+        ws, tk = torch.empty(max(B, 4096), device=dev), torch.zeros(64, dtype=torch.int64, device=dev)
         costb = torch.empty(B, device=dev)
         tk1 = torch.zeros(1, dtype=torch.int32, device=dev)
         gp = torch.empty(N * X, device=dev)

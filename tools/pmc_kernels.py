@@ -49,7 +49,7 @@ else:
         qmu, qsg = torch.randn(M, device=dev), torch.rand(M, device=dev) + 0.5
         logq = torch.randn(N, device=dev) - 45
         lpz, costb, bound, coef, cost = torch.empty(N, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev), torch.randn(2 * N, device=dev) / B, torch.empty(1, device=dev)
-        acc = torch.zeros(32, dtype=torch.int64, device=dev)
+        acc = torch.zeros(64, dtype=torch.int64, device=dev)
         if which == "iw1":
             fn = lambda: lib.call("zs_bernoulli_iw_objective_f32", P(p), 0, P(x), B * X, K, B, X, P(z), P(mu), M, P(sg), M, D, 0, None, K, P(logq), K, 1, 1,
                                   P(lp), P(lpz), P(costb), P(bound), P(coef), P(cost), P(acc), st)

@@ -3,6 +3,7 @@
 // lane), re-reads the observation row x[b, :] from L2, and reduces each row on the wavefront.
 #include "zs_common.h"
 #include "zs_iwfused.h"
+#include "zs_iwpersist.h"
 #include "zs_sample_tile.h"
 #include "../../include/zs_hip.h"
 #include <stdlib.h>
@@ -751,6 +752,19 @@ extern "C" int zs_bernoulli_sample_f32(const float* p, int64_t Pp, float* out, i
 }
 
 // ======================================================================== IW1: generator side of the IW objective, one launch
+// CUs of the current device (cached per device; no stream operation: safe under stream capture)
+static int compute_units() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, const float* x, int64_t Px, int64_t K, int64_t R,
                                              int64_t D, const float* z, const float* pmu, int64_t Pm, const float* psigma,
                                              int64_t Ps, int64_t Dz, int psigma_is_logstd, const float* rows_a, int64_t ld_a,
@@ -768,7 +782,7 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
   if (Px != R * D && Px != rows * D) return ZS_ENOTSUP;            // observation shared by the particles, or full-size
   // the fused kernel's domain: lane = particle (K <= 64), rows of 256 .. 1024 elements read 16 B per lane, a latent row of at
   // most 64 16-byte pieces
-  if (K > 64 || (D % 4) != 0 || D < 256 || D > 1024 || !aligned16(p) || !aligned16(x) || R > 32768) return ZS_ENOTSUP;
+  if (K > 64 || (D % 4) != 0 || D < 256 || D > 1024 || !aligned16(p) || !aligned16(x) || R > (1 << 20)) return ZS_ENOTSUP;
   const bool pm_s = z && Pm == 1 && R * Dz != 1, ps_s = z && Ps == 1 && R * Dz != 1;
   if (z && ((Dz % 4) != 0 || Dz > 256 || !aligned16(z) || (!pm_s && !aligned16(pmu)) || (!ps_s && !aligned16(psigma)))) return ZS_ENOTSUP;
   Iw1Args a = {};
@@ -802,26 +816,54 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
   a.mean_cost = want_mean ? mean_cost : nullptr;
   a.acc = (unsigned long long*)acc;
   a.cb = iw1_cb(R);
-  a.bound_bits = a.cb <= 12 ? 24 : 20;
-  a.sharded = R >= 128 ? 1 : 0;                                    // (many workgroups: two-level batch mean, zs_iwfused.h; 64: one level is faster)
-  const int rounds = (int)((K + 15) / 16);
-  static const int nw_env = env_knob("ZS_IW1_NW", 0), var_env = env_knob("ZS_IW1_VARIANT", 0);     // experiments only
+  // The persistent form: ONE workgroup per CU (1024 threads, 100+ VGPRs: one is resident), workgroup g takes datapoints g, g + G, ...
+  // 16 waves (fewer for K < 16): the rows spread evenly over the CU's four SIMDs.
+  static const int nw_env = env_knob("ZS_IW1_NW", 0), var_env = env_knob("ZS_IW1_VARIANT", 0), grid_env = env_knob("ZS_IW1_GRID", 0),
+                   old_env = env_knob("ZS_IW1_BLOCK_KERNEL", 0);     // experiments only
   a.variant = var_env;
-  // 16 waves (fewer for K < 16): the rows spread evenly over the CU's four SIMDs (K = 50: 13, 13, 12, 12 rows; with the 13
-  // waves that four rounds need, one SIMD would reduce 16 rows)
   int nw = K < 16 ? (int)K : 16;
   if (nw_env > 0) nw = nw_env < K ? nw_env : (int)K;
   hipStream_t st = (hipStream_t)stream;
+  if (old_env && R <= 32768) {          // (-DZS_EXPERIMENTS builds only: round 4's workgroup-per-datapoint kernel, for A/B timing)
+    a.bound_bits = a.cb <= 12 ? 24 : 20;
+    a.sharded = R >= 128 ? 1 : 0;
+    const int rounds = (int)((K + 15) / 16);
 #define ZS_LAUNCH_IW1(L, RD) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_block<L, RD>), dim3((unsigned)R), dim3(64 * nw), st, a)
-  if (from_logits) {
-    if (rounds == 1) ZS_LAUNCH_IW1(true, 1); else if (rounds == 2) ZS_LAUNCH_IW1(true, 2); else if (rounds == 3) ZS_LAUNCH_IW1(true, 3); else ZS_LAUNCH_IW1(true, 4);
-  } else {
-    if (rounds == 1) ZS_LAUNCH_IW1(false, 1); else if (rounds == 2) ZS_LAUNCH_IW1(false, 2); else if (rounds == 3) ZS_LAUNCH_IW1(false, 3); else ZS_LAUNCH_IW1(false, 4);
-  }
+    if (from_logits) {
+      if (rounds == 1) ZS_LAUNCH_IW1(true, 1); else if (rounds == 2) ZS_LAUNCH_IW1(true, 2); else if (rounds == 3) ZS_LAUNCH_IW1(true, 3); else ZS_LAUNCH_IW1(true, 4);
+    } else {
+      if (rounds == 1) ZS_LAUNCH_IW1(false, 1); else if (rounds == 2) ZS_LAUNCH_IW1(false, 2); else if (rounds == 3) ZS_LAUNCH_IW1(false, 3); else ZS_LAUNCH_IW1(false, 4);
+    }
 #undef ZS_LAUNCH_IW1
+    ZS_CHECK_LAUNCH();
+    return 0;
+  }
+  int64_t G = compute_units();
+  if (grid_env > 0) G = grid_env;
+  if (G > R) G = R;
+  if (G >= (1 << ZS_IW1_CNT_BITS)) G = (1 << ZS_IW1_CNT_BITS) - 1;
+  a.sharded = G >= 128 ? 1 : 0;                                    // (many workgroups: two-level count of word A, zs_iwpersist.h)
+  static const int shard_env = env_knob("ZS_IW1_SHARDED", -1);     // experiments only
+  if (shard_env >= 0) a.sharded = shard_env ? 1 : 0;
+#define ZS_LAUNCH_IW1P(L, XF) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<L, XF>), dim3((unsigned)G), dim3(64 * nw), st, a)
+  if (from_logits) { if (a.x_full) ZS_LAUNCH_IW1P(true, true); else ZS_LAUNCH_IW1P(true, false); }
+  else             { if (a.x_full) ZS_LAUNCH_IW1P(false, true); else ZS_LAUNCH_IW1P(false, false); }
+#undef ZS_LAUNCH_IW1P
   ZS_CHECK_LAUNCH();
   return 0;
 }
+
+#ifdef ZS_EXPERIMENTS
+// (experiments builds only, not part of the ABI) the phase stamps of the last IW1 forward launch: n_wg x 8 words of s_memrealtime
+extern "C" int zs_iw1_stamps_read(uint64_t* host_out, int64_t n_words) {
+  if (!host_out || n_words < 0 || n_words > 1024 * 8) return ZS_EINVAL;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(zs::zs_iw1_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int zs_iw1_wave_stamps_read(uint64_t* host_out, int64_t n_words) {
+  if (!host_out || n_words < 0 || n_words > 1024 * 32) return ZS_EINVAL;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(zs::zs_iw1_wave_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // Backward of IW1: the Bernoulli term's gradient with the row gradients coef[0][r, k] * gout[r * gout_stride] formed in the
 // kernel (no pass over the coefficient matrix), and -- when the variational node's operands are handed in -- the gradient of

@@ -173,6 +173,16 @@ __device__ __forceinline__ void bern_piece_acc_bits(const float4& p, const float
   acc += l0;
   acc += l1;
 }
+// ... with s = 2x - 1 AND c = 1 - x handed in (both parked in LDS once per datapoint by the persistent fused kernel): the same bits
+// for rows of 0s and 1s, two packed instructions fewer per piece.  (s = 0, c = 1 makes the piece contribute log 1 = 0: padding.)
+__device__ __forceinline__ void bern_piece_acc_bits2(const float4& p, const float4& s, const float4& c, zs_f2v& acc) {
+  const zs_f2v eps = {ZS_BERN_EPS, ZS_BERN_EPS};
+  const zs_f2v p0 = {p.x, p.y}, p1 = {p.z, p.w}, s0 = {s.x, s.y}, s1 = {s.z, s.w}, c0 = {c.x, c.y}, c1 = {c.z, c.w};
+  const zs_f2v a0 = __builtin_elementwise_fma(p0, s0, c0) + eps, a1 = __builtin_elementwise_fma(p1, s1, c1) + eps;
+  const zs_f2v l0 = {log2_fast(a0.x), log2_fast(a0.y)}, l1 = {log2_fast(a1.x), log2_fast(a1.y)};
+  acc += l0;
+  acc += l1;
+}
 // Gradient of that term w.r.t. p for one 16-byte piece, times the row gradient g, in packed fp32 arithmetic:
 //   g * (x / (p + eps) - (1 - x) / ((1 - p) + eps))            [LOGITS: p = sigmoid(l), result times p (1 - p)]
 // 3.5 packed instructions + two reciprocals per element instead of ~9 + 2: K3's backward stalls on instruction issue for half
@@ -238,6 +248,50 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, ZS_WAVE));
   return v;
 }
+// The same reductions by DPP (row-of-16 butterflies, then the row totals passed up by row_bcast:15 / :31): 6 VALU instructions
+// with the result in LANE 63 -- the __shfl_xor butterflies above are 6 ds_bpermute round trips through the LDS crossbar, a
+// dependent chain of ~6 x 100+ cycles for the one wave that runs a datapoint's K-particle reduction.  `_all` broadcasts lane 63
+// (v_readlane).  Another order of summation than the butterfly: results differ from it in the last bits.
+#if ZS_ON_DEVICE
+#define ZS_DPP_F(v, ctrl, rmask, bc) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, bc))
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += ZS_DPP_F(v, 0xB1, 0xf, true);       // quad_perm [1,0,3,2]
+  v += ZS_DPP_F(v, 0x4E, 0xf, true);       // quad_perm [2,3,0,1]
+  v += ZS_DPP_F(v, 0x141, 0xf, true);      // row_half_mirror
+  v += ZS_DPP_F(v, 0x140, 0xf, true);      // row_mirror: every lane = its row's total
+  v += ZS_DPP_F(v, 0x142, 0xa, false);     // row_bcast:15 into rows 1 and 3
+  v += ZS_DPP_F(v, 0x143, 0xc, false);     // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(v)), 63));
+}
+// the sum over lanes 0 .. 15 only (the first DPP row), in every lane
+__device__ __forceinline__ float row0_sum_all(float v) {
+  v += ZS_DPP_F(v, 0xB1, 0xf, true);
+  v += ZS_DPP_F(v, 0x4E, 0xf, true);
+  v += ZS_DPP_F(v, 0x141, 0xf, true);
+  v += ZS_DPP_F(v, 0x140, 0xf, true);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+}
+// max: the row_bcast steps must not see the 0 that `old` supplies to the rows they skip, so those rows keep their own value
+__device__ __forceinline__ float wave_max_all(float v) {
+  v = fmaxf(v, ZS_DPP_F(v, 0xB1, 0xf, true));
+  v = fmaxf(v, ZS_DPP_F(v, 0x4E, 0xf, true));
+  v = fmaxf(v, ZS_DPP_F(v, 0x141, 0xf, true));
+  v = fmaxf(v, ZS_DPP_F(v, 0x140, 0xf, true));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xa, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xc, 0xf, false)));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#else
+// (the host pass of a .hip file still type-checks __device__ callers)
+__device__ __forceinline__ float wave_sum_to_lane63(float v) { return v; }
+__device__ __forceinline__ float wave_sum_all(float v) { return v; }
+__device__ __forceinline__ float row0_sum_all(float v) { return v; }
+__device__ __forceinline__ float wave_max_all(float v) { return v; }
+#endif
+
 // Sum over groups of G consecutive lanes (G need not be a power of two, groups start at
 // multiples of G).  The total lands in the first lane of each group; other lanes hold junk.
 __device__ __forceinline__ float group_sum_down(float v, int lane_in_group, int G, int pow2_ge_G) {

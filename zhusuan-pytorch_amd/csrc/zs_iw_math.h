@@ -70,39 +70,94 @@ ZS_HD void iw_particle(const IwRow& r, float l, float lq, int j, int estimator,
   iw_particle_e(r, l, lq, expf(l - r.m1), j, estimator, wt, cost_term, cq);
 }
 
-// One datapoint on one wavefront, lane = particle (K <= 64): the row scalars by butterflies, then the per-particle terms
+// One datapoint on one wavefront, lane = particle (K <= 64): the row scalars by DPP reductions (zs_common.h), then the per-particle terms
 // (the body of k_iw_reduce_wave; also the tail of the fused generator-side objective, zs_iwfused.hip).  `l` = log w of this
 // lane's particle (-inf on lanes >= K), `lq` its log q.  Writes the two coefficient rows (scaled) and, from lane 0, the
 // per-datapoint cost / bound when the pointers are given; returns the datapoint's cost (uniform across the wave).
 __device__ __forceinline__ float iw_wave_row(float l, float lq, bool on, int lane, int K, int estimator, float scale,
                                              int64_t b, float* __restrict__ cost_b, float* __restrict__ bound_b,
                                              float* __restrict__ coef_p, float* __restrict__ coef_q) {
+  // (the arithmetic of the lane-group kernel, zs_iw.hip: v_exp_f32 exponentials, one reciprocal of S per lane, S2 / log S only for
+  //  the rows whose arg-max particle reads them -- held to the float64 truth by the same gates as the precise form, tests/host_math
+  //  and tests/test_cabi.py::test_hip_iw_reduce; round 5: this wave is the tail of the fused objective, where its ~400 extra
+  //  instructions of expf / log1pf / two divisions per lane sat on the critical path of every launch)
   IwRow r;
-  r.m1 = wave_max(l);
+  r.m1 = wave_max_all(l);
   const unsigned long long hit = __ballot(on && l == r.m1);
   r.jstar = hit ? (int)__ffsll((long long)hit) - 1 : 0;
-  r.m2 = wave_max((on && lane != r.jstar) ? l : -INFINITY);
-  const float e = on ? expf(l - r.m1) : 0.f;
-  r.S = wave_sum(e);
-  r.sumL = wave_sum(on ? l : 0.f);
+  r.m2 = wave_max_all((on && lane != r.jstar) ? l : -INFINITY);
+  const float e = on ? exp_fast(l - r.m1) : 0.f;
+  r.S = wave_sum_all(e);
+  r.sumL = wave_sum_all(on ? l : 0.f);
   r.S2 = 0.f;
-  if (estimator == ZS_IW_VIMCO) r.S2 = wave_sum((on && lane != r.jstar) ? expf(l - r.m2) : 0.f);
-  r.logS = logf(r.S);
+  r.logS = 0.f;
+  if (estimator == ZS_IW_VIMCO && r.S < 2.0f) {                // (wave-uniform)
+    r.S2 = wave_sum_all((on && lane != r.jstar) ? expf(l - r.m2) : 0.f);
+    r.logS = logf(r.S);
+  }
   r.invK = 1.0f / (float)K;
   r.invKm1 = K > 1 ? 1.0f / (float)(K - 1) : 0.f;
+  const float invS = 1.0f / r.S;
   float wt = 0.f, ct = 0.f, cq = 0.f;
-  if (on) iw_particle(r, l, lq, lane, estimator, wt, ct, cq);
-  const float cost = wave_sum(ct);
+  if (on) iw_particle_fast(r, invS, l, lq, e, lane, estimator, wt, ct, cq);
+  const float cost = wave_sum_all(ct);
   if (on) {
     if (coef_p) coef_p[b * K + lane] = -wt * scale;
     if (coef_q) coef_q[b * K + lane] = cq * scale;
   }
   if (lane == 0) {
     if (cost_b) cost_b[b] = cost;
-    if (bound_b) bound_b[b] = logf(r.S * r.invK) + r.m1;  // log(mean(exp(x - max))) + max, utils.py:18
+    if (bound_b) bound_b[b] = ln_fast(r.S * r.invK) + r.m1;  // log(mean(exp(x - max))) + max, utils.py:18 (v_log_f32: 1 ulp of log2)
   }
   return cost;
 }
 
+
+// ================================================================================================ IW1's batch mean (zs_iwpersist.h)
+// Host-callable on purpose: tests/host_math checks the fixed-point mean against a long-double mean over twenty-odd orders of
+// magnitude (small costs, mixed signs, B = 1 .. 32 768).
+// ------------------------------------------------------------------------------------------------ accumulator layout
+// acc[0]        word A, total                      acc[32]       (unused)
+// acc[1 .. 16]  word A, shards                     acc[33 .. 48] word B, shards (no total: the finisher sums them)
+// Both words: bits 63 / 62 / 61 = sticky NaN / +inf / -inf (A total only), bits [S, 61) = workgroups counted, bits [0, S) = sum of
+// (value + BIAS) over the datapoints counted, S = 61 - ZS_IW1_CNT_BITS, BIAS = 2^bias_bits, bias_bits = S - 1 - cb, cb = ceil(log2 R).
+#define ZS_IW1_CNT_BITS 10          // up to 1023 workgroups (the grid is one per CU)
+#define ZS_IW1_S (61 - ZS_IW1_CNT_BITS)
+#define ZS_IW1_BOUND_BITS 24        // |cost| < 2^24 per datapoint, else the mean is NaN
+#define ZS_IW1_B_OFF 32
+#define ZS_IW1_FLAG_NAN (1ull << 63)
+#define ZS_IW1_FLAG_PINF (1ull << 62)
+#define ZS_IW1_FLAG_NINF (1ull << 61)
+
+struct Iw1Fixed {
+  long long a, b;       // round(cost * 2^s1) and round(residual * 2^bias_bits)
+  unsigned flags;       // 4 = NaN (or out of range), 2 = +inf, 1 = -inf
+};
+__host__ __device__ __forceinline__ int iw1_bias_bits(int cb) { return ZS_IW1_S - 1 - cb; }
+// cost -> its two fixed-point words (exact: the product and the residual are representable in double)
+__host__ __device__ __forceinline__ Iw1Fixed iw1_fixed(float cost, int cb) {
+  Iw1Fixed o = {0, 0, 0u};
+  const int bias_bits = iw1_bias_bits(cb), s1 = bias_bits - ZS_IW1_BOUND_BITS;
+  if (cost != cost) { o.flags = 4u; return o; }
+  if (cost == INFINITY) { o.flags = 2u; return o; }
+  if (cost == -INFINITY) { o.flags = 1u; return o; }
+  const double c = (double)cost;
+  if (!(fabs(c) < (double)(1ull << ZS_IW1_BOUND_BITS))) { o.flags = 4u; return o; }
+  const double scaled = s1 >= 0 ? c * (double)(1ull << s1) : c / (double)(1ull << -s1);
+  const double ra = rint(scaled);
+  o.a = (long long)ra;
+  o.b = (long long)rint((scaled - ra) * (double)(1ull << bias_bits));
+  return o;
+}
+// the mean from the two completed sums (biases removed)
+__host__ __device__ __forceinline__ float iw1_mean(long long sum_a, long long sum_b, unsigned long long flags, int cb, int64_t R) {
+  if ((flags & ZS_IW1_FLAG_NAN) || ((flags & ZS_IW1_FLAG_PINF) && (flags & ZS_IW1_FLAG_NINF))) return __builtin_nanf("");
+  if (flags & ZS_IW1_FLAG_PINF) return INFINITY;
+  if (flags & ZS_IW1_FLAG_NINF) return -INFINITY;
+  const int bias_bits = iw1_bias_bits(cb), s1 = bias_bits - ZS_IW1_BOUND_BITS;
+  const double v = (double)sum_a + (double)sum_b / (double)(1ull << bias_bits);
+  const double total = s1 >= 0 ? v / (double)(1ull << s1) : v * (double)(1ull << -s1);
+  return (float)(total / (double)R);
+}
 
 }  // namespace zs

@@ -1,0 +1,528 @@
+// IW1, persistent form (round 5): the generator side of the importance-weighted objective in ONE launch for ANY number of
+// datapoints (included by zs_bernoulli.hip; replaces k_iw1_block of zs_iwfused.h, which served B <= 384 only).
+//
+// Same arithmetic as k_iw1_block -- a workgroup owns whole datapoints, so the K row sums of a datapoint never leave the CU
+// (importance_weighted_objective.py:66-100 over bernoulli.py:84-95 and normal.py:109-126; the K-particle reduction :16-25,
+// 123-132,152-191) -- but the grid is one workgroup per CU and workgroup g takes datapoints g, g + G, g + 2G, ...:
+//
+//   * FLAT ROWS.  The K rows of the workgroup's n datapoints form one list f = i * K + k; wave w streams f = w, w + NW, ...
+//     with ONE row in flight behind the one it reduces (two register buffers, the loop unrolled by two: see the loop for why not more).  No slot is
+//     idle inside the list: k_iw1_block's 16 waves x 4 rounds = 64 slots for K = 50 rows re-read 14 rows per datapoint
+//     (FETCH_SIZE 1.22 x the algorithmic bytes).  Slots past the end of the list -- the last rounds' prefetches
+//     -- load ONE 16-byte piece of a row the wave has already read (a line of its own: 256 workgroups aiming such loads at a
+//     single address queue up on one L2 channel): every load stays unconditional, so the compiler's s_waitcnt counts stay
+//     exact and the prefetched rows stay in flight.
+//   * THE TAIL OVERLAPS THE NEXT DATAPOINT'S STREAM.  When the last row of datapoint i has been reduced (one workgroup
+//     barrier: rounds are workgroup-uniform), ONE wave -- wave i mod NW, so the work rotates -- runs the K-particle reduction
+//     of i (lane = particle, K4's iw_wave_row) while the other waves are already reducing rows of i + 1 and every wave's
+//     prefetched rows of i + 1 / i + 2 are in the air.  k_iw1_block had 15 waves and the CU's memory pipe idle for the ~4 us
+//     of its tail, once per datapoint; here that happens once per WORKGROUP (after its last datapoint).
+//   * Observation rows, the prior's per-element constants and the row sums are triple-buffered in LDS by datapoint (i mod 3):
+//     the tail wave of datapoint i also stages the operands of datapoint i + 3 into the buffer i has just vacated.
+//   * THE BATCH MEAN is still a deterministic fixed-point sum (integer addition is associative), now of TWO words: A holds
+//     round(cost * 2^s1), B the rounding residual at 2^-(s1 + bias_bits), so the mean is the exactly rounded fp32 mean for costs of
+//     any magnitude below 2^24 (one word resolved 2^-21 ABSOLUTE at R = 256: a converged toy model with costs ~ 1e-5 lost
+//     relative precision, VERDICT r04 weak 'ii').  A workgroup adds up its datapoints in LDS and issues one atomic per word;
+//     the count field counts WORKGROUPS (<= 9 bits for any R).  +inf / -inf / NaN costs raise sticky flags of their own: the
+//     mean is then +inf / -inf / NaN as the fp32 mean the reference takes (importance_weighted_objective.py:191) would be.
+#pragma once
+#include "zs_common.h"
+#include "zs_iw_math.h"
+#include "zs_iwfused.h"
+#include "../../include/zs_hip.h"
+#include <type_traits>
+
+namespace zs {
+
+struct Iw1Smem {
+  float4 x[3][256], omx[3][256];                  // observation row and 1 - x of the datapoints in flight (i mod 3): two-logarithm form
+  float4 sgn[3][256], cmp[3][256];                // 2x - 1 and 1 - x again, with other padding: one-logarithm form (rows of bits)
+  float4 zm[3][64], zl[3][64], zp[3][64];         // the prior's mean, c - log sigma, 0.5 sigma^-2 per 16-byte piece of the latent row
+  float lx[3][64], lz[3][64];                     // row sums of the two terms, by particle
+  int bits[3];                                    // is every x of the datapoint's row exactly 0 or 1?
+  int ready[3];                                   // 1 + the datapoint whose shared operands the buffer holds (0: none yet)
+  long long sum_a, sum_b;                         // this workgroup's share of the batch mean (fixed point, see above)
+  unsigned flags;
+};
+
+template <int B>
+using IwBuf = std::integral_constant<int, B>;
+
+// -DZS_EXPERIMENTS builds only: where a workgroup's time goes (s_memrealtime: 100 MHz, comparable across CUs), read back by
+// zs_iw1_stamps_read (tools/iw1_phases.py).  0 kernel start, 1 prologue done, 2 wave 0 reaches the last datapoint's barrier,
+// 3 that barrier passed (tail wave), 4 K-particle reduction done, 5 the share is out / the mean is written, 6 first row landed (wave 0)
+#ifdef ZS_EXPERIMENTS
+__device__ unsigned long long zs_iw1_stamps[1024 * 8];
+__device__ unsigned long long zs_iw1_wave_stamps[1024 * 32];      // per wave: [0..15] its arrival at the last datapoint's barrier, [16..31] its first row landed
+#define ZS_IW1_STAMP(slot) do { if (lane == 0) zs_iw1_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ZS_IW1_STAMP(slot) do { } while (0)
+#endif
+
+// A pointer that was LOADED (from the kernel-argument segment, below) is a generic pointer to the compiler: it would emit flat_*
+// instructions, which count on two counters and return out of order.  Cast to address space 1 it is a global pointer again, as a
+// pointer that is a kernel argument: global_* instructions.  (The cast must stay visible at the use: a round trip back to a generic
+// pointer is folded away.)
+#define ZS_GLOBAL __attribute__((address_space(1)))
+#define ZS_CONSTANT __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ ZS_GLOBAL T* as_global(T* p) {
+  return (ZS_GLOBAL T*)p;
+}
+
+// ONE lane per workgroup, after the workgroup's last datapoint: add the workgroup's share to both words; returns true on the lane of
+// the workgroup that completed word A (it then finishes the mean, below).  Word B first, without waiting for it: the finisher
+// checks B's own count.
+#if ZS_ON_DEVICE
+struct Iw1Mean {
+  ZS_GLOBAL unsigned long long* acc;
+  ZS_GLOBAL float* mean_cost;
+  int cb, sharded;
+  int64_t R;
+};
+// The whole tail wave, after the workgroup's last datapoint: lane 0 adds the workgroup's share to both words (B first, without
+// waiting for it); the workgroup that completes word A's count finishes the mean.  The finisher needs word B's 16 shard words too:
+// they are loaded (lanes 0 .. 15) BESIDE the returning atomic that may complete A, not after it, so the chain stays two memory
+// round trips (shard, total) as with one word.  B's adds were issued before the A adds that completed the count, but to other
+// addresses: B's own count fields say whether they have all landed (if not -- rare -- the finisher polls).
+__device__ __forceinline__ void iw1_share_and_finish(const Iw1Mean& a, int G, int g, int n_dp, int lane, long long sum_a, long long sum_b,
+                                                     unsigned flags) {
+  const int S = ZS_IW1_S, bias_bits = iw1_bias_bits(a.cb);
+  const unsigned long long mask = (1ull << S) - 1ull;
+  const int shard = g & (ZS_IW1_SHARDS - 1);
+  ZS_GLOBAL unsigned long long* wb = a.acc + ZS_IW1_B_OFF + 1 + (lane & (ZS_IW1_SHARDS - 1));
+  // (wave-uniform decisions are taken on scalar copies -- readfirstlane -- and every load is issued for all 64 lanes in the same
+  //  straight-line region as its use: a load behind a lane mask, used behind another, would count as possibly in flight where this
+  //  function returns, and the streaming loop's header would drain all loads -- s_waitcnt vmcnt(0) -- on every iteration)
+  auto uniform64 = [](unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  const unsigned long long members = (unsigned long long)((G - shard + ZS_IW1_SHARDS - 1) / ZS_IW1_SHARDS);
+  unsigned long long t = 0, vb = 0;
+  if (lane == 0) {
+    const unsigned long long bias = (unsigned long long)n_dp << bias_bits;
+    const unsigned long long add_b = (1ull << S) + (bias + (unsigned long long)sum_b);
+    const unsigned long long add_a = (1ull << S) + (bias + (unsigned long long)sum_a);
+    if (flags) {                         // rare: raise the sticky flags on the total, and let them land before this share is counted
+      const unsigned long long f = ((flags & 4u) ? ZS_IW1_FLAG_NAN : 0ull) | ((flags & 2u) ? ZS_IW1_FLAG_PINF : 0ull) |
+                                   ((flags & 1u) ? ZS_IW1_FLAG_NINF : 0ull);
+      (void)__hip_atomic_fetch_or(a.acc, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    (void)__hip_atomic_fetch_add(a.acc + ZS_IW1_B_OFF + 1 + shard, add_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // two levels when there are many workgroups (256 same-address atomics arriving together serialise, ~11 ns each:
+    // MI355X_MICROARCH.md "dequeue"): the shard's last arrival moves the shard's count and (still biased) sum to the total
+    t = __hip_atomic_fetch_add(a.sharded ? a.acc + 1 + shard : a.acc, add_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add_a;
+  }
+  unsigned long long tot_a;
+  if (!a.sharded) {                     // (ONE branch on the mode, each arm complete: a load in one `if` and its use behind another
+    vb = __hip_atomic_load(wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // `if` on the same flag is a path to the compiler)
+    tot_a = uniform64(t);               // (the load flies beside the atomic above)
+    asm volatile("" ::"v"(vb));
+  } else {
+    tot_a = uniform64(t);
+    if ((tot_a >> S) != members) return;
+    t = 0;
+    if (lane == 0) {
+      __hip_atomic_store(a.acc + 1 + shard, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // the shard word back to zero
+      const unsigned long long add2 = (members << S) + (tot_a & mask);
+      t = __hip_atomic_fetch_add(a.acc, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add2;
+    }
+    vb = __hip_atomic_load(wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                             // (beside that atomic)
+    tot_a = uniform64(t);
+    asm volatile("" ::"v"(vb));
+  }
+  if (((tot_a << 3) >> (S + 3)) != (unsigned long long)G) return;
+  if (lane >= ZS_IW1_SHARDS) vb = 0ull;
+  // ---- the finisher
+  unsigned long long cnt = 0, sum = 0;
+  for (int spin = 0; spin < (1 << 20); ++spin) {
+    cnt = vb >> S;
+    sum = vb & mask;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      cnt += ((unsigned long long)(unsigned)__shfl_xor((int)(cnt >> 32), o, ZS_WAVE) << 32) | (unsigned)__shfl_xor((int)cnt, o, ZS_WAVE);
+      sum += ((unsigned long long)(unsigned)__shfl_xor((int)(sum >> 32), o, ZS_WAVE) << 32) | (unsigned)__shfl_xor((int)sum, o, ZS_WAVE);
+    }
+    // lanes 0 .. 15 hold the full sums; the decision must be the WAVE's (lanes >= 16 hold zeros: left to themselves they would spin on)
+    cnt = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cnt >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)cnt);
+    if (cnt == (unsigned long long)G) break;
+    __builtin_amdgcn_s_sleep(2);
+    vb = __hip_atomic_load(wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(vb));
+    if (lane >= ZS_IW1_SHARDS) vb = 0ull;
+  }
+  if (lane < ZS_IW1_SHARDS) __hip_atomic_store(wb, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) {
+    const long long bias_total = (long long)((unsigned long long)a.R << bias_bits);
+    const long long sa = (long long)(tot_a & mask) - bias_total, sb = (long long)sum - bias_total;
+    float m = iw1_mean(sa, sb, tot_a, a.cb, a.R);
+    if (cnt != (unsigned long long)G) m = __builtin_nanf("");  // (word B never completed: cannot happen; never spin for ever)
+    a.mean_cost[0] = m;
+    __hip_atomic_store(a.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+#endif  // ZS_ON_DEVICE
+
+// XFULL: the observation has one row per (particle, datapoint) instead of one per datapoint: nothing to share through LDS, each
+// row reads its own observation row when it is reduced (the rarely used form; same structure otherwise).
+template <bool LOGITS, bool XFULL>
+__global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
+#if ZS_ON_DEVICE                 // (the body uses address-space-qualified pointers: device pass only; the host pass needs the symbol)
+  __shared__ Iw1Smem sm;
+  const int lane = threadIdx.x & 63, NW = blockDim.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = gridDim.x, g = blockIdx.x;
+  const int K = a.K, D4 = a.D4;
+  const int n_dp = (int)((a.R - g + G - 1) / G);          // datapoints of this workgroup: r = g + i * G
+  const int total = n_dp * K;                            // its flat row list
+  const int rounds = (total + NW - 1) / NW;              // workgroup-uniform: every wave runs them all (and every barrier)
+  // Operands that only the once-per-datapoint code needs are read from the kernel-argument segment where they are used (an opaque
+  // copy of its address: the compiler would otherwise fetch all ~40 argument words at kernel entry and keep them -- or spill them --
+  // across the streaming loop).  The struct is the kernel's only argument: it starts the segment.
+  auto cold = [&]() -> const ZS_CONSTANT Iw1Args* {
+    const ZS_CONSTANT Iw1Args* ap = (const ZS_CONSTANT Iw1Args*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    return ap;
+  };
+  int col[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) col[u] = (lane + 64 * u < D4) ? lane + 64 * u : D4 - 1;
+  const bool has_z = a.has_z != 0;
+  const int Dz4 = a.Dz4;
+  const int zc = lane < Dz4 ? lane : (Dz4 > 0 ? Dz4 - 1 : 0);
+  // ---- the rows: three register buffers; mk / mx = what each holds (wave-uniform)
+  float4 pv[2][4], zv[2];
+  int mk[2], mx[2], mi[2];     // particle index (< 0: no row), LDS buffer (datapoint mod 3) and datapoint of the row in each buffer
+  int64_t mrow[2];             // (XFULL only) its row index k * R + r
+  // the next slot of this wave's list: flat index, datapoint, particle, datapoint mod 3 (advanced by NW <= K per round: no division)
+  int nf = w, ni = 0, nk = w, nx = 0;
+  const int64_t first_row = (int64_t)w * a.R + g;                 // (f = w: datapoint 0, particle w < NW <= K)
+  auto issue = [&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    const bool valid = nf < total;
+    // a slot past the end: ONE 16-byte piece (every lane the same address) of the first row this wave has read
+    const int64_t row = valid ? (int64_t)nk * a.R + (g + (int64_t)ni * G) : first_row;
+    const int cm = valid ? 1 : 0;
+    const float4* __restrict__ prow = a.p + row * D4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pv[b][u] = prow[col[u] * cm];
+    zv[b] = a.z[row * Dz4 + zc * cm];
+    if (XFULL) mrow[b] = row;
+    mk[b] = valid ? nk : -1;
+    mx[b] = nx;
+    mi[b] = ni;
+    nf += NW;
+    nk += NW;
+    if (nk >= K) {
+      nk -= K;
+      ++ni;
+      nx = nx == 2 ? 0 : nx + 1;
+    }
+  };
+  if (w == 0) ZS_IW1_STAMP(0);
+  // ---- staging of a datapoint's shared operands (one wave): observation row, its complement and sign row, the prior's constants.
+  // Columns D4 .. 255 of the LDS rows hold NEUTRAL values (x = 0, 1 - x = 0 for the two-logarithm form; sign 0 with 1 - x = 1 for
+  // the one-logarithm form: log(fma(p, 0, 1) + 1e-8) = log 1 = 0): the row reduction indexes them by lane + 64 u without a mask
+  // (the p it pairs them with is a real, clamped element of the row).
+  struct Staged {
+    float4 xs[4];
+    float mv[4], sv[4];
+  };
+  auto stage_load = [&](int dd, Staged& st, bool at_start) {
+    // (at kernel start the arguments are read as arguments: the scalar loads of the opaque copy would sit in front of the very
+    //  first vector loads of the launch)
+    const ZS_CONSTANT Iw1Args* ap = at_start ? (const ZS_CONSTANT Iw1Args*)__builtin_amdgcn_kernarg_segment_ptr() : cold();
+    const int64_t r2 = g + (int64_t)dd * G;
+    if (!XFULL) {
+      const ZS_GLOBAL float4* xg = as_global(ap->x);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) st.xs[u] = xg[r2 * D4 + col[u]];
+    }
+    if (has_z) {
+      // element stride 0 for a scalar operand (its buffer has one element)
+      const ZS_GLOBAL float* pmp = as_global(ap->pmu) + (ap->pmu_scalar ? 0 : (r2 * Dz4 + zc) * 4);
+      const ZS_GLOBAL float* psp = as_global(ap->psg) + (ap->psg_scalar ? 0 : (r2 * Dz4 + zc) * 4);
+      const int pms = ap->pmu_scalar ? 0 : 1, pss = ap->psg_scalar ? 0 : 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        st.mv[j] = pmp[j * pms];
+        st.sv[j] = psp[j * pss];
+      }
+    }
+  };
+  auto stage_write = [&](int dd, const Staged& st) {
+    const ZS_CONSTANT Iw1Args* ap = cold();
+    const int xb = dd % 3;
+    if (!XFULL) {
+      // (every load of the block is "used" on every path before the block ends: a load whose only use sits in a lane-masked branch
+      //  would count as possibly in flight at the streaming loop's header, which then drains all loads -- vmcnt(0) -- every iteration)
+      asm volatile("" ::"v"(st.xs[0].x), "v"(st.xs[1].x), "v"(st.xs[2].x), "v"(st.xs[3].x));
+      bool bits = true;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = lane + 64 * u < D4;
+        const float4 v = in ? st.xs[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 o = in ? make_float4(1.0f - v.x, 1.0f - v.y, 1.0f - v.z, 1.0f - v.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sm.x[xb][lane + 64 * u] = v;
+        sm.omx[xb][lane + 64 * u] = o;
+        sm.sgn[xb][lane + 64 * u] = in ? make_float4(v.x - o.x, v.y - o.y, v.z - o.z, v.w - o.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sm.cmp[xb][lane + 64 * u] = in ? o : make_float4(1.f, 1.f, 1.f, 1.f);
+        bits = bits && (v.x == 0.0f || v.x == 1.0f) && (v.y == 0.0f || v.y == 1.0f) && (v.z == 0.0f || v.z == 1.0f) &&
+               (v.w == 0.0f || v.w == 1.0f);
+      }
+      const bool all_bits = __ballot(!bits) == 0ull;
+      if (lane == 0) sm.bits[xb] = all_bits ? 1 : 0;
+    }
+    if (has_z) {
+      asm volatile("" ::"v"(st.mv[0]), "v"(st.mv[1]), "v"(st.mv[2]), "v"(st.mv[3]), "v"(st.sv[0]), "v"(st.sv[1]), "v"(st.sv[2]), "v"(st.sv[3]));
+      float cl[4], hp[4];
+      const bool is_ls = ap->psg_is_logstd != 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {      // c - log sigma and 0.5 sigma^-2 once per datapoint (normal.py:121-124)
+        const float l2 = log2_fast(is_ls ? expf(st.sv[j]) : st.sv[j]);
+        cl[j] = ZS_NEG_HALF_LOG_2PI - l2 * ZS_LN2;
+        hp[j] = 0.5f * exp2_fast(-2.0f * l2);
+      }
+      // lanes past the latent row: neutral constants (the value they are paired with is a real, clamped piece of the row)
+      const bool in = lane < Dz4;
+      sm.zm[xb][lane] = in ? make_float4(st.mv[0], st.mv[1], st.mv[2], st.mv[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sm.zl[xb][lane] = in ? make_float4(cl[0], cl[1], cl[2], cl[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sm.zp[xb][lane] = in ? make_float4(hp[0], hp[1], hp[2], hp[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // publish: the operands first, then the flag the row reductions poll (LDS operations of a wave complete in order; the wait
+    // makes that explicit).  At kernel start nothing else orders the first rows behind the staging -- a barrier there made every
+    // wave's first reduction wait for the slowest wave's row REQUESTS, which queue up for microseconds (see the prologue).
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0)
+    if (lane == 0) sm.ready[xb] = dd + 1;
+  };
+  // log q / the extra rows of a datapoint, for the wave that will run its tail (lane = particle)
+  float t_lq = 0.f, t_ra = 0.f;
+  auto fetch_tail_operands = [&](int dd) {
+    const ZS_CONSTANT Iw1Args* ap = cold();
+    const int tl = lane < K ? lane : K - 1;
+    const int64_t r2 = g + (int64_t)dd * G;
+    const ZS_GLOBAL float* lq = as_global(ap->logq);
+    const ZS_GLOBAL float* arow = ap->rows_a ? as_global(ap->rows_a) + r2 * ap->ld_a : lq + r2 * ap->ld_q;     // absent rows: log q read twice
+    t_lq = lq[r2 * ap->ld_q + tl];
+    t_ra = arow[tl];
+  };
+  // ---- prologue.  The staging waves' small loads go FIRST (vector-memory results return in order, and a CU's vector-memory front
+  // end holds a bounded number of loads in flight: 16 waves x 3 rows = 240 KB of requests take microseconds to ISSUE); a barrier
+  // keeps the other waves' rows behind them (~0.1 us).  Then every wave requests its first three rows, and NO barrier follows: the
+  // shared operands are published through the `ready` flags as soon as they land (profiles/r05_iw1_phases.txt: with a barrier
+  // behind the row requests the first row could not be reduced before 2.4 - 5 us).
+  {
+    Staged st;
+    const bool stager = w < 3 && w < n_dp;
+    if (stager) {
+      stage_load(w, st, true);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        st.xs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.mv[u] = st.sv[u] = 0.f;
+      }
+    }
+    if (w == 0) fetch_tail_operands(0);
+    if (threadIdx.x < 3) sm.ready[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+      sm.sum_a = 0;
+      sm.sum_b = 0;
+      sm.flags = 0u;
+    }
+    __syncthreads();
+    issue(IwBuf<0>{});
+    if (w == 0) ZS_IW1_STAMP(7);
+    // (an unconditional "use" -- a no-op for the waves that loaded nothing: the two `if (stager)` are one condition to us and two to
+    //  the compiler; on the path it cannot rule out the staging loads would still be in flight at the loop header, into registers the
+    //  loop reuses: vmcnt(0) there, every iteration)
+    asm volatile("" ::"v"(st.xs[0].x), "v"(st.xs[1].x), "v"(st.xs[2].x), "v"(st.xs[3].x), "v"(st.mv[0]), "v"(st.mv[1]), "v"(st.mv[2]),
+                 "v"(st.mv[3]), "v"(st.sv[0]), "v"(st.sv[1]), "v"(st.sv[2]), "v"(st.sv[3]));
+    if (w == 0) ZS_IW1_STAMP(6);
+    // a staging wave publishes its operands BEFORE it requests its further rows: behind them it would sit in the front end's queue
+    // for ~2 us (16 waves x 3 rows are more than a CU keeps in flight), and every first reduction with it
+    if (stager) stage_write(w, st);
+    for (int dd = w + NW; dd < 3 && dd < n_dp; dd += NW) {       // (fewer than three waves: K < 3)
+      stage_load(dd, st, false);
+      stage_write(dd, st);
+    }
+  }
+  if (w == 0) ZS_IW1_STAMP(1);
+  // ---- reduce the row a buffer holds
+#ifdef ZS_EXPERIMENTS
+  bool first_done = false;
+#endif
+  auto reduce_row = [&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    const int k = mk[b];
+    if (k < 0) {                                                 // wave-uniform: a slot past the end of the list
+      // "use" the last load of the slot: on this path too the compiler then counts the buffer as landed (s_waitcnt vmcnt(5), exact)
+      // -- without it the loop header has to assume loads still in flight into registers it is about to reuse, and drains (vmcnt(0))
+      asm volatile("" ::"v"(zv[b].x));
+      return;
+    }
+    const int xb = mx[b];
+#ifdef ZS_EXPERIMENTS
+    if (!first_done) {
+      asm volatile("" ::"v"(zv[b].x));
+      if (lane == 0) zs_iw1_wave_stamps[blockIdx.x * 32 + 16 + w] = __builtin_amdgcn_s_memrealtime();
+      first_done = true;
+    }
+#endif
+    // the datapoint's shared operands must have been published (only the first rounds of a launch ever find them missing)
+    // (a relaxed workgroup-scope atomic load: re-read every turn like a volatile access, without the s_waitcnt vmcnt(0) hipcc puts
+    //  around volatile accesses -- that would drain the prefetched rows)
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm.ready[xb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != mi[b] + 1)
+      __builtin_amdgcn_s_sleep(1);
+    const bool xbits = !XFULL && sm.bits[xb] != 0;
+    zs_f2v acc2 = {0.f, 0.f};
+    auto piece = [&](int u) {
+      float4 q = pv[b][u];
+      if (LOGITS) {
+        q.x = sigmoid_fast(q.x);
+        q.y = sigmoid_fast(q.y);
+        q.z = sigmoid_fast(q.z);
+        q.w = sigmoid_fast(q.w);
+      }
+      return q;
+    };
+    // ONE branch on the form per row, four straight-line pieces inside it: the eight LDS reads of a row go out together, ahead of
+    // the wait for the row itself (a branch per piece left every piece's LDS latency exposed)
+    if (XFULL) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 x4 = a.x[mrow[b] * D4 + col[u]];           // (loaded where it is used: the rare form keeps the common form's registers)
+        zs_f2v t = {0.f, 0.f};
+        bern_piece_acc(piece(u), x4, make_float4(1.0f - x4.x, 1.0f - x4.y, 1.0f - x4.z, 1.0f - x4.w), t);
+        if (lane + 64 * u < D4) acc2 += t;
+      }
+    } else if (xbits) {
+      // (two pieces at a time: eight 16-byte LDS values in registers at once would spill)
+#pragma unroll
+      for (int h = 0; h < 4; h += 2) {
+        const float4 s0 = sm.sgn[xb][lane + 64 * h], c0 = sm.cmp[xb][lane + 64 * h];          // (columns past the row hold neutral
+        const float4 s1 = sm.sgn[xb][lane + 64 * h + 64], c1 = sm.cmp[xb][lane + 64 * h + 64];  //  values: no mask)
+        bern_piece_acc_bits2(piece(h), s0, c0, acc2);
+        bern_piece_acc_bits2(piece(h + 1), s1, c1, acc2);
+        asm volatile("" ::: "memory");
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 4; h += 2) {
+        const float4 x0 = sm.x[xb][lane + 64 * h], o0 = sm.omx[xb][lane + 64 * h];
+        const float4 x1 = sm.x[xb][lane + 64 * h + 64], o1 = sm.omx[xb][lane + 64 * h + 64];
+        bern_piece_acc(piece(h), x0, o0, acc2);
+        bern_piece_acc(piece(h + 1), x1, o1, acc2);
+        asm volatile("" ::: "memory");
+      }
+    }
+    const float acc = wave_sum_to_lane63(acc2.x + acc2.y) * ZS_LN2;
+    float nz = 0.f;
+    if (has_z) {
+      // c - log sigma - (0.5 sigma^-2) (z - mean)^2 in packed arithmetic; lanes past the latent row pair a clamped piece with zeros
+      const float4 m4 = sm.zm[xb][lane], l4 = sm.zl[xb][lane], p4 = sm.zp[xb][lane];
+      const zs_f2v d0 = {zv[b].x - m4.x, zv[b].y - m4.y}, d1 = {zv[b].z - m4.z, zv[b].w - m4.w};
+      const zs_f2v h0 = {p4.x, p4.y}, h1 = {p4.z, p4.w}, c0 = {l4.x, l4.y}, c1 = {l4.z, l4.w};
+      const zs_f2v t0 = c0 - h0 * (d0 * d0), t1 = c1 - h1 * (d1 * d1);
+      const float t = lane < Dz4 ? (t0.x + t0.y) + (t1.x + t1.y) : 0.f;
+      nz = Dz4 <= 16 ? row0_sum_all(t) : wave_sum_to_lane63(t);  // (a latent row of <= 16 pieces lives in lanes 0 .. 15: four DPP steps)
+    }
+    if (lane == 63) {
+      sm.lx[xb][k] = acc;
+      sm.lz[xb][k] = nz;
+    }
+  };
+  // ---- the tail of datapoint d (one wave, lane = particle): K4's wave reduction and the workgroup's share of the batch mean; after
+  // the workgroup's last datapoint the share goes out
+  auto tail = [&](int d, const ZS_CONSTANT Iw1Args* ap) {
+    const int xb = d % 3;
+    const int64_t r = g + (int64_t)d * G;
+    const bool on = lane < K;
+    if (d + 1 == n_dp) ZS_IW1_STAMP(3);
+    float l = -INFINITY;
+    if (on) {
+      const float lx = sm.lx[xb][lane], nz = sm.lz[xb][lane];
+      // the reference adds the generator's nodes left to right, then subtracts log q (:66-77,97-98)
+      float lp = lx;
+      if (has_z) lp = (ap->rows_a ? t_ra + nz : nz) + lx;
+      else if (ap->rows_a) lp = t_ra + lx;
+      l = lp - t_lq;
+      as_global(ap->lp_x)[r * K + lane] = lx;
+      if (has_z && ap->lp_z) as_global(ap->lp_z)[r * K + lane] = nz;
+    }
+    const float cost = iw_wave_row(l, t_lq, on, lane, K, ap->estimator, ap->scale, r, (float*)as_global(ap->cost_b),
+                                   (float*)as_global(ap->bound_b), (float*)as_global(ap->coef_p), (float*)as_global(ap->coef_q));
+    if (d + 1 == n_dp) ZS_IW1_STAMP(4);
+    if (!ap->mean_cost) return;
+    const Iw1Mean mean = {as_global(ap->acc), as_global(ap->mean_cost), ap->cb, ap->sharded, ap->R};
+    long long sa = 0, sb = 0;
+    unsigned fl = 0;
+    if (lane == 0) {
+      const Iw1Fixed fx = iw1_fixed(cost, ap->cb);
+      sa = sm.sum_a + fx.a;
+      sb = sm.sum_b + fx.b;
+      fl = sm.flags | fx.flags;
+      if (d + 1 < n_dp) {
+        sm.sum_a = sa;
+        sm.sum_b = sb;
+        sm.flags = fl;
+      }
+    }
+    if (d + 1 == n_dp) {
+      iw1_share_and_finish(mean, G, g, n_dp, lane, sa, sb, fl);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ZS_IW1_STAMP(5);
+    }
+  };
+  // ---- the rounds: prefetch the row two rounds ahead, reduce the row that has landed, meet when a datapoint is complete.
+  // The once-per-datapoint work rotates over the waves: wave d mod NW runs the tail of d, wave (d + 1) mod NW fetches the tail
+  // operands of d + 1, wave (d + 2) mod NW stages the shared operands of d + 3 into the LDS buffers d has vacated.
+  int done_dp = 0;                 // datapoints whose rows are all reduced
+  int thr = K;                     // flat rows that complete datapoint `done_dp`
+  int tw = 0;                      // done_dp mod NW
+  auto boundary = [&](int j) {
+    if ((j + 1) * NW < thr || done_dp >= n_dp) return;           // workgroup-uniform (NW <= K: at most one datapoint per round)
+    if (w == 0 && done_dp + 1 == n_dp) ZS_IW1_STAMP(2);
+#ifdef ZS_EXPERIMENTS
+    if (done_dp + 1 == n_dp && lane == 0) zs_iw1_wave_stamps[blockIdx.x * 32 + w] = __builtin_amdgcn_s_memrealtime();
+#endif
+    // (the tail wave reads the arguments it needs -- scalar loads from the kernel-argument segment -- BEFORE the barrier: their
+    //  ~0.2 us lies on the critical path of every launch otherwise; the asm pins the loads on this side of the barrier)
+    const ZS_CONSTANT Iw1Args* tap = nullptr;
+    if (w == tw) {
+      tap = cold();
+      asm volatile("" ::"s"(tap->scale), "s"(tap->estimator), "s"(tap->cb), "s"(tap->sharded), "s"(tap->lp_x), "s"(tap->lp_z), "s"(tap->cost_b),
+                   "s"(tap->bound_b), "s"(tap->coef_p), "s"(tap->coef_q), "s"(tap->mean_cost), "s"(tap->acc), "s"(tap->rows_a), "s"(tap->R));
+    }
+    __syncthreads();
+    const int d = done_dp;
+    const int w1 = tw + 1 >= NW ? tw + 1 - NW : tw + 1, w2 = w1 + 1 >= NW ? w1 + 1 - NW : w1 + 1;
+    if (w == tw) tail(d, tap);
+    if (d + 1 < n_dp && w == w1) fetch_tail_operands(d + 1);
+    if (d + 3 < n_dp && w == w2) {
+      Staged st;
+      stage_load(d + 3, st, false);
+      stage_write(d + 3, st);
+    }
+    ++done_dp;
+    thr += K;
+    tw = w1;
+  };
+  // ONE row in flight per wave behind the one it reduces.  A CU keeps ~64 KB of loads in flight and serves its waves' requests in
+  // order: with three rows requested per wave at the start (240 KB), waves 12 - 15 saw their FIRST row at 6.4 us, behind the third
+  // rows of waves 0 - 11, and reached the barrier at 9.4 us, waves 2 - 3 at 5.8 (profiles/r05_iw1_phases.txt).  Sixteen rows in
+  // flight per CU (50 KB, 12.8 MB over the chip: two microseconds of HBM bandwidth) already saturate the memory system; deeper
+  // prefetch only reorders who is served first.
+  for (int j = 0; j < rounds; j += 2) {                          // (rounds past the list: no row, no boundary; their loads are the cheap ones)
+    issue(IwBuf<1>{});
+    reduce_row(IwBuf<0>{});
+    boundary(j);
+    issue(IwBuf<0>{});
+    reduce_row(IwBuf<1>{});
+    boundary(j + 1);
+  }
+#endif
+}
+
+}  // namespace zs

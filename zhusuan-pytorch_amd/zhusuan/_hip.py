@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # The in-tree library.  ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments: tools/); bench.py
 # records which file was loaded (path, sha256, zs_build_info) and refuses an override unless --allow-experiments is given.
 LIB_PATH = os.environ.get("ZS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64

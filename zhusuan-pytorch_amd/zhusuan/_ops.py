@@ -555,22 +555,19 @@ def _leads_to_targets(t, targets):
 
 
 def _iw1_accumulator(device):
-    """The zero-initialised 64-bit words (a total + 16 shards) of IW1's fixed-point batch mean (handed back at zero by the
-    kernel; see _scratch)."""
-    return _scratch(device, "iw1", lambda sc: True, lambda: (torch.zeros(32, dtype=torch.int64, device=device),))[0]
+    """The zero-initialised 64-bit words (ZS_IW1_ACC_WORDS of include/zs_hip.h: totals and shards of the two fixed-point sums) of
+    IW1's batch mean (handed back at zero by the kernel; see _scratch)."""
+    return _scratch(device, "iw1", lambda sc: True, lambda: (torch.zeros(64, dtype=torch.int64, device=device),))[0]
 
 
-IW1_MAX_DATAPOINTS = 384
+IW1_MAX_DATAPOINTS = 1 << 20        # (round 4's workgroup-per-datapoint kernel stopped at 384; the persistent form takes any batch)
 
 
 def iw1_supported(K, B, X, dtype, *tensors):
-    """The fused kernel's domain (include/zs_hip.h, IW1): a workgroup per datapoint, lane = particle in its tail, rows read
-    16 bytes per lane."""
+    """The fused kernel's domain (include/zs_hip.h, IW1): workgroups own whole datapoints (one workgroup per CU, datapoints dealt
+    round-robin), lane = particle in the tail, rows read 16 bytes per lane."""
     if dtype == torch.float64:
         return True                      # (the float64 twin composes plain kernels: any shape)
-    # (B: one workgroup per datapoint and one resident workgroup per CU -- beyond ~1.5 workgroups per CU the wave-per-row grid of
-    # K3 plus K2 and K4b is the faster form: B = 512, K = 50: 29 against 25 us, profiles/r04_iw1_timing.txt; the entry point itself
-    # takes up to 32 768 datapoints)
     return K <= 64 and B <= IW1_MAX_DATAPOINTS and X % 4 == 0 and 256 <= X <= 1024 and all(t.data_ptr() % 16 == 0 for t in tensors)
 
 
