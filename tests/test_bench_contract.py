@@ -173,7 +173,7 @@ def test_bench_line_single_rank():
     ab1 = hk["zs_dense_act_bwd_f32"]            # caller-side layer kernels: bytes of all their launches, from the calls
     assert ab1["launches_per_step"] == 5 and ab1["algorithmic_bytes_per_step"] == 12 * (12800 * (2 * 500 + 784) + 256 * 2 * 500) + 4 * (4 * 500 + 784)
     lib = rec["library"]
-    assert lib["abi"] == 13 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
+    assert lib["abi"] == 14 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
     assert lib["path"].endswith("lib/libzs_hip.so") and rec["env_overrides"] == {}
     assert full["trial_ms_per_step"]["min"] <= rec["ms_per_step"] <= full["trial_ms_per_step"]["max"]
     # the same kernels on working sets beyond the Infinity Cache, measured in this run (full record)

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(1024) void k_adam_step(const Tensors<T> ts, T* __re
   __syncthreads();
   __shared__ unsigned last;
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, ZS_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     last = (t == gridDim.x - 1) ? 1u : 0u;
   }
   __syncthreads();

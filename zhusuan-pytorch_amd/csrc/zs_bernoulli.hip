@@ -879,8 +879,9 @@ extern "C" int zs_bernoulli_iw_objective_bwd_f32(const float* p, int from_logits
   if (!coef || !gout) return ZS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   // both gradients wanted and both roles on their 16-byte paths: ONE launch
+  static const int64_t bwd_rows = env_knob("ZS_IW1_BWD_ROWS", 32768);      // experiments only
   if (gp && zq && qmu && qsigma && gqmu && gqsigma && Dq >= 1 && p && x && (D % 4) == 0 && D >= 256 && D <= 1024 && K <= 65534 &&
-      K * R <= 32768 && (Px == R * D || Px == K * R * D) && aligned16(p) && aligned16(x) && aligned16(gp) && (Dq % 4) == 0 &&
+      K * R <= bwd_rows && (Px == R * D || Px == K * R * D) && aligned16(p) && aligned16(x) && aligned16(gp) && (Dq % 4) == 0 &&
       aligned16(zq) && aligned16(qmu) && aligned16(qsigma) && aligned16(gqmu) && aligned16(gqsigma)) {
     const int64_t Mq4 = R * Dq / 4;
     const int64_t bx_rows = (R + 3) / 4, bx_q = (Mq4 + 63) / 64;

@@ -24,6 +24,23 @@ namespace zs {
 // The SHIPPED library never reads the environment: dispatch depends on the arguments of a call and on nothing else.  The
 // ZS_* knobs that kernel experiments use (tools/) exist only in a library built with
 // `make EXTRA=-DZS_EXPERIMENTS`; zs_build_info() of a loaded library says which kind it is, and bench.py records it.
+// ---------------------------------------------------------------- the hand-off between workgroups, two builds
+// The one-launch kernels end with "every workgroup writes partials, the LAST to arrive combines them".  The shipped build orders that
+// hand-off the cheap way MI355X_MICROARCH.md lists as MEASURED on gfx950 (write-through sc1 stores, every storing wave's
+// s_waitcnt vmcnt(0), a workgroup barrier, ONE relaxed agent-scope atomic on the ticket, sc1 loads or one agent acquire on the
+// consuming side: zs_onelaunch.h) -- not an architectural guarantee.  `make strict` (-DZS_STRICT_HANDOFF) builds the same kernels
+// with the ticket taken ACQ_REL at agent scope -- buffer_wbl2 + wait before it, buffer_inv after it: the form the HIP memory
+// model guarantees, 2 - 7 us slower per workgroup -- and tests/test_strict_handoff.py requires both builds to return the same
+// bits over thousands of launches: a compiler or firmware change that breaks the cheap form shows there instead of as a rare
+// wrong number.  Never shipped: zs_build_info() says which build a library is.
+#ifdef ZS_STRICT_HANDOFF
+#define ZS_TICKET_ORDER __ATOMIC_ACQ_REL
+#define ZS_HANDOFF_KIND ", strict hand-off (agent-scope acq_rel tickets)"
+#else
+#define ZS_TICKET_ORDER __ATOMIC_RELAXED
+#define ZS_HANDOFF_KIND ""
+#endif
+
 #ifdef ZS_EXPERIMENTS
 inline int env_knob(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -353,34 +370,57 @@ ZS_HD uint32_t uniform_u32(uint32_t v) {
 // device.  On the GPU every entry point that draws is compared with the oracle (tests/test_cabi.py::test_hip_rng,
 // ::test_hip_normal_sample_and_backward, ::test_hip_device_rng_state; tests/test_locscale.py::test_hip_logistic_sample_and_backward,
 // ::test_hip_uniform_sample).
-ZS_HD Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) {
-  uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32);
-  uint32_t c2 = (uint32_t)call, c3 = (uint32_t)(call >> 32);
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < ZS_PHILOX_ROUNDS; ++r) {
+// Everything of rounds 1 and 2 that depends on (seed, call) only -- uniform over a launch: formed ONCE per batch of particles by
+// philox_call() and handed to the generator (round 5: left inside the generator, the three v_readfirstlane pins were re-executed for
+// every group of four draws -- the compiler does not hoist a convergent operation out of the particle loop; K1 is bound by VALU
+// issue, 77 instructions per four draws, so three of them are 4 %).
+struct PhiloxCall {
+  uint32_t u0, u1, u2, u3;      // hi(M1 * lo(call)) ^ k0;  lo(M1 * lo(call));  hi(call) ^ k1;  u1 ^ (k0 + W0)
+  uint32_t k0, k1;
+};
+ZS_HD PhiloxCall philox_call(uint64_t call, uint64_t seed) {
+  const uint32_t c2 = (uint32_t)call, c3 = (uint32_t)(call >> 32), k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+  PhiloxCall pc;
+  pc.u0 = uniform_u32((uint32_t)(p1 >> 32) ^ k0);
+  pc.u1 = uniform_u32((uint32_t)p1);
+  pc.u2 = uniform_u32(c3 ^ k1);
+  pc.u3 = uniform_u32(pc.u1 ^ (k0 + 0x9E3779B9u));
+  pc.k0 = uniform_u32(k0);
+  pc.k1 = uniform_u32(k1);
+  return pc;
+}
+ZS_HD Philox4 philox4x32_10(uint64_t group, const PhiloxCall& pc) {
+  uint32_t c0 = (uint32_t)group, c1 = (uint32_t)(group >> 32), c2, c3;
+  uint32_t k0 = pc.k0, k1 = pc.k1;
+  {                                              // round 1: one multiply, two xors with uniform words
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint32_t n0 = pc.u0 ^ c1, n2 = (uint32_t)(p0 >> 32) ^ pc.u2;
+    c0 = n0; c1 = pc.u1; c2 = n2; c3 = (uint32_t)p0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  {                                              // round 2: c1 is still uniform
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0, n2;
-    // readfirstlane pins a uniform xor to the scalar unit (the optimiser otherwise re-associates it into two v_xor)
-    if (r == 0) {                                  // uniform here: p1 (both halves), k0, c3, k1
-      n0 = uniform_u32((uint32_t)(p1 >> 32) ^ k0) ^ c1;   // one v_xor with the lane's c1 = hi(group)
-      n2 = (uint32_t)(p0 >> 32) ^ uniform_u32(c3 ^ k1);   // one v_xor
-    } else if (r == 1) {                           // uniform here: c1 (= lo(p1) of round 0), k0, k1
-      n0 = (uint32_t)(p1 >> 32) ^ uniform_u32(c1 ^ k0);   // one v_xor
-      n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
-    } else {
-      n0 = xor3_key((uint32_t)(p1 >> 32), c1, k0);
-      n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
-    }
-    const uint32_t n1 = (uint32_t)p1, n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ pc.u3, n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
+    c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int r = 2; r < ZS_PHILOX_ROUNDS; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = xor3_key((uint32_t)(p1 >> 32), c1, k0), n2 = xor3_key((uint32_t)(p0 >> 32), c3, k1);
+    c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
   Philox4 o = {c0, c1, c2, c3};
   return o;
 }
+ZS_HD Philox4 philox4x32_10(uint64_t group, uint64_t call, uint64_t seed) { return philox4x32_10(group, philox_call(call, seed)); }
 // Uniform STRICTLY inside (0, 1): (m + 0.5) * 2^-23 with m = v >> 9, i.e. the 2^23 midpoints 2^-24 ... 1 - 2^-24.  m + 0.5
 // needs 24 significant bits, so every value is exact in fp32 (shift, convert, one fma).  Round 1 used m = v >> 8 and
 // 2^-24: there m + 0.5 needs 25 bits, the top 256 words rounded up to exactly 1.0 and a Logistic draw log(u) - log(1 - u)
@@ -418,8 +458,8 @@ ZS_HD float angle_rev(uint32_t w) {
 //   radius from the uniform u01(x) strictly inside (0, 1) (at most 5.77 sigma), angle 2*pi*t from the upper 23 bits of y.
 // (The logarithm is taken of the scaled uniform itself: log2(m + 0.5) - 24 would save nothing after the fma in u01 and
 // cancels catastrophically for u close to 1, i.e. for radii close to 0.)
-ZS_HD float4 philox_normal4(uint64_t group, uint64_t call, uint64_t seed) {
-  Philox4 r = philox4x32_10(group, call, seed);
+ZS_HD float4 philox_normal4(uint64_t group, const PhiloxCall& pc) {
+  Philox4 r = philox4x32_10(group, pc);
   const float u0 = u01(r.x), u2 = u01(r.z);
   const float a1 = angle_rev(r.y), a3 = angle_rev(r.w);
   const float ra = sqrt_fast(-2.0f * ZS_LN2 * log2_fast(u0));
@@ -431,6 +471,7 @@ ZS_HD float4 philox_normal4(uint64_t group, uint64_t call, uint64_t seed) {
   n.w = rb * sin_rev(a3);
   return n;
 }
+ZS_HD float4 philox_normal4(uint64_t group, uint64_t call, uint64_t seed) { return philox_normal4(group, philox_call(call, seed)); }
 
 ZS_HD float f4_get(const float4& v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));

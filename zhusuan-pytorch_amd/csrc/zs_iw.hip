@@ -584,7 +584,7 @@ extern "C" int64_t zs_prof_durations(int kernel_id, double* out_ms, int64_t capa
 #define ZS_STR_(x) #x
 #define ZS_STR(x) ZS_STR_(x)
 extern "C" int zs_abi_version(void) { return ZS_ABI_VERSION; }
-extern "C" const char* zs_build_info(void) { return "libzs_hip gfx950 ABI " ZS_STR(ZS_ABI_VERSION) ", " ZS_BUILD_KIND; }
+extern "C" const char* zs_build_info(void) { return "libzs_hip gfx950 ABI " ZS_STR(ZS_ABI_VERSION) ", " ZS_BUILD_KIND ZS_HANDOFF_KIND; }
 
 extern "C" const char* zs_error_string(int code) {
   if (code == 0) return "success";

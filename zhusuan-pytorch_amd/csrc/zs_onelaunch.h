@@ -81,7 +81,7 @@ __device__ __forceinline__ void store_wt(T* p, T v) { __hip_atomic_store(p, v, _
 template <typename T>
 __device__ __forceinline__ T load_wt(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned ticket_take(unsigned* t) {
-  return __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_fetch_add(t, 1u, ZS_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);      // (relaxed; acq_rel in the strict build, zs_common.h)
 }
 __device__ __forceinline__ void ticket_return(unsigned* t) { __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(R1_BLOCK) void k_reinforce_many(const T* __restrict
     __hip_atomic_store(ws + 3 * blockIdx.x + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(ws + 3 * blockIdx.x + 2, s3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    last = __hip_atomic_fetch_add(ticket, 1u, ZS_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
       if (Kp && kb0 < Kp && kb0 + kb > Kp) kb = Kp - kb0;              // (two draws: a batch stays inside one of them)
       const bool second = Kp && kb0 >= Kp;
       const uint64_t callx = second ? call + 1 : call;
+      const PhiloxCall pc = philox_call(callx, seed);                 // the uniform part of the generator, once per batch (zs_common.h)
       if (on) {
         const uint64_t base = (uint64_t)kb0 * M4;                      // uniform
         // uniform base pointer per particle (scalar registers) + this lane's 32-bit byte offset: the stores need no
@@ -175,14 +176,18 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
           particle(make_float4((float)(uint32_t)g, 1.f, 2.f, 3.f), 0.f);
 #else
           if (DIST == D_NORMAL) {
+#ifdef ZS_K1_OLD_PHILOX       // (A/B builds only: round 4's generator call, uniform words re-formed per group)
             particle(philox_normal4(g, callx, seed), 0.f);
+#else
+            particle(philox_normal4(g, pc), 0.f);
+#endif
           } else if (DIST == D_UNIFORM) {
-            const Philox4 r = philox4x32_10(g, callx, seed);
+            const Philox4 r = philox4x32_10(g, pc);
             particle_uniform(make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w)));
           } else {
             // Logistic draw (logistic.py:64-66): eps = log u - log(1 - u); its own log-density -eps - 2 softplus(-eps)
             // is log u + log(1 - u): the two logarithms serve both
-            const Philox4 r = philox4x32_10(g, callx, seed);
+            const Philox4 r = philox4x32_10(g, pc);
             float4 e;
             float d0, d1, d2, d3;
             logistic_draw(u01(r.x), e.x, d0);

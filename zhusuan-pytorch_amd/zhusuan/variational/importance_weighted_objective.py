@@ -16,6 +16,9 @@ _ERR_VIMCO = ("VIMCO is a multi-sample gradient estimator, size along "
               "`axis` in the objective should be larger than 1.")
 
 
+_LOGQ = object()      # key of log q among the log-probabilities a fused attempt hands to the per-node path (cannot be a node's name)
+
+
 class ImportanceWeightedObjective(nn.Module):
     """
     :param generator: BayesianNet p(x, z).
@@ -71,11 +74,12 @@ class ImportanceWeightedObjective(nn.Module):
             # a subclass overrides one of the reference's hooks: keep calling them like the reference does (:97-100)
             logpxz, logqz = self.log_joint(nodes_p), self.log_joint(nodes_q)
             return self.sgvb(logpxz, logqz, reduce_mean) if self.estimator == 'sgvb' else self.vimco(logpxz, logqz, reduce_mean)
-        fused = self._generator_side_in_one_launch(nodes_p, nodes_q, reduce_mean)
+        done = {}           # log-probabilities the fused attempt has already evaluated (a layout rejected late used to
+        fused = self._generator_side_in_one_launch(nodes_p, nodes_q, reduce_mean, done)       # evaluate them a second time below)
         if fused is not None:
             return fused
-        terms_p = [nodes_p[n].log_prob() for n in nodes_p.keys()]
-        logqz = self.log_joint(nodes_q)
+        terms_p = [done[n] if n in done else nodes_p[n].log_prob() for n in nodes_p.keys()]
+        logqz = done[_LOGQ] if _LOGQ in done else self.log_joint(nodes_q)
         head = None
         for t in terms_p[:-1]:                      # left-to-right, as log_joint sums them
             head = t if head is None else head + t
@@ -83,7 +87,7 @@ class ImportanceWeightedObjective(nn.Module):
             return self._objective(terms_p[0], None, logqz, reduce_mean)
         return self._objective(head, terms_p[-1], logqz, reduce_mean)
 
-    def _generator_side_in_one_launch(self, nodes_p, nodes_q, reduce_mean):
+    def _generator_side_in_one_launch(self, nodes_p, nodes_q, reduce_mean, done):
         """IW1 (``_ops.BernoulliIWObjective``): when the generator's LAST node is a Bernoulli likelihood over [K, B, X] whose
         log-probability reduces to [K, B] -- the IWAE caller, examples/variational_autoencoder/iwae.py:49-81 -- its row sums,
         the log-density of the latent under a Normal prior node, the sum of the generator's terms, the subtraction of log q,
@@ -114,11 +118,11 @@ class ImportanceWeightedObjective(nn.Module):
                 z, pmu, psigma, Pm, Ps, p_ls = term
                 others = others[:-1]
             for n in others:
-                lp = nodes_p[n].log_prob()
+                lp = done[n] = nodes_p[n].log_prob()
                 if tuple(lp.shape) != (K, B):
                     return None
                 rows_a = lp if rows_a is None else rows_a + lp
-        logqz = self.log_joint(nodes_q)
+        logqz = done[_LOGQ] = self.log_joint(nodes_q)
         if not isinstance(logqz, torch.Tensor) or tuple(logqz.shape) != (K, B) or logqz.dtype != par.dtype or logqz.device != par.device:
             return None
         if rows_a is not None and (rows_a.dtype != par.dtype or rows_a.device != par.device):
