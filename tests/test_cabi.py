@@ -916,3 +916,56 @@ def test_hip_adam_f64(hip64, orc64):
     a, b = _adam_run(hip64, [777, 12, 5], 4), _adam_run(orc64, [777, 12, 5], 4)
     for x, y in zip(a, b):
         np.testing.assert_allclose(x, y, rtol=1e-13, atol=1e-15 * np.abs(y).max())
+
+
+def test_both_libraries_pair_draws_on_the_same_shapes():
+    """the C oracle restates by hand the shape rule by which the sampling kernel takes both draws of a latent in one
+    launch (zs_normal_sample_pair_one_launch; csrc/zs_normal.hip derives it from k1_tile).  If the two predicates drifted apart,
+    the host and GPU back-ends would pair draws -- and hand out Philox call ids among several latents -- differently.  A host
+    function of both libraries: compared over a grid of shapes, no GPU needed."""
+    hip_lib = _hip.KernelLibrary(_hip.LIB_PATH).cdll
+    orc_lib = host_kernel_library().cdll
+    for f in (hip_lib, orc_lib):
+        f.zs_normal_sample_pair_one_launch.restype = ctypes.c_int
+        f.zs_normal_sample_pair_one_launch.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int]
+    n = paired = 0
+    for K in (1, 2, 5, 10, 40, 50, 64, 65, 512, 4096):
+        for D in (1, 2, 3, 4, 8, 12, 13, 14, 40, 51, 64, 100, 256, 784, 1024, 4096):
+            for R in (1, 3, 16, 50, 64, 256, 257, 512, 4096, 100000):
+                for want_lp in (0, 1):
+                    a = hip_lib.zs_normal_sample_pair_one_launch(K, R * D, D, want_lp)
+                    b = orc_lib.zs_normal_sample_pair_one_launch(K, R * D, D, want_lp)
+                    assert a == b, ("K=%d R=%d D=%d want_lp=%d: libzs_hip says %d, the oracle %d" % (K, R, D, want_lp, a, b))
+                    n += 1
+                    paired += a == 1
+    assert n == 10 * 16 * 10 * 2 and 0 < paired < n          # (both answers occur: the grid crosses the rule's boundary)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,D", [(9, 49157, 40), (3, 70001, 40), (50, 12300, 160)])
+def test_hip_given_value_logprob_beyond_a_tile_per_resident_workgroup(hip, K, R, D):
+    """The given-value kernels (K2 / L2 / U2) at sizes with more parameter-plane tiles than resident workgroups (R * D / 4 >= 1536
+    tiles of 320 or 640 lanes; several chunks of particles per tile, ragged last tile): every row sum against a float64 evaluation.
+    (Written for round 5's equal-contiguous-shares form of the kernel, which passed it and was measured slower -- docs/history.md;
+    the parity tests of the suite otherwise stop at sizes the serial oracle finishes in seconds.)"""
+    rng = np.random.RandomState(K + R)
+    M = R * D
+    x = rng.standard_normal((K, R, D)).astype(np.float32)
+    mu = rng.standard_normal((R, D)).astype(np.float32)
+    sd = np.exp(0.3 * rng.standard_normal((R, D))).astype(np.float32)
+    for kfast in (True, False):
+        got = hip.normal_lp(x.reshape(-1), mu.reshape(-1), sd.reshape(-1), K, R, D, kfast)["lp"].reshape(K, R)
+        want = (-0.9189385332046727 - np.log(sd.astype(np.float64)) - 0.5 * ((x.astype(np.float64) - mu) / sd.astype(np.float64)) ** 2).sum(-1)
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * D)
+    # Logistic and Uniform, same kernel (L2, U2)
+    import scipy.stats as st
+    lp = hip.empty(K, R)
+    hip.call("zs_logistic_logprob_f32", hip.t(x.reshape(-1)), x.size, hip.t(mu.reshape(-1)), M, hip.t(sd.reshape(-1)), M, lp, K, R, D, R, 1)
+    np.testing.assert_allclose(lp.cpu().numpy(), st.logistic.logpdf(x.astype(np.float64), mu, sd).sum(-1), rtol=2e-5, atol=2e-5 * D)
+    low, high = (mu - 3.0 * sd - 6.0).astype(np.float32), (mu + 3.0 * sd + 6.0).astype(np.float32)      # (every x inside the support)
+    hip.call("zs_uniform_logprob_f32", hip.t(x.reshape(-1)), x.size, hip.t(low.reshape(-1)), M, hip.t(high.reshape(-1)), M, lp, K, R, D, R, 1)
+    inside = (x >= low) & (x < high)
+    want = np.where(inside, -np.log(high.astype(np.float64) - low), -np.inf).sum(-1)
+    got = lp.cpu().numpy()
+    np.testing.assert_array_equal(np.isfinite(got), np.isfinite(want))
+    np.testing.assert_allclose(got[np.isfinite(want)], want[np.isfinite(want)], rtol=2e-5, atol=2e-5 * D)

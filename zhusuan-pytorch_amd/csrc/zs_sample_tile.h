@@ -429,8 +429,29 @@ __global__ __launch_bounds__(1024) void k_logprob_tile(
   extern __shared__ float zs_k2_stage[];
   const uint32_t TB = blockDim.x, LDW = TB + 1, tid = threadIdx.x;
   const uint32_t rows_in_tile = TB / D4;
-  for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
-    const uint32_t kt = t / n_ptiles, pt = t - kt * n_ptiles;
+  // Two ways of sharing out the (tile, particle) plane.  kchunk > 0: items of one tile x kchunk particles, one per workgroup (the
+  // dispatcher evens the CUs out; every item re-reads the tile's parameters: 1.14 x the algorithmic traffic at 4.2 M rows with four
+  // chunks per tile, profiles/r04_pmc_k2_4M.json) -- the shipped form.  kchunk == 0 (round 5 experiment, -DZS_EXPERIMENTS +
+  // ZS_K2_BALANCED=1 only): the grid is the resident workgroups and each takes an EQUAL, CONTIGUOUS range of the n_ptiles x K
+  // particle-tiles -- at most three tiles' parameters per workgroup instead of one read per chunk; measured slower (see the launcher).
+  const bool balanced = kchunk == 0;
+  const uint64_t units = (uint64_t)n_ptiles * K;
+  uint64_t u = balanced ? units * blockIdx.x / gridDim.x : 0, u_end = balanced ? units * (blockIdx.x + 1) / gridDim.x : 0;
+  for (uint32_t t = blockIdx.x;; t += gridDim.x) {
+    uint32_t pt, k0, k1;
+    if (balanced) {
+      if (u >= u_end) break;
+      pt = (uint32_t)(u / K);
+      k0 = (uint32_t)(u - (uint64_t)pt * K);
+      k1 = (uint64_t)(K - k0) < u_end - u ? K : k0 + (uint32_t)(u_end - u);
+      u += k1 - k0;
+    } else {
+      if (t >= total) break;
+      const uint32_t kt = t / n_ptiles;
+      pt = t - kt * n_ptiles;
+      k0 = kt * kchunk;
+      k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
+    }
     const uint32_t m4 = pt * TB + tid;
     const bool on = m4 < M4;
     const uint32_t m4c = on ? m4 : M4 - 1;                  // (idle lanes of the last tile re-read its last piece: loads stay unconditional)
@@ -457,8 +478,6 @@ __global__ __launch_bounds__(1024) void k_logprob_tile(
         }
       }
     }
-    const uint32_t k0 = kt * kchunk;
-    const uint32_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
     const int64_t rbase = (int64_t)pt * rows_in_tile;
     for (uint32_t kb0 = k0; kb0 < k1; kb0 += KB) {
       const uint32_t kb = (k1 - kb0 < KB) ? (k1 - kb0) : KB;
@@ -559,8 +578,21 @@ inline void launch_logprob_krep(int kid, const float* x, const float* mu, const 
   // L2 57 -> 73 %, U2 70 -> 75 %, 2 M rows 58 -> 64 %, 4.2 M rows 61 -> 64-69 % (non-temporal loads beyond the Infinity Cache).
   static const int tile_env = env_knob("ZS_K2_TILE", -1);      // experiments only: 0 = the row-tile kernel, 1 / 2 = plain / non-temporal loads
   if (tile_env != 0) {
-    const K1Tile g = k1_tile(K, R, D4, true);
+    K1Tile g = k1_tile(K, R, D4, true);
     if (g.ok) {
+      // Equal contiguous shares of the particle-tile plane for the resident workgroups (see the kernel): MEASURED AND NOT TAKEN.
+      // It does remove the per-chunk parameter re-reads, and the 4.2 M-row stream got SLOWER, 71 - 73 % -> 59 - 63 % of 8 TB/s
+      // (K2 / L2 / U2, one box, two alternations: profiles/r05_k2_balanced.txt): 1 536 long-lived workgroups walking their ranges in
+      // lockstep lose more to the memory system than 10 488 short items handed out by the dispatcher lose to 1.14 x traffic.
+      // Kept behind the experiments knob only.
+      static const int bal_env = env_knob("ZS_K2_BALANCED", 0);      // experiments only
+      const int64_t per_cu = 2048 / g.threads > 8 ? 8 : 2048 / g.threads;
+      const int64_t lds_cu = g.smem ? 163840 / (int64_t)g.smem : per_cu;
+      const int64_t resident = 256 * (per_cu < lds_cu ? per_cu : lds_cu);
+      if (bal_env > 0 && (int64_t)g.n_ptiles * K >= resident) {
+        g.kchunk = 0;
+        g.grid = (unsigned)resident;
+      }
       const bool stream_once = tile_env > 0 ? tile_env == 2 : (double)K * (double)R * (double)D4 * 16.0 > 268435456.0;
       if (stream_once)
         ZS_LAUNCH_SMEM(kid, (k_logprob_tile<DIST, true>), dim3(g.grid), dim3(g.threads), g.smem, st, (const float4*)x, (const float4*)mu,

@@ -7,6 +7,7 @@ K particles of a datapoint stay contiguous for the importance-weight reduction (
 """
 import ctypes
 import math
+import threading
 import weakref
 
 import torch
@@ -513,9 +514,12 @@ class IWObjective(torch.autograd.Function):
 # dataparallel.StagedBuckets) still runs every node that lies on a path to them, and a node cannot see which of ITS inputs the
 # pass is after.  IW1's backward serves two sides (the decoder through p, the variational parameters through log q): told the
 # targets of the pass, it launches only the side(s) that lead there instead of both in every stage.  A module global, not a
-# contextvar: the autograd engine runs Python backward functions of GPU tensors on its own thread.
+# contextvar: the autograd engine runs Python backward functions of GPU tensors on its own thread -- so restricted passes of
+# DIFFERENT Python threads are serialised by a lock held for the length of the `with` block (two threads used to
+# overwrite each other's target set, and launches were then skipped silently); the same thread may nest.
 # ------------------------------------------------------------------------------------------------
 _GRAD_TARGETS = None
+_GRAD_TARGETS_LOCK = threading.RLock()
 
 
 class grad_targets(object):
@@ -526,22 +530,34 @@ class grad_targets(object):
 
     def __enter__(self):
         global _GRAD_TARGETS
+        _GRAD_TARGETS_LOCK.acquire()
         self._prev, _GRAD_TARGETS = _GRAD_TARGETS, self._ids
         return self
 
     def __exit__(self, *exc):
         global _GRAD_TARGETS
         _GRAD_TARGETS = self._prev
+        _GRAD_TARGETS_LOCK.release()
         return False
 
 
-def _leads_to_targets(t, targets):
-    """Whether the autograd graph above tensor `t` reaches one of the leaf tensors whose ids are in `targets`."""
+def _graph_handle(t):
+    """What `_leads_to_targets` needs of an input tensor, WITHOUT the tensor: (grad_fn, None) for a computed tensor, (None, id) for
+    a leaf that requires a gradient, None otherwise.  Kept on a Function's ctx instead of the tensor itself: a ctx attribute is
+    not released when backward frees the saved tensors (p [K, B, X] is 40 MB at config 3)."""
     if t is None or not t.requires_grad:
+        return None
+    return (t.grad_fn, None) if t.grad_fn is not None else (None, id(t))
+
+
+def _leads_to_targets(handle, targets):
+    """Whether the autograd graph above the tensor `handle` describes reaches one of the leaf tensors whose ids are in `targets`."""
+    if handle is None:
         return False
-    if t.grad_fn is None:
-        return id(t) in targets
-    seen, stack = set(), [t.grad_fn]
+    grad_fn, leaf_id = handle
+    if grad_fn is None:
+        return leaf_id in targets
+    seen, stack = set(), [grad_fn]
     while stack:
         fn = stack.pop()
         if fn is None or fn in seen:
@@ -616,7 +632,7 @@ class BernoulliIWObjective(torch.autograd.Function):
         ctx.meta = meta
         ctx.fold_q = qz is not None
         # (for passes restricted to some parameters: which side leads where is a property of the graph ABOVE the inputs)
-        ctx.sides = (p, qmu, qsigma)
+        ctx.sides = (_graph_handle(p), _graph_handle(qmu), _graph_handle(qsigma))
         ctx.save_for_backward(p, x, z, pmu, psigma, out, qmu, qsigma, qz)
         ctx.mark_non_differentiable(bound)
         return cost, bound
