@@ -607,7 +607,8 @@ def hbm_resident_kernels(klib, dev, launches=30):
 
 # kernel-name fragment -> C-ABI entry point (most specific first); logits forms carry <true, ...> as first template argument
 # (the kernels shared by the location-scale families live in namespace zs: first template argument 0 = Normal, 1 = Logistic)
-_KERNEL_ENTRY = [("k_iw1_block", "zs_bernoulli_iw_objective_f32"), ("k_iw1_bwd", "zs_bernoulli_iw_objective_bwd_f32"),
+_KERNEL_ENTRY = [("k_iw1_persist", "zs_bernoulli_iw_objective_f32"), ("k_iw1_block", "zs_bernoulli_iw_objective_f32"),
+                 ("k_iw1_bwd", "zs_bernoulli_iw_objective_bwd_f32"),
                  ("k_column_sum", "zs_column_sum_f32"), ("k_logjoint_bwd", "zs_logjoint_scalar_bwd_f32"), ("k_logjoint_fwd", "zs_logjoint_scalar_f32"),
                  ("k_normal_sample_multi_bwd", "zs_normal_sample_logprob_multi_bwd_f32"),
                  ("k_normal_sample_multi", "zs_normal_sample_logprob_multi_f32"),

@@ -36,7 +36,8 @@ ALGO = {
     "zs_bernoulli_iw_objective_bwd_f32": (8 * N * X + 4 * B * X + 4 * N) + (4 * N * D + 4 * N + 16 * B * D),
 }
 # (the kernels shared by the location-scale families live in namespace zs: template argument 0 = Normal)
-FRAGS = [("k_iw1_block", "zs_bernoulli_iw_objective_f32"), ("k_iw1_bwd", "zs_bernoulli_iw_objective_bwd_f32"),
+FRAGS = [("k_iw1_persist", "zs_bernoulli_iw_objective_f32"), ("k_iw1_block", "zs_bernoulli_iw_objective_f32"),
+                 ("k_iw1_bwd", "zs_bernoulli_iw_objective_bwd_f32"),
          ("k_bern_logprob_bwd", "zs_bernoulli%s_logprob_bwd_f32"), ("k_bern_logprob", "zs_bernoulli%s_logprob_f32"),
          ("k_sample_tile<0", "zs_normal_sample_logprob_pair_f32"), ("k_logprob_bwd_ksum<0", "zs_normal_logprob_bwd_ksum_f32"),
          ("k_logprob_krep<0", "zs_normal_logprob_f32"), ("k_adam_step<float", "zs_adam_step_f32"),

@@ -824,6 +824,7 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
   int nw = K < 16 ? (int)K : 16;
   if (nw_env > 0) nw = nw_env < K ? nw_env : (int)K;
   hipStream_t st = (hipStream_t)stream;
+#ifdef ZS_EXPERIMENTS
   if (old_env && R <= 32768) {          // (-DZS_EXPERIMENTS builds only: round 4's workgroup-per-datapoint kernel, for A/B timing)
     a.bound_bits = a.cb <= 12 ? 24 : 20;
     a.sharded = R >= 128 ? 1 : 0;
@@ -838,6 +839,9 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
     ZS_CHECK_LAUNCH();
     return 0;
   }
+#else
+  (void)old_env;
+#endif
   int64_t G = compute_units();
   if (grid_env > 0) G = grid_env;
   if (G > R) G = R;
@@ -845,6 +849,22 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
   a.sharded = G >= 128 ? 1 : 0;                                    // (many workgroups: two-level count of word A, zs_iwpersist.h)
   static const int shard_env = env_knob("ZS_IW1_SHARDED", -1);     // experiments only
   if (shard_env >= 0) a.sharded = shard_env ? 1 : 0;
+#ifdef ZS_EXPERIMENTS
+  static const int nbuf_env = env_knob("ZS_IW1_NBUF", 2);
+  if (nbuf_env == 3 && !a.x_full) {
+    if (from_logits) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<true, false, false, 3>), dim3((unsigned)G), dim3(64 * nw), st, a);
+    else ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<false, false, false, 3>), dim3((unsigned)G), dim3(64 * nw), st, a);
+    ZS_CHECK_LAUNCH();
+    return 0;
+  }
+  static const int nt_env = env_knob("ZS_IW1_NT", 0);
+  if (nt_env && !a.x_full) {
+    if (from_logits) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<true, false, true>), dim3((unsigned)G), dim3(64 * nw), st, a);
+    else ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<false, false, true>), dim3((unsigned)G), dim3(64 * nw), st, a);
+    ZS_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
 #define ZS_LAUNCH_IW1P(L, XF) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<L, XF>), dim3((unsigned)G), dim3(64 * nw), st, a)
   if (from_logits) { if (a.x_full) ZS_LAUNCH_IW1P(true, true); else ZS_LAUNCH_IW1P(true, false); }
   else             { if (a.x_full) ZS_LAUNCH_IW1P(false, true); else ZS_LAUNCH_IW1P(false, false); }

@@ -166,7 +166,7 @@ __device__ __forceinline__ void iw1_share_and_finish(const Iw1Mean& a, int G, in
 
 // XFULL: the observation has one row per (particle, datapoint) instead of one per datapoint: nothing to share through LDS, each
 // row reads its own observation row when it is reduced (the rarely used form; same structure otherwise).
-template <bool LOGITS, bool XFULL>
+template <bool LOGITS, bool XFULL, bool NT = false, int NBUF = 2>
 __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
 #if ZS_ON_DEVICE                 // (the body uses address-space-qualified pointers: device pass only; the host pass needs the symbol)
   __shared__ Iw1Smem sm;
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
   const int Dz4 = a.Dz4;
   const int zc = lane < Dz4 ? lane : (Dz4 > 0 ? Dz4 - 1 : 0);
   // ---- the rows: three register buffers; mk / mx = what each holds (wave-uniform)
-  float4 pv[2][4], zv[2];
-  int mk[2], mx[2], mi[2];     // particle index (< 0: no row), LDS buffer (datapoint mod 3) and datapoint of the row in each buffer
-  int64_t mrow[2];             // (XFULL only) its row index k * R + r
+  float4 pv[NBUF][4], zv[NBUF];
+  int mk[NBUF], mx[NBUF], mi[NBUF];     // particle index (< 0: no row), LDS buffer (datapoint mod 3) and datapoint of the row in each buffer
+  int64_t mrow[NBUF];             // (XFULL only) its row index k * R + r
   // the next slot of this wave's list: flat index, datapoint, particle, datapoint mod 3 (advanced by NW <= K per round: no division)
   int nf = w, ni = 0, nk = w, nx = 0;
   const int64_t first_row = (int64_t)w * a.R + g;                 // (f = w: datapoint 0, particle w < NW <= K)
@@ -206,7 +206,14 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     const int cm = valid ? 1 : 0;
     const float4* __restrict__ prow = a.p + row * D4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) pv[b][u] = prow[col[u] * cm];
+    for (int u = 0; u < 4; ++u) {
+      if (NT) {          // (read-once stream: non-temporal loads; experiments only so far)
+        const zs_f4v v = __builtin_nontemporal_load(reinterpret_cast<const zs_f4v*>(prow + col[u] * cm));
+        pv[b][u] = make_float4(v.x, v.y, v.z, v.w);
+      } else {
+        pv[b][u] = prow[col[u] * cm];
+      }
+    }
     zv[b] = a.z[row * Dz4 + zc * cm];
     if (XFULL) mrow[b] = row;
     mk[b] = valid ? nk : -1;
@@ -307,12 +314,20 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     t_lq = lq[r2 * ap->ld_q + tl];
     t_ra = arow[tl];
   };
-  // ---- prologue.  The staging waves' small loads go FIRST (vector-memory results return in order, and a CU's vector-memory front
-  // end holds a bounded number of loads in flight: 16 waves x 3 rows = 240 KB of requests take microseconds to ISSUE); a barrier
-  // keeps the other waves' rows behind them (~0.1 us).  Then every wave requests its first three rows, and NO barrier follows: the
-  // shared operands are published through the `ready` flags as soon as they land (profiles/r05_iw1_phases.txt: with a barrier
-  // behind the row requests the first row could not be reduced before 2.4 - 5 us).
+  // ---- prologue.  One barrier at once (the `ready` flags and the workgroup's sums must be zero before anybody looks at them; no
+  // wave has anything to wait for yet), then no other: the staging waves request the shared operands of the first datapoints ahead
+  // of their own first row and publish them through the `ready` flags as soon as they land; every wave requests its first row at
+  // once.  (With a barrier BEHIND the row requests -- and two or three rows requested per wave -- the first row could not be
+  // reduced before 2.4 - 5 us: a CU's vector-memory front end holds a bounded number of loads in flight, and the slowest wave's
+  // requests queue up for microseconds: profiles/r05_iw1_phases.txt.)
   {
+    if (threadIdx.x < 3) sm.ready[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+      sm.sum_a = 0;
+      sm.sum_b = 0;
+      sm.flags = 0u;
+    }
+    __syncthreads();
     Staged st;
     const bool stager = w < 3 && w < n_dp;
     if (stager) {
@@ -325,13 +340,6 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
       }
     }
     if (w == 0) fetch_tail_operands(0);
-    if (threadIdx.x < 3) sm.ready[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-      sm.sum_a = 0;
-      sm.sum_b = 0;
-      sm.flags = 0u;
-    }
-    __syncthreads();
     issue(IwBuf<0>{});
     if (w == 0) ZS_IW1_STAMP(7);
     // (an unconditional "use" -- a no-op for the waves that loaded nothing: the two `if (stager)` are one condition to us and two to
@@ -514,13 +522,30 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
   // rows of waves 0 - 11, and reached the barrier at 9.4 us, waves 2 - 3 at 5.8 (profiles/r05_iw1_phases.txt).  Sixteen rows in
   // flight per CU (50 KB, 12.8 MB over the chip: two microseconds of HBM bandwidth) already saturate the memory system; deeper
   // prefetch only reorders who is served first.
-  for (int j = 0; j < rounds; j += 2) {                          // (rounds past the list: no row, no boundary; their loads are the cheap ones)
+  if (NBUF == 2) {
+    for (int j = 0; j < rounds; j += 2) {                        // (rounds past the list: no row, no boundary; their loads are the cheap ones)
+      issue(IwBuf<1>{});
+      reduce_row(IwBuf<0>{});
+      boundary(j);
+      issue(IwBuf<0>{});
+      reduce_row(IwBuf<1>{});
+      boundary(j + 1);
+    }
+  } else {
+    // (-DZS_EXPERIMENTS, ZS_IW1_NBUF=3: TWO rows in flight behind the one being reduced, the second requested after the shared
+    //  operands have been published)
     issue(IwBuf<1>{});
-    reduce_row(IwBuf<0>{});
-    boundary(j);
-    issue(IwBuf<0>{});
-    reduce_row(IwBuf<1>{});
-    boundary(j + 1);
+    for (int j = 0; j < rounds; j += 3) {
+      issue(IwBuf<(NBUF > 2 ? 2 : 0)>{});
+      reduce_row(IwBuf<0>{});
+      boundary(j);
+      issue(IwBuf<0>{});
+      reduce_row(IwBuf<1>{});
+      boundary(j + 1);
+      issue(IwBuf<1>{});
+      reduce_row(IwBuf<(NBUF > 2 ? 2 : 0)>{});
+      boundary(j + 2);
+    }
   }
 #endif
 }
