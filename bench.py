@@ -1067,7 +1067,9 @@ def main():
             "zs_bernoulli_iw_objective_f32": 4 * N * X + 4 * B * X + 4 * N * D + 8 * B * D + 4 * N + 16 * N + 8 * B + 4,
             # its backward: K3's backward (read p, x, coefficients; write gp) + K2's K-summed backward (read z, mu, sigma, coefficients;
             # write gmu, gsigma) in one launch
-            "zs_bernoulli_iw_objective_bwd_f32": (8 * N * X + 4 * B * X + 4 * N) + (4 * N * D + 4 * N + 16 * B * D),
+            # (beyond 32 768 rows the entry point runs K3's x-reuse backward -- accounted under zs_bernoulli_logprob_bwd_f32, its own
+            #  launch -- and only the K-summed log q gradient under this name: --strong-scaling on few ranks)
+            "zs_bernoulli_iw_objective_bwd_f32": ((8 * N * X + 4 * B * X + 4 * N) if N <= 32768 else 0) + (4 * N * D + 4 * N + 16 * B * D),
             "zs_adam_step_f32": 28 * sum(p.numel() for p in model.parameters()),  # read p, g, m, v; write p, m, v
         }
         # the IW kernels serve two entry points; the tracer sees kernel names only

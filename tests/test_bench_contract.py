@@ -214,9 +214,12 @@ def test_bench_line_with_torch_adam():
 
 @pytest.mark.gpu
 def test_bench_line_strong_scaling_on_one_rank():
-    """--strong-scaling: config 4's global batch of 2048 split over the ranks (here: all of it on one GPU, where the generator
-    side of the objective takes the streaming kernels -- IW1 serves up to 384 datapoints per GPU)."""
-    rec = _run_bench("--no-cpu-baseline", "--no-extras", "--strong-scaling")
+    """--strong-scaling: config 4's global batch of 2048 split over the ranks (here: all of it on one GPU: eight datapoints per
+    workgroup of the persistent IW1 forward -- round 4's kernel stopped at 384 datapoints; its backward beyond 32 768 rows is K3's
+    x-reuse backward plus the K-summed log q gradient, two launches)."""
+    rec, full = _run_bench("--no-cpu-baseline", "--no-extras", "--strong-scaling", full=True)
+    hk = full["hip_kernels"]
+    assert hk["zs_bernoulli_iw_objective_f32"]["launches_per_step"] == 1 and "zs_bernoulli_logprob_f32" not in hk and "zs_iw_objective_f32" not in hk
     assert rec["scaling"] == "strong" and rec["config"]["global_batch"] == 2048 and "batch=2048 per GPU" in rec["config"]["workload"]
     assert abs(rec["value"] - 2048 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"] and np.isfinite(rec["final_loss"])
     assert rec["roofline"]["kernel"] == "zs_bernoulli_logprob_bwd_f32" and 0.4 < rec["roofline"]["frac"] < 1.0

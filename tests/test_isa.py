@@ -34,26 +34,32 @@ def _kernel(asm, mangled):
     return asm[i:j], asm[j:asm.index("\n\t.text", j) if "\n\t.text" in asm[j:] else j + 4000]
 
 
-@pytest.mark.parametrize("mangled", ["_ZN2zs13k_iw1_persistILb0ELb0ELb0ELi2EEEvNS_7Iw1ArgsE", "_ZN2zs13k_iw1_persistILb1ELb0ELb0ELi2EEEvNS_7Iw1ArgsE"])
+@pytest.mark.parametrize("mangled", ["_ZN2zs13k_iw1_persistILb0ELb0ELb0EEEvNS_7Iw1ArgsE", "_ZN2zs13k_iw1_persistILb1ELb0ELb0EEEvNS_7Iw1ArgsE"])
 def test_iw1_streaming_loop_keeps_its_prefetched_rows_in_flight(bernoulli_asm, mangled):
     body, _ = _kernel(bernoulli_asm, mangled)
     lines = body.split("\n")
     headers = [n for n, l in enumerate(lines) if "Loop Header: Depth=1" in l]
     assert headers, "no loop found in %s" % mangled
-    seg = lines[headers[-1]:]                       # the streaming loop is the last depth-1 loop of the kernel
-    waits, loads = [], 0
-    for l in seg:
-        t = l.strip()
-        if t.startswith("s_barrier"):
-            break
-        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
-        if m:
-            waits.append(int(m.group(1)))
-        if t.startswith("global_load_dwordx4"):
-            loads += 1
-    # one round: the next row is requested (5 loads), then the row that has landed is waited for with those 5 left in flight
-    assert loads == 5, (loads, waits)
-    assert waits and min(waits) >= 5, "the streaming loop drains its prefetch: s_waitcnt vmcnt(%d) before the first barrier" % min(waits)
+
+    def scan(start):            # waits and row loads from a loop header to the first barrier behind it
+        waits, loads = [], 0
+        for l in lines[start:]:
+            t = l.strip()
+            if t.startswith("s_barrier"):
+                break
+            m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+            if m:
+                waits.append(int(m.group(1)))
+            if t.startswith("global_load_dwordx4"):
+                loads += 1
+        return waits, loads
+    # the streaming loop: the depth-1 loop whose body requests rows (two rounds of five loads) ahead of its barrier
+    found = [(h,) + scan(h) for h in headers]
+    streaming = [f for f in found if f[2] == 10]
+    assert len(streaming) == 1, [(f[0], f[2]) for f in found]
+    _, waits, loads = streaming[0]
+    # per round: the next row is requested (5 loads), then the row that has landed is waited for with those 5 left in flight
+    assert waits and min(waits) >= 5, "the streaming loop drains its prefetch: s_waitcnt vmcnt(%d) before its barrier" % min(waits)
     # and no register of the loop lives in scratch
     assert not re.search(r"\bscratch_(load|store)", body), "k_iw1_persist spills to scratch"
     assert "flat_load" not in body and "flat_store" not in body and "flat_atomic" not in body, "generic-address memory instructions (lost address space)"

@@ -227,7 +227,7 @@ def test_in_place_ops_on_a_latent_of_a_paired_draw(dev, reparam):
     the value its factory returned must work with pair_draws on (the default) exactly as with pair_draws(False)."""
     class Q(BayesianNet):
         def __init__(self):
-            super().__init__()
+            super().__init__(device=dev)
             self.mu = torch.nn.Parameter(torch.full((6, 8), 0.25))
             self.ls = torch.nn.Parameter(torch.full((6, 8), -0.5))
             self.two = False
@@ -244,9 +244,13 @@ def test_in_place_ops_on_a_latent_of_a_paired_draw(dev, reparam):
             return self
 
     class P(BayesianNet):
+        def __init__(self):
+            super().__init__(device=dev)      # (a net without parameters: nothing else tells it where its nodes live)
+            self.two = False
+
         def forward(self, observed):
             self.observe(observed)
-            one = torch.ones(6, 8, device=observed["z1"].device if "z1" in observed else None)
+            one = torch.ones(6, 8, device=dev)
             z1 = self.normal("z1", mean=0 * one, std=one, reduce_mean_dims=[0], reduce_sum_dims=[1])
             z2 = self.normal("z2", mean=z1, std=one, reduce_mean_dims=[0], reduce_sum_dims=[1]) if self.two else z1
             self.normal("x", mean=z2, std=one, reduce_mean_dims=[0], reduce_sum_dims=[1])

@@ -1,8 +1,8 @@
 # Round-end GPU verification: build + smoke, the gpu test-suite, the PMC traffic passes (first: the bench line quotes them), the
-# bench line and its rocprofv3 kernel-trace summary.  Run through gpurun from the repository root:  gpurun --timeout 2400 -- 'bash tools/gpu_final_check.sh r04'
+# bench line and its rocprofv3 kernel-trace summary.  Run through gpurun from the repository root:  gpurun --timeout 2700 -- 'bash tools/gpu_final_check.sh r05'
 cd "$(dirname "$0")/.." || exit 1
 ROOT=$(pwd)
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"
 timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -16

@@ -850,13 +850,6 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
   static const int shard_env = env_knob("ZS_IW1_SHARDED", -1);     // experiments only
   if (shard_env >= 0) a.sharded = shard_env ? 1 : 0;
 #ifdef ZS_EXPERIMENTS
-  static const int nbuf_env = env_knob("ZS_IW1_NBUF", 2);
-  if (nbuf_env == 3 && !a.x_full) {
-    if (from_logits) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<true, false, false, 3>), dim3((unsigned)G), dim3(64 * nw), st, a);
-    else ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<false, false, false, 3>), dim3((unsigned)G), dim3(64 * nw), st, a);
-    ZS_CHECK_LAUNCH();
-    return 0;
-  }
   static const int nt_env = env_knob("ZS_IW1_NT", 0);
   if (nt_env && !a.x_full) {
     if (from_logits) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<true, false, true>), dim3((unsigned)G), dim3(64 * nw), st, a);

@@ -166,7 +166,7 @@ __device__ __forceinline__ void iw1_share_and_finish(const Iw1Mean& a, int G, in
 
 // XFULL: the observation has one row per (particle, datapoint) instead of one per datapoint: nothing to share through LDS, each
 // row reads its own observation row when it is reduced (the rarely used form; same structure otherwise).
-template <bool LOGITS, bool XFULL, bool NT = false, int NBUF = 2>
+template <bool LOGITS, bool XFULL, bool NT = false>
 __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
 #if ZS_ON_DEVICE                 // (the body uses address-space-qualified pointers: device pass only; the host pass needs the symbol)
   __shared__ Iw1Smem sm;
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
   const int Dz4 = a.Dz4;
   const int zc = lane < Dz4 ? lane : (Dz4 > 0 ? Dz4 - 1 : 0);
   // ---- the rows: three register buffers; mk / mx = what each holds (wave-uniform)
-  float4 pv[NBUF][4], zv[NBUF];
-  int mk[NBUF], mx[NBUF], mi[NBUF];     // particle index (< 0: no row), LDS buffer (datapoint mod 3) and datapoint of the row in each buffer
-  int64_t mrow[NBUF];             // (XFULL only) its row index k * R + r
+  float4 pv[2][4], zv[2];
+  int mk[2], mx[2], mi[2];     // particle index (< 0: no row), LDS buffer (datapoint mod 3) and datapoint of the row in each buffer
+  int64_t mrow[2];             // (XFULL only) its row index k * R + r
   // the next slot of this wave's list: flat index, datapoint, particle, datapoint mod 3 (advanced by NW <= K per round: no division)
   int nf = w, ni = 0, nk = w, nx = 0;
   const int64_t first_row = (int64_t)w * a.R + g;                 // (f = w: datapoint 0, particle w < NW <= K)
@@ -314,13 +314,14 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     t_lq = lq[r2 * ap->ld_q + tl];
     t_ra = arow[tl];
   };
-  // ---- prologue.  One barrier at once (the `ready` flags and the workgroup's sums must be zero before anybody looks at them; no
-  // wave has anything to wait for yet), then no other: the staging waves request the shared operands of the first datapoints ahead
-  // of their own first row and publish them through the `ready` flags as soon as they land; every wave requests its first row at
-  // once.  (With a barrier BEHIND the row requests -- and two or three rows requested per wave -- the first row could not be
+  // ---- prologue.  Every wave requests its first row at once; one barrier (the `ready` flags and the workgroup's sums must be zero
+  // before anybody looks at them; no wave has anything to wait for yet), then no other: the staging waves request the shared operands
+  // of the first datapoints and publish them through the `ready` flags as soon as they land.  (With a barrier BEHIND the row requests -- and two or three rows requested per wave -- the first row could not be
   // reduced before 2.4 - 5 us: a CU's vector-memory front end holds a bounded number of loads in flight, and the slowest wave's
   // requests queue up for microseconds: profiles/r05_iw1_phases.txt.)
   {
+    issue(IwBuf<0>{});                                           // (the stream starts before anything else: rows need nothing from LDS)
+    if (w == 0) ZS_IW1_STAMP(7);
     if (threadIdx.x < 3) sm.ready[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
       sm.sum_a = 0;
@@ -340,8 +341,6 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
       }
     }
     if (w == 0) fetch_tail_operands(0);
-    issue(IwBuf<0>{});
-    if (w == 0) ZS_IW1_STAMP(7);
     // (an unconditional "use" -- a no-op for the waves that loaded nothing: the two `if (stager)` are one condition to us and two to
     //  the compiler; on the path it cannot rule out the staging loads would still be in flight at the loop header, into registers the
     //  loop reuses: vmcnt(0) there, every iteration)
@@ -463,24 +462,11 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
                                    (float*)as_global(ap->bound_b), (float*)as_global(ap->coef_p), (float*)as_global(ap->coef_q));
     if (d + 1 == n_dp) ZS_IW1_STAMP(4);
     if (!ap->mean_cost) return;
-    const Iw1Mean mean = {as_global(ap->acc), as_global(ap->mean_cost), ap->cb, ap->sharded, ap->R};
-    long long sa = 0, sb = 0;
-    unsigned fl = 0;
-    if (lane == 0) {
-      const Iw1Fixed fx = iw1_fixed(cost, ap->cb);
-      sa = sm.sum_a + fx.a;
-      sb = sm.sum_b + fx.b;
-      fl = sm.flags | fx.flags;
-      if (d + 1 < n_dp) {
-        sm.sum_a = sa;
-        sm.sum_b = sb;
-        sm.flags = fl;
-      }
-    }
-    if (d + 1 == n_dp) {
-      iw1_share_and_finish(mean, G, g, n_dp, lane, sa, sb, fl);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ZS_IW1_STAMP(5);
+    if (lane == 0) {                                             // the workgroup's share of the batch mean, in LDS (tails run one
+      const Iw1Fixed fx = iw1_fixed(cost, ap->cb);               // at a time: a barrier lies between any two of them)
+      sm.sum_a += fx.a;
+      sm.sum_b += fx.b;
+      sm.flags |= fx.flags;
     }
   };
   // ---- the rounds: prefetch the row two rounds ahead, reduce the row that has landed, meet when a datapoint is complete.
@@ -489,8 +475,7 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
   int done_dp = 0;                 // datapoints whose rows are all reduced
   int thr = K;                     // flat rows that complete datapoint `done_dp`
   int tw = 0;                      // done_dp mod NW
-  auto boundary = [&](int j) {
-    if ((j + 1) * NW < thr || done_dp >= n_dp) return;           // workgroup-uniform (NW <= K: at most one datapoint per round)
+  auto boundary = [&]() {
     if (w == 0 && done_dp + 1 == n_dp) ZS_IW1_STAMP(2);
 #ifdef ZS_EXPERIMENTS
     if (done_dp + 1 == n_dp && lane == 0) zs_iw1_wave_stamps[blockIdx.x * 32 + w] = __builtin_amdgcn_s_memrealtime();
@@ -500,8 +485,8 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     const ZS_CONSTANT Iw1Args* tap = nullptr;
     if (w == tw) {
       tap = cold();
-      asm volatile("" ::"s"(tap->scale), "s"(tap->estimator), "s"(tap->cb), "s"(tap->sharded), "s"(tap->lp_x), "s"(tap->lp_z), "s"(tap->cost_b),
-                   "s"(tap->bound_b), "s"(tap->coef_p), "s"(tap->coef_q), "s"(tap->mean_cost), "s"(tap->acc), "s"(tap->rows_a), "s"(tap->R));
+      asm volatile("" ::"s"(tap->scale), "s"(tap->estimator), "s"(tap->cb), "s"(tap->lp_x), "s"(tap->lp_z), "s"(tap->cost_b),
+                   "s"(tap->bound_b), "s"(tap->coef_p), "s"(tap->coef_q), "s"(tap->mean_cost), "s"(tap->rows_a));
     }
     __syncthreads();
     const int d = done_dp;
@@ -517,34 +502,41 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     thr += K;
     tw = w1;
   };
-  // ONE row in flight per wave behind the one it reduces.  A CU keeps ~64 KB of loads in flight and serves its waves' requests in
-  // order: with three rows requested per wave at the start (240 KB), waves 12 - 15 saw their FIRST row at 6.4 us, behind the third
-  // rows of waves 0 - 11, and reached the barrier at 9.4 us, waves 2 - 3 at 5.8 (profiles/r05_iw1_phases.txt).  Sixteen rows in
-  // flight per CU (50 KB, 12.8 MB over the chip: two microseconds of HBM bandwidth) already saturate the memory system; deeper
-  // prefetch only reorders who is served first.
-  if (NBUF == 2) {
-    for (int j = 0; j < rounds; j += 2) {                        // (rounds past the list: no row, no boundary; their loads are the cheap ones)
-      issue(IwBuf<1>{});
-      reduce_row(IwBuf<0>{});
-      boundary(j);
-      issue(IwBuf<0>{});
-      reduce_row(IwBuf<1>{});
-      boundary(j + 1);
-    }
-  } else {
-    // (-DZS_EXPERIMENTS, ZS_IW1_NBUF=3: TWO rows in flight behind the one being reduced, the second requested after the shared
-    //  operands have been published)
+  // ONE row in flight per wave behind the one it reduces.  A CU serves its waves' requests in order and the chip's memory system is
+  // saturated by sixteen rows in flight per CU (50 KB; 12.8 MB over the chip: two microseconds of bandwidth): with three rows
+  // requested per wave at the start (240 KB per CU), waves 12 - 15 saw their FIRST row at 6.4 us, behind the third rows of waves
+  // 0 - 11, and reached the barrier at 9.4 us, waves 2 - 3 at 5.8 (profiles/r05_iw1_phases.txt); two rows in flight in steady
+  // state: 14.8 instead of 12.7 us at B = 256.  Deeper prefetch only reorders who is served first.
+  // The datapoints that have been completed are looked after ONCE per two rounds, in one place (the tail, the staging and the
+  // arguments' scalar loads are ~3 000 instructions: inlined behind both rounds the kernel was 27 KB of code, and in the training
+  // step -- where every launch starts with a cold instruction cache -- it lost 0.5 - 0.9 us to round 4's 8-KB kernel that it
+  // beats back to back: profiles/r05_iw1_instep.txt).  A datapoint completed by the first of the two rounds waits one round for
+  // its barrier: its row sums, its observation row and its flag live in buffers of their own (i mod 3).
+  for (int j = 0; j < rounds; j += 2) {                          // (rounds past the list: no row; their loads are the cheap ones)
     issue(IwBuf<1>{});
-    for (int j = 0; j < rounds; j += 3) {
-      issue(IwBuf<(NBUF > 2 ? 2 : 0)>{});
-      reduce_row(IwBuf<0>{});
-      boundary(j);
-      issue(IwBuf<0>{});
-      reduce_row(IwBuf<1>{});
-      boundary(j + 1);
-      issue(IwBuf<1>{});
-      reduce_row(IwBuf<(NBUF > 2 ? 2 : 0)>{});
-      boundary(j + 2);
+    reduce_row(IwBuf<0>{});
+    issue(IwBuf<0>{});
+    reduce_row(IwBuf<1>{});
+    while (done_dp < n_dp && (j + 2) * NW >= thr) boundary();    // workgroup-uniform
+  }
+  // ---- the workgroup's share of the batch mean goes out (the wave that ran the last tail: its LDS writes are its own)
+  {
+    const int last_tw = (n_dp - 1) % NW;
+    if (w == last_tw) {
+      const ZS_CONSTANT Iw1Args* ap = cold();
+      if (ap->mean_cost) {
+        const Iw1Mean mean = {as_global(ap->acc), as_global(ap->mean_cost), ap->cb, ap->sharded, ap->R};
+        long long sa = 0, sb = 0;
+        unsigned fl = 0;
+        if (lane == 0) {
+          sa = sm.sum_a;
+          sb = sm.sum_b;
+          fl = sm.flags;
+        }
+        iw1_share_and_finish(mean, G, g, n_dp, lane, sa, sb, fl);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ZS_IW1_STAMP(5);
+      }
     }
   }
 #endif
