@@ -315,10 +315,11 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     t_ra = arow[tl];
   };
   // ---- prologue.  Every wave requests its first row at once; one barrier (the `ready` flags and the workgroup's sums must be zero
-  // before anybody looks at them; no wave has anything to wait for yet), then no other: the staging waves request the shared operands
-  // of the first datapoints and publish them through the `ready` flags as soon as they land.  (With a barrier BEHIND the row requests -- and two or three rows requested per wave -- the first row could not be
-  // reduced before 2.4 - 5 us: a CU's vector-memory front end holds a bounded number of loads in flight, and the slowest wave's
-  // requests queue up for microseconds: profiles/r05_iw1_phases.txt.)
+  // before anybody looks at them; no wave has anything to wait for yet), then no other: the staging waves request the shared
+  // operands of the first datapoints and publish them through the `ready` flags as soon as they land.  (With a barrier BEHIND the
+  // row requests -- and two or three rows requested per wave -- the first row could not be reduced before 2.4 - 5 us: a CU's
+  // vector-memory front end serves its waves' requests in order, and the slowest wave's queue up for microseconds:
+  // profiles/r05_iw1_phases.txt.)
   {
     issue(IwBuf<0>{});                                           // (the stream starts before anything else: rows need nothing from LDS)
     if (w == 0) ZS_IW1_STAMP(7);
@@ -329,29 +330,11 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
       sm.flags = 0u;
     }
     __syncthreads();
-    Staged st;
-    const bool stager = w < 3 && w < n_dp;
-    if (stager) {
-      stage_load(w, st, true);
-    } else {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        st.xs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        st.mv[u] = st.sv[u] = 0.f;
-      }
-    }
     if (w == 0) fetch_tail_operands(0);
-    // (an unconditional "use" -- a no-op for the waves that loaded nothing: the two `if (stager)` are one condition to us and two to
-    //  the compiler; on the path it cannot rule out the staging loads would still be in flight at the loop header, into registers the
-    //  loop reuses: vmcnt(0) there, every iteration)
-    asm volatile("" ::"v"(st.xs[0].x), "v"(st.xs[1].x), "v"(st.xs[2].x), "v"(st.xs[3].x), "v"(st.mv[0]), "v"(st.mv[1]), "v"(st.mv[2]),
-                 "v"(st.mv[3]), "v"(st.sv[0]), "v"(st.sv[1]), "v"(st.sv[2]), "v"(st.sv[3]));
-    if (w == 0) ZS_IW1_STAMP(6);
-    // a staging wave publishes its operands BEFORE it requests its further rows: behind them it would sit in the front end's queue
-    // for ~2 us (16 waves x 3 rows are more than a CU keeps in flight), and every first reduction with it
-    if (stager) stage_write(w, st);
-    for (int dd = w + NW; dd < 3 && dd < n_dp; dd += NW) {       // (fewer than three waves: K < 3)
-      stage_load(dd, st, false);
+    for (int dd = w; dd < 3 && dd < n_dp; dd += NW) {            // (one instance of the staging code: kernels start with a cold
+      Staged st;                                                 //  instruction cache inside a training step, and size counts)
+      stage_load(dd, st, true);
+      if (w == 0 && dd == 0) ZS_IW1_STAMP(6);
       stage_write(dd, st);
     }
   }
