@@ -99,6 +99,10 @@ def parse_args(argv=None):
                     help="split config 4's GLOBAL batch of 2048 over the ranks (2048 / N datapoints per GPU; N must divide 2048) instead of "
                          "256 per GPU: the line then says \"scaling\": \"strong\" (SURVEY.md 8d: 'also strong scaling B = 2048 total'). "
                          "The default, and what the driver runs, is weak scaling")
+    ap.add_argument("--batch-per-gpu", type=int, default=0,
+                    help="(kernel studies only, not a BASELINE config: the line's config.workload says so) datapoints per GPU instead of 256")
+    ap.add_argument("--iw1-max-stream-bytes", type=int, default=-1,
+                    help="(kernel studies only) override zhusuan._ops.IW1_MAX_STREAM_BYTES: 0 = never the fused generator-side launch")
     ap.add_argument("--torch-adam", action="store_true",
                     help="update with torch.optim.Adam(fused=True, capturable=True) instead of zhusuan.optim.FlatAdam "
                          "(the same update over flat buckets, one launch)")
@@ -767,8 +771,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    global BATCH_PER_GPU
+    if args.batch_per_gpu > 0:
+        BATCH_PER_GPU = args.batch_per_gpu
     if args.strong_scaling:
-        global BATCH_PER_GPU
         if 2048 % world:
             raise SystemExit("bench: --strong-scaling splits 2048 datapoints; %d ranks do not divide it" % world)
         BATCH_PER_GPU = 2048 // world
@@ -810,6 +816,9 @@ def main():
     tuned = gemm_tuning(not args.no_gemm_tuning)
     import zhusuan  # noqa: F401
     from zhusuan import _hip, dataparallel
+    if args.iw1_max_stream_bytes >= 0:
+        from zhusuan import _ops
+        _ops.IW1_MAX_STREAM_BYTES = args.iw1_max_stream_bytes
 
     k1_first = {}
     if world == 1 and rank == 0 and not args.no_extras and not args.force_collective_path:
@@ -1133,6 +1142,8 @@ def main():
             "workload": "IWAE-MNIST VIMCO, batch=%d per GPU (global %d), K=%d, latent=%d, x=%d, hidden=%d, full training step "
                         "(fwd+bwd+all-reduce+Adam)" % (BATCH_PER_GPU, BATCH_PER_GPU * world, PARTICLES, Z_DIM, X_DIM, HIDDEN),
             "global_batch": BATCH_PER_GPU * world, "particles": PARTICLES,
+            **({"not_a_baseline_config": "--batch-per-gpu %d / --iw1-max-stream-bytes %d: a kernel study, not BASELINE.json's configs[1]"
+                % (args.batch_per_gpu, args.iw1_max_stream_bytes)} if (args.batch_per_gpu > 0 or args.iw1_max_stream_bytes >= 0) else {}),
             "parallelism": "dp%d (minibatch shards; %s, %d bytes per step)" % (
                 world, "two flat buckets (decoder | encoder gradients + objective)" if (staged or hooks)
                 else "one flat bucket [gradients | objective]", nbytes),
