@@ -25,6 +25,7 @@ import torch
 REF = "/root/reference"
 sys.dont_write_bytecode = True   # the reference tree is read-only: no __pycache__ next to its sources
 OUT = os.path.dirname(os.path.abspath(__file__))
+OUT_SRC = OUT             # (OUT is redirected by tests/test_golden_regeneration.py; the tree's location is not)
 sys.path.insert(0, REF)
 
 import zhusuan  # noqa: E402  (the reference)
@@ -664,9 +665,11 @@ def _pack_grads(out, prefix, module, elementwise=False, stride=None, tag=""):
         out[prefix + "grad_absmax" + tag] = np.array(absmax)
 
 
-def gen_vae():
+def gen_vae(philox=False):
     vae = _load(os.path.join(REF, "examples/variational_autoencoder/vae_mnist.py"), "ref_vae")
     for tag, B, full in [("small", 8, True), ("c1", 64, False), ("c2", 512, False)]:
+        if philox and tag == "c1":
+            continue
         rng = np.random.RandomState(600 + B)
         x_dim, z_dim = 784, 40
         gen = vae.Generator(x_dim, z_dim, B)
@@ -676,12 +679,17 @@ def gen_vae():
         x = (rng.uniform(size=(B, x_dim)) < 0.5).astype(F32)
         e1 = rng.standard_normal((B, z_dim)).astype(F32)
         e2 = rng.standard_normal((B, z_dim)).astype(F32)
+        if philox:
+            e1 = philox_epsilon(1, B * z_dim, z_dim, PHILOX_SEED, 0).reshape(B, z_dim)
+            e2 = philox_epsilon(1, B * z_dim, z_dim, PHILOX_SEED, 1).reshape(B, z_dim)
         with EpsQueue([e1, e2]) as q:
             loss = model({"x": t(x)})
         model.zero_grad()
         loss.backward()
         out = {"B": np.array(B), "seed_params": np.array(1000 + B), "seed_data": np.array(600 + B),
                "loss": loss, "draws": np.array([c[1] for c in q.calls])}
+        if philox:
+            out["philox_seed"] = np.array(PHILOX_SEED)
         out["logpz"] = gen.nodes["z"].log_prob()
         out["logpx"] = gen.nodes["x"].log_prob()
         out["logqz"] = var.nodes["z"].log_prob()
@@ -690,17 +698,44 @@ def gen_vae():
             out["x"], out["e1"], out["e2"] = x, e1, e2
             out["z"] = var.nodes["z"].dist.sample_cache
             out["x_mean"] = gen.cache["x_mean"]
-        save("g_vae_" + tag, **out)
+        save("g_vae_" + tag + ("_philox" if philox else ""), **out)
+
+
+def gen_vae_philox():
+    gen_vae(philox=True)
 
 
 GRAD_STRIDE_BIG = 997      # config-shape goldens: every 997th element of every gradient
 
 
-def gen_iwae():
+PHILOX_SEED = 20240229     # gen_iwae_philox: the seed of the Philox4x32-10 stream the draws are taken from
+
+
+def philox_epsilon(K, M, D, seed, call):
+    """[K, M] standard-normal draws of the package's sampling kernel for Philox (seed, call id): the C oracle's restatement of
+    that kernel (oracle/zs_oracle_c.c, pinned bit for bit against the HIP kernel by tests/test_cabi.py) asked for
+    z = 0 + 1 * eps.  Test infrastructure generating INPUTS for the reference; nothing of the oracle's arithmetic beyond the
+    stream itself enters the fixture."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(OUT_SRC)), "oracle", "_build", "libzs_oracle.so"))
+    fn = lib.zs_normal_sample_logprob_f32
+    P, U, L = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64
+    fn.argtypes = [P, P, P, U, U, P, P, P, L, L, L, L, L, ctypes.c_int, P, P]
+    fn.restype = ctypes.c_int
+    mu, sigma = np.zeros(M, F32), np.ones(M, F32)
+    z, lp = np.empty((K, M), F32), np.empty((K, M // D), F32)
+    rc = fn(mu.ctypes.data, sigma.ctypes.data, None, seed, call, None, z.ctypes.data, lp.ctypes.data, K, M, D, M // D, 1, 0, None, None)
+    assert rc == 0, rc
+    return z
+
+
+def gen_iwae(philox=False):
     iw = _load(os.path.join(REF, "examples/variational_autoencoder/iwae.py"), "ref_iwae")
     for est in ["sgvb", "vimco"]:
         # c4g: the GLOBAL batch of BASELINE config 4 (8 GPUs x 256) evaluated by the reference in one process (both estimators)
         for tag, B, K, hidden, full in [("small", 8, 5, 32, True), ("c3", 256, 50, 500, False), ("c4g", 2048, 50, 500, False)]:
+            if philox and tag == "c4g":
+                continue
             out = {}
             # Two passes of the SAME reference code: float32 (the parity target) and float64 (torch default dtype
             # switched, identical weights / data / epsilon values).  VIMCO's learning signal subtracts two ~|log w|-sized
@@ -720,6 +755,9 @@ def gen_iwae():
                     x = (rng.uniform(size=(B, x_dim)) < 0.5).astype(F32)
                     e1 = rng.standard_normal((K, B, z_dim)).astype(F32)
                     e2 = rng.standard_normal((K, B, z_dim)).astype(F32)
+                    if philox:   # the two draws of the latent as the package's kernel makes them for (seed, call ids 0 and 1)
+                        e1 = philox_epsilon(K, B * z_dim, z_dim, PHILOX_SEED, 0).reshape(K, B, z_dim)
+                        e2 = philox_epsilon(K, B * z_dim, z_dim, PHILOX_SEED, 1).reshape(K, B, z_dim)
                     with EpsQueue([torch.tensor(e1, dtype=dt), torch.tensor(e2, dtype=dt)]) as q:
                         loss = model({"x": torch.tensor(x, dtype=dt)})
                     assert loss.dtype == dt
@@ -751,13 +789,26 @@ def gen_iwae():
                         out["bound_b_every16"] = zhusuan.log_mean_exp(log_w, 0)[::16]
                 finally:
                     torch.set_default_dtype(torch.float32)
-            save("g_iwae_%s_%s" % (est, tag), **out)
+            if philox:
+                out["philox_seed"] = np.array(PHILOX_SEED)
+            save("g_iwae_%s_%s%s" % (est, tag, "_philox" if philox else ""), **out)
 
 
-def gen_bnn():
+def gen_iwae_philox():
+    """The IWAE goldens again with the reference's two draws of the latent taken from the Philox stream the package's OWN
+    sampling kernel produces for (PHILOX_SEED, call ids 0 and 1): the product run with that seed and NO injected draw (the
+    in-kernel Philox path, both draws in one launch) must reproduce these reference outputs directly."""
+    gen_iwae(philox=True)
+
+
+def gen_bnn(philox=False):
+    """philox: the reference's four draws (w0#1, w1#1, w0#2, w1#2) carry the Philox call ids 0, 1, 2, 3 -- ids in the order of
+    the draws, which is how the package numbers them for this model (one id per draw of each node, pass by pass)."""
     bnn = _load(os.path.join(REF, "examples/bayesian_neural_nets/bnn_vi.py"), "ref_bnn")
     # c5g: the GLOBAL batch of BASELINE config 5 (8 GPUs x 512) evaluated by the reference in one process
     for tag, B, K, full in [("small", 16, 4, True), ("c5", 512, 10, False), ("c5g", 4096, 10, False)]:
+        if philox and tag == "c5g":
+            continue
         rng = np.random.RandomState(800 + B + K)
         layer_sizes = [13, 50, 1]
         net = bnn.Net(layer_sizes, K)
@@ -777,6 +828,9 @@ def gen_bnn():
         for _ in range(2):  # draw order w0#1, w1#1, then w0#2, w1#2
             eps.append(rng.standard_normal((K, 50, 14)).astype(F32))
             eps.append(rng.standard_normal((K, 1, 51)).astype(F32))
+        if philox:
+            ids = (0, 1, 2, 3)
+            eps = [philox_epsilon(K, int(np.prod(e.shape[1:])), e.shape[-1], PHILOX_SEED, c).reshape(e.shape) for e, c in zip(eps, ids)]
         with EpsQueue(list(eps)) as q:
             loss = model({"x": t(x), "y": t(y)})
         model.zero_grad()
@@ -798,7 +852,16 @@ def gen_bnn():
             out["x"], out["y"] = x, y
             for i, e in enumerate(eps):
                 out["eps%d" % i] = e
-        save("g_bnn_" + tag, **out)
+        if philox:
+            out["philox_seed"], out["philox_call_ids"] = np.array(PHILOX_SEED), np.array(ids)
+            if full:
+                for i in range(4):
+                    del out["eps%d" % i]
+        save("g_bnn_" + tag + ("_philox" if philox else ""), **out)
+
+
+def gen_bnn_philox():
+    gen_bnn(philox=True)
 
 
 def gen_uniform_latent():
@@ -1032,3 +1095,6 @@ if __name__ == "__main__":
     gen_reinforce()
     gen_uniform_latent()
     gen_seeded()
+    gen_iwae_philox()
+    gen_vae_philox()
+    gen_bnn_philox()

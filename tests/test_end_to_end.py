@@ -150,6 +150,104 @@ def test_iwae(dev, est, tag, B, K, hidden, fused_logits):
         np.testing.assert_allclose(model.last_iw_bound.detach().cpu().numpy()[::16], g["bound_b_every16"], rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("est", ["sgvb", "vimco"])
+@pytest.mark.parametrize("tag,B,K,hidden", [("small", 8, 5, 32), ("c3", 256, 50, 500)])
+@pytest.mark.parametrize("fused_logits,paired", [(False, True), (True, True), (False, False)])
+def test_iwae_on_the_in_kernel_philox_stream(dev, est, tag, B, K, hidden, fused_logits, paired):
+    """The PRODUCTION sampling path against the reference in one hop (nuance (i)): nothing is injected here.
+    The fixtures hold the reference's outputs for draws taken from the Philox4x32-10 stream of (seed, call ids 0 and 1)
+    (tests/golden/gen_golden.py:gen_iwae_philox); the package, seeded the same way, draws inside its sampling kernel --
+    both draws of the latent in ONE launch (`paired`), or one launch per draw -- and must land on the same objective,
+    log-importance-weights and gradients as the reference."""
+    g = load_golden("g_iwae_%s_%s_philox" % (est, tag))
+    seed = int(g["philox_seed"])
+    model = iwae.build(n_samples=K, estimator=est, hidden=hidden, device=dev, fused_logits=fused_logits)
+    H.load_params_into(model, 2000 + B + K)
+    x, _, _ = H.iwae_data(B, K)
+    _seed_philox(dev, seed)
+    with zs.pair_draws(paired):
+        loss = model({"x": T(x, dev)})
+    assert rel(loss, g["loss"]) < 5e-5, (float(loss), float(g["loss"]))
+    assert rel(model.last_iw_bound.mean(), g["iw_bound"]) < 2e-5
+    model.zero_grad()
+    loss.backward()
+    n_el = _check_grads(g, model, rtol_norm=1e-3, full=(tag == "small"))
+    assert n_el > (50000 if tag == "small" else 1000)
+    ref_err = abs(float(g["loss"]) - float(g["loss64"]))
+    assert abs(float(loss.detach()) - float(g["loss64"])) <= 2e-5 * abs(float(g["loss64"])) + 1.5 * ref_err
+    gen, var = model.generator, model.variational
+    lq, lpz, lpx = var.nodes["z"].log_prob(), gen.nodes["z"].log_prob(), gen.nodes["x"].log_prob()
+    if tag == "small":
+        _check_z(var.nodes["z"].dist.sample_cache, g["z"], dev)
+    np.testing.assert_allclose((lpz + lpx - lq).detach().cpu().numpy(), g["log_w"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(lq.detach().cpu().numpy(), g["logqz"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(lpz.detach().cpu().numpy(), g["logpz"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(lpx.detach().cpu().numpy(), g["logpx"], rtol=2e-5, atol=2e-4)
+
+
+def _seed_philox(dev, seed):
+    if dev.type == "cpu":
+        host_backend.manual_seed(seed)
+    else:
+        torch.cuda.manual_seed(seed)            # call id = generator offset // 4 = 0 for the first draw
+
+
+@pytest.mark.parametrize("tag,B", [("small", 8), ("c2", 512)])
+@pytest.mark.parametrize("paired", [True, False])
+def test_vae_on_the_in_kernel_philox_stream(dev, tag, B, paired):
+    """As test_iwae_on_the_in_kernel_philox_stream for the VAE (ELBO.sgvb, one particle): nothing injected."""
+    g = load_golden("g_vae_%s_philox" % tag)
+    model = vae_mnist.build(batch_size=B, device=dev)
+    H.load_params_into(model, 1000 + B)
+    x, _, _ = H.vae_data(B)
+    _seed_philox(dev, int(g["philox_seed"]))
+    with zs.pair_draws(paired):
+        loss = model({"x": T(x, dev)})
+    assert rel(loss, g["loss"]) < 2e-5
+    gen, var = model.generator, model.variational
+    assert rel(gen.nodes["z"].log_prob(), g["logpz"]) < 2e-5
+    assert rel(gen.nodes["x"].log_prob(), g["logpx"]) < 2e-5
+    assert rel(var.nodes["z"].log_prob(), g["logqz"]) < 2e-5
+    model.zero_grad()
+    loss.backward()
+    _check_grads(g, model, full=(tag == "small"))
+    if tag == "small":
+        _check_z(var.nodes["z"].dist.sample_cache, g["z"], dev)
+
+
+@pytest.mark.parametrize("tag,B,K", [("small", 16, 4), ("c5", 512, 10)])
+@pytest.mark.parametrize("materialize,paired", [(False, True), (True, True), (True, False)])
+def test_bnn_on_the_in_kernel_philox_stream(dev, tag, B, K, materialize, paired):
+    """The BNN step (two latents, each drawn twice) with nothing injected: the four draws carry the Philox call ids 0, 1, 2, 3
+    in the order the reference makes them (w0, w1, w0 again, w1 again), in every launch mode of the package (one launch for
+    all of a pass's draws, or one per draw)."""
+    model = bnn_vi.build(n_particles=K, device=dev, materialize=materialize)
+    wm, wl, yl = H.bnn_params(B, K)
+    with torch.no_grad():
+        for i in range(2):
+            model.variational.w_means[i].copy_(wm[i])
+            model.variational.w_logstds[i].copy_(wl[i])
+        model.generator.y_logstd.copy_(yl)
+    x, y, _ = H.bnn_data(B, K)
+    g = load_golden("g_bnn_%s_philox" % tag)
+    _seed_philox(dev, int(g["philox_seed"]))
+    with zs.pair_draws(paired):
+        loss = model({"x": T(x, dev), "y": T(y, dev)})
+    net, var = model.generator, model.variational
+    assert rel(loss, g["loss"]) < 2e-5
+    assert rel(net.cache["rmse"], g["rmse"]) < 2e-5
+    for name in ("w0", "w1"):
+        assert rel(net.nodes[name].log_prob(), g["logp_" + name]) < 2e-5
+        assert rel(var.nodes[name].log_prob(), g["logq_" + name]) < 2e-5
+    assert rel(net.nodes["y"].log_prob(), g["logp_y"]) < 2e-5
+    model.zero_grad()
+    loss.backward()
+    for i in range(2):
+        np.testing.assert_allclose(var.w_means[i].grad.cpu().numpy(), g["g_w_mean_%d" % i], rtol=1e-3, atol=5e-5)
+        np.testing.assert_allclose(var.w_logstds[i].grad.cpu().numpy(), g["g_w_logstd_%d" % i], rtol=1e-3, atol=5e-5)
+    np.testing.assert_allclose(net.y_logstd.grad.cpu().numpy(), g["g_y_logstd"], rtol=1e-3, atol=1e-4)
+
+
 @pytest.mark.parametrize("tag,B,K", [("small", 16, 4), ("c5", 512, 10), ("c5g", 4096, 10)])      # c5g: config 5's GLOBAL batch
 @pytest.mark.parametrize("materialize", [False, True])
 def test_bnn(dev, tag, B, K, materialize):

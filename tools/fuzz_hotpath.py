@@ -188,7 +188,11 @@ def case_iw1():
     """IW1 over its whole domain (K 2..64, D a multiple of 4 in 256..1024, latent rows of whole 16-byte pieces): against the oracle, and --
     fed its own row sums -- bit for bit K4b; the merged backward against the oracle."""
     K, R, D = int(rng.randint(2, 65)), dim(300), 4 * int(rng.randint(64, 257))
-    while K * R * D > 1500000:
+    if rng.rand() < 0.3:                           # more datapoints than CUs: workgroups of the persistent kernel own 2 ... 12 of them
+        R = int(rng.randint(257, 3100))
+        while K > 2 and K * R * D > 3000000:
+            K = max(K // 2, 2)
+    while K * R * D > (3000000 if R > 256 else 1500000):
         R = max(R // 2, 1)
     Dz = 4 * int(rng.randint(1, 65 if rng.rand() < 0.2 else 12))
     logits, x_full, pms, pss, ls = [bool(rng.rand() < q) for q in (0.4, 0.3, 0.4, 0.4, 0.3)]
