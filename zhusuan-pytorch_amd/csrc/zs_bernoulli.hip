@@ -846,9 +846,9 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
   if (grid_env > 0) G = grid_env;
   if (G > R) G = R;
   if (G >= (1 << ZS_IW1_CNT_BITS)) G = (1 << ZS_IW1_CNT_BITS) - 1;
-  a.sharded = G >= 128 ? 1 : 0;                                    // (many workgroups: two-level count of word A, zs_iwpersist.h)
+  a.sharded = 2;            // watcher mode (zs_iwpersist.h; 0 / 1: the last arrival finishes, one- / two-level count: experiments builds)
   static const int shard_env = env_knob("ZS_IW1_SHARDED", -1);     // experiments only
-  if (shard_env >= 0) a.sharded = shard_env ? 1 : 0;
+  if (shard_env >= 0) a.sharded = shard_env;
 #ifdef ZS_EXPERIMENTS
   static const int nt_env = env_knob("ZS_IW1_NT", 0);
   if (nt_env && !a.x_full) {

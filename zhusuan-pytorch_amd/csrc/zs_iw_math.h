@@ -155,8 +155,9 @@ __host__ __device__ __forceinline__ float iw1_mean(long long sum_a, long long su
   if (flags & ZS_IW1_FLAG_PINF) return INFINITY;
   if (flags & ZS_IW1_FLAG_NINF) return -INFINITY;
   const int bias_bits = iw1_bias_bits(cb), s1 = bias_bits - ZS_IW1_BOUND_BITS;
-  const double v = (double)sum_a + (double)sum_b / (double)(1ull << bias_bits);
-  const double total = s1 >= 0 ? v / (double)(1ull << s1) : v * (double)(1ull << -s1);
+  // (scalings by powers of two: exact, one instruction each -- this runs once per launch, at its very end, on the critical path)
+  const double v = (double)sum_a + __builtin_ldexp((double)sum_b, -bias_bits);
+  const double total = __builtin_ldexp(v, -s1);
   return (float)(total / (double)R);
 }
 

@@ -90,6 +90,13 @@ __device__ __forceinline__ void iw1_share_and_finish(const Iw1Mean& a, int G, in
   const int S = ZS_IW1_S, bias_bits = iw1_bias_bits(a.cb);
   const unsigned long long mask = (1ull << S) - 1ull;
   const int shard = g & (ZS_IW1_SHARDS - 1);
+  // 2: watcher mode (iw1_watch, below), the release build's only mode; 0 / 1: the workgroup that completes the count finishes the
+  // mean, with a one- / two-level count (round 4 and the first half of round 5: kept in experiments builds for the comparison)
+#ifdef ZS_EXPERIMENTS
+  const int mode = a.sharded;
+#else
+  constexpr int mode = 2;
+#endif
   ZS_GLOBAL unsigned long long* wb = a.acc + ZS_IW1_B_OFF + 1 + (lane & (ZS_IW1_SHARDS - 1));
   // (wave-uniform decisions are taken on scalar copies -- readfirstlane -- and every load is issued for all 64 lanes in the same
   //  straight-line region as its use: a load behind a lane mask, used behind another, would count as possibly in flight where this
@@ -106,16 +113,22 @@ __device__ __forceinline__ void iw1_share_and_finish(const Iw1Mean& a, int G, in
     if (flags) {                         // rare: raise the sticky flags on the total, and let them land before this share is counted
       const unsigned long long f = ((flags & 4u) ? ZS_IW1_FLAG_NAN : 0ull) | ((flags & 2u) ? ZS_IW1_FLAG_PINF : 0ull) |
                                    ((flags & 1u) ? ZS_IW1_FLAG_NINF : 0ull);
-      (void)__hip_atomic_fetch_or(a.acc, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (watcher mode: on the workgroup's own shard word of A, the word its count goes to -- one location, so whoever reads the
+      //  count reads the flags; bits 61 .. 63 are above the count field.  Otherwise: on the total, which the finisher reads last.)
+      (void)__hip_atomic_fetch_or(mode == 2 ? a.acc + 1 + shard : a.acc, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     (void)__hip_atomic_fetch_add(a.acc + ZS_IW1_B_OFF + 1 + shard, add_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (mode == 2) {                     // watcher mode (below): nobody needs the old value -- nothing to wait for
+      (void)__hip_atomic_fetch_add(a.acc + 1 + shard, add_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
     // two levels when there are many workgroups (256 same-address atomics arriving together serialise, ~11 ns each:
     // MI355X_MICROARCH.md "dequeue"): the shard's last arrival moves the shard's count and (still biased) sum to the total
-    t = __hip_atomic_fetch_add(a.sharded ? a.acc + 1 + shard : a.acc, add_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add_a;
+    t = __hip_atomic_fetch_add(mode ? a.acc + 1 + shard : a.acc, add_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add_a;
   }
+  if (mode == 2) return;                // watcher mode: sent and forgotten; workgroup 0's tail wave watches the words (iw1_watch, below)
   unsigned long long tot_a;
-  if (!a.sharded) {                     // (ONE branch on the mode, each arm complete: a load in one `if` and its use behind another
+  if (!mode) {                          // (ONE branch on the mode, each arm complete: a load in one `if` and its use behind another
     vb = __hip_atomic_load(wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // `if` on the same flag is a path to the compiler)
     tot_a = uniform64(t);               // (the load flies beside the atomic above)
     asm volatile("" ::"v"(vb));
@@ -160,6 +173,60 @@ __device__ __forceinline__ void iw1_share_and_finish(const Iw1Mean& a, int G, in
     if (cnt != (unsigned long long)G) m = __builtin_nanf("");  // (word B never completed: cannot happen; never spin for ever)
     a.mean_cost[0] = m;
     __hip_atomic_store(a.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Watcher mode (Iw1Mean::sharded == 2, the release build's): the shares are sent and forgotten -- no returning atomic, a workgroup
+// is done when its adds are on their way -- and the tail wave of WORKGROUP 0, once its own share is out, WATCHES the 32 shard words
+// (lanes 0 .. 15 word A's with the sticky flags, lanes 16 .. 31 word B's) until both counts are complete, then finishes the mean.
+// After the LAST workgroup's reduction the chain is: its adds land, the next sample sees them -- instead of three dependent round
+// trips (shard count, total count, the B words), each ~1 us under the other workgroups' streams: 12.1 - 12.4 us instead of
+// 12.6 - 12.9 at B = 256, 18.9 - 19.1 instead of 19.3 at B = 512 (profiles/r05_iw1_watch_variants.txt; more than one watching
+// wave, or working every sample out in full, measured no better: the samples compete with the adds for the same 32 words).
+// The words carry their own counts and flags: no ordering between different addresses is relied upon.  A watcher that starts
+// before the other workgroups are resident just samples longer; nobody waits for the watcher.
+__device__ __forceinline__ void iw1_watch(const Iw1Mean& a, int G, int lane) {
+  const int S = ZS_IW1_S, bias_bits = iw1_bias_bits(a.cb);
+  const unsigned long long mask = (1ull << S) - 1ull;
+  const int wlane = lane & (2 * ZS_IW1_SHARDS - 1);            // (lanes 32 .. 63 repeat the addresses of 0 .. 31; their values are ignored)
+  ZS_GLOBAL unsigned long long* wl = wlane < ZS_IW1_SHARDS ? a.acc + 1 + wlane : a.acc + ZS_IW1_B_OFF + 1 + (wlane - ZS_IW1_SHARDS);
+  unsigned long long v = 0;
+  bool complete = false;
+  for (int spin = 0; spin < (1 << 18) && !complete; ++spin) {
+    v = __hip_atomic_load(wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(v));
+    int c = (int)(v >> S) & ((1 << ZS_IW1_CNT_BITS) - 1);       // this shard's count
+    c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xf, 0xf, true);                // row-of-16 butterfly: every lane = its row's total
+    c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, true);
+    c += __builtin_amdgcn_update_dpp(0, c, 0x141, 0xf, 0xf, true);
+    c += __builtin_amdgcn_update_dpp(0, c, 0x140, 0xf, 0xf, true);
+    complete = __builtin_amdgcn_readlane(c, 0) == G && __builtin_amdgcn_readlane(c, ZS_IW1_SHARDS) == G;
+    if (!complete) __builtin_amdgcn_s_sleep(1);
+  }
+  // the two 64-bit sums: the same row-of-16 butterfly on both halves of the word (DPP: four steps of two moves and one 64-bit add;
+  // __shfl_xor would be eight trips through the LDS crossbar at the very end of the launch)
+  unsigned long long sum = v & mask;
+#define ZS_DPP_U64(x, ctrl) (((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)((x) >> 32), ctrl, 0xf, 0xf, true) << 32) | \
+                             (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xf, 0xf, true))
+  sum += ZS_DPP_U64(sum, 0xB1);
+  sum += ZS_DPP_U64(sum, 0x4E);
+  sum += ZS_DPP_U64(sum, 0x141);
+  sum += ZS_DPP_U64(sum, 0x140);
+#undef ZS_DPP_U64
+  auto lane64 = [&](unsigned long long x, int l) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(x >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)x, l);
+  };
+  const unsigned long long tot_a = lane64(sum, 0), tot_b = lane64(sum, ZS_IW1_SHARDS);
+  const bool in_a = lane < ZS_IW1_SHARDS;
+  const unsigned long long fl = (__builtin_amdgcn_ballot_w64(in_a && (v & ZS_IW1_FLAG_NAN)) ? ZS_IW1_FLAG_NAN : 0ull) |
+                                (__builtin_amdgcn_ballot_w64(in_a && (v & ZS_IW1_FLAG_PINF)) ? ZS_IW1_FLAG_PINF : 0ull) |
+                                (__builtin_amdgcn_ballot_w64(in_a && (v & ZS_IW1_FLAG_NINF)) ? ZS_IW1_FLAG_NINF : 0ull);
+  if (lane < 2 * ZS_IW1_SHARDS) __hip_atomic_store(wl, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // the 32 words back to zero
+  if (lane == 0) {
+    const long long bias_total = (long long)((unsigned long long)a.R << bias_bits);
+    float m = iw1_mean((long long)tot_a - bias_total, (long long)tot_b - bias_total, fl, a.cb, a.R);
+    if (!complete) m = __builtin_nanf("");                       // (cannot happen -- every workgroup sends its share; never watch for ever)
+    a.mean_cost[0] = m;
   }
 }
 #endif  // ZS_ON_DEVICE
@@ -517,6 +584,11 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
           fl = sm.flags;
         }
         iw1_share_and_finish(mean, G, g, n_dp, lane, sa, sb, fl);
+#ifdef ZS_EXPERIMENTS
+        if (g == 0 && mean.sharded == 2) iw1_watch(mean, G, lane);
+#else
+        if (g == 0) iw1_watch(mean, G, lane);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ZS_IW1_STAMP(5);
       }
