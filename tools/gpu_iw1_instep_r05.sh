@@ -18,5 +18,6 @@ PY
 for i in 1 2; do
   run "release (persistent)" ZS_NONE=1
   run "round-4 block kernel" ZS_HIP_LIBRARY=tools/_exp/libzs_hip_exp.so ZS_IW1_BLOCK_KERNEL=1
+  run "persistent, last arrival finishes" ZS_HIP_LIBRARY=tools/_exp/libzs_hip_exp.so ZS_IW1_SHARDED=1
 done
 } | tee gpurun_out/r05_iw1_instep.txt

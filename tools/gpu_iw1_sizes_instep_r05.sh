@@ -15,7 +15,7 @@ print("%-28s step %.4f ms | %s" % (sys.argv[1], d["ms_per_step"], "  ".join("%s 
 PY
 }
 {
-for B in ${SIZES:-512 1024 1536 2048}; do
+for B in ${SIZES:-512 1024 1280 1536 2048}; do
   run "B=$B fused" --batch-per-gpu $B --iw1-max-stream-bytes 1099511627776
   run "B=$B K3+K2+K4b" --batch-per-gpu $B --iw1-max-stream-bytes 0
 done

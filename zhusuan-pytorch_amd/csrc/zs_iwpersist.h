@@ -192,7 +192,10 @@ __device__ __forceinline__ void iw1_watch(const Iw1Mean& a, int G, int lane) {
   ZS_GLOBAL unsigned long long* wl = wlane < ZS_IW1_SHARDS ? a.acc + 1 + wlane : a.acc + ZS_IW1_B_OFF + 1 + (wlane - ZS_IW1_SHARDS);
   unsigned long long v = 0;
   bool complete = false;
-  for (int spin = 0; spin < (1 << 18) && !complete; ++spin) {
+  // (a bound in TIME, 10 s of the 100 MHz clock: when the GPU is shared, another process's kernels can keep this launch's other
+  //  workgroups waiting for many milliseconds; only a launch that lost workgroups would reach the bound, and gets NaN instead of a hang)
+  const unsigned long long give_up = __builtin_amdgcn_s_memrealtime() + 1000000000ull;
+  while (!complete && __builtin_amdgcn_s_memrealtime() < give_up) {
     v = __hip_atomic_load(wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::"v"(v));
     int c = (int)(v >> S) & ((1 << ZS_IW1_CNT_BITS) - 1);       // this shard's count

@@ -579,8 +579,8 @@ def _iw1_accumulator(device):
 IW1_MAX_DATAPOINTS = 1 << 20        # (round 4's workgroup-per-datapoint kernel stopped at 384; the persistent form takes any batch)
 # No limit on the [K, B, X] stream's size either: launched cold (the stream in HBM only) the fused launch loses to K3's x-reuse kernel
 # + K2 + K4b beyond B = 1024 (124 us against 83 at B = 2048, profiles/r05_iw1_timing.txt), but a step evaluates the stream right after
-# the decoder produced it, and there it wins at every size measured (B = 512 ... 2048: 22.7 / 35.4 / 52.6 / 73.9 us against
-# 26.6 / 47.8 / 69.9 / 92.6, profiles/r05_iw1_sizes_instep.txt).  bench.py --iw1-max-stream-bytes sets this for such studies.
+# the decoder produced it, and there it wins at every size measured (B = 512 ... 2048: 21.1 / 34.2 / 52.3 / 72.0 us against
+# 27.1 / 49.4 / 70.7 / 92.8, profiles/r05_iw1_sizes_instep.txt).  bench.py --iw1-max-stream-bytes sets this for such studies.
 IW1_MAX_STREAM_BYTES = 1 << 62
 
 
