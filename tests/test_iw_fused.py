@@ -11,6 +11,8 @@ gpu     : libzs_hip.so against the oracle and against its own unfused kernels on
           the second), tickets back at zero, a deterministic batch mean; the backward with the incoming gradient as a device
           scalar / a per-datapoint vector.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -447,3 +449,36 @@ def test_staged_backward_launches_only_the_side_each_stage_needs(dev, monkeypatc
     for p, r in zip(model.parameters(), ref):
         # (the merged single-pass launch sums the K particles in 4 slices, the stand-alone log q launch in 16: last-bit differences)
         np.testing.assert_allclose(p.grad.detach().cpu().numpy(), r.cpu().numpy(), rtol=2e-4, atol=1e-6 * float(r.abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_iw1_launches_on_two_streams_at_once(hip):
+    """The batch mean is finished by a wave of workgroup 0 that WATCHES the shard words (zs_iwpersist.h: iw1_watch) while the other
+    workgroups of its launch may not even be resident yet.  Two launches in flight at once -- two streams, an accumulator each,
+    256 + 256 workgroups of 1 024 threads competing for the same CUs, 40 rounds without a synchronisation in between -- must each
+    end with their own mean, the one a launch alone on the device gives, and with their accumulators back at zero."""
+    K, D = 50, 784
+    shapes = (300, 700)                     # more datapoints than CUs on both: every CU is wanted by both launches
+    rng = np.random.RandomState(11)
+    P = _hip.ptr
+    sets = []
+    for R in shapes:
+        p, x, z, pmu, psg, rows_a, logq = [a.astype(np.float32) for a in _inputs(rng, K, R, D, 40, False, False, False, False, False)]
+        alone = iw1(hip, p, x, K, R, D, z, pmu, psg, False, None, logq, 1, True, False)
+        t = dict(p=hip.t(p), x=hip.t(x), z=hip.t(z), pmu=hip.t(pmu), psg=hip.t(psg), logq=hip.t(logq),
+                 lp_x=hip.empty(R, K), lp_z=hip.empty(R, K), cost_b=hip.empty(R), bound=hip.empty(R), coef=hip.empty(2, R, K),
+                 means=hip.empty(40), acc=torch.zeros(64, dtype=torch.int64, device=hip.dev), R=R, stream=torch.cuda.Stream(hip.dev))
+        sets.append((t, alone))
+    torch.cuda.synchronize()
+    for i in range(40):
+        for t, _ in sets:
+            R = t["R"]
+            hip.k.call("zs_bernoulli_iw_objective_f32", P(t["p"]), 0, P(t["x"]), R * D, K, R, D, P(t["z"]), P(t["pmu"]), R * 40, P(t["psg"]), R * 40,
+                       40, 0, None, K, P(t["logq"]), K, 1, 1, P(t["lp_x"]), P(t["lp_z"]), P(t["cost_b"]), P(t["bound"]), P(t["coef"]),
+                       P(t["means"][i:]), P(t["acc"]), ctypes.c_void_p(t["stream"].cuda_stream))
+    torch.cuda.synchronize()
+    for t, alone in sets:
+        means = t["means"].cpu().numpy()
+        assert (means == alone["mean"][0]).all(), (means, alone["mean"][0])
+        assert int(t["acc"].abs().sum().item()) == 0
+        np.testing.assert_array_equal(t["cost_b"].cpu().numpy(), alone["cost"])
