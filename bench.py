@@ -61,11 +61,22 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs and the HBM-resident kernel figures")
     ap.add_argument("--force-collective-path", action="store_true",
                     help="run the multi-rank code path (bucket pack + all-reduce + split graphs) even with one rank")
+    ap.add_argument("--overlap", action="store_true",
+                    help="multi-rank, graphs: the STAGED step -- two buckets, three graphs: the decoder-gradient all-reduce runs on "
+                         "the collective library's stream beside the encoder's backward (zhusuan.dataparallel.StagedBuckets).  Not "
+                         "the default since round 6: at this model's size the fork / join around the overlapped collective costs "
+                         "about what it hides (DESIGN.md section 7, profiles/r06_stream_links.txt)")
+    ap.add_argument("--no-direct-rccl", action="store_true",
+                    help="all-reduce through torch.distributed (two HIP event records per call) instead of this job's own RCCL "
+                         "communicator driven on the compute stream (zhusuan.dataparallel.DirectAllReduce)")
+    ap.add_argument("--timeline", default="",
+                    help="write a chrome trace (torch.profiler: host runtime calls + device activity) of 5 steps in the timed "
+                         "region's launch mode to this path (tools/timeline_gaps.py reads it)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python each step instead of replaying captured hipGraphs")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="multi-rank, graphs: ONE bucket all-reduced after the whole backward (graph A -> all-reduce -> "
-                         "graph B) instead of the staged step whose decoder-gradient all-reduce overlaps the encoder's backward")
+                    help="(the default since round 6; kept for old command lines) multi-rank, graphs: ONE bucket all-reduced on "
+                         "the compute stream after the whole backward: graph A -> all-reduce -> graph B (the update)")
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="eager launches only (--no-graph): all-reduce gradient buckets from autograd hooks while backward "
                          "is still running (zhusuan.dataparallel.OverlappedBuckets)")
@@ -503,16 +514,52 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
             "optimizer": opt_label}
 
 
+def dp_step_on_one_rank(args, headline_value, timeout_s=420):
+    """extra_configs.c3_dp_step_n1: the headline's settings through the DEFAULT MULTI-RANK FORM of the step (flat bucket filled
+    by the backward pass, graph A -> all-reduce over RCCL on the compute stream -> graph B = the update) with ONE rank -- the
+    fixed cost of the data-parallel path, which caps the 1 -> 8 curve before a byte crosses xGMI and is the only part of that
+    curve one GPU can measure.  Runs in a CHILD process (this one never initialises a process group), which also replays the
+    same model as a single graph, alternating, for a ratio free of process-to-process differences (`same_process`)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--force-collective-path", "--no-extras", "--no-cpu-baseline", "--full-record", os.devnull]
+    for flag, on in (("--fused-logits", args.fused_logits), ("--torch-adam", args.torch_adam), ("--torch-linear", args.torch_linear),
+                     ("--no-gemm-tuning", args.no_gemm_tuning), ("--skip-discarded-draws", args.skip_discarded_draws),
+                     ("--allow-experiments", args.allow_experiments), ("--unfused-activations", args.unfused_activations)):
+        if on:
+            cmd.append(flag)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("the one-rank collective-path run ended with code %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+    rec = json.loads(lines[-1])
+    sp = rec.get("same_process") or {}
+    return {"workload": rec["config"]["workload"], "ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit": rec["unit"],
+            "vs_headline": rec["value"] / headline_value, "launch_mode": rec["config"]["launch_mode"],
+            "collective_library": rec.get("collective_library"), "collective_path": rec.get("collective_path"),
+            "parallelism": rec["config"]["parallelism"], "final_loss": rec.get("final_loss"),
+            "same_process_single_graph_ms": sp.get("single_graph_ms_per_step"),
+            "same_process_collective_path_ms": sp.get("collective_path_ms_per_step"),
+            "same_process_ratio": sp.get("collective_path_vs_single_graph"), "extra_us_per_step": sp.get("extra_us_per_step")}
+
+
 DENSE_LABEL = {"fused": "zhusuan.Linear in zhusuan.Sequential (ReLU in the GEMM epilogue; activation backward + bias gradient: AB1)",
                "zhusuan": "zhusuan.Linear in torch.nn.Sequential (bias gradient: CS1; torch's activation passes)",
                "torch": "torch.nn.Linear in torch.nn.Sequential"}
 
 
 def _timed_launches(klib, out, launches):
-    def timed(entry, nbytes, fn, rows, width, key=None):
+    def timed(entry, nbytes, fn, rows, width, key=None, idle_s=0.0):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
+        if idle_s > 0:
+            time.sleep(idle_s)           # the shader clock falls back while the GPU idles (the K1 cold figures)
         klib.prof_enable(True)
         for _ in range(launches):
             fn()
@@ -520,8 +567,10 @@ def _timed_launches(klib, out, launches):
         klib.prof_enable(False)
         d = sorted(1e3 * v for v in klib.prof_durations(entry))
         med = d[len(d) // 2]
+        avg = sum(d) / len(d)
         out[key or entry] = {"rows": rows, "row_length": width, "algorithmic_bytes": nbytes, "median_us": med, "min_us": d[0],
-                             "launches": len(d), "GBps": nbytes / med / 1e3, "frac_of_hbm_peak": nbytes / med / 1e3 / HBM_PEAK_GBS}
+                             "avg_us": avg, "launches": len(d), "GBps": nbytes / med / 1e3,
+                             "frac_of_hbm_peak": nbytes / med / 1e3 / HBM_PEAK_GBS, "frac_of_hbm_peak_avg": nbytes / avg / 1e3 / HBM_PEAK_GBS}
     return timed
 
 
@@ -544,6 +593,9 @@ def k1_resident(klib, dev, launches=30):
         mu, sg = torch.randn(M, device=dev), torch.rand(M, device=dev) + 0.5
         z, lp = torch.empty(K * M, device=dev), torch.empty(B * K, device=dev)
         fn = lambda: klib.call("zs_normal_sample_logprob_f32", P(mu), P(sg), None, 1, 2, None, P(z), P(lp), K, M, D, 1, K, 0, None, st)
+        # COLD: the same 30 launches right after a second of idling -- the condition of a kernel sweep, or of a training loop
+        # that waits for its data; the clock ramps up inside these launches (roofline.k1_frac_*_cold = bytes / their AVERAGE)
+        timed("zs_normal_sample_logprob_f32", 4 * N * D + 4 * N + 8 * M, fn, N, D, key=key + ("" if "@" in key else "@4M") + "_cold", idle_s=1.0)
         # sustained clock (see the docstring): 50 ms windows of back-to-back launches until six windows in a row bring no
         # improvement of more than 1 % (at least 1 s, at most 4 s: on some boxes the ramp from a cold process is slow -- one box
         # showed 58.5 % at 1 M rows after 0.3 s where the sweep in the same call, seconds of launches later, measured 63.3 %)
@@ -834,14 +886,29 @@ def main():
 
     multi = world > 1 or args.force_collective_path
     hooks = multi and args.no_graph and args.overlap_allreduce
-    staged = multi and not args.no_graph and not args.no_overlap
-    bucket = dataparallel.GradientBucket(model)
+    staged = multi and not args.no_graph and args.overlap
+    # The data path's collective: this job's own RCCL communicator, driven on the compute stream with no event around it
+    # (collective set-up: every rank, here; a communicator on every rank or on none -- then torch.distributed's all_reduce)
+    rccl = None
+    if multi and dist.is_initialized() and not share_device and not args.no_direct_rccl:
+        kick("RCCL communicator of the data path")
+        rccl = dataparallel.DirectAllReduce.create(timeout_s=120.0)
+        if rccl is None and rank == 0:
+            sys.stderr.write("bench: direct RCCL communicator unavailable (%s); all-reducing through torch.distributed\n"
+                             % dataparallel.DirectAllReduce.last_error)
+    # Gradients are written into the flat buckets by the backward pass itself (direct=True: the dense layers' weight GEMMs and
+    # bias reductions take the bucket slices as their outputs), so no concatenation pass runs before a collective; with one
+    # rank and no collective there is no bucket to fill.  (One registration per parameter: only the form in use registers.)
+    bucket = dataparallel.GradientBucket(model, direct=multi and not staged and not hooks)
     obuckets = dataparallel.OverlappedBuckets(model, n_buckets=2) if hooks else None
-    # backward reaches the decoder's (generator's) parameters first, then the encoder's: two stages, two buckets
-    sbuckets = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()]) if staged else None
-    # one optimizer bucket per gradient bucket: the update reads the averaged gradients where the collective left them
-    opt = make_optimizer(model, args.torch_adam,
-                         groups=[list(model.generator.parameters()), list(model.variational.parameters())] if staged else None)
+    # --overlap: backward reaches the decoder's (generator's) parameters first, then the encoder's: two stages, two buckets;
+    # --force-collective-path with one rank issues the all-reduces all the same (what the path costs before a byte moves)
+    sbuckets = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()], direct=True,
+                                          always_collective=args.force_collective_path) if staged else None
+    # the update reads the summed gradients where the collective left them, 1/world folded into the read (FlatAdam takes a
+    # pointer per tensor: one launch whatever the buckets; round 5 launched once per bucket)
+    opt = make_optimizer(model, args.torch_adam)
+    grad_scale = 1.0 / world
     held = {}
 
     one = torch.ones((), device=dev)          # backward's seed, allocated once (loss.backward() fills a fresh one per step)
@@ -857,13 +924,22 @@ def main():
         return loss.detach()
 
     def exchange_part(loss):
-        """one collective after the whole backward: all-reduce of the flat bucket over RCCL/xGMI, then 1/world"""
+        """ONE collective after the whole backward, on the compute stream: all-reduce (SUM) of the flat bucket over RCCL / xGMI.
+        Returns the objective's slot: the SUM over the ranks (the line divides by the world size once, after the timed region)."""
         if not multi:
             return loss
-        if dist.is_initialized():
-            dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM)
-        bucket.flat.mul_(1.0 / world)
+        bucket.exchange(direct=rccl, always=args.force_collective_path)
         return bucket.flat[bucket.n_grad]
+
+    def update_part():
+        """Adam; the 1/world of the gradient mean rides in FlatAdam's gradient read (torch's Adam: one pass over the bucket first)"""
+        if not multi or hooks:
+            opt.step()
+        elif args.torch_adam:
+            bucket.scale()
+            opt.step()
+        else:
+            opt.step(grad_scale=grad_scale)
 
     def step_body():
         """the step launched eagerly (also what the HIP-event kernel timing pass runs)"""
@@ -876,11 +952,14 @@ def main():
             g = obuckets.finish()
         else:
             g = exchange_part(compute_part())
-        opt.step()
+        update_part()
         return g
 
     # the staged step (default with more than one rank): decoder backward | all-reduce bucket 0 (asynchronous, on
     # RCCL's stream) | encoder backward, overlapping it | all-reduce bucket 1, wait | 1/world + Adam
+    # (With VIMCO the encoder's gradients do not pass through the decoder: stage 2 repeats nothing but the objective's own
+    #  backward.  StagedBuckets.backward_stage(also=..., roots=...) cuts the stages at the variational net's outputs instead --
+    #  what a reparameterised objective wants; here it was measured and lost 8 us to the boundary tensors' gradient copies.)
     def stage_forward_and_decoder_backward():
         rng.begin_step()
         sbuckets.zero()
@@ -916,15 +995,24 @@ def main():
     def agree(ok):
         return dataparallel.all_ranks_agree(ok, device=dev)
 
+    # bucket 1's result is needed by the very next kernel (the update): its all-reduce goes on the compute stream itself (no
+    # cross-stream hops), bucket 0's runs beside the encoder's backward and is joined here
+    def second_exchange():
+        sbuckets.launch(1, overlap=False, direct=rccl)
+        sbuckets.wait()
+
     def eager_staged_step():
         """the staged step without graphs: the SAME stages, hence the same two all-reduces, launched from Python"""
         stage_forward_and_decoder_backward()
         sbuckets.launch(0)
         stage_encoder_backward()
-        sbuckets.launch(1)
-        sbuckets.wait()
+        second_exchange()
         stage_update()
-        return sbuckets.loss()
+        return sbuckets.loss_slot()
+
+    # what a step returns is the objective's slot of the bucket as the update left it: the SUM over the ranks when the 1/world
+    # rode in FlatAdam's gradient read (the line divides once, after the timed region -- no kernel per step for a diagnostic)
+    slot_is_sum = multi and not hooks and not args.torch_adam
 
     with zhusuan.device_rng(rng), zhusuan.skip_discarded_draws(skip_discarded):
         step = step_body
@@ -951,23 +1039,23 @@ def main():
                         maybe_fail_capture()
                         return stage_forward_and_decoder_backward()
                     stages = [("graph", first_stage), ("eager", lambda: sbuckets.launch(0)),
-                              ("graph", stage_encoder_backward), ("eager", lambda: (sbuckets.launch(1), sbuckets.wait())),
+                              ("graph", stage_encoder_backward), ("eager", second_exchange),
                               ("graph", stage_update)]
                     gs = zhusuan.GraphedStages(stages, rng=rng, warmup=max(args.warmup, 3), agree=agree if world > 1 else None)
                     captured, capture_note = gs.captured, gs.capture_error
 
                     def step():
                         gs()
-                        return sbuckets.loss()
+                        return sbuckets.loss_slot()
                     mode = "hipgraph x3, all-reduce of the decoder's gradients overlapped with the encoder's backward"
                 else:
                     def compute_graphed():
                         maybe_fail_capture()
                         return compute_part()
-                    step = gstep = zhusuan.GraphedStep(compute_graphed, opt.step, exchange=exchange_part if multi else None, rng=rng,
-                                                       warmup=max(args.warmup, 3), agree=agree if world > 1 else None)
+                    step = gstep = zhusuan.GraphedStep(compute_graphed, update_part, exchange=exchange_part if multi else None, rng=rng,
+                                                       warmup=max(args.warmup, 3), agree=agree if world > 1 else None, optimizer=opt)
                     captured, capture_note = gstep.captured, gstep.capture_error
-                    mode = "hipgraph x2 around an eager all-reduce" if multi else "hipgraph"
+                    mode = "hipgraph x2 around ONE all-reduce on the compute stream" if multi else "hipgraph"
             except Exception as e:                      # noqa: BLE001
                 if world > 1:        # not at a meeting point: the peers may be inside a collective this rank will never join
                     fail(rank, "graph warm-up failed outside a capture (stage '%s')" % (wd.stage if wd else "?"), e)
@@ -988,9 +1076,31 @@ def main():
         if rank == stall_rank:              # test hook: this rank stops here; its peers wait in the first trial's barrier
             time.sleep(10 ** 6)
         trials, last = timed_trials(step, args.steps, world, dev, kick=kick)
+        # one rank on the collective path: the SAME model, optimizer, GEMM picks and box as a single graph, alternating with
+        # the multi-rank form -- what the path costs before a byte crosses xGMI, free of process-to-process differences
+        same_process = None
+        if args.force_collective_path and world == 1 and mode.startswith("hipgraph"):
+            def compute_single():
+                rng.begin_step()
+                bucket.zero()
+                if sbuckets is not None:
+                    sbuckets.zero()
+                loss = model(obs)
+                loss.backward(one)
+                return loss.detach()
+            twin = zhusuan.GraphedStep(compute_single, opt.step, rng=rng, warmup=3)
+            t_multi, t_single = [], []
+            for _ in range(3):
+                t_single += timed_trials(twin, args.steps, 1, dev, min_seconds=0.25)[0]
+                t_multi += timed_trials(step, args.steps, 1, dev, min_seconds=0.25)[0]
+            m_multi, m_single = float(np.median(t_multi)), float(np.median(t_single))
+            same_process = {"single_graph_ms_per_step": 1e3 * m_single / args.steps, "collective_path_ms_per_step": 1e3 * m_multi / args.steps,
+                            "collective_path_vs_single_graph": m_single / m_multi,
+                            "extra_us_per_step": 1e6 * (m_multi - m_single) / args.steps, "trials_each": len(t_multi)}
+            del twin
         kick("per-kernel timing passes")
         elapsed = float(np.median(trials))
-        final_loss = float(last)
+        final_loss = float(last) * (grad_scale if slot_is_sum else 1.0)
         # per-kernel durations: the same steps launched eagerly with start/stop HIP events bound to each
         # kernel dispatch on its stream (events cannot ride inside a graph replay)
         n_prof = min(args.steps, 50)
@@ -1039,6 +1149,18 @@ def main():
             run_steps(n_dev)
             dev_times = {}
         torch.cuda.synchronize()
+        if args.timeline and rank == 0:
+            try:
+                from torch.profiler import profile, ProfilerActivity
+                with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as tprof:
+                    run_steps(5)
+                    torch.cuda.synchronize()
+                tprof.export_chrome_trace(args.timeline)
+            except Exception as e:                                  # noqa: BLE001
+                sys.stderr.write("bench: --timeline: %r\n" % (e,))
+        elif args.timeline:
+            run_steps(5)                 # (the other ranks run the same collectives)
+            torch.cuda.synchronize()
         # every replica started from rank 0's weights and applied the same averaged gradients: their parameters must be
         # bit-identical after any number of steps.  A collective that summed the wrong buffers shows up here.
         replicas = None
@@ -1183,6 +1305,11 @@ def main():
             "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "replicas_in_sync": None if replicas is None else replicas["in_sync"],
             "collective_library": collective_library(share_device) if dist.is_initialized() else None,
+            "collective_path": None if not multi else (
+                ("RCCL called directly on the compute stream (own communicator, no event records)" if rccl is not None
+                 else "torch.distributed all_reduce (synchronous form, current stream)") +
+                ("; the decoder bucket asynchronously on the collective library's stream" if staged else "")),
+            **({"same_process": same_process} if same_process else {}),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "trials": len(trials), "timed_seconds_total": float(sum(trials)),
@@ -1216,6 +1343,10 @@ def main():
                 for key, label in (("zs_normal_sample_logprob_f32@1M", "k1_frac_1M"), ("zs_normal_sample_logprob_f32", "k1_frac_4M")):
                     if key in hb:
                         roof[label] = hb[key]["frac_of_hbm_peak"]
+                # ... and the same launches after a second of idling (average of the 30: the clock ramps inside them)
+                for key, label in (("zs_normal_sample_logprob_f32@1M_cold", "k1_frac_1M_cold"), ("zs_normal_sample_logprob_f32@4M_cold", "k1_frac_4M_cold")):
+                    if key in hb:
+                        roof[label] = hb[key]["frac_of_hbm_peak_avg"]
                 dom = hb.get("zs_bernoulli_logprob_bwd_f32")
                 if dom:
                     roof["hbm_resident_frac"] = dom["frac_of_hbm_peak"]       # the Bernoulli backward stream at 831 MB (beyond the cache)
@@ -1224,7 +1355,8 @@ def main():
                 full["roofline_notes"]["k1"] = (
                     "zs_normal_sample_logprob_f32 (in-kernel Philox4x32-10, K = 50, D = 40) at 1 M / 4.2 M rows: median of 30 back-to-back "
                     "launches, HIP events bound to each dispatch, each size right after 1 - 4 s of the kernel's own launches (VALU-issue "
-                    "bound: the shader clock follows the recent load); bytes per row 4*D + 4 written + 8*D/K read (SURVEY.md 8d)")
+                    "bound: the shader clock follows the recent load); k1_frac_*_cold: the AVERAGE of the same 30 launches right after one "
+                    "second of idling (a kernel sweep's condition); bytes per row 4*D + 4 written + 8*D/K read (SURVEY.md 8d)")
             except Exception as e:                                  # noqa: BLE001
                 full["hbm_resident"] = {"error": short(e)}
             del model, opt, bucket
@@ -1270,8 +1402,18 @@ def main():
                 extra("c3_torch_linear", "c3", fused_logits=args.fused_logits, **dict(base, dense="torch"))
             if not args.torch_adam:     # ... and with torch's multi-tensor Adam
                 extra("c3_torch_adam", "c3", fused_logits=args.fused_logits, **dict(base, torch_adam=True))
+            # the step in its default multi-rank form on ONE rank over RCCL (a child process): SURVEY 8e's fixed cost
+            try:
+                ex["c3_dp_step_n1"] = dp_step_on_one_rank(args, out["value"])
+            except Exception as e:                                  # noqa: BLE001
+                ex["c3_dp_step_n1"] = {"error": short(e)}
             out["extra_configs"] = dict((k, ({"ms_per_step": v["ms_per_step"], "value": v["value"]} if "error" not in v else v))
                                         for k, v in ex.items())
+            if "error" not in ex["c3_dp_step_n1"]:
+                out["extra_configs"]["c3_dp_step_n1"].update(
+                    vs_headline=ex["c3_dp_step_n1"]["vs_headline"], same_process_ratio=ex["c3_dp_step_n1"]["same_process_ratio"],
+                    extra_us_per_step=ex["c3_dp_step_n1"]["extra_us_per_step"],
+                    collective_library=ex["c3_dp_step_n1"]["collective_library"])
             if "error" not in ex.get("c3_refresh", {"error": 1}):
                 # how far a new minibatch per step is from the headline (same settings, same box, same run)
                 out["extra_configs"]["c3_refresh"]["vs_headline"] = ex["c3_refresh"]["value"] / out["value"]
@@ -1297,6 +1439,8 @@ def main():
         print(fit_line(out), flush=True)
     if wd is not None:
         wd.kick("shutdown")
+    if rccl is not None:
+        rccl.close()
     if dist.is_initialized():
         dist.destroy_process_group()
     if wd is not None:

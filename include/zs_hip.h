@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 14
+#define ZS_ABI_VERSION 15
 #define ZS_EINVAL (-1)
 #define ZS_ENOTSUP (-2)
 
@@ -166,6 +166,18 @@ int zs_bernoulli_logprob_f32(const float* p, const float* x, int64_t Px, float* 
 int zs_bernoulli_logprob_bwd_f32(const float* p, const float* x, int64_t Px,
                                  const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
                                  float* gp, int64_t K, int64_t R, int64_t D, void* stream);
+
+/* Gradient w.r.t. the OBSERVATION: bernoulli.py:94 is differentiable in `sample`, and `given` keeps its graph through
+ * base.py:161-178 (a model whose observed Bernoulli value comes out of a differentiable net).  The observation is periodic
+ * with Px, so its gradient is the sum over the elements that read it:
+ *   gx[j] = sum over i in [0, K*R*D), i % Px == j, of  glp[k, r] * s[r] * ( log(p_i + 1e-8) - log((1 - p_i) + 1e-8) ),
+ * (k, r) = the row of element i, s[r] = gscale[r * gscale_stride] when gscale is given (the device-resident incoming
+ * gradient of the objectives that keep their row gradients as coefficients), else 1; from_logits: p = sigmoid(streamed
+ * operand).  gx has Px elements; added in ascending i (deterministic). */
+int zs_bernoulli_logprob_bwd_x_f32(const float* p, int from_logits, int64_t Px,
+                                   const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
+                                   const float* gscale, int64_t gscale_stride,
+                                   float* gx, int64_t K, int64_t R, int64_t D, void* stream);
 
 /* Same density evaluated from logits: p = sigmoid(logit) = 1/(1 + exp(-logit))
  * (bernoulli.py:46-50) followed by the formula above; removes the separate
@@ -619,6 +631,7 @@ int zs_normal_logprob_bwd_f64(const double* x, int64_t Px, const double* mu, int
 int zs_normal_logprob_bwd_ksum_f64(const double* x, const double* mu, const double* sigma, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gx, double* gmu, double* gsigma, int64_t K, int64_t R, int64_t D, int sigma_is_logstd, void* stream);
 int zs_bernoulli_logprob_f64(const double* p, const double* x, int64_t Px, double* lp, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
 int zs_bernoulli_logprob_bwd_f64(const double* p, const double* x, int64_t Px, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* gp, int64_t K, int64_t R, int64_t D, void* stream);
+int zs_bernoulli_logprob_bwd_x_f64(const double* p, int from_logits, int64_t Px, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, const double* gscale, int64_t gscale_stride, double* gx, int64_t K, int64_t R, int64_t D, void* stream);
 int zs_bernoulli_logits_logprob_f64(const double* logits, const double* x, int64_t Px, double* lp, double* probs_out, int64_t K, int64_t R, int64_t D, int64_t lp_stride_k, int64_t lp_stride_r, void* stream);
 int zs_bernoulli_logits_logprob_bwd_f64(const double* logits, const double* x, int64_t Px, const double* glp, int64_t glp_stride_k, int64_t glp_stride_r, double* glogits, int64_t K, int64_t R, int64_t D, void* stream);
 int zs_bernoulli_sample_f64(const double* p, int64_t Pp, double* out, int64_t N, uint64_t seed, uint64_t offset, const uint64_t* rng_state, void* stream);

@@ -1079,6 +1079,81 @@ def gen_error_conventions():
     save("g_error_conventions", **out)
 
 
+# --------------------------------------------------------------------------
+# G-OBS: gradients w.r.t. a Bernoulli OBSERVATION (bernoulli.py:94 is differentiable in `sample`; `given` keeps its graph
+# through base.py:161-178): a model whose observed value comes out of a differentiable net
+# --------------------------------------------------------------------------
+def gen_observation_grad():
+    rng = np.random.RandomState(909)
+    out = {}
+    case = 0
+    # distribution level: x fractional, a leaf that requires a gradient; x [B, X] against p [K, B, X] (the gradient sums over
+    # K), x of full size, a row vector x [X]; probs and logits constructors; group_ndims 0 / 1
+    for pshape, xshape, g, from_logits in [((3, 6, 16), (6, 16), 1, 0), ((3, 6, 16), (3, 6, 16), 1, 0), ((4, 5, 12), (12,), 0, 0),
+                                           ((3, 6, 16), (6, 16), 1, 1), ((2, 5, 784), (5, 784), 1, 0), ((7, 9), (7, 9), 0, 1)]:
+        x = rng.uniform(0.02, 0.98, xshape).astype(F32)
+        x_t = t(x, True)
+        if from_logits:
+            par = (2.5 * rng.standard_normal(pshape)).astype(F32)
+            par_t = t(par, True)
+            d = Bernoulli(logits=par_t, group_ndims=g)
+        else:
+            par = rng.uniform(0.001, 0.999, pshape).astype(F32)
+            par_t = t(par, True)
+            d = Bernoulli(probs=par_t, group_ndims=g)
+        lp = d.log_prob(x_t)
+        w = rng.standard_normal(tuple(lp.shape)).astype(F32)
+        gpar, gx = torch.autograd.grad((lp * t(w)).sum(), [par_t, x_t])
+        p = "c%03d_" % case
+        out[p + "param"], out[p + "x"], out[p + "lp"], out[p + "w"] = par, x, lp, w
+        out[p + "gparam"], out[p + "gx"] = gpar, gx
+        out[p + "from_logits"], out[p + "g"] = np.array(from_logits), np.array(g)
+        case += 1
+    out["n_cases"] = np.array(case)
+    # objective level, the reference's examples with the observation a leaf that requires a gradient:
+    #   IWAE (both estimators; the package's one-launch generator side) and the VAE's scalar ELBO (the one-launch log-joint)
+    iw = _load(os.path.join(REF, "examples/variational_autoencoder/iwae.py"), "ref_iwae_obs")
+    B, K, hidden, x_dim, z_dim = 8, 5, 32, 784, 40
+    for est in ["sgvb", "vimco"]:
+        iw.hidden_dim = hidden
+        iw.reparameterization = (est == "sgvb")
+        r2 = np.random.RandomState(910)
+        gen = iw.Generator(x_dim, z_dim, K)
+        var = iw.Variational(x_dim, z_dim, K)
+        model = ImportanceWeightedObjective(gen, var, axis=0, estimator=est)
+        fill_params(model, 2000 + B + K)
+        x = r2.uniform(0.02, 0.98, (B, x_dim)).astype(F32)
+        e1 = r2.standard_normal((K, B, z_dim)).astype(F32)
+        e2 = r2.standard_normal((K, B, z_dim)).astype(F32)
+        x_t = t(x, True)
+        with EpsQueue([t(e1), t(e2)]):
+            loss = model({"x": x_t})
+        model.zero_grad()
+        loss.backward()
+        pre = "iwae_%s_" % est
+        out[pre + "x"], out[pre + "e1"], out[pre + "e2"], out[pre + "loss"], out[pre + "gx"] = x, e1, e2, loss, x_t.grad
+        _pack_grads(out, pre, model, stride=GRAD_STRIDE)          # (the parameters' gradients: a strided sample; gx is whole)
+        out[pre + "shape"] = np.array([B, K, hidden])
+    vae = _load(os.path.join(REF, "examples/variational_autoencoder/vae_mnist.py"), "ref_vae_obs")
+    B = 8
+    r3 = np.random.RandomState(911)
+    gen = vae.Generator(x_dim, z_dim, B)
+    var = vae.Variational(x_dim, z_dim, B)
+    model = ELBO(gen, var)
+    fill_params(model, 1000 + B)
+    x = r3.uniform(0.02, 0.98, (B, x_dim)).astype(F32)
+    e1 = r3.standard_normal((B, z_dim)).astype(F32)
+    e2 = r3.standard_normal((B, z_dim)).astype(F32)
+    x_t = t(x, True)
+    with EpsQueue([e1, e2]):
+        loss = model({"x": x_t})
+    model.zero_grad()
+    loss.backward()
+    out["vae_x"], out["vae_e1"], out["vae_e2"], out["vae_loss"], out["vae_gx"] = x, e1, e2, loss, x_t.grad
+    _pack_grads(out, "vae_", model, stride=GRAD_STRIDE)
+    save("g_observation_grad", **out)
+
+
 if __name__ == "__main__":
     gen_error_conventions()
     gen_normal()
@@ -1098,3 +1173,4 @@ if __name__ == "__main__":
     gen_iwae_philox()
     gen_vae_philox()
     gen_bnn_philox()
+    gen_observation_grad()

@@ -50,8 +50,8 @@ def test_shipped_library_reads_no_environment():
     assert "getenv" not in out, "libzs_hip.so imports getenv: built with -DZS_EXPERIMENTS?"
 
 
-def _run_bench(*extra, full=False):
-    env = dict(os.environ)
+def _run_bench(*extra, full=False, env=None):
+    env = dict(os.environ if env is None else env)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("MASTER_PORT", "29533")
     full_path = os.path.join(ROOT, "gpurun_out", "bench_full_test.json")
@@ -156,7 +156,7 @@ def test_bench_line_single_rank():
     # a 6-step trial is ~7 ms: the timed region is repeated until it covers at least half a second, median reported
     assert rec["trials"] >= 3 and rec["timed_seconds_total"] >= 0.45
     # the north-star kernel's own fraction (beyond the cache), the forward Bernoulli stream and the HBM-resident backward: flat
-    for key in ("k1_frac_1M", "k1_frac_4M", "hbm_resident_frac", "k3_fwd_frac", "iw1_fwd_frac"):
+    for key in ("k1_frac_1M", "k1_frac_4M", "k1_frac_1M_cold", "k1_frac_4M_cold", "hbm_resident_frac", "k3_fwd_frac", "iw1_fwd_frac"):
         assert 0.2 < roof[key] <= 1.0, (key, roof.get(key))
     # THE HEADLINE IS THE PACKAGE DEFAULT: both draws of every latent executed, as the reference does
     assert rec["config"]["discarded_draws"].startswith("executed") and "c3_skip_discarded_draws" in rec["extra_configs"]
@@ -173,7 +173,7 @@ def test_bench_line_single_rank():
     ab1 = hk["zs_dense_act_bwd_f32"]            # caller-side layer kernels: bytes of all their launches, from the calls
     assert ab1["launches_per_step"] == 5 and ab1["algorithmic_bytes_per_step"] == 12 * (12800 * (2 * 500 + 784) + 256 * 2 * 500) + 4 * (4 * 500 + 784)
     lib = rec["library"]
-    assert lib["abi"] == 14 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
+    assert lib["abi"] == 15 and len(lib["sha256"]) == 64 and "release" in lib["build"] and lib["default_path"] is True
     assert lib["path"].endswith("lib/libzs_hip.so") and rec["env_overrides"] == {}
     assert full["trial_ms_per_step"]["min"] <= rec["ms_per_step"] <= full["trial_ms_per_step"]["max"]
     # the same kernels on working sets beyond the Infinity Cache, measured in this run (full record)
@@ -202,6 +202,11 @@ def test_bench_line_single_rank():
         assert cb["value"] > 0 and cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0 and ex[name]["cpu_value"] == cb["value"]
     assert "FlatAdam" in rec["config"]["optimizer"] and "torch.optim.Adam" in fx["c3_torch_adam"]["optimizer"]
     assert np.isfinite(rec["final_loss"]) and rec["full_record"]
+    # the step in its default multi-rank form on one rank over RCCL (a child process; this one has no process group)
+    dp = ex["c3_dp_step_n1"]
+    assert rec["collective_library"] is None and dp["collective_library"].startswith("RCCL") and "hipgraph x2" in fx["c3_dp_step_n1"]["launch_mode"]
+    assert fx["c3_dp_step_n1"]["collective_path"].startswith("RCCL called directly")
+    assert 0.85 < dp["vs_headline"] < 1.05 and 0.9 < dp["same_process_ratio"] < 1.02 and dp["extra_us_per_step"] < 40.0, dp
 
 
 @pytest.mark.gpu
@@ -226,11 +231,23 @@ def test_bench_line_strong_scaling_on_one_rank():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--no-overlap"]])
+@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--no-direct-rccl"]])
 def test_bench_line_collective_path_on_one_rank(extra):
-    rec = _run_bench("--no-cpu-baseline", "--force-collective-path", *extra)
-    assert rec["n_gpus"] == 1 and rec["value"] > 1e5
-    assert ("hipgraph x3" in rec["config"]["launch_mode"]) == (not extra)
+    """The multi-rank forms of the step on ONE rank over RCCL (a process group of one): the default -- one flat bucket filled by
+    the backward pass, graph A -> all-reduce on the compute stream -> graph B -- , the staged form (--overlap) and the default
+    with torch.distributed's all_reduce instead of the job's own communicator.  The run also replays the same model as a single
+    graph, alternating: `same_process` is the path's fixed cost."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
+    rec = _run_bench("--no-cpu-baseline", "--no-extras", "--force-collective-path", *extra, env=env)
+    assert rec["n_gpus"] == 1 and rec["value"] > 1e5 and rec["collective_library"].startswith("RCCL")
+    assert ("hipgraph x3" in rec["config"]["launch_mode"]) == (extra == ["--overlap"])
+    assert ("hipgraph x2" in rec["config"]["launch_mode"]) == (extra != ["--overlap"])
+    assert rec["collective_path"].startswith("torch.distributed" if extra == ["--no-direct-rccl"] else "RCCL called directly")
+    sp = rec["same_process"]
+    assert sp["trials_each"] >= 9 and sp["single_graph_ms_per_step"] > 0
+    assert 0.85 < sp["collective_path_vs_single_graph"] < 1.02
+    if extra == []:          # (6-step trials: graph launches weigh more than in the 200-step line; the bench line is held to 0.97)
+        assert sp["extra_us_per_step"] < 40.0, sp
 
 
 @pytest.mark.gpu
@@ -272,7 +289,7 @@ def test_bench_parent_does_not_load_torch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--no-overlap"], ["--no-graph", "--overlap-allreduce"]])
+@pytest.mark.parametrize("extra", [[], ["--overlap"], ["--no-graph", "--overlap-allreduce"]])
 def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
     """The N = 2 control flow end to end (torch.distributed.run, shards, flat bucket, graph A -> all-reduce -> graph B,
     max-over-ranks timing, rank-0 JSON line) on a one-GPU box: both ranks on GPU 0, gloo instead of RCCL."""
@@ -288,10 +305,12 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec["n_ranks_seen"] == 2 and "gloo" in rec["collective_library"] and rec["replicas_in_sync"] is True
-    # default: three hipGraphs, the decoder-gradient all-reduce overlapping the encoder's backward; --no-overlap: two graphs
-    # around one all-reduce; --no-graph --overlap-allreduce: eager launches, buckets leaving from autograd hooks
-    assert ("overlapped" in rec["config"]["launch_mode"]) == (extra != ["--no-overlap"])
-    assert ("hipgraph x3" in rec["config"]["launch_mode"]) == (extra == [])
+    # default: two graphs around ONE all-reduce on the compute stream; --overlap: three hipGraphs, the decoder-gradient all-reduce
+    # overlapping the encoder's backward; --no-graph --overlap-allreduce: eager launches, buckets leaving from autograd hooks
+    assert ("overlapped" in rec["config"]["launch_mode"]) == (extra != [])
+    assert ("hipgraph x3" in rec["config"]["launch_mode"]) == (extra == ["--overlap"])
+    assert ("hipgraph x2" in rec["config"]["launch_mode"]) == (extra == [])
+    assert rec["collective_path"].startswith("torch.distributed")          # (gloo test mode: no RCCL communicator)
     assert "NOT a measurement" in rec["test_mode"]
     assert abs(rec["value"] - 2 * 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
     assert "graph capture failed" not in r.stderr, r.stderr[-2000:]
@@ -300,8 +319,8 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
 @pytest.mark.gpu
 def test_bench_eight_ranks_sharing_one_gpu_over_gloo():
     """The driver's N = 8 command line end to end on a one-GPU box: 8 ranks (torch.distributed.run) on GPU 0 over gloo --
-    per-rank shards and Philox streams, the staged buckets (three hipGraphs per rank around two eagerly launched
-    collectives), max-over-ranks timing, ONE JSON line from rank 0 with n_gpus = n_ranks_seen = 8.  A control-flow test
+    per-rank shards and Philox streams, the flat bucket (two hipGraphs per rank around one eagerly launched collective),
+    max-over-ranks timing, ONE JSON line from rank 0 with n_gpus = n_ranks_seen = 8.  A control-flow test
     (RCCL refuses two ranks on one device): no 2 / 4 / 8-GPU NUMBER exists until the driver runs one."""
     env = dict(os.environ)
     env["ZS_BENCH_SHARE_DEVICE"] = "1"
@@ -315,15 +334,15 @@ def test_bench_eight_ranks_sharing_one_gpu_over_gloo():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 8 and rec["n_ranks_seen"] == 8 and rec["scaling"] == "weak" and "gloo" in rec["collective_library"]
     assert rec["replicas_in_sync"] is True
-    assert "hipgraph x3" in rec["config"]["launch_mode"] and rec["config"]["global_batch"] == 2048
-    assert "dp8" in rec["config"]["parallelism"] and "two flat buckets" in rec["config"]["parallelism"]
+    assert "hipgraph x2" in rec["config"]["launch_mode"] and rec["config"]["global_batch"] == 2048
+    assert "dp8" in rec["config"]["parallelism"] and "one flat bucket" in rec["config"]["parallelism"]
     assert abs(rec["value"] - 8 * 256 * 50 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
     assert "NOT a measurement" in rec["test_mode"] and np.isfinite(rec["final_loss"])
     assert "graph capture failed" not in r.stderr, r.stderr[-2000:]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--no-overlap"]])
+@pytest.mark.parametrize("extra", [[], ["--overlap"]])
 def test_one_ranks_failed_capture_takes_every_rank_to_eager_launches_together(extra):
     """VERDICT r04 item 1 (a, d): rank 1's graph capture is made to fail.  The ranks meet (all-reduce MIN of "capture ok") and
     fall back TOGETHER to the same stages launched eagerly -- the same collectives, so nobody waits for ever and nothing is
@@ -342,7 +361,7 @@ def test_one_ranks_failed_capture_takes_every_rank_to_eager_launches_together(ex
     rec = json.loads(lines[0])
     assert rec["n_ranks_seen"] == 2 and rec["replicas_in_sync"] is True and np.isfinite(rec["final_loss"])
     assert rec["config"]["launch_mode"].startswith("eager (graph capture failed on a rank; all ranks fell back together)")
-    assert ("two staged all-reduces" in rec["config"]["launch_mode"]) == (extra == [])
+    assert ("two staged all-reduces" in rec["config"]["launch_mode"]) == (extra == ["--overlap"])
     assert "capture failure injected on rank 1" in r.stderr          # rank 1 says why
     assert r.stderr.count("gave way to eager launches on every rank") == 2        # ... and BOTH ranks changed mode
     assert rec["env_overrides"].get("ZS_BENCH_FAIL_CAPTURE_RANK") == "1"

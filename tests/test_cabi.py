@@ -27,15 +27,15 @@ def declared_symbols():
 
 def test_header_symbols_exported_by_both_libraries():
     names = declared_symbols()
-    assert len(names) == 86 and set(_hip.PROTOTYPES) <= set(names)
+    assert len(names) == 88 and set(_hip.PROTOTYPES) <= set(names)
     hip = ctypes.CDLL(_hip.LIB_PATH)           # loads without a GPU; no compute call is made here
     orc = ctypes.CDLL(build_oracle_lib())
     for n in names:
         assert hasattr(hip, n), "libzs_hip.so lacks %s" % n
         assert hasattr(orc, n), "libzs_oracle.so lacks %s" % n
     k = _hip.KernelLibrary(_hip.LIB_PATH)
-    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 14
-    assert "release (no environment knobs)" in k.build_info() and "ABI 14" in k.build_info()
+    assert k.cdll.zs_abi_version() == _hip.ABI_VERSION == 15
+    assert "release (no environment knobs)" in k.build_info() and "ABI 15" in k.build_info()
     assert b"invalid argument" in k.cdll.zs_error_string(-1)
 
 

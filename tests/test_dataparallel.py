@@ -519,3 +519,220 @@ def test_ranks_agree_on_the_launch_mode_and_the_eager_fallback_stays_matched(tmp
     host_backend.uninstall()
     assert abs(a0["loss"] - loss) <= 2e-6 * abs(loss)
     np.testing.assert_allclose(a0["flat"].numpy(), flat.numpy(), rtol=2e-4, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 6: gradients written into the buckets by the backward pass itself (no pack copy), and backward launches narrowed to
+# what the running pass is after (the engine is asked; no module state).
+# ---------------------------------------------------------------------------------------------
+def _staged_grads(dense, direct, estimator, spy=None):
+    import zhusuan as zs
+    from zhusuan import dataparallel
+    from examples import iwae
+    model = iwae.build(n_samples=K, estimator=estimator, hidden=HID, device=torch.device("cpu"), dense=dense)
+    H.load_params_into(model, 4242)
+    sb = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()], direct=direct)
+    try:
+        x, e1, e2 = _data()
+        sb.zero()
+        with zs.inject_epsilon([e1, e2]):
+            loss = model({"x": torch.tensor(x)})
+        if spy is not None:
+            spy(True)
+        sb.backward_stage(loss, 0)
+        assert all(p.grad is None for p in model.variational.parameters())
+        sb.backward_stage(loss, 1)
+        if spy is not None:
+            spy(False)
+        for st in sb.stages:
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(st["params"], st["views"]))
+        return float(sb.loss()), torch.cat([st["flat"][:st["n"]] for st in sb.stages]).clone(), float(loss.detach())
+    finally:
+        sb.release()
+
+
+@pytest.mark.parametrize("estimator", ["vimco", "sgvb"])
+def test_backward_writes_gradients_into_the_buckets_without_a_pack_copy(monkeypatch, estimator):
+    """zhusuan.Linear layers: weight and bias gradients land in their bucket slices during backward (autograd adopts the
+    aliases); what is left for the bucket to copy is the objective's scalar.  Same numbers as the copying bucket."""
+    from zhusuan import dataparallel, _ops
+    host_backend.install(host_kernel_library())
+    try:
+        copies = []
+        real_cat, real_fc = torch.cat, torch._foreach_copy_
+        on = [False]
+        monkeypatch.setattr(torch, "cat", lambda ts, *a, **k: (copies.append(("cat", len(ts))) if on[0] and "out" in k else None) or real_cat(ts, *a, **k))
+        monkeypatch.setattr(torch, "_foreach_copy_", lambda d, s_: (copies.append(("foreach_copy", len(d))) if on[0] else None) or real_fc(d, s_))
+        loss_d, flat_d, l_d = _staged_grads("fused", True, estimator, spy=lambda v: on.__setitem__(0, v))
+        assert copies == [], copies                       # no gradient was copied into a bucket
+        import gc
+        gc.collect()
+        assert not _ops._GRAD_DEST      # release() withdrew every registration (and those of dead models went with their parameters)
+        loss_c, flat_c, l_c = _staged_grads("fused", False, estimator, spy=lambda v: on.__setitem__(0, v))
+        assert [c[0] for c in copies] == ["cat", "cat"]   # the copying form: one concatenation per stage
+        assert loss_d == l_d == loss_c == l_c
+        assert torch.equal(flat_d, flat_c)
+        # torch.nn modules know nothing about destinations: their gradients still reach the bucket through the copy
+        loss_t, flat_t, _ = _staged_grads("torch", True, estimator)
+        assert torch.allclose(flat_t, flat_d, rtol=1e-4, atol=1e-6)
+    finally:
+        host_backend.uninstall()
+
+
+def test_gradient_destinations_weight_used_twice_and_accumulation_without_zero():
+    """One producer per parameter per pass may write the slice: a layer applied twice in one graph (the second use allocates
+    and autograd adds), a parameter that still holds last step's gradient (never written over: autograd accumulates)."""
+    import zhusuan as zs
+    from zhusuan import dataparallel
+    host_backend.install(host_kernel_library())
+    try:
+        torch.manual_seed(3)
+        lin = zs.Linear(6, 6, activation="relu")
+        ref = torch.nn.Linear(6, 6)
+        ref.load_state_dict(lin.state_dict())
+        x = torch.randn(5, 6)
+        bucket = dataparallel.GradientBucket(lin)
+        try:
+            for rounds in (1, 2):          # second round: no zero() in between -> accumulation onto the aliased slices
+                loss = lin(lin(x)).sum()
+                loss.backward()
+                bucket.pack(loss)
+                rl = torch.relu(ref(torch.relu(ref(x)))).sum()
+                rl.backward()
+                for p, q in zip(lin.parameters(), ref.parameters()):
+                    assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), rounds
+                assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+                assert float(bucket.flat[bucket.n_grad]) == float(loss)
+            bucket.zero()
+            ref.zero_grad()
+            loss = lin(x).sum()
+            loss.backward()
+            torch.relu(ref(x)).sum().backward()
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))      # adopted, not copied
+            for p, q in zip(lin.parameters(), ref.parameters()):
+                assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6)
+        finally:
+            bucket.release()
+    finally:
+        host_backend.uninstall()
+
+
+def test_a_restricted_pass_launches_only_the_sides_it_is_after():
+    """torch.autograd.grad(y, [x]) through a dense layer: no bias reduction, no weight GEMM result; the engine is asked per
+    pass (two passes over one retained graph get different answers), nothing is held in module state."""
+    import zhusuan as zs
+    from zhusuan import _ops
+    klib = host_kernel_library()
+    host_backend.install(klib)
+    calls, real = [], klib.call
+    klib.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+    try:
+        lin = zs.Linear(6, 4)
+        x = torch.randn(5, 6, requires_grad=True)
+        y = lin(x).sum()
+        (gx,) = torch.autograd.grad(y, [x], retain_graph=True)
+        assert calls == [] and torch.allclose(gx, lin.weight.detach().sum(0).expand(5, 6))
+        torch.autograd.backward(y, inputs=[lin.bias], retain_graph=True)
+        assert calls == ["zs_column_sum_f32"] and lin.weight.grad is None and x.grad is None
+        y.backward()
+        assert lin.weight.grad is not None and x.grad is not None and torch.allclose(lin.bias.grad, torch.full((4,), 10.0))
+        assert not hasattr(_ops, "_GRAD_TARGETS")
+    finally:
+        klib.call = real
+        host_backend.uninstall()
+
+
+@pytest.mark.parametrize("estimator", ["vimco", "sgvb"])
+def test_staged_backward_cut_at_the_encoder_outputs_runs_the_objective_backward_once(estimator):
+    """backward_stage(..., also=cut) / backward_stage(..., roots=cut): the first stage delivers the objective's gradient at the
+    variational net's outputs, the second starts there -- same gradients as two walks from the loss, IW1's backward launched
+    once instead of twice (vimco), the decoder walked once instead of twice (sgvb)."""
+    import zhusuan as zs
+    from zhusuan import dataparallel
+    from examples import iwae
+    klib = host_kernel_library()
+    host_backend.install(klib)
+    calls, real = [], klib.call
+    klib.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+    try:
+        out = {}
+        for cut in (False, True):
+            model = iwae.build(n_samples=K, estimator=estimator, hidden=HID, device=torch.device("cpu"), dense="fused")
+            H.load_params_into(model, 4242)
+            sb = dataparallel.StagedBuckets([model.generator.parameters(), model.variational.parameters()])
+            try:
+                x, e1, e2 = _data()
+                sb.zero()
+                with zs.inject_epsilon([e1, e2]):
+                    loss = model({"x": torch.tensor(x)})
+                del calls[:]
+                if cut:
+                    q = model.variational.nodes["z"].dist
+                    boundary = [q.mean, q.std]
+                    sb.backward_stage(loss, 0, also=boundary)
+                    assert all(t.grad is not None for t in boundary)
+                    assert all(p.grad is None for p in model.variational.parameters())
+                    n0 = len(calls)
+                    sb.backward_stage(None, 1, roots=boundary)
+                    assert all(t.grad is None for t in boundary)
+                    # the second stage is the encoder's MLP and nothing else: no objective, no sampling, no decoder kernels
+                    assert set(calls[n0:]) <= {"zs_dense_act_bwd_f32", "zs_column_sum_f32"}, calls[n0:]
+                else:
+                    sb.backward_stage(loss, 0)
+                    sb.backward_stage(loss, 1)
+                for st in sb.stages:
+                    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(st["params"], st["views"]))
+                out[cut] = (torch.cat([st["flat"] for st in sb.stages]).clone(), list(calls))
+            finally:
+                sb.release()
+        assert torch.allclose(out[True][0], out[False][0], rtol=1e-6, atol=1e-7)
+        n_obj = lambda names: sum(n.startswith(("zs_bernoulli_iw_objective_bwd", "zs_iw_objective")) for n in names)
+        assert len(out[True][1]) < len(out[False][1])
+        if estimator == "vimco":
+            assert sum(n == "zs_bernoulli_iw_objective_bwd_f32" for n in out[True][1]) == 1
+            assert sum(n == "zs_bernoulli_iw_objective_bwd_f32" for n in out[False][1]) == 2
+    finally:
+        klib.call = real
+        host_backend.uninstall()
+
+
+@pytest.mark.gpu
+def test_direct_rccl_communicator_on_one_rank():
+    """zhusuan.dataparallel.DirectAllReduce with a process group of one over RCCL (a child process: this one keeps no process
+    group): the communicator comes up, an all-reduce on a side stream is stream-ordered and leaves a one-rank sum unchanged,
+    the bucket's exchange() goes through it, close() tears it down."""
+    import subprocess
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%r, "zhusuan-pytorch_amd"))
+import torch, torch.distributed as dist
+from zhusuan import dataparallel
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+d = dataparallel.DirectAllReduce.create(timeout_s=60)
+assert d is not None, dataparallel.DirectAllReduce.last_error
+assert d.world == 1
+x = torch.arange(1000, dtype=torch.float32, device="cuda")
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    y = x * 2
+    d.all_reduce_sum_(y)
+    z = y + 1
+side.synchronize()
+assert torch.equal(z, x * 2 + 1)
+lin = torch.nn.Linear(8, 4).cuda()
+b = dataparallel.GradientBucket(lin)
+lin(torch.ones(3, 8, device="cuda")).sum().backward()
+b.pack(torch.tensor(2.5, device="cuda"))
+before = b.flat.clone()
+b.exchange(direct=d, always=True)
+torch.cuda.synchronize()
+assert torch.equal(b.flat, before) and float(b.loss()) == 2.5 and b.grad_scale() == 1.0
+d.close()
+dist.destroy_process_group()
+print("direct rccl ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "direct rccl ok" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -325,7 +325,7 @@ def _operand(rng, kind, n, period, lo=None):
     raise ValueError(kind)
 
 
-def _term(rng, family, n, periods=(None, None, None), coef=1.0, want=(False, False, False), misalign=False):
+def _term(rng, family, n, periods=(None, None, None), coef=1.0, want=(False, False, False), misalign=False, frac=False):
     px, pa, pb = [n if p is None else p for p in periods]
     tm = {"family": family, "n": n, "coef": coef, "want": want, "misalign": misalign}
     if family == LJ.LJ_ROWS:
@@ -334,8 +334,12 @@ def _term(rng, family, n, periods=(None, None, None), coef=1.0, want=(False, Fal
         tm["x"], tm["a"] = _operand(rng, "value", n, px), _operand(rng, "mean", n, pa)
         tm["b"] = _operand(rng, "logstd" if family == LJ.LJ_NORMAL_LOGSTD else "std", n, pb)
     else:
-        tm["x"] = _operand(rng, "bits", n, px)
+        tm["x"] = rng.uniform(0.05, 0.95, size=px) if frac else _operand(rng, "bits", n, px)     # (frac: a differentiable observation)
         tm["a"] = _operand(rng, "logits" if family == LJ.LJ_BERNOULLI_LOGITS else "probs", n, pa)
+        if frac and family == LJ.LJ_BERNOULLI_LOGITS:
+            # (milder logits: with a fractional observation BOTH logarithms carry weight, and 1 - sigmoid(9) in fp32 -- the
+            #  reference's own arithmetic, bernoulli.py:50,94 -- is good to 1e-3 only: the float64 truth is not the fp32 target there)
+            tm["a"] = 1.2 * rng.standard_normal(pa)
     return tm
 
 
@@ -399,6 +403,12 @@ def _cases(rng, small=False):
         # ragged / large: more than one workgroup per term, a tail that is not a multiple of 4
         [_term(rng, N, big, coef=1.0 / big, want=all3), _term(rng, BL, big - 1, coef=-1.0 / big, want=a_only, misalign=True),
          _term(rng, R, big // 3, coef=1e-3)],
+        # the OBSERVATION of a Bernoulli term receives a gradient too (bernoulli.py:94 is differentiable in `sample`): full size,
+        # periodic (a fold job: the sum over the rows that read it), scalar; both parameterisations; unaligned
+        [_term(rng, B, 16 * 48, coef=-1 / 16., want=(True, True, False), frac=True),
+         _term(rng, BL, 9 * 20, (20, None, None), coef=2.0, want=(True, True, False), frac=True),
+         _term(rng, B, 333, (1, None, None), coef=0.5, want=(True, False, False), frac=True),
+         _term(rng, BL, 8 * 36, (36, 72, None), coef=-0.3, want=(True, True, False), frac=True, misalign=True)],
         # eight terms (the table's capacity)
         [_term(rng, f, 50 + 7 * i, coef=(-1.0) ** i * 0.25, want=(f in (N, NL), f != R, f in (N, NL)))
          for i, f in enumerate([N, NL, B, BL, R, N, B, R])],
@@ -438,8 +448,10 @@ def test_c_oracle_logjoint_rejects_bad_tables(orc):
         orc.lj_fwd([bad])
     with pytest.raises(RuntimeError, match="code -1"):
         orc.lj_fwd([dict(_term(rng, LJ.LJ_NORMAL, 8), family=7)])
-    with pytest.raises(RuntimeError, match="code -2"):                             # d/d observation of a Bernoulli term
-        orc.lj_bwd([_term(rng, LJ.LJ_BERNOULLI, 8, want=(True, False, False))], 1.0)
+    # (d/d observation of a Bernoulli term was refused with code -2 until ABI 15; now it is an ordinary gradient)
+    tm = _term(rng, LJ.LJ_BERNOULLI, 8, want=(True, False, False), frac=True)
+    got, _ = orc.lj_bwd([tm], 1.0)
+    _compare_bwd(got, _truth([tm], g=1.0)[1], [tm], 2e-4, 2e-6)
 
 
 def test_c_oracle_multi_sampler_is_k1_per_node(orc, orc64):
@@ -568,8 +580,8 @@ def test_hip_logjoint(hip, orc, hip64, orc64):
         hip.lj_fwd([_term(rng, LJ.LJ_ROWS, 4) for _ in range(9)])
     with pytest.raises(RuntimeError, match="code -1"):
         hip.lj_fwd([_term(rng, LJ.LJ_NORMAL, 12, (None, 5, None))])
-    with pytest.raises(RuntimeError, match="code -2"):
-        hip.lj_bwd([_term(rng, LJ.LJ_BERNOULLI, 8, want=(True, False, False))], 1.0)
+    tm = _term(rng, LJ.LJ_BERNOULLI, 8, want=(True, False, False), frac=True)          # (refused with code -2 until ABI 15)
+    _compare_bwd(hip.lj_bwd([tm], 1.0)[0], _truth([tm], g=1.0)[1], [tm], 3e-4, 3e-6)
     assert hip.lj_fwd([_term(rng, LJ.LJ_ROWS, 0)]) == 0.0                       # all terms empty
 
 

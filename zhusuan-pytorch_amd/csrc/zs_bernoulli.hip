@@ -728,6 +728,74 @@ extern "C" int zs_bernoulli_logprob_bwd_f32(const float* p, const float* x, int6
   return launch_bwd<false>(p, x, Px, glp, gsk, gsr, gp, K, R, D, (hipStream_t)stream);
 }
 
+// Gradient w.r.t. the observation (include/zs_hip.h): thread j owns gx[j] and walks the elements j, j + Px, j + 2 Px, ... of the
+// [K, R, D] problem in ascending order -- consecutive threads read consecutive elements of p in every round (coalesced), the row
+// gradient is a broadcast load, the row index advances by Px / D per round without a division (rows_step; the general case, a
+// period that is not a whole number of rows, divides).  Four rounds in flight.  A rare path (an observed Bernoulli value that
+// comes out of a differentiable net): written for correctness and coalescing, not tuned.
+template <typename T, bool LOGITS>
+__global__ __launch_bounds__(256) void k_bern_obs_grad(const T* __restrict__ p, int64_t Px, const T* __restrict__ glp, int64_t sk,
+                                                        int64_t sr, const T* __restrict__ gscale, int64_t gss, T* __restrict__ gx,
+                                                        int64_t n, int64_t R, int64_t D, int64_t rows_step) {
+  const int64_t reps = n / Px;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < Px; j += (int64_t)gridDim.x * 256) {
+    T acc = (T)0;
+    int64_t row = j / D, k = row / R, r = row - k * R;
+    for (int64_t m0 = 0; m0 < reps; m0 += 4) {
+      T pv[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t m = m0 + u;
+        const bool live = m < reps;
+        const int64_t i = j + (live ? m : m0) * Px;
+        if (rows_step < 0 && live) {            // a period that cuts rows: the row of every element by division
+          row = i / D; k = row / R; r = row - k * R;
+        }
+        pv[u] = live ? p[i] : (T)0.5;
+        g[u] = live ? glp[k * sk + r * sr] * (gscale ? gscale[r * gss] : (T)1) : (T)0;
+        if (rows_step >= 0 && live) {
+          r += rows_step;
+          while (r >= R) { r -= R; ++k; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        T q = pv[u];
+        if (LOGITS) q = sigmoid_any(q);
+        acc += g[u] * log_ratio_any(q);
+      }
+    }
+    gx[j] = acc;
+  }
+}
+template <typename T>
+int launch_bern_obs_grad(const T* p, int from_logits, int64_t Px, const T* glp, int64_t sk, int64_t sr, const T* gscale, int64_t gss,
+                         T* gx, int64_t K, int64_t R, int64_t D, hipStream_t st) {
+  if (K < 1 || R < 0 || D < 1 || Px < 1 || gss < 0) return ZS_EINVAL;
+  const int64_t n = K * R * D;
+  if (n == 0) return 0;
+  if (!p || !glp || !gx) return ZS_EINVAL;
+  if (n % Px) return ZS_EINVAL;
+  const int64_t rows_step = (Px % D == 0) ? Px / D : -1;
+  const dim3 grid(grid_for(Px, 256));
+  if (from_logits) ZS_LAUNCH(KID_BERN_LOGPROB_BWD_X, (k_bern_obs_grad<T, true>), grid, dim3(256), st, p, Px, glp, sk, sr, gscale, gss, gx, n, R, D, rows_step);
+  else ZS_LAUNCH(KID_BERN_LOGPROB_BWD_X, (k_bern_obs_grad<T, false>), grid, dim3(256), st, p, Px, glp, sk, sr, gscale, gss, gx, n, R, D, rows_step);
+  ZS_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int zs_bernoulli_logprob_bwd_x_f32(const float* p, int from_logits, int64_t Px, const float* glp, int64_t glp_stride_k,
+                                              int64_t glp_stride_r, const float* gscale, int64_t gscale_stride, float* gx,
+                                              int64_t K, int64_t R, int64_t D, void* stream) {
+  return launch_bern_obs_grad<float>(p, from_logits, Px, glp, glp_stride_k, glp_stride_r, gscale, gscale_stride, gx, K, R, D,
+                                     (hipStream_t)stream);
+}
+extern "C" int zs_bernoulli_logprob_bwd_x_f64(const double* p, int from_logits, int64_t Px, const double* glp, int64_t glp_stride_k,
+                                              int64_t glp_stride_r, const double* gscale, int64_t gscale_stride, double* gx,
+                                              int64_t K, int64_t R, int64_t D, void* stream) {
+  return launch_bern_obs_grad<double>(p, from_logits, Px, glp, glp_stride_k, glp_stride_r, gscale, gscale_stride, gx, K, R, D,
+                                      (hipStream_t)stream);
+}
+
 extern "C" int zs_bernoulli_logits_logprob_f32(const float* logits, const float* x, int64_t Px, float* lp,
                                                float* probs_out, int64_t K, int64_t R, int64_t D, int64_t sk,
                                                int64_t sr, void* stream) {

@@ -65,7 +65,7 @@ enum KernelId {
   KID_UNIFORM_SAMPLE, KID_UNIFORM_LOGPROB, KID_PHILOX_UNIFORM, KID_REINFORCE, KID_IW_OBJECTIVE, KID_SCALAR_OBJECTIVE, KID_ADAM, KID_LOGISTIC_LOGPROB_BWD_KSUM,
   KID_LOGJOINT, KID_LOGJOINT_BWD, KID_NORMAL_SAMPLE_MULTI, KID_NORMAL_SAMPLE_MULTI_BWD, KID_PARTICLE_LINEAR, KID_PARTICLE_LINEAR_BWD, KID_COLUMN_SUM,
   KID_DENSE_ACT_BWD, KID_PARTICLE_RMSE, KID_PARTICLE_MLP, KID_PARTICLE_MLP_BWD, KID_BERN_IW_OBJECTIVE, KID_BERN_IW_OBJECTIVE_BWD,
-  KID_NORMAL_SAMPLE_PAIR,
+  KID_NORMAL_SAMPLE_PAIR, KID_BERN_LOGPROB_BWD_X,
   KID_COUNT
 };
 bool prof_begin_launch(int kid, hipEvent_t* start, hipEvent_t* stop);  // defined in zs_iw.hip
@@ -233,6 +233,12 @@ ZS_HD float sigmoid_fast(float l) { return rcp_fast(1.0f + exp_fast(-l)); }
 ZS_HD float bern_dp(float p, float x) {
   return x * rcp_fast(p + ZS_BERN_EPS) - (1.0f - x) * rcp_fast((1.0f - p) + ZS_BERN_EPS);
 }
+
+// d/dx of x*log(p+e) + (1-x)*log((1-p)+e) = log(p+e) - log((1-p)+e): the gradient w.r.t. the observation (bernoulli.py:94)
+ZS_HD float log_ratio_any(float p) { return (log2_fast(p + ZS_BERN_EPS) - log2_fast((1.0f - p) + ZS_BERN_EPS)) * ZS_LN2; }
+ZS_HD double log_ratio_any(double p) { return log(p + 1e-8) - log((1.0 - p) + 1e-8); }
+ZS_HD float sigmoid_any(float l) { return sigmoid_fast(l); }
+ZS_HD double sigmoid_any(double l) { return 1.0 / (1.0 + exp(-l)); }
 
 // ---------------------------------------------------------------- index arithmetic
 // 64-bit integer division expands to ~100 VALU instructions on CDNA; row / tile indices almost always fit

@@ -491,7 +491,7 @@ const char* const kKernelNames[zs::KID_COUNT] = {
     "zs_normal_sample_logprob_multi_f32", "zs_normal_sample_logprob_multi_bwd_f32", "zs_particle_linear_f32",
     "zs_particle_linear_bwd_f32", "zs_column_sum_f32", "zs_dense_act_bwd_f32", "zs_particle_rmse_f32", "zs_particle_mlp_f32",
     "zs_particle_mlp_bwd_f32", "zs_bernoulli_iw_objective_f32", "zs_bernoulli_iw_objective_bwd_f32",
-    "zs_normal_sample_logprob_pair_f32"};
+    "zs_normal_sample_logprob_pair_f32", "zs_bernoulli_logprob_bwd_x_f32"};
 void prof_clear(ProfState& s) {
   for (int k = 0; k < zs::KID_COUNT; ++k) {
     for (auto& p : s.ev[k]) {

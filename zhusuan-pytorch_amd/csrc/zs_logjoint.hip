@@ -54,11 +54,18 @@ struct LJArgs {
   unsigned n_elem_blocks, n_blocks;
 };
 
+// Backward only: a Bernoulli term whose OBSERVATION wants a gradient (bernoulli.py:94 is differentiable in `sample`) runs as a
+// family of its own -- two more logarithms per element that the ordinary term (observed data) must not pay for.
+constexpr int LJ_BERNOULLI_GX = ZS_LJ_BERNOULLI_LOGITS + 1, LJ_BERNOULLI_LOGITS_GX = ZS_LJ_BERNOULLI_LOGITS + 2;
+
 // ---- per-family element arithmetic
 template <typename T, int FAM>
 struct Fam {
   static constexpr bool has_a = FAM != ZS_LJ_ROWS;
   static constexpr bool has_b = FAM == ZS_LJ_NORMAL || FAM == ZS_LJ_NORMAL_LOGSTD;
+  static constexpr bool bern_gx = FAM == LJ_BERNOULLI_GX || FAM == LJ_BERNOULLI_LOGITS_GX;
+  static constexpr bool bern_logits = FAM == ZS_LJ_BERNOULLI_LOGITS || FAM == LJ_BERNOULLI_LOGITS_GX;
+  static constexpr bool has_gx = has_b || bern_gx;          // families whose first operand can receive a gradient
   static __device__ __forceinline__ T term(T x, T a, T b) {
     typedef Mth<T> M;
     if (FAM == ZS_LJ_ROWS) return x;
@@ -68,7 +75,7 @@ struct Fam {
       M::parts(sg, logstd, prec);
       return M::normal_term(x - a, logstd, prec);
     }
-    return M::bern_term(FAM == ZS_LJ_BERNOULLI_LOGITS ? M::sigmoid(a) : a, x);
+    return M::bern_term(bern_logits ? M::sigmoid(a) : a, x);
   }
   // d term / d (x, a, b) times gc = g * coef
   static __device__ __forceinline__ void partials(T x, T a, T b, T gc, T& dx, T& da, T& db) {
@@ -85,14 +92,10 @@ struct Fam {
       const T v = gc * (prec * d * d - (T)1);
       db = ls ? v : v / sg;                     // d/d log std = sigma * d/d sigma
     } else {                                    // Bernoulli: d/d probs, or d/d logits = d/dp * p * (1 - p)
-      dx = (T)0;
       db = (T)0;
-      if (FAM == ZS_LJ_BERNOULLI_LOGITS) {
-        const T p = M::sigmoid(a);
-        da = gc * M::bern_dp(p, x) * p * ((T)1 - p);
-      } else {
-        da = gc * M::bern_dp(a, x);
-      }
+      const T p = bern_logits ? M::sigmoid(a) : a;
+      da = gc * M::bern_dp(p, x) * (bern_logits ? p * ((T)1 - p) : (T)1);
+      dx = bern_gx ? gc * log_ratio_any(p) : (T)0;          // d/dx = log(p + 1e-8) - log(1 - p + 1e-8)
     }
   }
 };
@@ -226,7 +229,7 @@ __device__ __forceinline__ void lj_bwd_vec(const LJTerm<T>& t, unsigned blk, T g
   const T* __restrict__ pa = sa ? t.dummy : t.a;
   const T* __restrict__ pb = (!F::has_b || sb) ? t.dummy : t.b;
   const bool mx = PER && t.cx == CLS_PERIODIC, ma = PER && t.ca == CLS_PERIODIC, mb = PER && t.cb == CLS_PERIODIC;
-  const bool full_x = F::has_b && t.gx && t.cx == CLS_FULL, full_a = t.ga && t.ca == CLS_FULL,
+  const bool full_x = F::has_gx && t.gx && t.cx == CLS_FULL, full_a = t.ga && t.ca == CLS_FULL,
              full_b = F::has_b && t.gb && t.cb == CLS_FULL;
   for (uint32_t g0 = blk * LJ_BLOCK + threadIdx.x; g0 < ng; g0 += stride * LJ_U) {
     V4<T> x[LJ_U], a[LJ_U], b[LJ_U];
@@ -271,7 +274,7 @@ template <typename T, int FAM>
 __device__ __forceinline__ void lj_bwd_elem(const LJTerm<T>& t, unsigned blk, T gc, double& rx, double& ra, double& rb) {
   typedef Fam<T, FAM> F;
   const uint32_t n = t.n, stride = t.nblocks * LJ_BLOCK;
-  const bool full_x = F::has_b && t.gx && t.cx == CLS_FULL, full_a = t.ga && t.ca == CLS_FULL,
+  const bool full_x = F::has_gx && t.gx && t.cx == CLS_FULL, full_a = t.ga && t.ca == CLS_FULL,
              full_b = F::has_b && t.gb && t.cb == CLS_FULL;
   for (uint32_t e0 = blk * LJ_BLOCK + threadIdx.x; e0 < n; e0 += stride * LJ_U) {
     T x[LJ_U], a[LJ_U], b[LJ_U];
@@ -336,6 +339,8 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_bwd(const LJArgs<T> A, co
       case ZS_LJ_NORMAL: lj_bwd_family<T, ZS_LJ_NORMAL>(t, blk, gc, sx, sa, sb); break;
       case ZS_LJ_NORMAL_LOGSTD: lj_bwd_family<T, ZS_LJ_NORMAL_LOGSTD>(t, blk, gc, sx, sa, sb); break;
       case ZS_LJ_BERNOULLI: lj_bwd_family<T, ZS_LJ_BERNOULLI>(t, blk, gc, sx, sa, sb); break;
+      case LJ_BERNOULLI_GX: lj_bwd_family<T, LJ_BERNOULLI_GX>(t, blk, gc, sx, sa, sb); break;
+      case LJ_BERNOULLI_LOGITS_GX: lj_bwd_family<T, LJ_BERNOULLI_LOGITS_GX>(t, blk, gc, sx, sa, sb); break;
       default: lj_bwd_family<T, ZS_LJ_BERNOULLI_LOGITS>(t, blk, gc, sx, sa, sb); break;
     }
     const bool sc_x = t.gx && t.cx == CLS_SCALAR && t.n > 1, sc_a = t.ga && t.ca == CLS_SCALAR && t.n > 1,
@@ -365,6 +370,8 @@ __global__ __launch_bounds__(LJ_BLOCK) void k_logjoint_bwd(const LJArgs<T> A, co
         case ZS_LJ_NORMAL: v = lj_fold_sum<T, ZS_LJ_NORMAL>(t, f.operand, j, P, gc); break;
         case ZS_LJ_NORMAL_LOGSTD: v = lj_fold_sum<T, ZS_LJ_NORMAL_LOGSTD>(t, f.operand, j, P, gc); break;
         case ZS_LJ_BERNOULLI: v = lj_fold_sum<T, ZS_LJ_BERNOULLI>(t, f.operand, j, P, gc); break;
+        case LJ_BERNOULLI_GX: v = lj_fold_sum<T, LJ_BERNOULLI_GX>(t, f.operand, j, P, gc); break;
+        case LJ_BERNOULLI_LOGITS_GX: v = lj_fold_sum<T, LJ_BERNOULLI_LOGITS_GX>(t, f.operand, j, P, gc); break;
         default: v = lj_fold_sum<T, ZS_LJ_BERNOULLI_LOGITS>(t, f.operand, j, P, gc); break;
       }
       dst[j] = v;
@@ -431,8 +438,8 @@ int lj_build(const zs_lj_term* terms, int n_terms, bool backward, LJArgs<T>& A) 
       t.gx = (T*)s.gx; t.ga = (T*)s.ga; t.gb = (T*)s.gb;
       if (rows) { t.gx = t.ga = t.gb = nullptr; }
       if (!normal) {
-        if (t.gx) return ZS_ENOTSUP;            // gradient w.r.t. the Bernoulli observation is not provided
         t.gb = nullptr;
+        if (t.gx) t.family = s.family == ZS_LJ_BERNOULLI ? LJ_BERNOULLI_GX : LJ_BERNOULLI_LOGITS_GX;     // (see Fam)
       }
       if (rows || !(t.gx || t.ga || t.gb)) continue;     // nothing to compute element-wise for this term
     }

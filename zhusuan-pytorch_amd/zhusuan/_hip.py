@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # The in-tree library.  ZS_HIP_LIBRARY points at an alternative build of the same ABI (kernel experiments: tools/); bench.py
 # records which file was loaded (path, sha256, zs_build_info) and refuses an override unless --allow-experiments is given.
 LIB_PATH = os.environ.get("ZS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libzs_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -33,6 +33,8 @@ PROTOTYPES = {
     "zs_normal_logprob_bwd_ksum_f32": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _int, _p],
     "zs_bernoulli_logprob_f32": [_p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_bernoulli_logprob_bwd_f32": [_p, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
+    # p, from_logits, Px, glp, glp_stride_k, glp_stride_r, gscale, gscale_stride, gx, K, R, D, stream
+    "zs_bernoulli_logprob_bwd_x_f32": [_p, _int, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p],
     "zs_bernoulli_logits_logprob_f32": [_p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "zs_bernoulli_logits_logprob_bwd_f32": [_p, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
     "zs_bernoulli_sample_f32": [_p, _i64, _p, _i64, _u64, _u64, _p, _p],

@@ -7,7 +7,6 @@ K particles of a datapoint stay contiguous for the importance-weight reduction (
 """
 import ctypes
 import math
-import threading
 import weakref
 
 import torch
@@ -345,6 +344,7 @@ class BernoulliLogProb(torch.autograd.Function):
                 lib.call("zs_bernoulli_logprob" + sfx, _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(buf), K, R, D, sk, sr,
                          _hip.stream_for(p))
         ctx.meta = (K, R, D, Px, from_logits)
+        ctx.edge_of = _edge_positions((p, x, n_fold, Px, kfast, from_logits))
         ctx.save_for_backward(p, x)
         return lp
 
@@ -352,17 +352,24 @@ class BernoulliLogProb(torch.autograd.Function):
     def backward(ctx, glp):
         K, R, D, Px, from_logits = ctx.meta
         p, x = ctx.saved_tensors
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("zhusuan (MI355X build): gradient w.r.t. the Bernoulli observation is not built")
-        if not ctx.needs_input_grad[0] or K * R * D == 0:
+        need = _pass_needs(ctx, ctx.edge_of)
+        if not (need[0] or need[1]) or K * R * D == 0:
             return (None,) * 6
         glp, gsk, gsr = _kr_view(glp, K, R)
-        gp = torch.empty_like(p)
         sfx = _sfx(p)
-        name = ("zs_bernoulli_logits_logprob_bwd" if from_logits else "zs_bernoulli_logprob_bwd") + sfx
-        _hip.lib().call(name, _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(glp), gsk, gsr, _hip.ptr(gp), K, R, D,
-                        _hip.stream_for(p))
-        return gp, None, None, None, None, None
+        gp = gx = None
+        if need[0]:
+            gp = torch.empty_like(p)
+            name = ("zs_bernoulli_logits_logprob_bwd" if from_logits else "zs_bernoulli_logprob_bwd") + sfx
+            _hip.lib().call(name, _hip.ptr(p), _hip.ptr(x), Px, _hip.ptr(glp), gsk, gsr, _hip.ptr(gp), K, R, D,
+                            _hip.stream_for(p))
+        if need[1]:
+            # the observation is differentiable too (bernoulli.py:94; `given` keeps its graph through base.py:161-178): its
+            # gradient sums over the elements that read it (x [B, X] against p [K, B, X])
+            gx = torch.empty_like(x)
+            _hip.lib().call("zs_bernoulli_logprob_bwd_x" + sfx, _hip.ptr(p), 1 if from_logits else 0, Px, _hip.ptr(glp), gsk, gsr,
+                            None, 0, _hip.ptr(gx), K, R, D, _hip.stream_for(p))
+        return gp, gx, None, None, None, None
 
 
 class IWReduce(torch.autograd.Function):
@@ -511,63 +518,105 @@ class IWObjective(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------
 # A backward pass restricted to some parameters (``torch.autograd.backward(loss, inputs=params)``: the stages of
-# dataparallel.StagedBuckets) still runs every node that lies on a path to them, and a node cannot see which of ITS inputs the
-# pass is after.  IW1's backward serves two sides (the decoder through p, the variational parameters through log q): told the
-# targets of the pass, it launches only the side(s) that lead there instead of both in every stage.  A module global, not a
-# contextvar: the autograd engine runs Python backward functions of GPU tensors on its own thread -- so restricted passes of
-# DIFFERENT Python threads are serialised by a lock held for the length of the `with` block (two threads used to
-# overwrite each other's target set, and launches were then skipped silently); the same thread may nest.
+# dataparallel.StagedBuckets; ``torch.autograd.grad(loss, some)``) still runs every node that lies on a path to them, and
+# ``ctx.needs_input_grad`` only says which inputs CAN receive a gradient, not which the pass is after.  A backward that serves
+# several sides with separate launches (IW1: the decoder through p, the variational parameters through log q; a dense layer:
+# its input, its weight, its bias) asks the ENGINE which of its input edges the running pass will execute
+# (``torch._C._will_engine_execute_node`` on ``ctx.next_functions``) and launches only those.  The answer belongs to the pass
+# that is running this node, on whatever thread: no module state, nothing to serialise (round 5 kept the pass's targets in a
+# module global behind a lock, and an unrestricted backward of another thread could read them -- ADVICE r05).
 # ------------------------------------------------------------------------------------------------
-_GRAD_TARGETS = None
-_GRAD_TARGETS_LOCK = threading.RLock()
+_WILL_EXECUTE = getattr(torch._C, "_will_engine_execute_node", None)
+
+
+def _edge_positions(args):
+    """Forward-argument index -> index into ``ctx.next_functions`` (which holds one edge per TENSOR argument, in order)."""
+    pos, n = {}, 0
+    for i, a in enumerate(args):
+        if isinstance(a, torch.Tensor):
+            pos[i] = n
+            n += 1
+    return pos
+
+
+def _pass_needs(ctx, edge_of):
+    """``ctx.needs_input_grad`` narrowed to what the running backward pass will use: an input whose producer (or, for a leaf,
+    whose gradient accumulator) the engine is not going to execute in this pass needs no gradient from this node."""
+    need = list(ctx.needs_input_grad)
+    if _WILL_EXECUTE is None:
+        return need
+    edges = ctx.next_functions
+    for i, e in edge_of.items():
+        if need[i] and e < len(edges) and edges[e][0] is not None:
+            try:
+                need[i] = bool(_WILL_EXECUTE(edges[e][0]))
+            except RuntimeError:          # (not inside a backward pass: e.g. backward() called by hand)
+                pass
+    return need
 
 
 class grad_targets(object):
-    """``with grad_targets(params): torch.autograd.backward(loss, inputs=params)``."""
+    """Kept for callers of round 5's interface: a no-op (the engine is asked instead, see above)."""
 
     def __init__(self, params):
-        self._ids = frozenset(id(p) for p in params)
+        pass
 
     def __enter__(self):
-        global _GRAD_TARGETS
-        _GRAD_TARGETS_LOCK.acquire()
-        self._prev, _GRAD_TARGETS = _GRAD_TARGETS, self._ids
         return self
 
     def __exit__(self, *exc):
-        global _GRAD_TARGETS
-        _GRAD_TARGETS = self._prev
-        _GRAD_TARGETS_LOCK.release()
         return False
 
 
-def _graph_handle(t):
-    """What `_leads_to_targets` needs of an input tensor, WITHOUT the tensor: (grad_fn, None) for a computed tensor, (None, id) for
-    a leaf that requires a gradient, None otherwise.  Kept on a Function's ctx instead of the tensor itself: a ctx attribute is
-    not released when backward frees the saved tensors (p [K, B, X] is 40 MB at config 3)."""
-    if t is None or not t.requires_grad:
+# ------------------------------------------------------------------------------------------------
+# Gradient destinations.  A data-parallel step all-reduces ONE flat buffer per stage; autograd allocates every gradient where
+# it likes, so the buffer used to be filled by a concatenation pass per step (2 x 2.7 MB read + written at the IWAE shape).
+# A bucket registers, per parameter, the slice of its flat buffer that shadows it; a backward of this package that produces a
+# parameter's gradient (the dense layers' weight GEMM and bias reduction) then writes it THERE and returns a fresh alias,
+# which autograd's accumulator adopts as ``p.grad`` without a copy when ``p.grad`` is None (torch's "steal" rule: sole owner,
+# same layout).  One producer per parameter per backward pass may claim the slice (a weight used twice in one graph: the
+# second use allocates as before and autograd adds); a parameter that already holds a gradient is never written over.
+# Everything else -- torch.nn modules, parameters used elsewhere -- still ends up in the bucket through the bucket's own copy.
+# ------------------------------------------------------------------------------------------------
+_GRAD_DEST = {}        # data_ptr of a parameter -> [slice (a view of a bucket, shaped like the parameter), id of the claiming pass, weak ref to the parameter]
+_TASK_ID = getattr(torch._C, "_current_graph_task_id", None)
+
+
+def register_grad_destination(param, view):
+    if view.shape != param.shape or view.dtype != param.dtype or view.device != param.device or not view.is_contiguous():
+        raise ValueError("gradient destination must match the parameter's shape, dtype, device and be contiguous")
+    key = param.data_ptr()
+
+    def forget(ref, key=key):          # the parameter is gone: drop the registration (and with it the hold on the bucket)
+        entry = _GRAD_DEST.get(key)
+        if entry is not None and entry[2] is ref:
+            del _GRAD_DEST[key]
+    _GRAD_DEST[key] = [view, None, weakref.ref(param, forget)]
+
+
+def unregister_grad_destination(param):
+    _GRAD_DEST.pop(param.data_ptr(), None)
+
+
+def _claim_grad_destination(key):
+    """The registered slice for the gradient of the parameter at address ``key`` if this backward pass may write it there,
+    else None."""
+    if not _GRAD_DEST or _TASK_ID is None or key is None:
         return None
-    return (t.grad_fn, None) if t.grad_fn is not None else (None, id(t))
-
-
-def _leads_to_targets(handle, targets):
-    """Whether the autograd graph above the tensor `handle` describes reaches one of the leaf tensors whose ids are in `targets`."""
-    if handle is None:
-        return False
-    grad_fn, leaf_id = handle
-    if grad_fn is None:
-        return leaf_id in targets
-    seen, stack = set(), [grad_fn]
-    while stack:
-        fn = stack.pop()
-        if fn is None or fn in seen:
-            continue
-        seen.add(fn)
-        var = getattr(fn, "variable", None)           # AccumulateGrad
-        if var is not None and id(var) in targets:
-            return True
-        stack.extend(nf for nf, _ in fn.next_functions)
-    return False
+    entry = _GRAD_DEST.get(key)
+    if entry is None:
+        return None
+    param = entry[2]()
+    if param is None or param.data_ptr() != key or param.grad is not None:
+        return None
+    view = entry[0]
+    if view.shape != param.shape or view.dtype != param.dtype or view.device != param.device:
+        return None
+    task = _TASK_ID()
+    if task < 0 or entry[1] == task:          # not inside a backward pass / a second producer in the same pass
+        return None
+    entry[1] = task
+    return view
 
 
 def _iw1_accumulator(device):
@@ -638,8 +687,7 @@ class BernoulliIWObjective(torch.autograd.Function):
                         _hip.ptr(acc), _hip.stream_for(p))
         ctx.meta = meta
         ctx.fold_q = qz is not None
-        # (for passes restricted to some parameters: which side leads where is a property of the graph ABOVE the inputs)
-        ctx.sides = (_graph_handle(p), _graph_handle(qmu), _graph_handle(qsigma))
+        ctx.edge_of = _edge_positions((p, x, z, pmu, psigma, rows_a, logq, qmu, qsigma, qz, meta))
         ctx.save_for_backward(p, x, z, pmu, psigma, out, qmu, qsigma, qz)
         ctx.mark_non_differentiable(bound)
         return cost, bound
@@ -650,17 +698,10 @@ class BernoulliIWObjective(torch.autograd.Function):
             return (None,) * 11
         from_logits, Px, Pm, Ps, p_ls, estimator, want_mean, q_ls = ctx.meta
         p, x, z, pmu, psigma, out, qmu, qsigma, qz = ctx.saved_tensors
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("zhusuan (MI355X build): gradient w.r.t. the Bernoulli observation is not built")
         K, B, X = p.shape
         coef = out[:2]
         g = g_cost.contiguous()
-        need = list(ctx.needs_input_grad)
-        if _GRAD_TARGETS is not None:          # a pass restricted to some parameters: only the side(s) that lead to them
-            tp, tqm, tqs = ctx.sides
-            need[0] = need[0] and _leads_to_targets(tp, _GRAD_TARGETS)
-            need[7] = need[7] and _leads_to_targets(tqm, _GRAD_TARGETS)
-            need[8] = need[8] and _leads_to_targets(tqs, _GRAD_TARGETS)
+        need = _pass_needs(ctx, ctx.edge_of)   # (a pass restricted to some parameters: only the side(s) that lead to them)
         gp = torch.empty_like(p) if need[0] else None
         fold = ctx.fold_q and (need[7] or need[8])
         gqmu = torch.empty_like(qmu) if fold else None
@@ -670,6 +711,13 @@ class BernoulliIWObjective(torch.autograd.Function):
                             _hip.ptr(coef), _hip.ptr(g), 0 if want_mean else 1, _hip.ptr(gp),
                             _hip.ptr(qz) if fold else None, _hip.ptr(qmu) if fold else None, _hip.ptr(qsigma) if fold else None,
                             qz.shape[-1] if fold else 1, 1 if q_ls else 0, _hip.ptr(gqmu), _hip.ptr(gqsigma), _hip.stream_for(p))
+        gx = None
+        if need[1]:
+            # the observation's gradient (bernoulli.py:94 is differentiable in `sample`): its own launch -- a model whose observed
+            # value comes out of a differentiable net is rare --, row gradients coef[0] * g formed in the kernel as above
+            gx = torch.empty_like(x)
+            _hip.lib().call("zs_bernoulli_logprob_bwd_x" + _sfx(p), _hip.ptr(p), 1 if from_logits else 0, Px, _hip.ptr(coef), 1, K,
+                            _hip.ptr(g), 0 if want_mean else 1, _hip.ptr(gx), K, B, X, _hip.stream_for(p))
         gz = gpm = gps = ga = gq = None
         # the rarer consumers take the row gradients as a tensor (one multiply, as K4b's backward)
         if need[2] or need[3] or need[4] or need[5] or need[6]:
@@ -682,7 +730,7 @@ class BernoulliIWObjective(torch.autograd.Function):
                 Dz = z.shape[-1]
                 gz, gpm, gps = _normal_logprob_grads(z, pmu, psigma, gc[0].t(), K, B, Dz, (K * B * Dz, Pm, Ps), 1 if p_ls else 0,
                                                      (need[2], need[3], need[4]))
-        return gp, None, gz, gpm, gps, ga, gq, (gqmu if need[7] else None), (gqsigma if need[8] else None), None, None
+        return gp, gx, gz, gpm, gps, ga, gq, (gqmu if need[7] else None), (gqsigma if need[8] else None), None, None
 
 
 MAX_TERMS = 6      # ZS_MAX_TERMS of include/zs_hip.h
@@ -1110,8 +1158,6 @@ class LogJointScalar(torch.autograd.Function):
             tm.b, tm.pb = (b.data_ptr() if b is not None else None), int(pb)
             if fam == _hip.LJ_ROWS:
                 continue
-            if need[3 * i] and fam in (_hip.LJ_BERNOULLI, _hip.LJ_BERNOULLI_LOGITS):
-                raise NotImplementedError("zhusuan (MI355X build): gradient w.r.t. the Bernoulli observation is not built")
             for j, name in enumerate(("gx", "ga", "gb")):
                 t = tensors[3 * i + j]
                 if t is not None and need[3 * i + j]:
@@ -1333,13 +1379,15 @@ class ParticleMLP(torch.autograd.Function):
         return (gx,) + tuple(g if ctx.needs_input_grad[1 + l] else None for l, g in enumerate(gws))
 
 
-def column_sum(x2d):
-    """CS1: ``x2d.sum(0)`` of a contiguous [rows, cols] matrix in one launch, deterministic (include/zs_hip.h)."""
+def column_sum(x2d, out=None):
+    """CS1: ``x2d.sum(0)`` of a contiguous [rows, cols] matrix in one launch, deterministic (include/zs_hip.h).  ``out``: where
+    the sums go (a contiguous [cols] tensor, e.g. a gradient bucket's slice) instead of a fresh tensor."""
     _hip.require_device(x2d)
     sfx = _sfx(x2d)
     rows, cols = x2d.shape
     dev = x2d.device
-    out = torch.empty(cols, dtype=x2d.dtype, device=dev)
+    if out is None:
+        out = torch.empty(cols, dtype=x2d.dtype, device=dev)
     if cols == 0:
         return out
     ws, tickets = _cs_scratch(dev, x2d.dtype, cols)
@@ -1377,14 +1425,15 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2          # ZS_ACT_* of include/zs_hip.
 _ADDMM_RELU = getattr(torch, '_addmm_activation', None)      # bias + ReLU epilogue of the GEMM (a private torch entry point: optional)
 
 
-def dense_act_bwd(g2d, y2d, act):
-    """AB1: ``(g * act'(y), (g * act'(y)).sum(0))`` of contiguous [rows, cols] matrices in one launch (include/zs_hip.h)."""
+def dense_act_bwd(g2d, y2d, act, gb_out=None):
+    """AB1: ``(g * act'(y), (g * act'(y)).sum(0))`` of contiguous [rows, cols] matrices in one launch (include/zs_hip.h).
+    ``gb_out``: where the column sums go (a contiguous [cols] tensor) instead of a fresh tensor."""
     _hip.require_device(g2d)
     sfx = _sfx(g2d)
     rows, cols = g2d.shape
     dev = g2d.device
     gpre = torch.empty_like(g2d)
-    gb = torch.empty(cols, dtype=g2d.dtype, device=dev)
+    gb = torch.empty(cols, dtype=g2d.dtype, device=dev) if gb_out is None else gb_out
     if cols == 0:
         return gpre, gb
     ws, tickets = _cs_scratch(dev, g2d.dtype, cols)
@@ -1404,6 +1453,8 @@ class DenseLayer(torch.autograd.Function):
     def forward(ctx, x, w, b, act=ACT_NONE):
         ctx.has_bias = b is not None
         ctx.act = act
+        ctx.edge_of = _edge_positions((x, w, b, act))
+        ctx.bias_key = b.data_ptr() if (b is not None and _GRAD_DEST) else None      # (finds the bias gradient's destination)
         if act == ACT_RELU and b is not None and x.dim() >= 1 and x.shape[-1] == w.shape[1] and b.dim() == 1 and _ADDMM_RELU is not None:
             y = _ADDMM_RELU(b, x.reshape(-1, x.shape[-1]), w.t()).reshape(*x.shape[:-1], w.shape[0])
         else:
@@ -1421,17 +1472,28 @@ class DenseLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors[:2]
+        need = _pass_needs(ctx, ctx.edge_of)          # (a staged backward visits this layer for its input's sake only)
         g2 = g.reshape(-1, g.shape[-1]).contiguous()
         gx = gw = gb = None
+        want_gb = ctx.has_bias and need[2]
+        # a registered gradient destination (a data-parallel bucket's slice): the bias sums and the weight GEMM write there
+        b_dest = _claim_grad_destination(ctx.bias_key) if want_gb else None
         if ctx.act != ACT_NONE:
             y = ctx.saved_tensors[2]
-            g2, gb = dense_act_bwd(g2, y.reshape(-1, y.shape[-1]), ctx.act)
-        elif ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = column_sum(g2)
-        if not (ctx.has_bias and ctx.needs_input_grad[2]):
+            g2, gb = dense_act_bwd(g2, y.reshape(-1, y.shape[-1]), ctx.act, gb_out=b_dest)
+        elif want_gb:
+            gb = column_sum(g2, out=b_dest)
+        if not want_gb:
             gb = None
-        if ctx.needs_input_grad[0]:
+        elif b_dest is not None:
+            gb = gb.view_as(gb)          # a fresh alias: autograd adopts a gradient it is the sole owner of
+        if need[0]:
             gx = (g2 @ w).reshape(x.shape)
-        if ctx.needs_input_grad[1]:
-            gw = g2.t() @ x.reshape(-1, x.shape[-1])
+        if need[1]:
+            w_dest = _claim_grad_destination(w.data_ptr())
+            x2 = x.reshape(-1, x.shape[-1])
+            if w_dest is not None:
+                gw = torch.mm(g2.t(), x2, out=w_dest).view_as(w_dest)
+            else:
+                gw = g2.t() @ x2
         return gx, gw, gb, None

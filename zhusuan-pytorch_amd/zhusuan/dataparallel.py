@@ -21,6 +21,20 @@ def _bucket_dtype(params):
     return dtypes.pop()
 
 
+def _register_destinations(params, views):
+    """Make every slice its parameter's gradient destination (zhusuan._ops: backward passes of this package's layers then
+    write the gradient into the bucket themselves and ``_fill_flat`` finds it in place)."""
+    for p, v in zip(params, views):
+        _ops.register_grad_destination(p, v)
+
+
+def _release_destinations(params, views):
+    for p, v in zip(params, views):
+        entry = _ops._GRAD_DEST.get(p.data_ptr())
+        if entry is not None and entry[0] is v:
+            _ops.unregister_grad_destination(p)
+
+
 def _fill_flat(flat, params, views, tail):
     """Write the gradients of `params` (and `tail`, a list of 1-element tensors) into `flat`, whose slices `views`
     shadow the parameters.  One ``cat`` kernel when no gradient lives in the buffer yet; gradients that already alias
@@ -43,15 +57,93 @@ def _fill_flat(flat, params, views, tail):
         flat[n + i:n + i + 1].copy_(t.detach().reshape(1))
 
 
+class DirectAllReduce(object):
+    """An RCCL communicator of this job's own, driven without torch.distributed's per-collective bookkeeping:
+    ``all_reduce_sum_(flat)`` enqueues ONE ``ncclAllReduce`` on the CURRENT stream and nothing else.
+
+    Why: between two hipGraph launches every HIP event record costs ~5 us of idle GPU and every cross-stream hop 13-20 us
+    (profiles/r06_stream_links.txt); ``dist.all_reduce`` records two events in its synchronous form (+10 us per call) and
+    forks to / joins from its own stream in the asynchronous one (+35 us) -- with a 0.74 ms step that is the difference
+    between 0.97 and 0.99 of the single-GPU rate before a byte has crossed xGMI.  The reduction itself is the same RCCL
+    kernel over the same links.
+
+    Construction is COLLECTIVE (every rank of ``group``, at the same point): rank 0's ``ncclUniqueId`` travels over the
+    process group, every rank joins the communicator (``ncclCommInitRank``, bounded by ``timeout_s``: a rank whose set-up does
+    not return gives up instead of hanging), one probe all-reduce checks the sum of the ranks, and the ranks AGREE
+    (``all_ranks_agree``) -- ``create`` returns a communicator on every rank or None on every rank, never a mixture; callers
+    fall back to ``dist.all_reduce``.  Needs the "nccl" backend (RCCL on ROCm); RCCL's C API is bound in ``zhusuan/_rccl.py``."""
+
+    def __init__(self, comm, world, device):
+        self._comm, self.world, self.device = comm, world, device
+
+    @classmethod
+    def create(cls, group=None, timeout_s=120.0):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+            return None
+        import threading
+        from . import _rccl
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        device = torch.device("cuda", torch.cuda.current_device())
+        box = {}
+        try:
+            uid = [_rccl.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+
+            def join():
+                try:
+                    torch.cuda.set_device(device)          # (the current device is per thread)
+                    comm = _rccl.comm_init_rank(world, uid[0], rank)
+                    probe = torch.full((4,), float(rank + 1), device=device)
+                    _rccl.all_reduce_sum_(probe, comm, torch.cuda.current_stream(device).cuda_stream)
+                    torch.cuda.synchronize(device)
+                    box["sum"], box["comm"] = float(probe[0].item()), comm
+                except Exception as e:                     # noqa: BLE001
+                    box["error"] = repr(e)
+            t = threading.Thread(target=join, name="zhusuan-rccl-init", daemon=True)
+            t.start()
+            t.join(timeout_s)
+            ok = (not t.is_alive()) and "comm" in box and box.get("sum") == world * (world + 1) / 2.0
+        except Exception as e:                             # noqa: BLE001
+            box["error"], ok = repr(e), False
+        if not all_ranks_agree(ok, group=group, device=device):
+            cls.last_error = box.get("error") or ("set-up did not return within %.0f s" % timeout_s if "comm" not in box
+                                                  else "another rank's set-up failed")
+            return None
+        return cls(box["comm"], world, device)
+
+    last_error = None
+
+    def all_reduce_sum_(self, flat):
+        """In-place SUM over the ranks, enqueued on the current stream (stream-ordered like any kernel; capturable or not is
+        RCCL's business -- this package launches it eagerly between graphs)."""
+        from . import _hip, _rccl
+        if not flat.is_contiguous() or flat.device != self.device:
+            raise RuntimeError("DirectAllReduce: a contiguous tensor on %s expected" % (self.device,))
+        _rccl.all_reduce_sum_(flat, self._comm, _hip.stream_for(flat))
+
+    def close(self):
+        """Destroy the communicator (collective in spirit: every rank, after its last all-reduce has completed)."""
+        if self._comm is not None:
+            from . import _rccl
+            torch.cuda.synchronize(self.device)
+            _rccl.comm_destroy(self._comm)
+            self._comm = None
+
+
 class GradientBucket(object):
     """One flat buffer [all gradients | objective] (in the parameters' dtype) for the single all-reduce of a step.
 
     Per step: autograd produces the gradients as usual; ``all_reduce_mean`` packs them (one ``cat`` kernel
     straight into the persistent buffer), all-reduces the buffer, scales it by 1/world and re-points every
     ``p.grad`` at its slice of the buffer, so the optimizer reads the averaged gradients without an unpack
-    copy.  With a single rank nothing is packed or sent at all."""
+    copy.  With a single rank nothing is packed or sent at all.
 
-    def __init__(self, module):
+    ``direct=True`` (default): the slices are registered as the parameters' gradient destinations -- the backward of
+    ``zhusuan.Linear`` layers writes weight and bias gradients straight into the buffer (``zero()`` before every backward, so
+    that autograd adopts them), and ``pack`` copies only what arrived elsewhere (torch.nn modules) and the objective.
+    ``release()`` withdraws the registrations (a bucket that is dropped while its model lives on)."""
+
+    def __init__(self, module, direct=True):
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -62,6 +154,12 @@ class GradientBucket(object):
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.n_grad = n
+        self.direct = bool(direct)
+        if self.direct:
+            _register_destinations(self.params, self.views)
+
+    def release(self):
+        _release_destinations(self.params, self.views)
 
     def zero(self):
         """Drop last step's gradients (autograd then writes fresh ones instead of accumulating)."""
@@ -81,6 +179,34 @@ class GradientBucket(object):
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.flat.mul_(1.0 / dist.get_world_size(group))
         return self.flat[self.n_grad]
+
+    def exchange(self, group=None, direct=None, always=False):
+        """All-reduce (SUM) of the packed buffer on the CURRENT stream: through ``direct`` (a ``DirectAllReduce``: one RCCL
+        call, no events) or ``dist.all_reduce``'s synchronous form.  The 1/world is left to the caller: ``scale()`` (a pass over
+        the buffer) or ``zhusuan.optim.FlatAdam.step(grad_scale=bucket.grad_scale())`` (no pass), with ``loss()`` scaling the
+        objective's slot on its own.  A no-op with one rank unless ``always`` (a measurement aid)."""
+        active = dist.is_available() and dist.is_initialized()
+        if not active or (dist.get_world_size(group) == 1 and not always):
+            return
+        if direct is not None:
+            direct.all_reduce_sum_(self.flat)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+    def grad_scale(self, group=None):
+        active = dist.is_available() and dist.is_initialized()
+        return 1.0 / dist.get_world_size(group) if active else 1.0
+
+    def scale(self, group=None):
+        f = self.grad_scale(group)
+        if f != 1.0:
+            self.flat.mul_(f)
+
+    def loss(self, scaled=False, group=None):
+        """The objective's slot (the all-reduced SUM after ``exchange``; the mean when ``scaled`` or after ``scale()``)."""
+        v = self.flat[self.n_grad]
+        f = self.grad_scale(group) if scaled else 1.0
+        return v if f == 1.0 else v * f
 
     def nbytes(self):
         return self.flat.numel() * self.flat.element_size()
@@ -215,18 +341,23 @@ class StagedBuckets(object):
     back for an eager step):
 
         b = dataparallel.StagedBuckets([gen.parameters(), var.parameters()])
-        b.zero(); loss = model(obs); b.backward_stage(loss, 0)     # 1 (graph)  decoder backward, bucket 0 packed
+        b.zero(); loss = model(obs); b.backward_stage(loss, 0)     # 1 (graph)  decoder backward, bucket 0 filled
         b.launch(0)                                                # 2 (eager)  asynchronous all-reduce of bucket 0
-        b.backward_stage(loss, 1)                                  # 3 (graph)  encoder backward, bucket 1 packed
-        b.launch(1); b.wait()                                      # 4 (eager)
+        b.backward_stage(loss, 1)                                  # 3 (graph)  encoder backward, bucket 1 filled
+        b.launch(1, overlap=False); b.wait()                       # 4 (eager)  bucket 1 on the current stream; join bucket 0
         b.scale(); optimizer.step()                                # 5 (graph)  1/world, update  (or b.scale(gradients=False);
                                                                    #            FlatAdam.step(grad_scale=b.grad_scale()): one pass less)
         global_loss = b.loss()
 
-    The objective rides in bucket 0 (the first to leave).  Every ``p.grad`` ends up aliasing its slice of a bucket."""
+    The objective rides in bucket 0 (the first to leave).  Every ``p.grad`` ends up aliasing its slice of a bucket.
+    ``direct=True`` (default): as for ``GradientBucket`` -- gradients produced by this package's layers are written into the
+    buckets by the backward pass itself; only the objective (and gradients that arrived elsewhere) are copied.
+    ``always_collective=True`` issues the all-reduces with ONE rank too (a measurement aid: what the path costs before a byte
+    crosses xGMI; needs an initialised process group)."""
 
-    def __init__(self, stage_params, group=None):
+    def __init__(self, stage_params, group=None, direct=True, always_collective=False):
         self.group = group
+        self.always_collective = bool(always_collective)
         self.stages = []
         for i, params in enumerate(stage_params):
             params = [p for p in params if p.requires_grad]
@@ -247,6 +378,14 @@ class StagedBuckets(object):
                 if id(p) in seen:
                     raise ValueError("a parameter appears in two stages")
                 seen.add(id(p))
+        self.direct = bool(direct)
+        if self.direct:
+            for st in self.stages:
+                _register_destinations(st["params"], st["views"])
+
+    def release(self):
+        for st in self.stages:
+            _release_destinations(st["params"], st["views"])
 
     def _world(self):
         active = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -259,9 +398,15 @@ class StagedBuckets(object):
             for p in st["params"]:
                 p.grad = None
 
-    def backward_stage(self, loss, i):
+    def backward_stage(self, loss, i, also=None, roots=None):
         """Gradients of stage i's parameters only (autograd prunes everything that does not lead to them), packed into
-        bucket i.  All but the last stage keep the autograd graph alive for the stages that follow."""
+        bucket i.  All but the last stage keep the autograd graph alive for the stages that follow.
+
+        ``also``: tensors on the boundary to LATER stages (e.g. the variational net's outputs, the distribution parameters of
+        the latent): this pass delivers d loss / d t into ``t.grad`` for each of them as well, so that the objective's own
+        backward (and everything between it and the boundary) runs ONCE, here, with every side in one launch.  The later
+        stage then passes the same tensors as ``roots`` and starts there, seeded with those gradients, instead of at the loss
+        (``loss`` is ignored).  Without them every stage walks down from the loss again."""
         st = self.stages[i]
         last = i == len(self.stages) - 1
         if self._holds_sum and any(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
@@ -270,17 +415,36 @@ class StagedBuckets(object):
             # step's gradients onto it would feed world-times-too-large stale values into the next all-reduce
             raise RuntimeError("zhusuan.dataparallel.StagedBuckets: the buckets hold last step's all-reduced SUM "
                                "(scale(gradients=False)); call zero() before the next backward")
-        with _ops.grad_targets(st["params"]):          # (kernels that serve several sides launch only this stage's)
-            torch.autograd.backward(loss, inputs=st["params"], retain_graph=not last)
+        # (a backward of this package that serves several sides -- IW1, the dense layers -- asks the engine which of them THIS
+        #  pass is after and launches only those: zhusuan._ops._pass_needs)
+        also = [t for t in (also or []) if t.requires_grad]
+        if roots is not None:
+            roots = [t for t in roots if t.requires_grad and t.grad is not None]
+            seeds = [t.grad for t in roots]
+            torch.autograd.backward(roots, seeds, inputs=st["params"] + also, retain_graph=not last)
+            for t in roots:          # (after the pass: a tensor that retains its gradient is handed its seed back)
+                t.grad = None
+        else:
+            torch.autograd.backward(loss, inputs=st["params"] + also, retain_graph=not last)
         _fill_flat(st["flat"], st["params"], st["views"], [loss] if i == 0 else [])
         for p, v in zip(st["params"], st["views"]):
             p.grad = v
 
-    def launch(self, i):
-        """Start the all-reduce of bucket i without waiting for it (a no-op with one rank)."""
+    def launch(self, i, overlap=True, direct=None):
+        """The all-reduce of bucket i (a no-op with one rank).  ``overlap=True``: started without waiting for it -- it runs
+        on the collective library's own stream beside whatever the compute stream does next (the later stages' backward);
+        ``wait()`` joins it.  ``overlap=False``: the synchronous form, which torch enqueues on the CURRENT stream -- for a
+        bucket whose result the very next kernel needs (the last stage's, in front of the update) that saves the two
+        cross-stream event hops of the asynchronous form (measured: profiles/r06_stream_links.txt); nothing to join.
+        ``direct`` (a ``DirectAllReduce``, with ``overlap=False``): one RCCL call on the current stream, no event records."""
         st = self.stages[i]
-        if self._world() > 1:
-            st["handle"] = dist.all_reduce(st["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self._world() > 1 or (self.always_collective and dist.is_available() and dist.is_initialized()):
+            if overlap:
+                st["handle"] = dist.all_reduce(st["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            elif direct is not None:
+                direct.all_reduce_sum_(st["flat"])
+            else:
+                dist.all_reduce(st["flat"], op=dist.ReduceOp.SUM, group=self.group)
 
     def wait(self):
         for st in self.stages:
@@ -319,6 +483,11 @@ class StagedBuckets(object):
         v = self.stages[0]["flat"][self.stages[0]["n"]]
         f = self._loss_factor
         return v if f == 1.0 else v * f
+
+    def loss_slot(self):
+        """The objective's slot as it stands (no kernel): the mean after ``scale()``, the SUM over the ranks after
+        ``scale(gradients=False)`` -- multiply by ``grad_scale()`` when you read it."""
+        return self.stages[0]["flat"][self.stages[0]["n"]]
 
     def nbytes(self):
         return sum(st["flat"].numel() * st["flat"].element_size() for st in self.stages)
