@@ -261,6 +261,10 @@ int zs_iw_objective_f32(const float* logp_a, int64_t ld_a, const float* logp_b, 
  * fp32 costs whatever their magnitude (ABI 13: one word, 2^-21 absolute per datapoint at R = 256); a +inf / -inf / NaN cost gives
  * a +inf / -inf / NaN mean as the fp32 mean of importance_weighted_objective.py:191 would, a finite |cost| >= 2^24 gives NaN
  * (zs_iw_objective's float sum returns the finite mean there: the one documented divergence between the two entry points).
+ * The mean is finished by a wave that WATCHES the words until every workgroup's share has arrived; should a launch lose workgroups
+ * (it cannot in a healthy process) the watcher gives up after 2 s of the device clock, stores NaN, leaves the words as they are and
+ * raises acc[ZS_IW1_POISON_WORD]: a NaN mean over finite costs means "accumulator poisoned" -- every later launch on it would
+ * miscount -- and the owner re-zeroes all 64 words (zhusuan._ops.iw1_accumulators_ok() / reset_iw1_accumulators()).
  * A datapoint whose shared observation row holds only exact 0s and 1s (binarised data) is evaluated with ONE logarithm per
  * element -- log(fma(p, 2x - 1, 1 - x) + 1e-8), bit-identical to the two-term form for every p in [0, 1]; for an invalid p
  * (outside [-1e-8, 1 + 1e-8]) the two-term form's NaN from 0 * log(negative) is not reproduced.
@@ -268,6 +272,7 @@ int zs_iw_objective_f32(const float* logp_a, int64_t ld_a, const float* logp_b, 
  * Dz <= 256, 16-byte aligned operands): the caller then composes K2 / K3 / K4b itself.
  * -------------------------------------------------------------------------*/
 #define ZS_IW1_ACC_WORDS 64
+#define ZS_IW1_POISON_WORD 63
 int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, const float* x, int64_t Px,
                                   int64_t K, int64_t R, int64_t D,
                                   const float* z, const float* pmu, int64_t Pm, const float* psigma, int64_t Ps,

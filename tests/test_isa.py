@@ -34,7 +34,7 @@ def _kernel(asm, mangled):
     return asm[i:j], asm[j:asm.index("\n\t.text", j) if "\n\t.text" in asm[j:] else j + 4000]
 
 
-@pytest.mark.parametrize("mangled", ["_ZN2zs13k_iw1_persistILb0ELb0ELb0EEEvNS_7Iw1ArgsE", "_ZN2zs13k_iw1_persistILb1ELb0ELb0EEEvNS_7Iw1ArgsE"])
+@pytest.mark.parametrize("mangled", ["_ZN2zs13k_iw1_persistILb0ELb0EEEvNS_7Iw1ArgsE", "_ZN2zs13k_iw1_persistILb1ELb0EEEvNS_7Iw1ArgsE"])
 def test_iw1_streaming_loop_keeps_its_prefetched_rows_in_flight(bernoulli_asm, mangled):
     body, _ = _kernel(bernoulli_asm, mangled)
     lines = body.split("\n")

@@ -571,3 +571,35 @@ def test_uniform_latent_keeps_its_pathwise_gradient(dev, est):
     close(q.low.grad, g[est + "_g_low"], 1e-3, 1e-5)
     close(q.logw.grad, g[est + "_g_logw"], 1e-3, 1e-5)
     close(p.scale.grad, g[est + "_g_scale"], 1e-3, 1e-5)
+
+
+def test_explain_names_the_path_an_objective_took_and_why(dev):
+    """zhusuan.explain / objective.last_path / zhusuan.warn_on_fallback: the reference walks its nodes in a
+    Python loop whatever the model (importance_weighted_objective.py:66-100); here a model outside the fused kernel's domain
+    silently took three launches instead of one -- now it says so."""
+    import warnings
+    from examples import iwae, vae_mnist
+    assert "has not been evaluated" in zs.explain(iwae.build(n_samples=5, estimator="vimco", hidden=16, device=dev))
+    for kw, expect in [(dict(n_samples=5), "IW1"), (dict(n_samples=5, x_dim=100), "rows of 100 elements"),
+                       (dict(n_samples=70), "K = 70 particles")]:
+        model = iwae.build(estimator="vimco", hidden=16, device=dev, **kw)
+        x = (torch.rand(4, kw.get("x_dim", 784), device=dev) < 0.5).float()
+        zs.warn_on_fallback(True)
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                model({"x": x})
+                model({"x": x})
+        finally:
+            zs.warn_on_fallback(False)
+        text = zs.explain(model)
+        assert expect in text, text
+        mine = [m for m in w if "zhusuan:" in str(m.message)]                 # (torch / hipBLASLt may warn about things of their own)
+        if expect == "IW1":
+            assert model.last_path["why"] is None and not mine
+        else:
+            assert text.startswith("per-node kernels") and "because" in text
+            assert len(mine) == 1 and expect in str(mine[0].message)          # once per reason, not once per step
+    vae = vae_mnist.build(batch_size=4, device=dev)
+    vae({"x": (torch.rand(4, 784, device=dev) < 0.5).float()})
+    assert zs.explain(vae).startswith("LJ1") and vae.last_path["why"] is None

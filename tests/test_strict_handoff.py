@@ -23,7 +23,15 @@ STRICT = os.path.join(ROOT, "tools", "_exp", "libzs_hip_strict.so")
 @pytest.fixture(scope="module")
 def builds():
     from zhusuan import _hip
-    assert os.path.exists(STRICT), "tools/_exp/libzs_hip_strict.so is missing: __graft_entry__.build() (make -C zhusuan-pytorch_amd/csrc strict)"
+    # the twin is test infrastructure: built HERE when it is missing or older than the sources (not a duty -- and not a
+    # failure mode -- of the product's build; `make strict` recompiles only what changed)
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "zhusuan-pytorch_amd", "csrc")
+    srcs = glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(ROOT, "include", "zs_hip.h")]
+    if not os.path.exists(STRICT) or os.path.getmtime(STRICT) < max(os.path.getmtime(f) for f in srcs):
+        r = subprocess.run(["make", "-j6", "-C", csrc, "strict"], capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, "make strict failed:\n" + (r.stdout + r.stderr)[-3000:]
     strict = _hip.KernelLibrary(STRICT)
     shipped = _hip.KernelLibrary(_hip.LIB_PATH)
     assert "strict hand-off" in strict.build_info() and "strict" not in shipped.build_info()

@@ -2,7 +2,7 @@
 // objectives: it streams p[K, B, 784] once (16 B per lane, four independent loads in flight per
 // lane), re-reads the observation row x[b, :] from L2, and reduces each row on the wavefront.
 #include "zs_common.h"
-#include "zs_iwfused.h"
+#include "zs_iw1_args.h"
 #include "zs_iwpersist.h"
 #include "zs_sample_tile.h"
 #include "../../include/zs_hip.h"
@@ -886,46 +886,16 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
   a.cb = iw1_cb(R);
   // The persistent form: ONE workgroup per CU (1024 threads, 100+ VGPRs: one is resident), workgroup g takes datapoints g, g + G, ...
   // 16 waves (fewer for K < 16): the rows spread evenly over the CU's four SIMDs.
-  static const int nw_env = env_knob("ZS_IW1_NW", 0), var_env = env_knob("ZS_IW1_VARIANT", 0), grid_env = env_knob("ZS_IW1_GRID", 0),
-                   old_env = env_knob("ZS_IW1_BLOCK_KERNEL", 0);     // experiments only
-  a.variant = var_env;
+  static const int nw_env = env_knob("ZS_IW1_NW", 0), grid_env = env_knob("ZS_IW1_GRID", 0);     // experiments only (zs_common.h)
+  a.variant = 0;
   int nw = K < 16 ? (int)K : 16;
   if (nw_env > 0) nw = nw_env < K ? nw_env : (int)K;
   hipStream_t st = (hipStream_t)stream;
-#ifdef ZS_EXPERIMENTS
-  if (old_env && R <= 32768) {          // (-DZS_EXPERIMENTS builds only: round 4's workgroup-per-datapoint kernel, for A/B timing)
-    a.bound_bits = a.cb <= 12 ? 24 : 20;
-    a.sharded = R >= 128 ? 1 : 0;
-    const int rounds = (int)((K + 15) / 16);
-#define ZS_LAUNCH_IW1(L, RD) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_block<L, RD>), dim3((unsigned)R), dim3(64 * nw), st, a)
-    if (from_logits) {
-      if (rounds == 1) ZS_LAUNCH_IW1(true, 1); else if (rounds == 2) ZS_LAUNCH_IW1(true, 2); else if (rounds == 3) ZS_LAUNCH_IW1(true, 3); else ZS_LAUNCH_IW1(true, 4);
-    } else {
-      if (rounds == 1) ZS_LAUNCH_IW1(false, 1); else if (rounds == 2) ZS_LAUNCH_IW1(false, 2); else if (rounds == 3) ZS_LAUNCH_IW1(false, 3); else ZS_LAUNCH_IW1(false, 4);
-    }
-#undef ZS_LAUNCH_IW1
-    ZS_CHECK_LAUNCH();
-    return 0;
-  }
-#else
-  (void)old_env;
-#endif
   int64_t G = compute_units();
   if (grid_env > 0) G = grid_env;
   if (G > R) G = R;
   if (G >= (1 << ZS_IW1_CNT_BITS)) G = (1 << ZS_IW1_CNT_BITS) - 1;
-  a.sharded = 2;            // watcher mode (zs_iwpersist.h; 0 / 1: the last arrival finishes, one- / two-level count: experiments builds)
-  static const int shard_env = env_knob("ZS_IW1_SHARDED", -1);     // experiments only
-  if (shard_env >= 0) a.sharded = shard_env;
-#ifdef ZS_EXPERIMENTS
-  static const int nt_env = env_knob("ZS_IW1_NT", 0);
-  if (nt_env && !a.x_full) {
-    if (from_logits) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<true, false, true>), dim3((unsigned)G), dim3(64 * nw), st, a);
-    else ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<false, false, true>), dim3((unsigned)G), dim3(64 * nw), st, a);
-    ZS_CHECK_LAUNCH();
-    return 0;
-  }
-#endif
+  a.sharded = 2;            // (reserved; the batch mean is finished by a watching wave: zs_iwpersist.h)
 #define ZS_LAUNCH_IW1P(L, XF) ZS_LAUNCH(KID_BERN_IW_OBJECTIVE, (k_iw1_persist<L, XF>), dim3((unsigned)G), dim3(64 * nw), st, a)
   if (from_logits) { if (a.x_full) ZS_LAUNCH_IW1P(true, true); else ZS_LAUNCH_IW1P(true, false); }
   else             { if (a.x_full) ZS_LAUNCH_IW1P(false, true); else ZS_LAUNCH_IW1P(false, false); }
@@ -933,18 +903,6 @@ extern "C" int zs_bernoulli_iw_objective_f32(const float* p, int from_logits, co
   ZS_CHECK_LAUNCH();
   return 0;
 }
-
-#ifdef ZS_EXPERIMENTS
-// (experiments builds only, not part of the ABI) the phase stamps of the last IW1 forward launch: n_wg x 8 words of s_memrealtime
-extern "C" int zs_iw1_stamps_read(uint64_t* host_out, int64_t n_words) {
-  if (!host_out || n_words < 0 || n_words > 1024 * 8) return ZS_EINVAL;
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(zs::zs_iw1_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
-}
-extern "C" int zs_iw1_wave_stamps_read(uint64_t* host_out, int64_t n_words) {
-  if (!host_out || n_words < 0 || n_words > 1024 * 32) return ZS_EINVAL;
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(zs::zs_iw1_wave_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
 // Backward of IW1: the Bernoulli term's gradient with the row gradients coef[0][r, k] * gout[r * gout_stride] formed in the
 // kernel (no pass over the coefficient matrix), and -- when the variational node's operands are handed in -- the gradient of

@@ -71,7 +71,7 @@ ZS_HD void iw_particle(const IwRow& r, float l, float lq, int j, int estimator,
 }
 
 // One datapoint on one wavefront, lane = particle (K <= 64): the row scalars by DPP reductions (zs_common.h), then the per-particle terms
-// (the body of k_iw_reduce_wave; also the tail of the fused generator-side objective, zs_iwfused.hip).  `l` = log w of this
+// (the body of k_iw_reduce_wave; also the tail of the fused generator-side objective, zs_iwpersist.h).  `l` = log w of this
 // lane's particle (-inf on lanes >= K), `lq` its log q.  Writes the two coefficient rows (scaled) and, from lane 0, the
 // per-datapoint cost / bound when the pointers are given; returns the datapoint's cost (uniform across the wave).
 __device__ __forceinline__ float iw_wave_row(float l, float lq, bool on, int lane, int K, int estimator, float scale,
@@ -125,6 +125,7 @@ __device__ __forceinline__ float iw_wave_row(float l, float lq, bool on, int lan
 #define ZS_IW1_S (61 - ZS_IW1_CNT_BITS)
 #define ZS_IW1_BOUND_BITS 24        // |cost| < 2^24 per datapoint, else the mean is NaN
 #define ZS_IW1_B_OFF 32
+// (ZS_IW1_POISON_WORD, include/zs_hip.h: raised by a watcher that gave up; the host re-zeroes the accumulator)
 #define ZS_IW1_FLAG_NAN (1ull << 63)
 #define ZS_IW1_FLAG_PINF (1ull << 62)
 #define ZS_IW1_FLAG_NINF (1ull << 61)

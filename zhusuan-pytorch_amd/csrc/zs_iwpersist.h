@@ -1,9 +1,10 @@
 // IW1, persistent form (round 5): the generator side of the importance-weighted objective in ONE launch for ANY number of
-// datapoints (included by zs_bernoulli.hip; replaces k_iw1_block of zs_iwfused.h, which served B <= 384 only).
+// datapoints (included by zs_bernoulli.hip; round 4's workgroup-per-datapoint kernel, which served B <= 384 only, lives on in
+// tools/lab/ for A/B timing).
 //
-// Same arithmetic as k_iw1_block -- a workgroup owns whole datapoints, so the K row sums of a datapoint never leave the CU
+// A workgroup owns whole datapoints, so the K row sums of a datapoint never leave the CU
 // (importance_weighted_objective.py:66-100 over bernoulli.py:84-95 and normal.py:109-126; the K-particle reduction :16-25,
-// 123-132,152-191) -- but the grid is one workgroup per CU and workgroup g takes datapoints g, g + G, g + 2G, ...:
+// 123-132,152-191); the grid is one workgroup per CU and workgroup g takes datapoints g, g + G, g + 2G, ...:
 //
 //   * FLAT ROWS.  The K rows of the workgroup's n datapoints form one list f = i * K + k; wave w streams f = w, w + NW, ...
 //     with ONE row in flight behind the one it reduces (two register buffers, the loop unrolled by two: see the loop for why not more).  No slot is
@@ -29,7 +30,7 @@
 #pragma once
 #include "zs_common.h"
 #include "zs_iw_math.h"
-#include "zs_iwfused.h"
+#include "zs_iw1_args.h"
 #include "../../include/zs_hip.h"
 #include <type_traits>
 
@@ -39,7 +40,11 @@ struct Iw1Smem {
   float4 x[3][256], omx[3][256];                  // observation row and 1 - x of the datapoints in flight (i mod 3): two-logarithm form
   float4 sgn[3][256], cmp[3][256];                // 2x - 1 and 1 - x again, with other padding: one-logarithm form (rows of bits)
   float4 zm[3][64], zl[3][64], zp[3][64];         // the prior's mean, c - log sigma, 0.5 sigma^-2 per 16-byte piece of the latent row
-  float lx[3][64], lz[3][64];                     // row sums of the two terms, by particle
+  // row sums of the two terms, by particle: FOUR buffers (datapoint mod 4).  With three, rows of datapoint d + 3 could be
+  // reduced (their shared operands' flag is published after barrier d) while the tail of d, also behind barrier d, still reads
+  // lx / lz[d mod 3] when NW < K < 2 NW -- ordered by timing only.  Rows of d + 4 wait for a flag published behind
+  // barrier d + 1, which the tail wave of d reaches only after its tail: a happens-before edge.
+  float lx[4][64], lz[4][64];
   int bits[3];                                    // is every x of the datapoint's row exactly 0 or 1?
   int ready[3];                                   // 1 + the datapoint whose shared operands the buffer holds (0: none yet)
   long long sum_a, sum_b;                         // this workgroup's share of the batch mean (fixed point, see above)
@@ -48,17 +53,6 @@ struct Iw1Smem {
 
 template <int B>
 using IwBuf = std::integral_constant<int, B>;
-
-// -DZS_EXPERIMENTS builds only: where a workgroup's time goes (s_memrealtime: 100 MHz, comparable across CUs), read back by
-// zs_iw1_stamps_read (tools/iw1_phases.py).  0 kernel start, 1 prologue done, 2 wave 0 reaches the last datapoint's barrier,
-// 3 that barrier passed (tail wave), 4 K-particle reduction done, 5 the share is out / the mean is written, 6 first row landed (wave 0)
-#ifdef ZS_EXPERIMENTS
-__device__ unsigned long long zs_iw1_stamps[1024 * 8];
-__device__ unsigned long long zs_iw1_wave_stamps[1024 * 32];      // per wave: [0..15] its arrival at the last datapoint's barrier, [16..31] its first row landed
-#define ZS_IW1_STAMP(slot) do { if (lane == 0) zs_iw1_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ZS_IW1_STAMP(slot) do { } while (0)
-#endif
 
 // A pointer that was LOADED (from the kernel-argument segment, below) is a generic pointer to the compiler: it would emit flat_*
 // instructions, which count on two counters and return out of order.  Cast to address space 1 it is a global pointer again, as a
@@ -75,107 +69,33 @@ __device__ __forceinline__ ZS_GLOBAL T* as_global(T* p) {
 struct Iw1Mean {
   ZS_GLOBAL unsigned long long* acc;
   ZS_GLOBAL float* mean_cost;
-  int cb, sharded;
+  int cb;
   int64_t R;
 };
-// The whole tail wave, after the workgroup's last datapoint: lane 0 adds the workgroup's share to both words.  Release builds: that
-// is all (watcher mode; iw1_watch below finishes the mean).  Experiments builds keep round 4's / early round 5's finish for the
-// comparison (modes 0 / 1): the workgroup that completes word A's count finishes the mean; it needs word B's 16 shard words too,
-// which are loaded (lanes 0 .. 15) BESIDE the returning atomic that may complete A, not after it; B's adds were issued before the
-// A adds that completed the count, but to other addresses: B's own count fields say whether they have all landed (if not --
-// rare -- the finisher polls).
-__device__ __forceinline__ void iw1_share_and_finish(const Iw1Mean& a, int G, int g, int n_dp, int lane, long long sum_a, long long sum_b,
-                                                     unsigned flags) {
+// The tail wave, after the workgroup's last datapoint: lane 0 adds the workgroup's share to its shard of both words WITHOUT waiting
+// for the adds (nobody needs the old values): a workgroup is done when its two adds are on their way; iw1_watch (below) finishes
+// the mean.  (Rounds 4 / 5 finished it by the last arrival -- a returning atomic per level: tools/lab/ keeps those forms.)
+__device__ __forceinline__ void iw1_send_share(const Iw1Mean& a, int g, int n_dp, int lane, long long sum_a, long long sum_b, unsigned flags) {
   const int S = ZS_IW1_S, bias_bits = iw1_bias_bits(a.cb);
-  const unsigned long long mask = (1ull << S) - 1ull;
   const int shard = g & (ZS_IW1_SHARDS - 1);
-  // 2: watcher mode (iw1_watch, below), the release build's only mode; 0 / 1: the workgroup that completes the count finishes the
-  // mean, with a one- / two-level count (round 4 and the first half of round 5: kept in experiments builds for the comparison)
-#ifdef ZS_EXPERIMENTS
-  const int mode = a.sharded;
-#else
-  constexpr int mode = 2;
-#endif
-  ZS_GLOBAL unsigned long long* wb = a.acc + ZS_IW1_B_OFF + 1 + (lane & (ZS_IW1_SHARDS - 1));
-  // (wave-uniform decisions are taken on scalar copies -- readfirstlane -- and every load is issued for all 64 lanes in the same
-  //  straight-line region as its use: a load behind a lane mask, used behind another, would count as possibly in flight where this
-  //  function returns, and the streaming loop's header would drain all loads -- s_waitcnt vmcnt(0) -- on every iteration)
-  auto uniform64 = [](unsigned long long v) {
-    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-  };
-  const unsigned long long members = (unsigned long long)((G - shard + ZS_IW1_SHARDS - 1) / ZS_IW1_SHARDS);
-  unsigned long long t = 0, vb = 0;
   if (lane == 0) {
     const unsigned long long bias = (unsigned long long)n_dp << bias_bits;
     const unsigned long long add_b = (1ull << S) + (bias + (unsigned long long)sum_b);
     const unsigned long long add_a = (1ull << S) + (bias + (unsigned long long)sum_a);
-    if (flags) {                         // rare: raise the sticky flags on the total, and let them land before this share is counted
+    if (flags) {                         // rare: raise the sticky flags, and let them land before this share is counted
       const unsigned long long f = ((flags & 4u) ? ZS_IW1_FLAG_NAN : 0ull) | ((flags & 2u) ? ZS_IW1_FLAG_PINF : 0ull) |
                                    ((flags & 1u) ? ZS_IW1_FLAG_NINF : 0ull);
-      // (watcher mode: on the workgroup's own shard word of A, the word its count goes to -- one location, so whoever reads the
-      //  count reads the flags; bits 61 .. 63 are above the count field.  Otherwise: on the total, which the finisher reads last.)
-      (void)__hip_atomic_fetch_or(mode == 2 ? a.acc + 1 + shard : a.acc, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (on the workgroup's own shard word of A, the word its count goes to -- one location, so whoever reads the count reads the
+      //  flags; bits 61 .. 63 are above the count field)
+      (void)__hip_atomic_fetch_or(a.acc + 1 + shard, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     (void)__hip_atomic_fetch_add(a.acc + ZS_IW1_B_OFF + 1 + shard, add_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (mode == 2) {                     // watcher mode (below): nobody needs the old value -- nothing to wait for
-      (void)__hip_atomic_fetch_add(a.acc + 1 + shard, add_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else
-    // two levels when there are many workgroups (256 same-address atomics arriving together serialise, ~11 ns each:
-    // MI355X_MICROARCH.md "dequeue"): the shard's last arrival moves the shard's count and (still biased) sum to the total
-    t = __hip_atomic_fetch_add(mode ? a.acc + 1 + shard : a.acc, add_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add_a;
-  }
-  if (mode == 2) return;                // watcher mode: sent and forgotten; workgroup 0's tail wave watches the words (iw1_watch, below)
-  unsigned long long tot_a;
-  if (!mode) {                          // (ONE branch on the mode, each arm complete: a load in one `if` and its use behind another
-    vb = __hip_atomic_load(wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // `if` on the same flag is a path to the compiler)
-    tot_a = uniform64(t);               // (the load flies beside the atomic above)
-    asm volatile("" ::"v"(vb));
-  } else {
-    tot_a = uniform64(t);
-    if ((tot_a >> S) != members) return;
-    t = 0;
-    if (lane == 0) {
-      __hip_atomic_store(a.acc + 1 + shard, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // the shard word back to zero
-      const unsigned long long add2 = (members << S) + (tot_a & mask);
-      t = __hip_atomic_fetch_add(a.acc, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add2;
-    }
-    vb = __hip_atomic_load(wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                             // (beside that atomic)
-    tot_a = uniform64(t);
-    asm volatile("" ::"v"(vb));
-  }
-  if (((tot_a << 3) >> (S + 3)) != (unsigned long long)G) return;
-  if (lane >= ZS_IW1_SHARDS) vb = 0ull;
-  // ---- the finisher
-  unsigned long long cnt = 0, sum = 0;
-  for (int spin = 0; spin < (1 << 20); ++spin) {
-    cnt = vb >> S;
-    sum = vb & mask;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      cnt += ((unsigned long long)(unsigned)__shfl_xor((int)(cnt >> 32), o, ZS_WAVE) << 32) | (unsigned)__shfl_xor((int)cnt, o, ZS_WAVE);
-      sum += ((unsigned long long)(unsigned)__shfl_xor((int)(sum >> 32), o, ZS_WAVE) << 32) | (unsigned)__shfl_xor((int)sum, o, ZS_WAVE);
-    }
-    // lanes 0 .. 15 hold the full sums; the decision must be the WAVE's (lanes >= 16 hold zeros: left to themselves they would spin on)
-    cnt = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cnt >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)cnt);
-    if (cnt == (unsigned long long)G) break;
-    __builtin_amdgcn_s_sleep(2);
-    vb = __hip_atomic_load(wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::"v"(vb));
-    if (lane >= ZS_IW1_SHARDS) vb = 0ull;
-  }
-  if (lane < ZS_IW1_SHARDS) __hip_atomic_store(wb, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (lane == 0) {
-    const long long bias_total = (long long)((unsigned long long)a.R << bias_bits);
-    const long long sa = (long long)(tot_a & mask) - bias_total, sb = (long long)sum - bias_total;
-    float m = iw1_mean(sa, sb, tot_a, a.cb, a.R);
-    if (cnt != (unsigned long long)G) m = __builtin_nanf("");  // (word B never completed: cannot happen; never spin for ever)
-    a.mean_cost[0] = m;
-    __hip_atomic_store(a.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_add(a.acc + 1 + shard, add_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-// Watcher mode (Iw1Mean::sharded == 2, the release build's): the shares are sent and forgotten -- no returning atomic, a workgroup
+// The shares are sent and forgotten -- no returning atomic, a workgroup
 // is done when its adds are on their way -- and the tail wave of WORKGROUP 0, once its own share is out, WATCHES the 32 shard words
 // (lanes 0 .. 15 word A's with the sticky flags, lanes 16 .. 31 word B's) until both counts are complete, then finishes the mean.
 // After the LAST workgroup's reduction the chain is: its adds land, the next sample sees them -- instead of three dependent round
@@ -191,9 +111,10 @@ __device__ __forceinline__ void iw1_watch(const Iw1Mean& a, int G, int lane) {
   ZS_GLOBAL unsigned long long* wl = wlane < ZS_IW1_SHARDS ? a.acc + 1 + wlane : a.acc + ZS_IW1_B_OFF + 1 + (wlane - ZS_IW1_SHARDS);
   unsigned long long v = 0;
   bool complete = false;
-  // (a bound in TIME, 10 s of the 100 MHz clock: when the GPU is shared, another process's kernels can keep this launch's other
-  //  workgroups waiting for many milliseconds; only a launch that lost workgroups would reach the bound, and gets NaN instead of a hang)
-  const unsigned long long give_up = __builtin_amdgcn_s_memrealtime() + 1000000000ull;
+  // (a bound in TIME, 2 s of the 100 MHz clock -- below the driver's own hang detection: when the GPU is shared, another process's
+  //  kernels can keep this launch's other workgroups waiting for many milliseconds; only a launch that lost workgroups would reach
+  //  the bound, and gets NaN instead of a hang)
+  const unsigned long long give_up = __builtin_amdgcn_s_memrealtime() + 200000000ull;
   while (!complete && __builtin_amdgcn_s_memrealtime() < give_up) {
     v = __hip_atomic_load(wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::"v"(v));
@@ -223,11 +144,17 @@ __device__ __forceinline__ void iw1_watch(const Iw1Mean& a, int G, int lane) {
   const unsigned long long fl = (__builtin_amdgcn_ballot_w64(in_a && (v & ZS_IW1_FLAG_NAN)) ? ZS_IW1_FLAG_NAN : 0ull) |
                                 (__builtin_amdgcn_ballot_w64(in_a && (v & ZS_IW1_FLAG_PINF)) ? ZS_IW1_FLAG_PINF : 0ull) |
                                 (__builtin_amdgcn_ballot_w64(in_a && (v & ZS_IW1_FLAG_NINF)) ? ZS_IW1_FLAG_NINF : 0ull);
-  if (lane < 2 * ZS_IW1_SHARDS) __hip_atomic_store(wl, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // the 32 words back to zero
+  // the 32 words back to zero -- only when every share was seen: a watcher that gave up leaves them alone (a straggler's adds
+  // would land on zeroed words and every later launch on this accumulator would miscount silently) and raises the POISON word,
+  // which stays up until the host re-zeroes the accumulator (include/zs_hip.h; zhusuan._ops.iw1_accumulators_ok / reset)
+  if (complete && lane < 2 * ZS_IW1_SHARDS) __hip_atomic_store(wl, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (lane == 0) {
     const long long bias_total = (long long)((unsigned long long)a.R << bias_bits);
     float m = iw1_mean((long long)tot_a - bias_total, (long long)tot_b - bias_total, fl, a.cb, a.R);
-    if (!complete) m = __builtin_nanf("");                       // (cannot happen -- every workgroup sends its share; never watch for ever)
+    if (!complete) {                                             // (cannot happen -- every workgroup sends its share; never watch for ever)
+      m = __builtin_nanf("");
+      __hip_atomic_store(a.acc + ZS_IW1_POISON_WORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     a.mean_cost[0] = m;
   }
 }
@@ -235,7 +162,7 @@ __device__ __forceinline__ void iw1_watch(const Iw1Mean& a, int G, int lane) {
 
 // XFULL: the observation has one row per (particle, datapoint) instead of one per datapoint: nothing to share through LDS, each
 // row reads its own observation row when it is reduced (the rarely used form; same structure otherwise).
-template <bool LOGITS, bool XFULL, bool NT = false>
+template <bool LOGITS, bool XFULL>
 __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
 #if ZS_ON_DEVICE                 // (the body uses address-space-qualified pointers: device pass only; the host pass needs the symbol)
   __shared__ Iw1Smem sm;
@@ -275,14 +202,7 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     const int cm = valid ? 1 : 0;
     const float4* __restrict__ prow = a.p + row * D4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (NT) {          // (read-once stream: non-temporal loads; experiments only so far)
-        const zs_f4v v = __builtin_nontemporal_load(reinterpret_cast<const zs_f4v*>(prow + col[u] * cm));
-        pv[b][u] = make_float4(v.x, v.y, v.z, v.w);
-      } else {
-        pv[b][u] = prow[col[u] * cm];
-      }
-    }
+    for (int u = 0; u < 4; ++u) pv[b][u] = prow[col[u] * cm];
     zv[b] = a.z[row * Dz4 + zc * cm];
     if (XFULL) mrow[b] = row;
     mk[b] = valid ? nk : -1;
@@ -296,7 +216,6 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
       nx = nx == 2 ? 0 : nx + 1;
     }
   };
-  if (w == 0) ZS_IW1_STAMP(0);
   // ---- staging of a datapoint's shared operands (one wave): observation row, its complement and sign row, the prior's constants.
   // Columns D4 .. 255 of the LDS rows hold NEUTRAL values (x = 0, 1 - x = 0 for the two-logarithm form; sign 0 with 1 - x = 1 for
   // the one-logarithm form: log(fma(p, 0, 1) + 1e-8) = log 1 = 0): the row reduction indexes them by lane + 64 u without a mask
@@ -369,8 +288,9 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     // publish: the operands first, then the flag the row reductions poll (LDS operations of a wave complete in order; the wait
     // makes that explicit).  At kernel start nothing else orders the first rows behind the staging -- a barrier there made every
     // wave's first reduction wait for the slowest wave's row REQUESTS, which queue up for microseconds (see the prologue).
-    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0)
-    if (lane == 0) sm.ready[xb] = dd + 1;
+    // (a RELEASE store at workgroup scope: on LDS that is the lgkmcnt(0) wait -- no vmcnt drain -- and, unlike the bare
+    //  s_waitcnt builtin, a barrier the COMPILER may not move the operands' stores across)
+    if (lane == 0) __hip_atomic_store(&sm.ready[xb], dd + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   // log q / the extra rows of a datapoint, for the wave that will run its tail (lane = particle)
   float t_lq = 0.f, t_ra = 0.f;
@@ -390,8 +310,13 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
   // vector-memory front end serves its waves' requests in order, and the slowest wave's queue up for microseconds:
   // profiles/r05_iw1_phases.txt.)
   {
-    issue(IwBuf<0>{});                                           // (the stream starts before anything else: rows need nothing from LDS)
-    if (w == 0) ZS_IW1_STAMP(7);
+    // (round 6) the staging waves request the shared operands of datapoints 0 .. 2 AHEAD of their own first rows: every wave's
+    // first reduction waits for datapoint 0's flag, and the flag waits for these twelve loads -- behind sixteen rows (50 KB) in
+    // the CU's in-order memory front end they landed last
+    Staged st0;
+    const bool stages_first = w < 3 && w < n_dp;                 // (wave-uniform)
+    if (stages_first) stage_load(w, st0, true);
+    issue(IwBuf<0>{});                                           // (the stream: rows need nothing from LDS)
     if (threadIdx.x < 3) sm.ready[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
       sm.sum_a = 0;
@@ -400,18 +325,14 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     }
     __syncthreads();
     if (w == 0) fetch_tail_operands(0);
-    for (int dd = w; dd < 3 && dd < n_dp; dd += NW) {            // (one instance of the staging code: kernels start with a cold
-      Staged st;                                                 //  instruction cache inside a training step, and size counts)
+    if (stages_first) stage_write(w, st0);
+    for (int dd = w + NW; dd < 3 && dd < n_dp; dd += NW) {       // (fewer than three waves only: K = 2)
+      Staged st;
       stage_load(dd, st, true);
-      if (w == 0 && dd == 0) ZS_IW1_STAMP(6);
       stage_write(dd, st);
     }
   }
-  if (w == 0) ZS_IW1_STAMP(1);
   // ---- reduce the row a buffer holds
-#ifdef ZS_EXPERIMENTS
-  bool first_done = false;
-#endif
   auto reduce_row = [&](auto bc) {
     constexpr int b = decltype(bc)::value;
     const int k = mk[b];
@@ -422,18 +343,14 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
       return;
     }
     const int xb = mx[b];
-#ifdef ZS_EXPERIMENTS
-    if (!first_done) {
-      asm volatile("" ::"v"(zv[b].x));
-      if (lane == 0) zs_iw1_wave_stamps[blockIdx.x * 32 + 16 + w] = __builtin_amdgcn_s_memrealtime();
-      first_done = true;
-    }
-#endif
     // the datapoint's shared operands must have been published (only the first rounds of a launch ever find them missing)
     // (a relaxed workgroup-scope atomic load: re-read every turn like a volatile access, without the s_waitcnt vmcnt(0) hipcc puts
     //  around volatile accesses -- that would drain the prefetched rows)
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm.ready[xb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != mi[b] + 1)
       __builtin_amdgcn_s_sleep(1);
+    // ... and the reads of the operands stay behind the flag: an ACQUIRE fence at workgroup scope (LDS: lgkmcnt only; the rows in
+    // flight are not waited for -- tests/test_isa.py pins the loop's vmcnt waits)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const bool xbits = !XFULL && sm.bits[xb] != 0;
     zs_f2v acc2 = {0.f, 0.f};
     auto piece = [&](int u) {
@@ -488,20 +405,18 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
       nz = Dz4 <= 16 ? row0_sum_all(t) : wave_sum_to_lane63(t);  // (a latent row of <= 16 pieces lives in lanes 0 .. 15: four DPP steps)
     }
     if (lane == 63) {
-      sm.lx[xb][k] = acc;
-      sm.lz[xb][k] = nz;
+      sm.lx[mi[b] & 3][k] = acc;
+      sm.lz[mi[b] & 3][k] = nz;
     }
   };
   // ---- the tail of datapoint d (one wave, lane = particle): K4's wave reduction and the workgroup's share of the batch mean; after
   // the workgroup's last datapoint the share goes out
   auto tail = [&](int d, const ZS_CONSTANT Iw1Args* ap) {
-    const int xb = d % 3;
     const int64_t r = g + (int64_t)d * G;
     const bool on = lane < K;
-    if (d + 1 == n_dp) ZS_IW1_STAMP(3);
     float l = -INFINITY;
     if (on) {
-      const float lx = sm.lx[xb][lane], nz = sm.lz[xb][lane];
+      const float lx = sm.lx[d & 3][lane], nz = sm.lz[d & 3][lane];
       // the reference adds the generator's nodes left to right, then subtracts log q (:66-77,97-98)
       float lp = lx;
       if (has_z) lp = (ap->rows_a ? t_ra + nz : nz) + lx;
@@ -512,7 +427,6 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     }
     const float cost = iw_wave_row(l, t_lq, on, lane, K, ap->estimator, ap->scale, r, (float*)as_global(ap->cost_b),
                                    (float*)as_global(ap->bound_b), (float*)as_global(ap->coef_p), (float*)as_global(ap->coef_q));
-    if (d + 1 == n_dp) ZS_IW1_STAMP(4);
     if (!ap->mean_cost) return;
     if (lane == 0) {                                             // the workgroup's share of the batch mean, in LDS (tails run one
       const Iw1Fixed fx = iw1_fixed(cost, ap->cb);               // at a time: a barrier lies between any two of them)
@@ -528,10 +442,6 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
   int thr = K;                     // flat rows that complete datapoint `done_dp`
   int tw = 0;                      // done_dp mod NW
   auto boundary = [&]() {
-    if (w == 0 && done_dp + 1 == n_dp) ZS_IW1_STAMP(2);
-#ifdef ZS_EXPERIMENTS
-    if (done_dp + 1 == n_dp && lane == 0) zs_iw1_wave_stamps[blockIdx.x * 32 + w] = __builtin_amdgcn_s_memrealtime();
-#endif
     // (the tail wave reads the arguments it needs -- scalar loads from the kernel-argument segment -- BEFORE the barrier: their
     //  ~0.2 us lies on the critical path of every launch otherwise; the asm pins the loads on this side of the barrier)
     const ZS_CONSTANT Iw1Args* tap = nullptr;
@@ -577,7 +487,7 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
     if (w == last_tw) {
       const ZS_CONSTANT Iw1Args* ap = cold();
       if (ap->mean_cost) {
-        const Iw1Mean mean = {as_global(ap->acc), as_global(ap->mean_cost), ap->cb, ap->sharded, ap->R};
+        const Iw1Mean mean = {as_global(ap->acc), as_global(ap->mean_cost), ap->cb, ap->R};
         long long sa = 0, sb = 0;
         unsigned fl = 0;
         if (lane == 0) {
@@ -585,14 +495,9 @@ __global__ __launch_bounds__(1024) void k_iw1_persist(Iw1Args a) {
           sb = sm.sum_b;
           fl = sm.flags;
         }
-        iw1_share_and_finish(mean, G, g, n_dp, lane, sa, sb, fl);
-#ifdef ZS_EXPERIMENTS
-        if (g == 0 && mean.sharded == 2) iw1_watch(mean, G, lane);
-#else
+        iw1_send_share(mean, g, n_dp, lane, sa, sb, fl);
         if (g == 0) iw1_watch(mean, G, lane);
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ZS_IW1_STAMP(5);
       }
     }
   }

@@ -6,10 +6,6 @@
 #include "zs_common.h"
 #include "zs_locscale_math.h"
 
-#ifndef ZS_K1_EXPERIMENT
-#define ZS_K1_EXPERIMENT 0      // 1 / 2: timing experiments on k_sample_tile (never shipped)
-#endif
-
 namespace zs {
 
 enum { D_NORMAL = 0, D_LOGISTIC = 1, D_UNIFORM = 2 };
@@ -123,9 +119,6 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
           zz.y = mul_add_2round(m.y, s.y, e.y);
           zz.z = mul_add_2round(m.z, s.z, e.z);
           zz.w = mul_add_2round(m.w, s.w, e.w);
-#if ZS_K1_EXPERIMENT == 1      // timing experiment: no z stores (generator + density only)
-          if (zz.x == 123.456f)
-#endif
           {
             // scalar base + 32-bit lane offset addressing, spelled out: the compiler keeps a 64-bit pointer per lane
             // (one more VALU instruction per particle) for the C form of this store.
@@ -172,15 +165,8 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
           zk2 += step;
         };
         for (uint32_t kk = 0; kk < kb; ++kk) {
-#if ZS_K1_EXPERIMENT == 2      // timing experiment: no generator (store + density only)
-          particle(make_float4((float)(uint32_t)g, 1.f, 2.f, 3.f), 0.f);
-#else
           if (DIST == D_NORMAL) {
-#ifdef ZS_K1_OLD_PHILOX       // (A/B builds only: round 4's generator call, uniform words re-formed per group)
-            particle(philox_normal4(g, callx, seed), 0.f);
-#else
             particle(philox_normal4(g, pc), 0.f);
-#endif
           } else if (DIST == D_UNIFORM) {
             const Philox4 r = philox4x32_10(g, pc);
             particle_uniform(make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w)));
@@ -196,7 +182,6 @@ __global__ __launch_bounds__(1024) void k_sample_tile(
             logistic_draw(u01(r.w), e.w, d3);
             particle(e, (d0 + d1) + (d2 + d3));
           }
-#endif
           g += M4;
         }
       }
@@ -429,29 +414,15 @@ __global__ __launch_bounds__(1024) void k_logprob_tile(
   extern __shared__ float zs_k2_stage[];
   const uint32_t TB = blockDim.x, LDW = TB + 1, tid = threadIdx.x;
   const uint32_t rows_in_tile = TB / D4;
-  // Two ways of sharing out the (tile, particle) plane.  kchunk > 0: items of one tile x kchunk particles, one per workgroup (the
-  // dispatcher evens the CUs out; every item re-reads the tile's parameters: 1.14 x the algorithmic traffic at 4.2 M rows with four
-  // chunks per tile, profiles/r04_pmc_k2_4M.json) -- the shipped form.  kchunk == 0 (round 5 experiment, -DZS_EXPERIMENTS +
-  // ZS_K2_BALANCED=1 only): the grid is the resident workgroups and each takes an EQUAL, CONTIGUOUS range of the n_ptiles x K
-  // particle-tiles -- at most three tiles' parameters per workgroup instead of one read per chunk; measured slower (see the launcher).
-  const bool balanced = kchunk == 0;
-  const uint64_t units = (uint64_t)n_ptiles * K;
-  uint64_t u = balanced ? units * blockIdx.x / gridDim.x : 0, u_end = balanced ? units * (blockIdx.x + 1) / gridDim.x : 0;
-  for (uint32_t t = blockIdx.x;; t += gridDim.x) {
-    uint32_t pt, k0, k1;
-    if (balanced) {
-      if (u >= u_end) break;
-      pt = (uint32_t)(u / K);
-      k0 = (uint32_t)(u - (uint64_t)pt * K);
-      k1 = (uint64_t)(K - k0) < u_end - u ? K : k0 + (uint32_t)(u_end - u);
-      u += k1 - k0;
-    } else {
-      if (t >= total) break;
-      const uint32_t kt = t / n_ptiles;
-      pt = t - kt * n_ptiles;
-      k0 = kt * kchunk;
-      k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
-    }
+  // Items of one tile x kchunk particles, one per workgroup: the dispatcher evens the CUs out.  Every item re-reads its tile's
+  // parameters: 1.14 x the algorithmic traffic at 4.2 M rows with four chunks per tile (profiles/r04_pmc_k2_4M.json).  (Equal
+  // contiguous shares of the particle-tile plane for the resident workgroups remove those re-reads and were SLOWER, 71 - 73 % ->
+  // 59 - 63 % of 8 TB/s at 4.2 M rows: profiles/r05_k2_balanced.txt; that variant lives in tools/lab/.)
+  for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+    const uint32_t kt = t / n_ptiles;
+    const uint32_t pt = t - kt * n_ptiles;
+    const uint32_t k0 = kt * kchunk;
+    const uint32_t k1 = (k0 + kchunk < K) ? k0 + kchunk : K;
     const uint32_t m4 = pt * TB + tid;
     const bool on = m4 < M4;
     const uint32_t m4c = on ? m4 : M4 - 1;                  // (idle lanes of the last tile re-read its last piece: loads stay unconditional)
@@ -580,19 +551,6 @@ inline void launch_logprob_krep(int kid, const float* x, const float* mu, const 
   if (tile_env != 0) {
     K1Tile g = k1_tile(K, R, D4, true);
     if (g.ok) {
-      // Equal contiguous shares of the particle-tile plane for the resident workgroups (see the kernel): MEASURED AND NOT TAKEN.
-      // It does remove the per-chunk parameter re-reads, and the 4.2 M-row stream got SLOWER, 71 - 73 % -> 59 - 63 % of 8 TB/s
-      // (K2 / L2 / U2, one box, two alternations: profiles/r05_k2_balanced.txt): 1 536 long-lived workgroups walking their ranges in
-      // lockstep lose more to the memory system than 10 488 short items handed out by the dispatcher lose to 1.14 x traffic.
-      // Kept behind the experiments knob only.
-      static const int bal_env = env_knob("ZS_K2_BALANCED", 0);      // experiments only
-      const int64_t per_cu = 2048 / g.threads > 8 ? 8 : 2048 / g.threads;
-      const int64_t lds_cu = g.smem ? 163840 / (int64_t)g.smem : per_cu;
-      const int64_t resident = 256 * (per_cu < lds_cu ? per_cu : lds_cu);
-      if (bal_env > 0 && (int64_t)g.n_ptiles * K >= resident) {
-        g.kchunk = 0;
-        g.grid = (unsigned)resident;
-      }
       const bool stream_once = tile_env > 0 ? tile_env == 2 : (double)K * (double)R * (double)D4 * 16.0 > 268435456.0;
       if (stream_once)
         ZS_LAUNCH_SMEM(kid, (k_logprob_tile<DIST, true>), dim3(g.grid), dim3(g.threads), g.smem, st, (const float4*)x, (const float4*)mu,

@@ -625,6 +625,30 @@ def _iw1_accumulator(device):
     return _scratch(device, "iw1", lambda sc: True, lambda: (torch.zeros(64, dtype=torch.int64, device=device),))[0]
 
 
+IW1_POISON_WORD = 63          # ZS_IW1_POISON_WORD of include/zs_hip.h
+
+
+def iw1_accumulators_ok():
+    """False when a launch of the fused objective gave up waiting for its workgroups' shares (it stored a NaN mean and raised
+    the accumulator's poison word, include/zs_hip.h): every later batch mean on that accumulator would be wrong.  Cannot happen
+    in a healthy process; a training loop that sees a NaN objective over finite costs can check here (synchronises) and call
+    ``reset_iw1_accumulators()``."""
+    ok = True
+    for key, sc in list(_SCRATCH.items()):
+        if key[2] == "iw1":
+            ok = ok and int(sc[0][IW1_POISON_WORD].item()) == 0
+    return ok
+
+
+def reset_iw1_accumulators():
+    """Re-zero every batch-mean accumulator (after ``iw1_accumulators_ok()`` returned False; no launch may be in flight)."""
+    for key, sc in list(_SCRATCH.items()):
+        if key[2] == "iw1":
+            if sc[0].is_cuda:
+                torch.cuda.synchronize(sc[0].device)
+            sc[0].zero_()
+
+
 IW1_MAX_DATAPOINTS = 1 << 20        # (round 4's workgroup-per-datapoint kernel stopped at 384; the persistent form takes any batch)
 # No limit on the [K, B, X] stream's size either: launched cold (the stream in HBM only) the fused launch loses to K3's x-reuse kernel
 # + K2 + K4b beyond B = 1024 (124 us against 83 at B = 2048, profiles/r05_iw1_timing.txt), but a step evaluates the stream right after
@@ -633,14 +657,27 @@ IW1_MAX_DATAPOINTS = 1 << 20        # (round 4's workgroup-per-datapoint kernel 
 IW1_MAX_STREAM_BYTES = 1 << 62
 
 
-def iw1_supported(K, B, X, dtype, *tensors):
-    """The fused kernel's domain (include/zs_hip.h, IW1): workgroups own whole datapoints (one workgroup per CU, datapoints dealt
-    round-robin), lane = particle in the tail, rows read 16 bytes per lane."""
+def iw1_unsupported_reason(K, B, X, dtype, *tensors):
+    """None inside the fused kernel's domain (include/zs_hip.h, IW1: workgroups own whole datapoints -- one workgroup per CU,
+    datapoints dealt round-robin --, lane = particle in the tail, rows read 16 bytes per lane), else WHY not, in words a user
+    can act on (``zhusuan.explain``)."""
     if dtype == torch.float64:
-        return True                      # (the float64 twin composes plain kernels: any shape)
+        return None                      # (the float64 twin composes plain kernels: any shape)
     if K * B * X * 4 > IW1_MAX_STREAM_BYTES:
-        return False
-    return K <= 64 and B <= IW1_MAX_DATAPOINTS and X % 4 == 0 and 256 <= X <= 1024 and all(t.data_ptr() % 16 == 0 for t in tensors)
+        return "the [K, B, X] stream is larger than zhusuan._ops.IW1_MAX_STREAM_BYTES"
+    if K > 64:
+        return "K = %d particles: the fused kernel reduces a datapoint's particles on one 64-lane wavefront (K <= 64)" % K
+    if B > IW1_MAX_DATAPOINTS:
+        return "B = %d datapoints (limit %d)" % (B, IW1_MAX_DATAPOINTS)
+    if X % 4 or not 256 <= X <= 1024:
+        return "rows of %d elements: the fused kernel streams rows of 256 .. 1024 floats, a multiple of 4" % X
+    if not all(t.data_ptr() % 16 == 0 for t in tensors):
+        return "an operand is not 16-byte aligned (a view into the middle of a tensor?)"
+    return None
+
+
+def iw1_supported(K, B, X, dtype, *tensors):
+    return iw1_unsupported_reason(K, B, X, dtype, *tensors) is None
 
 
 def iw1_term_supported(Dz, dtype, *tensors):

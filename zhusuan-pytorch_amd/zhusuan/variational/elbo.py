@@ -96,6 +96,11 @@ def draw_latents(nodes_q):
     return {k: values[k] for k in names}
 
 
+from ..utils import note_path as _note_path      # noqa: E402
+
+_PATH_NODES = "per-node kernels: one log-probability launch per node (+ torch's reductions), each way"
+
+
 class ELBO(nn.Module):
     """
     :param generator: BayesianNet p(x, z).
@@ -121,6 +126,7 @@ class ELBO(nn.Module):
                 "ELBO(transform=...) relies on zhusuan.invertible flows, which are outside the "
                 "variational-inference hot path of the MI355X build")
         self.transform = None
+        self.last_path = None          # which kernels the last evaluation ran on, and why (zhusuan.explain)
 
     def log_joint(self, nodes):
         """Sum of node log-probs in insertion order (elbo.py:58-79)."""
@@ -140,27 +146,37 @@ class ELBO(nn.Module):
         self.generator(_observed)
         nodes_p = self.generator.nodes
         if self.estimator == "sgvb" and type(self).sgvb is ELBO.sgvb and type(self).log_joint is ELBO.log_joint:
-            fused = self._scalar_sgvb(nodes_p, nodes_q)      # (a subclass that overrides either hook keeps its hooks)
+            why = []
+            fused = self._scalar_sgvb(nodes_p, nodes_q, why)      # (a subclass that overrides either hook keeps its hooks)
             if fused is not None:
+                _note_path(self, "LJ1: every node's log-probability, the reductions and the objective in one launch each way (zs_logjoint_scalar)")
                 return fused
+            _note_path(self, _PATH_NODES, why[0] if why else "some node's log-probability is not a scalar")
+        else:
+            _note_path(self, _PATH_NODES, "the 'reinforce' estimator takes its own one-launch epilogue (R1) after the per-node kernels"
+                       if self.estimator != "sgvb" else "a subclass overrides log_joint / sgvb: its hooks are called as the reference calls them")
         logpxz = self.log_joint(nodes_p)
         logqz = self.log_joint(nodes_q)
         if self.estimator == "sgvb":
             return self.sgvb(logpxz, logqz, reduce_mean)
         return self.reinforce(logpxz, logqz, reduce_mean, **kwargs)
 
-    def _scalar_sgvb(self, nodes_p, nodes_q):
+    def _scalar_sgvb(self, nodes_p, nodes_q, why=None):
         """When every node's log-probability reduces to a scalar (the VAE and BNN callers), the whole sgvb objective
         -(sum_p log p - sum_q log q) is ONE launch (LJ1, ``zs_logjoint_scalar``): the element-wise log-probs of every
         Normal / Bernoulli node, the fused log-densities the sampling kernel has already produced, their reductions
         (mean / sum over the reduce dims, multiplier: one coefficient per node) and the scalar arithmetic of
         elbo.py:58-79,155-161 -- instead of one log-prob launch per node plus a mean / sum / multiply per node and the
         adds; the backward of all of it is one more launch.  Returns None when some node keeps a non-scalar shape."""
+        why = [] if why is None else why
         plan = [(sign, nodes[name]) for sign, nodes in ((-1.0, nodes_p), (1.0, nodes_q)) for name in nodes.keys()]
         if not plan or len(plan) > _hip.LJ_MAX_TERMS:
+            why.append("the two nets have %d nodes (the one-launch log-joint takes 1 .. %d)" % (len(plan), _hip.LJ_MAX_TERMS))
             return None
         for _, node in plan:                        # decide first (no kernel is launched by the question)
             if not hasattr(node, '_scalar_coef') or node._scalar_coef() is None:
+                why.append("node %r keeps a non-scalar log-probability (or is of a family without a one-launch term)"
+                           % getattr(node, 'name', '?'))
                 return None
         def collect(rows_only):
             spec, tensors = [], []
@@ -173,6 +189,7 @@ class ELBO(nn.Module):
         if sum(t[2] for t in spec if t[0] != _hip.LJ_ROWS) > _LOGJOINT_MAX_ELEMENTS:
             spec, tensors = collect(True)
         if len({t.dtype for t in tensors if t is not None}) != 1 or len({t.device for t in tensors if t is not None}) != 1:
+            why.append("the nodes differ in dtype or device")
             return None
         return _ops.LogJointScalar.apply(tuple(spec), *tensors)
 

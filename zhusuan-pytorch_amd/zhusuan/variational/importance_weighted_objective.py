@@ -16,6 +16,11 @@ _ERR_VIMCO = ("VIMCO is a multi-sample gradient estimator, size along "
               "`axis` in the objective should be larger than 1.")
 
 
+from ..utils import note_path as _note_path      # noqa: E402
+
+_PATH_FUSED = "IW1: the generator side of the objective in one launch each way (zs_bernoulli_iw_objective)"
+_PATH_NODES = "per-node kernels (K3 / K2 per node) + the objective in one launch (K4b): three or more launches each way"
+
 _LOGQ = object()      # key of log q among the log-probabilities a fused attempt hands to the per-node path (cannot be a node's name)
 
 
@@ -44,6 +49,7 @@ class ImportanceWeightedObjective(nn.Module):
             raise NotImplementedError()
         self.estimator = estimator
         self.last_iw_bound = None
+        self.last_path = None          # which kernels the last evaluation ran on, and why (zhusuan.explain)
 
     def log_joint(self, nodes):
         log_joint_ = None
@@ -73,11 +79,15 @@ class ImportanceWeightedObjective(nn.Module):
                 or cls.vimco is not ImportanceWeightedObjective.vimco):
             # a subclass overrides one of the reference's hooks: keep calling them like the reference does (:97-100)
             logpxz, logqz = self.log_joint(nodes_p), self.log_joint(nodes_q)
+            _note_path(self, _PATH_NODES, "a subclass overrides log_joint / sgvb / vimco: its hooks are called as the reference calls them")
             return self.sgvb(logpxz, logqz, reduce_mean) if self.estimator == 'sgvb' else self.vimco(logpxz, logqz, reduce_mean)
         done = {}           # log-probabilities the fused attempt has already evaluated (a layout rejected late used to
-        fused = self._generator_side_in_one_launch(nodes_p, nodes_q, reduce_mean, done)       # evaluate them a second time below)
+        why = []
+        fused = self._generator_side_in_one_launch(nodes_p, nodes_q, reduce_mean, done, why)  # evaluate them a second time below)
         if fused is not None:
+            _note_path(self, _PATH_FUSED)
             return fused
+        _note_path(self, _PATH_NODES, why[0] if why else "the model's layout is not the one the fused kernel covers")
         terms_p = [done[n] if n in done else nodes_p[n].log_prob() for n in nodes_p.keys()]
         logqz = done[_LOGQ] if _LOGQ in done else self.log_joint(nodes_q)
         head = None
@@ -87,23 +97,31 @@ class ImportanceWeightedObjective(nn.Module):
             return self._objective(terms_p[0], None, logqz, reduce_mean)
         return self._objective(head, terms_p[-1], logqz, reduce_mean)
 
-    def _generator_side_in_one_launch(self, nodes_p, nodes_q, reduce_mean, done):
+    def _generator_side_in_one_launch(self, nodes_p, nodes_q, reduce_mean, done, why=None):
         """IW1 (``_ops.BernoulliIWObjective``): when the generator's LAST node is a Bernoulli likelihood over [K, B, X] whose
         log-probability reduces to [K, B] -- the IWAE caller, examples/variational_autoencoder/iwae.py:49-81 -- its row sums,
         the log-density of the latent under a Normal prior node, the sum of the generator's terms, the subtraction of log q,
         the K-particle reductions and the batch mean are ONE launch instead of the per-node loop (:66-100) + K4b; the backward
         is one call as well, which also takes over the gradient of a non-reparameterised Normal q node.  Returns None when
-        the layout is anything else (the per-node path then runs)."""
+        the layout is anything else (the per-node path then runs; ``why`` receives the reason, for ``zhusuan.explain``)."""
+        why = [] if why is None else why
         if self._axis != 0 or not nodes_p or not nodes_q:
+            why.append("the particle axis is not 0 (or a net has no nodes)")
             return None
         vimco = self.estimator == 'vimco'
         names = list(nodes_p.keys())
         last = nodes_p[names[-1]]
         plan = _bernoulli_rows_plan(last)
         if plan is None:
+            why.append("the generator's last node is not a Bernoulli likelihood over [K, B, X] whose log-probability is a plain "
+                       "sum over X to [K, B] (no mean dims, no multiplier, observation [B, X] or [K, B, X])")
             return None
         par, x, Px, from_logits, (K, B, X) = plan
-        if (vimco and K < 2) or not _ops.iw1_supported(K, B, X, par.dtype, par, x):
+        if vimco and K < 2:
+            return None
+        reason = _ops.iw1_unsupported_reason(K, B, X, par.dtype, par, x)
+        if reason is not None:
+            why.append(reason)
             return None
         # the other generator nodes: ONE Normal node of the latent value becomes a term of the launch; anything else enters as
         # ready-made rows from its own kernel (added left to right like log_joint, :66-77)
@@ -120,12 +138,15 @@ class ImportanceWeightedObjective(nn.Module):
             for n in others:
                 lp = done[n] = nodes_p[n].log_prob()
                 if tuple(lp.shape) != (K, B):
+                    why.append("generator node %r has a log-probability of shape %s, not [K, B]" % (n, tuple(lp.shape)))
                     return None
                 rows_a = lp if rows_a is None else rows_a + lp
         logqz = done[_LOGQ] = self.log_joint(nodes_q)
         if not isinstance(logqz, torch.Tensor) or tuple(logqz.shape) != (K, B) or logqz.dtype != par.dtype or logqz.device != par.device:
+            why.append("log q is not a [K, B] tensor of the likelihood's dtype and device")
             return None
         if rows_a is not None and (rows_a.dtype != par.dtype or rows_a.device != par.device):
+            why.append("the generator's nodes differ in dtype or device")
             return None
         # a single non-reparameterised Normal q node whose fused log-density is log q: IW1's backward forms its parameter
         # gradients itself (log q then enters detached; the sampler's own backward is not needed)
