@@ -6,6 +6,7 @@
 #   links       what one link between two hipGraph replays costs (event record, fork / join, all_reduce forms) -> profiles/r06_stream_links.txt
 #   dp_tests    the GPU tests of the data-parallel path, the graphs, the fused objective and the bench's control flow
 #   iw1_ab      IW1 forward in the step and back to back: this tree against tools/_exp/libzs_hip_prev.so
+#   k2_ab       K2 / L2 / U2 at 1 M and 4.2 M rows: this tree against tools/_exp/libzs_hip_prev.so
 #   bench       the default bench line + full record
 #   tests       the whole -m gpu suite
 #   final       round-end verification: build + smoke, the gpu suite, soak, the two PMC traffic passes of the bench step, the bench line
@@ -81,6 +82,15 @@ PY
   { echo "== back to back (tools/iw1_timing.py), this tree"; timeout 200 python tools/iw1_timing.py 2>/dev/null | grep -E "B=|IW1|fused" | head -24
     echo "== back to back, previous commit"; ZS_HIP_LIBRARY=tools/_exp/libzs_hip_prev.so timeout 200 python tools/iw1_timing.py 2>/dev/null | grep -E "B=|IW1|fused" | head -24; } >> $OUT
   cat $OUT
+  ;;
+k2_ab)
+  # the given-value kernels (K2 / L2 / U2) at 1 M and 4.2 M rows: this tree against tools/_exp/libzs_hip_prev.so, alternating on one box
+  OUT=gpurun_out/${TAG}_k2_ab.txt; : > $OUT
+  for i in 1 2 3; do
+    { echo "== this tree"; timeout 200 python tools/kernel_sweep.py --batches 20971 83886 --only "logprob" 2>/dev/null | grep -E "^(K2 normal logprob|L2 logistic logprob|U2 uniform logprob|K1 normal sample.lp .eps)"
+      echo "== previous kernels"; ZS_HIP_LIBRARY=tools/_exp/libzs_hip_prev.so timeout 200 python tools/kernel_sweep.py --batches 20971 83886 --only "logprob" 2>/dev/null | grep -E "^(K2 normal logprob|L2 logistic logprob|U2 uniform logprob|K1 normal sample.lp .eps)"; } >> $OUT
+  done
+  cut -c1-175 $OUT
   ;;
 bench)
   timeout 900 python bench.py --full-record gpurun_out/${TAG}_bench_full.json > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
