@@ -1080,13 +1080,16 @@ def main():
         # the multi-rank form -- what the path costs before a byte crosses xGMI, free of process-to-process differences
         same_process = None
         if args.force_collective_path and world == 1 and mode.startswith("hipgraph"):
-            def compute_single():
+            from zhusuan import _ops
+
+            def compute_single():          # the headline step exactly: gradients allocated by autograd, no bucket involved
                 rng.begin_step()
                 bucket.zero()
                 if sbuckets is not None:
                     sbuckets.zero()
                 loss = model(obs)
-                loss.backward(one)
+                with _ops.grad_destinations_paused():
+                    loss.backward(one)
                 return loss.detach()
             twin = zhusuan.GraphedStep(compute_single, opt.step, rng=rng, warmup=3)
             t_multi, t_single = [], []

@@ -60,7 +60,7 @@ def _run_shard(rank, world, estimator):
     flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
     if world > 1:
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
-        assert torch.equal(flat, bucket.flat[:bucket.n_grad])
+        assert torch.equal(flat, torch.cat([v.reshape(-1) for v in bucket.views]))
     return float(g), flat, [p.detach().clone() for p in model.parameters()]
 
 
@@ -246,8 +246,15 @@ def test_bucket_layout_and_sharding():
     from zhusuan import dataparallel
     lin = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
     bucket = dataparallel.GradientBucket(lin)
-    n = sum(p.numel() for p in lin.parameters())
-    assert bucket.flat.numel() == n + 1 and bucket.nbytes() == 4 * (n + 1)
+    # every slice starts on a 512-byte boundary (round 6: the slices are GEMM outputs when the backward pass fills the bucket);
+    # the objective's slot is the last element; the padding is zero
+    q = dataparallel.SLICE_ALIGN_BYTES // 4
+    offs, off = [], 0
+    for p in lin.parameters():
+        offs.append(off)
+        off = (off + p.numel() + q - 1) // q * q
+    n = bucket.n_grad
+    assert n == off and bucket.flat.numel() == n + 1 and bucket.nbytes() == 4 * (n + 1)
     bucket.zero()
     assert all(p.grad is None for p in lin.parameters())
     lin(torch.ones(5, 3)).sum().backward()
@@ -255,12 +262,14 @@ def test_bucket_layout_and_sharding():
     g = bucket.all_reduce_mean(torch.tensor(3.0))     # no process group: identity, nothing packed
     assert float(g) == 3.0
     bucket.pack(torch.tensor(3.0))                    # what a multi-rank step does before the all-reduce
-    off = 0
-    for p, r in zip(lin.parameters(), ref):           # .grad now aliases the flat buffer: no unpack copy
-        assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off
+    for p, r, o in zip(lin.parameters(), ref, offs):  # .grad now aliases the flat buffer: no unpack copy
+        assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * o and p.grad.data_ptr() % dataparallel.SLICE_ALIGN_BYTES == bucket.flat.data_ptr() % dataparallel.SLICE_ALIGN_BYTES
         assert torch.equal(p.grad, r)
-        off += p.numel()
     assert float(bucket.flat[n]) == 3.0
+    pad = torch.ones(n, dtype=torch.bool)
+    for p, o in zip(lin.parameters(), offs):
+        pad[o:o + p.numel()] = False
+    assert int(pad.sum()) > 0 and float(bucket.flat[:n][pad].abs().sum()) == 0.0      # the padding holds zeros
     x = torch.arange(12.).view(6, 2)
     assert torch.equal(dataparallel.shard_rows(x, 1, 3), x[2:4])
     with pytest.raises(ValueError, match="does not split evenly"):
@@ -288,7 +297,8 @@ def test_overlapped_buckets_partition_and_hook_order():
     ob = dataparallel.OverlappedBuckets(net, n_buckets=2)
     params = list(net.parameters())
     assert [p for b in ob.buckets for p in b["params"]] == list(reversed(params))     # backward order
-    assert len(ob.buckets) == 2 and ob.nbytes() == 4 * (sum(p.numel() for p in params) + 1)
+    assert len(ob.buckets) == 2 and ob.nbytes() == 4 * sum(b["flat"].numel() for b in ob.buckets)
+    assert ob.buckets[0]["n"] == ob.buckets[0]["flat"].numel() - 1 and ob.buckets[1]["n"] is None      # the objective rides in the first
     order = []
     orig = ob._launch
     ob._launch = lambda bi: (order.append(bi), orig(bi))[1]
@@ -311,7 +321,7 @@ def test_bucket_dtype_and_repack_without_zero():
     from zhusuan import dataparallel
     lin = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2)).double()
     bucket = dataparallel.GradientBucket(lin)
-    n = sum(p.numel() for p in lin.parameters())
+    n = bucket.n_grad
     assert bucket.flat.dtype == torch.float64 and bucket.nbytes() == 8 * (n + 1)
     x = torch.ones(5, 3, dtype=torch.float64)
     lin(x).sum().backward()
@@ -546,7 +556,7 @@ def _staged_grads(dense, direct, estimator, spy=None):
             spy(False)
         for st in sb.stages:
             assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(st["params"], st["views"]))
-        return float(sb.loss()), torch.cat([st["flat"][:st["n"]] for st in sb.stages]).clone(), float(loss.detach())
+        return float(sb.loss()), torch.cat([v.reshape(-1) for st in sb.stages for v in st["views"]]).clone(), float(loss.detach())
     finally:
         sb.release()
 
@@ -569,7 +579,7 @@ def test_backward_writes_gradients_into_the_buckets_without_a_pack_copy(monkeypa
         gc.collect()
         assert not _ops._GRAD_DEST      # release() withdrew every registration (and those of dead models went with their parameters)
         loss_c, flat_c, l_c = _staged_grads("fused", False, estimator, spy=lambda v: on.__setitem__(0, v))
-        assert [c[0] for c in copies] == ["cat", "cat"]   # the copying form: one concatenation per stage
+        assert [c[0] for c in copies] == ["foreach_copy", "foreach_copy"]   # the copying form: one multi-tensor copy per stage
         assert loss_d == l_d == loss_c == l_c
         assert torch.equal(flat_d, flat_c)
         # torch.nn modules know nothing about destinations: their gradients still reach the bucket through the copy
@@ -682,7 +692,7 @@ def test_staged_backward_cut_at_the_encoder_outputs_runs_the_objective_backward_
                     sb.backward_stage(loss, 1)
                 for st in sb.stages:
                     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(st["params"], st["views"]))
-                out[cut] = (torch.cat([st["flat"] for st in sb.stages]).clone(), list(calls))
+                out[cut] = (torch.cat([v.reshape(-1) for st in sb.stages for v in st["views"]]).clone(), list(calls))
             finally:
                 sb.release()
         assert torch.allclose(out[True][0], out[False][0], rtol=1e-6, atol=1e-7)

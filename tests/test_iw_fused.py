@@ -482,3 +482,22 @@ def test_hip_iw1_launches_on_two_streams_at_once(hip):
         assert (means == alone["mean"][0]).all(), (means, alone["mean"][0])
         assert int(t["acc"].abs().sum().item()) == 0
         np.testing.assert_array_equal(t["cost_b"].cpu().numpy(), alone["cost"])
+
+
+def test_accumulator_health_helpers(dev):
+    """A watcher that gives up (it cannot, in a healthy process) stores NaN, leaves the words alone and raises the accumulator's
+    poison word (include/zs_hip.h); `zhusuan._ops.iw1_accumulators_ok()` / `reset_iw1_accumulators()` are the owner's way to
+    see it and to re-zero.  Here: healthy after an evaluation; a raised word is seen; reset clears every word."""
+    import zhusuan as zs
+    from zhusuan import _ops
+    from examples import iwae
+    model = iwae.build(n_samples=5, estimator="vimco", hidden=16, device=dev)
+    model({"x": (torch.rand(4, 784, device=dev) < 0.5).float()})
+    assert zs.explain(model).startswith("IW1") and _ops.iw1_accumulators_ok()
+    accs = [sc[0] for key, sc in _ops._SCRATCH.items() if key[2] == "iw1"]
+    assert accs and all(int(a.abs().sum()) == 0 for a in accs)          # handed back at zero
+    accs[0][_ops.IW1_POISON_WORD] = 1
+    accs[0][3] = 12345
+    assert not _ops.iw1_accumulators_ok()
+    _ops.reset_iw1_accumulators()
+    assert _ops.iw1_accumulators_ok() and all(int(a.abs().sum()) == 0 for a in accs)

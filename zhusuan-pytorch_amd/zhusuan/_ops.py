@@ -598,10 +598,26 @@ def unregister_grad_destination(param):
     _GRAD_DEST.pop(param.data_ptr(), None)
 
 
+_GRAD_DEST_PAUSED = [0]
+
+
+class grad_destinations_paused(object):
+    """``with grad_destinations_paused():`` backward passes allocate their gradients as if no bucket were registered (a
+    measurement aid: bench.py's single-graph twin of the multi-rank step is the headline step exactly)."""
+
+    def __enter__(self):
+        _GRAD_DEST_PAUSED[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _GRAD_DEST_PAUSED[0] -= 1
+        return False
+
+
 def _claim_grad_destination(key):
     """The registered slice for the gradient of the parameter at address ``key`` if this backward pass may write it there,
     else None."""
-    if not _GRAD_DEST or _TASK_ID is None or key is None:
+    if not _GRAD_DEST or _TASK_ID is None or key is None or _GRAD_DEST_PAUSED[0]:
         return None
     entry = _GRAD_DEST.get(key)
     if entry is None:

@@ -21,6 +21,27 @@ def _bucket_dtype(params):
     return dtypes.pop()
 
 
+SLICE_ALIGN_BYTES = 512      # what torch's caching allocator gives a fresh tensor
+
+
+def _flat_layout(params, dtype, with_loss_slot):
+    """(flat buffer, one view per parameter, index of the objective's slot or None).  Every slice starts on a 512-byte boundary,
+    like a tensor of its own would: the slices are GEMM outputs when the backward pass writes gradients into the bucket
+    (``direct=True``), and hipBLASLt's kernels store slower to a C that is only 16-byte aligned -- packed back to back, the
+    IWAE step's three large weight-gradient GEMMs cost 2 % of the whole step (round 6, found as a process that was 17 us per
+    step slower than its twin).  The padding (a few KB in 5.4 MB) is zero and stays zero under a SUM all-reduce."""
+    item = torch.empty((), dtype=dtype).element_size()
+    q = max(SLICE_ALIGN_BYTES // item, 1)
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off = (off + p.numel() + q - 1) // q * q
+    loss_index = off if with_loss_slot else None
+    flat = torch.zeros(off + (1 if with_loss_slot else 0), dtype=dtype, device=params[0].device)
+    views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
+    return flat, views, loss_index
+
+
 def _register_destinations(params, views):
     """Make every slice its parameter's gradient destination (zhusuan._ops: backward passes of this package's layers then
     write the gradient into the bucket themselves and ``_fill_flat`` finds it in place)."""
@@ -36,15 +57,12 @@ def _release_destinations(params, views):
 
 
 def _fill_flat(flat, params, views, tail):
-    """Write the gradients of `params` (and `tail`, a list of 1-element tensors) into `flat`, whose slices `views`
-    shadow the parameters.  One ``cat`` kernel when no gradient lives in the buffer yet; gradients that already alias
-    their slice (autograd accumulated in place into last step's views because zero() was skipped) are left where they
-    are and only the others are copied."""
+    """Bring the gradients of `params` (and `tail`, a list of 1-element tensors: the objective) into `flat`, whose slices `views`
+    shadow the parameters and whose LAST elements are the tail's slots.  Gradients that already live in their slice -- the
+    backward pass wrote them there (gradient destinations), or autograd accumulated in place into last step's views because
+    zero() was skipped -- are left where they are; the others are copied by one multi-tensor kernel; a parameter without a
+    gradient gets zeros."""
     aliased = [p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views)]
-    if not any(aliased):
-        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
-        torch.cat(parts + [t.detach().reshape(1).to(flat.dtype) for t in tail], out=flat)
-        return
     dst = [v for p, v, a in zip(params, views, aliased) if not a and p.grad is not None]
     src = [p.grad for p, a in zip(params, aliased) if not a and p.grad is not None]
     if dst:
@@ -52,7 +70,7 @@ def _fill_flat(flat, params, views, tail):
     for p, v in zip(params, views):
         if p.grad is None:
             v.zero_()
-    n = sum(p.numel() for p in params)
+    n = flat.numel() - len(tail)
     for i, t in enumerate(tail):
         flat[n + i:n + i + 1].copy_(t.detach().reshape(1))
 
@@ -69,7 +87,7 @@ class DirectAllReduce(object):
 
     Construction is COLLECTIVE (every rank of ``group``, at the same point): rank 0's ``ncclUniqueId`` travels over the
     process group, every rank joins the communicator (``ncclCommInitRank``, bounded by ``timeout_s``: a rank whose set-up does
-    not return gives up instead of hanging), one probe all-reduce checks the sum of the ranks, and the ranks AGREE
+    not return gives up instead of hanging), one bucket-sized probe all-reduce checks the sum over the ranks element by element, and the ranks AGREE
     (``all_ranks_agree``) -- ``create`` returns a communicator on every rank or None on every rank, never a mixture; callers
     fall back to ``dist.all_reduce``.  Needs the "nccl" backend (RCCL on ROCm); RCCL's C API is bound in ``zhusuan/_rccl.py``."""
 
@@ -93,10 +111,15 @@ class DirectAllReduce(object):
                 try:
                     torch.cuda.set_device(device)          # (the current device is per thread)
                     comm = _rccl.comm_init_rank(world, uid[0], rank)
-                    probe = torch.full((4,), float(rank + 1), device=device)
+                    # the probe has the size of a gradient bucket (4 MB: the protocol / algorithm RCCL picks for the real call)
+                    # and rank-dependent values at both ends: the SUM over the ranks must come out exactly, everywhere
+                    probe = torch.full((1 << 20,), float(rank + 1), device=device)
+                    probe[-1] = float(2 * rank + 1)
                     _rccl.all_reduce_sum_(probe, comm, torch.cuda.current_stream(device).cuda_stream)
                     torch.cuda.synchronize(device)
-                    box["sum"], box["comm"] = float(probe[0].item()), comm
+                    want_a, want_b = world * (world + 1) / 2.0, float(world * world)
+                    exact = bool((probe[:-1] == want_a).all().item()) and float(probe[-1].item()) == want_b
+                    box["sum"], box["comm"] = (want_a if exact else float("nan")), comm
                 except Exception as e:                     # noqa: BLE001
                     box["error"] = repr(e)
             t = threading.Thread(target=join, name="zhusuan-rccl-init", daemon=True)
@@ -133,8 +156,8 @@ class DirectAllReduce(object):
 class GradientBucket(object):
     """One flat buffer [all gradients | objective] (in the parameters' dtype) for the single all-reduce of a step.
 
-    Per step: autograd produces the gradients as usual; ``all_reduce_mean`` packs them (one ``cat`` kernel
-    straight into the persistent buffer), all-reduces the buffer, scales it by 1/world and re-points every
+    Per step: autograd produces the gradients as usual; ``all_reduce_mean`` packs them (one multi-tensor copy
+    into the persistent buffer, whose slices are 512-byte aligned), all-reduces the buffer, scales it by 1/world and re-points every
     ``p.grad`` at its slice of the buffer, so the optimizer reads the averaged gradients without an unpack
     copy.  With a single rank nothing is packed or sent at all.
 
@@ -145,15 +168,7 @@ class GradientBucket(object):
 
     def __init__(self, module, direct=True):
         self.params = [p for p in module.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(n + 1, dtype=_bucket_dtype(self.params), device=dev)
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        self.n_grad = n
+        self.flat, self.views, self.n_grad = _flat_layout(self.params, _bucket_dtype(self.params), True)      # n_grad: the objective's slot
         self.direct = bool(direct)
         if self.direct:
             _register_destinations(self.params, self.views)
@@ -261,13 +276,8 @@ class OverlappedBuckets(object):
         self._next = 0          # index of the next bucket allowed to leave
 
     def _make(self, params):
-        n = sum(p.numel() for p in params)
-        flat = torch.zeros(n + (1 if not self.buckets else 0), dtype=self._dtype, device=params[0].device)
-        views, off = [], 0
-        for p in params:
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        return {"params": list(params), "flat": flat, "views": views, "n": n, "pending": len(params), "handle": None,
+        flat, views, slot = _flat_layout(params, self._dtype, not self.buckets)
+        return {"params": list(params), "flat": flat, "views": views, "n": slot, "pending": len(params), "handle": None,
                 "launched": False}
 
     def _active(self):
@@ -363,13 +373,8 @@ class StagedBuckets(object):
             params = [p for p in params if p.requires_grad]
             if not params:
                 raise ValueError("stage %d has no trainable parameters" % i)
-            n = sum(p.numel() for p in params)
-            flat = torch.zeros(n + (1 if i == 0 else 0), dtype=_bucket_dtype(params), device=params[0].device)
-            views, off = [], 0
-            for p in params:
-                views.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
-            self.stages.append({"params": params, "flat": flat, "views": views, "n": n, "handle": None})
+            flat, views, slot = _flat_layout(params, _bucket_dtype(params), i == 0)
+            self.stages.append({"params": params, "flat": flat, "views": views, "n": slot, "handle": None})      # "n": the objective's slot (stage 0)
         self._loss_factor = 1.0
         self._holds_sum = False          # the buckets hold the all-reduced SUM and the 1/world was left to the optimizer
         seen = set()
