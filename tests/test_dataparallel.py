@@ -746,3 +746,58 @@ print("direct rccl ok")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and "direct rccl ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def _worker_direct_setup(rank, world, port, fail_rank, out_dir):
+    """Two real processes on GPU 0 over gloo; RCCL's four entry points replaced by stand-ins (RCCL refuses two ranks on one device):
+    what is exercised is DirectAllReduce.create's COLLECTIVE logic -- the unique id travelling from rank 0, the bounded set-up
+    thread, the probe's element-wise check, the ranks' agreement."""
+    sys.path.insert(0, os.path.join(ROOT, "zhusuan-pytorch_amd"))
+    from zhusuan import dataparallel, _rccl
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    seen = {}
+
+    def fake_init(nranks, uid, r):
+        seen["uid"] = uid
+        if r == fail_rank:
+            raise RuntimeError("injected set-up failure on rank %d" % r)
+        return "comm-%d" % r
+
+    def fake_all_reduce(t, comm, stream):
+        if fail_rank >= 0:           # (a failing peer never joins: a real collective would wait; the stand-in returns garbage)
+            t.fill_(-1.0)
+            return
+        c = t.cpu()
+        dist.all_reduce(c)
+        t.copy_(c)
+    _rccl.comm_init_rank, _rccl.all_reduce_sum_, _rccl.comm_destroy = fake_init, fake_all_reduce, lambda comm: None
+    dataparallel.DirectAllReduce.REQUIRED_BACKEND = "gloo"
+    d = dataparallel.DirectAllReduce.create(timeout_s=30)
+    uids = [None] * world
+    dist.all_gather_object(uids, seen.get("uid"))
+    ok = {"created": d is not None, "same_uid": all(u == uids[0] and u is not None and len(u) == 128 for u in uids),
+          "error": dataparallel.DirectAllReduce.last_error}
+    if d is not None:
+        x = torch.full((1000,), float(rank + 1), device="cuda")
+        d.all_reduce_sum_(x)
+        ok["sum"] = float(x[0])
+        d.close()
+    torch.save(ok, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_direct_communicator_set_up_is_a_joint_decision(tmp_path, fail_rank):
+    """Every rank gets a communicator, or none does (then all fall back to torch.distributed's all_reduce together): rank 1's
+    set-up made to fail takes rank 0's perfectly good communicator away as well."""
+    world = 2
+    mp.spawn(_worker_direct_setup, args=(world, _free_port(), fail_rank, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
+    assert all(r["same_uid"] for r in res)                       # rank 0's id reached everybody
+    if fail_rank < 0:
+        assert all(r["created"] and r["sum"] == 3.0 for r in res)
+    else:
+        assert not any(r["created"] for r in res), res
+        assert "injected" in res[1]["error"] and res[0]["error"]

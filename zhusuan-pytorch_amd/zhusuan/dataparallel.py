@@ -94,9 +94,11 @@ class DirectAllReduce(object):
     def __init__(self, comm, world, device):
         self._comm, self.world, self.device = comm, world, device
 
+    REQUIRED_BACKEND = "nccl"          # (tests set it to "gloo" to run the collective set-up logic with a stand-in for RCCL)
+
     @classmethod
     def create(cls, group=None, timeout_s=120.0):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != cls.REQUIRED_BACKEND:
             return None
         import threading
         from . import _rccl
