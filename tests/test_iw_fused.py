@@ -501,3 +501,41 @@ def test_accumulator_health_helpers(dev):
     assert not _ops.iw1_accumulators_ok()
     _ops.reset_iw1_accumulators()
     assert _ops.iw1_accumulators_ok() and all(int(a.abs().sum()) == 0 for a in accs)
+
+
+@pytest.mark.gpu
+def test_lab_build_applies_and_its_last_arrival_finish_returns_the_watchers_bits(hip):
+    """The kernel laboratory is a patch on the release sources (tools/lab/csrc_lab.patch, `make experiments`): it must keep applying
+    and building.  And the two finishes of IW1's batch mean -- the release build's watching wave, the lab build's last arrival
+    (ZS_IW1_SHARDED=1: a returning atomic per level) -- add the same fixed-point shares: every output, the mean included, must be
+    bit-identical (an independent check of the watcher, which the strict-ordering twin does not cover)."""
+    import glob
+    import os
+    import subprocess
+    from conftest import ROOT
+    csrc = os.path.join(ROOT, "zhusuan-pytorch_amd", "csrc")
+    exp = os.path.join(ROOT, "tools", "_exp", "libzs_hip_exp.so")
+    srcs = glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + \
+        [os.path.join(ROOT, "include", "zs_hip.h"), os.path.join(ROOT, "tools", "lab", "csrc_lab.patch")]
+    if not os.path.exists(exp) or os.path.getmtime(exp) < max(os.path.getmtime(f) for f in srcs):
+        r = subprocess.run(["make", "-C", csrc, "experiments"], capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, "make experiments failed (does tools/lab/csrc_lab.patch still apply?):\n" + (r.stdout + r.stderr)[-3000:]
+    os.environ["ZS_IW1_SHARDED"] = "1"          # read once, at the lab library's first IW1 launch; the release library reads nothing
+    try:
+        lab = Raw(_hip.KernelLibrary(exp), "cuda:0")
+        assert "experiments" in lab.k.build_info() and "experiments" not in hip.k.build_info()
+        rng = np.random.RandomState(4)
+        first = True
+        for (K, R, D, Dz) in [(50, 256, 784, 40), (50, 300, 784, 40), (5, 8, 784, 40), (17, 1000, 512, 8), (64, 37, 1024, 12), (2, 4096, 256, 4)]:
+            p, x, z, pmu, psg, rows_a, logq = _inputs(rng, K, R, D, Dz, False, False, False, False, False)
+            for est in (0, 1):
+                a = iw1(hip, p, x, K, R, D, z, pmu, psg, False, None, logq, est, True, False)
+                b = iw1(lab, p, x, K, R, D, z, pmu, psg, False, None, logq, est, True, False)
+                if first:
+                    os.environ.pop("ZS_IW1_SHARDED", None)
+                    first = False
+                for key in ("lp_x", "lp_z", "cost", "bound", "coef", "mean"):
+                    assert np.array_equal(a[key], b[key]), (K, R, D, est, key)
+                assert np.isfinite(a["mean"]).all()
+    finally:
+        os.environ.pop("ZS_IW1_SHARDED", None)
