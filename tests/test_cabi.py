@@ -161,6 +161,14 @@ class Raw(object):
         self.call(name, self.t(p), self.t(x), x.size, self.t(glp), R, 1, gp, K, R, D)
         return dict(gp=gp.cpu().numpy())
 
+    def bern_lp_bwd_x(self, p, glp, K, R, D, Px, logits=False, kfast=False, gscale=None):
+        """zs_bernoulli_logprob_bwd_x: the gradient w.r.t. an observation of period Px; glp [K, R] (row-major, or K-fastest)."""
+        gx = self.empty(Px)
+        g2 = np.ascontiguousarray(glp.reshape(K, R).T) if kfast else glp
+        self.call("zs_bernoulli_logprob_bwd_x_f32", self.t(p), int(logits), Px, self.t(g2), 1 if kfast else R, K if kfast else 1,
+                  self.t(gscale), 0 if gscale is None else 1, gx, K, R, D)
+        return gx.cpu().numpy()
+
     def iw(self, logp, logq, est):
         B, K = logp.shape
         cost, bound = self.empty(B), self.empty(B)

@@ -141,6 +141,34 @@ def case_k3():
     close(ga["gp"], gb["gp"], 1e-4 if logits else 3e-5, 3e-5 * max(np.abs(gb["gp"]).max(), 1), "K3 bwd", shape)
 
 
+def case_obs_grad():
+    """zs_bernoulli_logprob_bwd_x (round 6): the gradient w.r.t. a differentiable observation of every period the product passes --
+    one row per datapoint, full size, a single row, a scalar -- and periods that cut rows (the division path)."""
+    K, R, D = shape3()
+    logits, kfast = bool(rng.rand() < 0.4), bool(rng.rand() < 0.5)
+    N = K * R * D
+    p = (np.clip(2.0 * rng.standard_normal(N), -6, 6) if logits else rng.uniform(0.001, 0.999, N)).astype(np.float32)
+    choice = rng.rand()
+    if choice < 0.4:
+        Px = R * D
+    elif choice < 0.6:
+        Px = N
+    elif choice < 0.75:
+        Px = D
+    elif choice < 0.85:
+        Px = 1
+    else:                                   # any divisor of N
+        divs = [d for d in range(1, min(N, 4096) + 1) if N % d == 0]
+        Px = divs[int(rng.randint(len(divs)))]
+    glp = rng.standard_normal(K * R).astype(np.float32)
+    gscale = rng.standard_normal(R).astype(np.float32) if rng.rand() < 0.5 else None
+    shape = (K, R, D, Px, logits, kfast, gscale is not None)
+    a = hip.bern_lp_bwd_x(p, glp, K, R, D, Px, logits=logits, kfast=kfast, gscale=gscale)
+    b = orc.bern_lp_bwd_x(p, glp, K, R, D, Px, logits=logits, kfast=kfast, gscale=gscale)
+    # a sum of N / Px terms of size |g| * |log ratio| (up to ~14 for p at the clip): the fp32 sums differ by rounding order only
+    close(a, b, 2e-4, 2e-5 * max(np.abs(b).max(), 1.0) + 3e-6 * (N // Px), "K3 bwd_x", shape)
+
+
 def case_k4():
     """The gate of tests/test_cabi.py::_check_iw_reduce: the fp32 reference arithmetic (the oracle) loses accuracy as K grows, so the
     kernel is held to the FLOAT64 truth -- at least as close to it as 1.5 x the oracle -- and to the oracle within the oracle's
@@ -235,7 +263,7 @@ def case_iw1():
         close(a[key], b[key], 2e-4, 2e-5 * max(np.abs(b[key]).max(), 1e-30), "IW1 bwd " + key, shape)
 
 
-cases = [case_k1, case_k2, case_k3, case_k4, case_rng, case_iw1, case_pair]
+cases = [case_k1, case_k2, case_k3, case_obs_grad, case_k4, case_rng, case_iw1, case_pair]
 t0 = time.time()
 while time.time() - t0 < budget:
     c = cases[int(rng.randint(len(cases)))]
