@@ -22,6 +22,9 @@ def hip_runtime():
     lib.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
     lib.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+    lib.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+    lib.hipStreamWriteValue32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint]
+    lib.hipStreamWaitValue32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint, ctypes.c_uint32]
     return lib
 
 
@@ -129,6 +132,24 @@ def main():
         with torch.cuda.stream(side):
             dist.all_reduce(bucket)
 
+    # stream memory operations instead of events: the compute stream WRITES a counter into signal memory, the side stream WAITS for
+    # it (and back for the join) -- no event object, no host-visible signal
+    sig = [ctypes.c_void_p(), ctypes.c_void_p()]
+    have_values = all(hip.hipExtMallocWithFlags(ctypes.byref(p), 8, 0x2) == 0 for p in sig)      # hipMallocSignalMemory
+    tick = [0]
+
+    def mk_values(join=True):
+        def f():
+            tick[0] += 1
+            cur = raw(torch.cuda.current_stream())
+            rc = hip.hipStreamWriteValue32(cur, sig[0], tick[0], 0)
+            rc |= hip.hipStreamWaitValue32(raw(side), sig[0], tick[0], 0, 0xFFFFFFFF)             # hipStreamWaitValueGte
+            if join:
+                rc |= hip.hipStreamWriteValue32(raw(side), sig[1], tick[0], 0)
+                rc |= hip.hipStreamWaitValue32(cur, sig[1], tick[0], 0, 0xFFFFFFFF)
+            assert rc == 0, rc
+        return f
+
     small = torch.zeros(1, device=dev)
 
     def link_eager_kernel():
@@ -145,6 +166,8 @@ def main():
              ("fork + join, HIP events (default flags)", mk_forkjoin_hip(ev_sys)),
              ("fork + join, HIP events (release to device)", mk_forkjoin_hip(ev_dev)),
              ("fork + join, HIP events (no system fence)", mk_forkjoin_hip(ev_nof)),
+             ("fork, stream write / wait value (signal memory)", mk_values(join=False)),
+             ("fork + join, stream write / wait value", mk_values(join=True)),
              ("all_reduce(async_op=True).wait()", link_allreduce_async_wait),
              ("all_reduce(async_op=True), joined one link later", link_allreduce_async_nowait),
              ("all_reduce() (synchronous form: current stream)", link_allreduce_sync),
@@ -164,6 +187,9 @@ def main():
           % ".".join(str(v) for v in torch.cuda.nccl.version()))
     base = None
     for name, link in links:
+        if "value" in name and not have_values:
+            print("%-58s (hipExtMallocWithFlags(hipMallocSignalMemory) failed: skipped)" % name)
+            continue
         run(link, 50)
         vals = sorted(run(link, 300) for _ in range(5))
         med = vals[2]
