@@ -436,7 +436,8 @@ def make_optimizer(model, torch_adam, groups=None):
 
 
 def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False, fused_logits=False, skip_discarded=False,
-                          dense="fused", eager=False, refresh=False, device_rng=True, forward_only=False, pair_draws=True):
+                          dense="fused", eager=False, refresh=False, device_rng=True, forward_only=False, pair_draws=True,
+                          steps_per_replay=1):
     """A workload on this GPU as full training steps -- replayed from one hipGraph (default) or launched eagerly from a
     Python loop (`eager`).  `refresh`: every step trains on ANOTHER minibatch, copied (device to device) into the step's
     input tensors from a resident stream of 8 batches, as the reference's loop feeds one (iwae.py:151-160).  `torch_adam`:
@@ -444,7 +445,9 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
     (torch.optim.Adam(params, lr) as the reference's example constructs it).  `device_rng`: the draws' Philox state lives in
     device memory (needed by graphs); without it they take their call ids from torch's generator, as plain eager code does.
     `forward_only`: a "step" is ONE EVALUATION OF THE OBJECTIVE (no backward, no optimizer): SURVEY.md 8d's metric (i).
-    `pair_draws=False`: zhusuan.pair_draws(False) -- the two draws of a latent as two launches (the package pairs them by default)."""
+    `pair_draws=False`: zhusuan.pair_draws(False) -- the two draws of a latent as two launches (the package pairs them by default).
+    `steps_per_replay` N > 1: zhusuan.GraphedStep(steps_per_replay=N) -- N consecutive training steps recorded into the one graph (the
+    ~8.5 us the GPU idles between two graph launches are paid once per N steps); every step is still executed and counted."""
     import contextlib
     import zhusuan
     gemm_tuning(tuned)
@@ -491,12 +494,15 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
             for _ in range(max(3, min(warmup, 10)) + 3):
                 step()
         else:
-            graphed = zhusuan.GraphedStep(compute, None if opt is None else opt.step, rng=rng, warmup=max(3, min(warmup, 10)), inputs=obs)
+            graphed = zhusuan.GraphedStep(compute, None if opt is None else opt.step, rng=rng, warmup=max(3, min(warmup, 10)), inputs=obs,
+                                          steps_per_replay=steps_per_replay)
             step = (lambda: graphed(**next_batch())) if refresh else graphed
         gemm_tuning(tuned, tune=False)       # every GEMM shape of the step has been seen: keep the picks, stop timing
         for _ in range(3):
             step()
-        trials, last = timed_trials(step, steps, 1, dev, min_seconds=0.3)
+        n_calls = max(steps // steps_per_replay, 1)          # (one call = steps_per_replay steps)
+        trials, last = timed_trials(step, n_calls, 1, dev, min_seconds=0.3)
+        steps = n_calls * steps_per_replay
     med = float(np.median(trials))
     assert np.isfinite(float(last))
     opt_label = {False: "zhusuan.optim.FlatAdam", True: "torch.optim.Adam(fused=True, capturable=True)",
@@ -505,7 +511,7 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
     if forward_only:
         opt_label = "none (objective evaluation only: forward under no_grad)"
     return {"workload": label, "ms_per_step": 1e3 * med / steps, "value": evals * steps / med, "unit": "ELBO-evals/s",
-            "launch_mode": "eager (Python loop)" if eager else "hipgraph", "steps": steps, "trials": len(trials), "final_loss": float(last),
+            "launch_mode": "eager (Python loop)" if eager else ("hipgraph" if steps_per_replay == 1 else "hipgraph, %d steps per replay" % steps_per_replay), "steps": steps, "trials": len(trials), "final_loss": float(last),
             "minibatch": "a new minibatch every step (8 resident batches, copied into the step's inputs)" if refresh else "one resident minibatch",
             "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else (
                 "executed (the package default)" if pair_draws else "executed, one launch per draw (zhusuan.pair_draws(False))"),
@@ -1386,6 +1392,11 @@ def main():
             # next resident batch in front of each graph launch) -- the reference's loop never trains twice on one batch
             # (iwae.py:151-160)
             extra("c3_refresh", "c3", fused_logits=args.fused_logits, refresh=True, **base)
+            # the launch-bound configs with FOUR steps recorded per graph (zhusuan.GraphedStep(steps_per_replay=4)): the idle
+            # time between two graph launches is 13 % of the BNN step, 3.5 % of the VAE step, 1 % of the headline step
+            extra("c5_4_steps_per_graph", "c5", steps_per_replay=4, **base)
+            extra("c2_4_steps_per_graph", "c2", steps_per_replay=4, **base)
+            extra("c3_4_steps_per_graph", "c3", fused_logits=args.fused_logits, steps_per_replay=4, **base)
             # the headline's settings launched eagerly from Python (no graph), one resident minibatch
             extra("c3_eager", "c3", eager=True, fused_logits=args.fused_logits, **base)
             extra("c3_eager_torch_linear", "c3", eager=True, fused_logits=args.fused_logits, **dict(base, dense="torch"))

@@ -185,7 +185,8 @@ def test_bench_line_single_rank():
     ex, fx = rec["extra_configs"], full["extra_configs"]
     for name in ("c2", "c5", "c3_logits", "iwae_default", "bnn_default", "c3_skip_discarded_draws", "c3_torch_linear", "c3_torch_adam",
                  "c3_default_gemm", "c3_reference_example", "c3_reference_example_graphed", "c5_reference_example",
-                 "c5_reference_example_graphed", "c3_eager", "c3_eager_torch_linear", "c5_eager", "c3_forward_only", "c3_one_launch_per_draw"):
+                 "c5_reference_example_graphed", "c3_eager", "c3_eager_torch_linear", "c5_eager", "c3_forward_only", "c3_one_launch_per_draw",
+                 "c5_4_steps_per_graph", "c2_4_steps_per_graph", "c3_4_steps_per_graph"):
         assert ex[name]["value"] > 1e4 and ex[name]["ms_per_step"] > 0 and set(ex[name]) <= {"ms_per_step", "value", "cpu_value"}, (name, ex[name])
         assert np.isfinite(fx[name]["final_loss"])
     # the reference example as written: torch.nn modules, torch.optim.Adam(params, lr), default GEMMs, both draws, eager, fresh batches
@@ -202,6 +203,7 @@ def test_bench_line_single_rank():
         assert cb["value"] > 0 and cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0 and ex[name]["cpu_value"] == cb["value"]
     assert "FlatAdam" in rec["config"]["optimizer"] and "torch.optim.Adam" in fx["c3_torch_adam"]["optimizer"]
     assert np.isfinite(rec["final_loss"]) and rec["full_record"]
+    assert "4 steps per replay" in fx["c5_4_steps_per_graph"]["launch_mode"] and fx["c5_4_steps_per_graph"]["steps"] % 4 == 0
     # the step in its default multi-rank form on one rank over RCCL (a child process; this one has no process group)
     dp = ex["c3_dp_step_n1"]
     assert rec["collective_library"] is None and dp["collective_library"].startswith("RCCL") and "hipgraph x2" in fx["c3_dp_step_n1"]["launch_mode"]

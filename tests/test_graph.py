@@ -80,6 +80,31 @@ def test_graphed_step_matches_eager(kind, with_exchange):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["vae", "iwae"])
+def test_several_steps_per_replay_equal_the_same_steps_one_by_one(kind):
+    """GraphedStep(steps_per_replay=4): one graph launch = four training steps, each with fresh draws and its own Adam step;
+    three replays equal twelve eager steps."""
+    dev = torch.device("cuda:0")
+    model_e, opt_e, rng_e, obs = _make(kind, dev)
+    model_g, opt_g, rng_g, _ = _make(kind, dev)
+    step = zs.GraphedStep(_compute(model_g, rng_g, obs), opt_g.step, rng=rng_g, warmup=3, restore=True, steps_per_replay=4)
+    assert len(step.graphs) == 1 and torch.equal(rng_g.state, rng_e.state)
+    comp_e = _compute(model_e, rng_e, obs)
+    le, lg = [], []
+    with zs.device_rng(rng_e):
+        for _ in range(12):
+            le.append(float(comp_e()))
+            opt_e.step()
+    for _ in range(3):
+        lg.append(float(step()))
+    np.testing.assert_allclose(lg, le[3::4], rtol=2e-5)        # the loss a replay returns is its last sub-step's
+    for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+        np.testing.assert_allclose(pg.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=2e-4, atol=2e-6)
+    with pytest.raises(ValueError, match="steps_per_replay"):
+        zs.GraphedStep(_compute(model_g, rng_g, obs), opt_g.step, exchange=lambda l: l, rng=rng_g, steps_per_replay=2)
+
+
+@pytest.mark.gpu
 def test_graphed_forward_only():
     dev = torch.device("cuda:0")
     model, _, rng, obs = _make("iwae", dev)

@@ -78,11 +78,20 @@ class GraphedStep(object):
         after the capture; if any rank's capture failed every rank runs the step eagerly (``captured`` False, ``capture_error``).
     :param inputs: dict name -> the STATIC tensor ``compute`` reads that observation from; ``step(name=batch)`` copies a new
         minibatch into it before replaying (shapes and dtypes must match: a graph has no dynamic shapes).
+    :param steps_per_replay: record N consecutive training steps into the ONE graph (single-process steps only: no
+        ``exchange``).  Between two graph launches the GPU idles for ~8.5 us (profiles/r06_stream_links.txt): 13 % of the BNN
+        example's 65 us step, 1 % of the IWAE step; N steps per replay pay it once.  Every sub-step draws fresh numbers (the RNG
+        state and the optimizer's step counts live on the device) and reads the same static inputs -- several passes over one
+        minibatch, or resident data; the returned loss is the last sub-step's.  One call = N steps.
     """
 
     def __init__(self, compute, optimizer_step=None, exchange=None, rng=None, warmup=3, restore=False, optimizer=None,
-                 parameters=None, inputs=None, agree=None):
+                 parameters=None, inputs=None, agree=None, steps_per_replay=1):
         self._inputs = dict(inputs) if inputs else {}
+        self.steps_per_replay = int(steps_per_replay)
+        if self.steps_per_replay < 1 or (self.steps_per_replay > 1 and exchange is not None):
+            raise ValueError("steps_per_replay: a positive number; more than one step per graph only without an `exchange` "
+                             "(a collective is launched eagerly between graphs)")
         self.captured, self.capture_error = True, None
         if not torch.cuda.is_available():
             raise RuntimeError("zhusuan.GraphedStep needs a HIP device: the MI355X build has no CPU path")
@@ -121,7 +130,8 @@ class GraphedStep(object):
                 if self._exchange is None:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        self._static_loss = eager_step()
+                        for _ in range(self.steps_per_replay):
+                            self._static_loss = eager_step()
                     self.graphs = [g]
                 else:
                     ga = torch.cuda.CUDAGraph()
@@ -192,6 +202,8 @@ class GraphedStep(object):
             sync()              # zhusuan.optim.FlatAdam: upload lr / betas / eps if the caller changed them (a 4-float compare)
         if not self.captured:
             with self._rng_scope():
+                for _ in range(self.steps_per_replay - 1):
+                    self._eager_step()
                 return self._eager_step()
         if self._exchange is None:
             self.graphs[0].replay()
