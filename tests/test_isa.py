@@ -63,3 +63,20 @@ def test_iw1_streaming_loop_keeps_its_prefetched_rows_in_flight(bernoulli_asm, m
     # and no register of the loop lives in scratch
     assert not re.search(r"\bscratch_(load|store)", body), "k_iw1_persist spills to scratch"
     assert "flat_load" not in body and "flat_store" not in body and "flat_atomic" not in body, "generic-address memory instructions (lost address space)"
+
+
+def test_the_laboratory_patch_applies_to_the_release_sources(tmp_path):
+    """csrc/ holds the kernels that ship and nothing else: no ZS_EXPERIMENTS block outside the knob reader; the
+    laboratory is tools/lab/csrc_lab.patch, which `make experiments` applies to a COPY of the sources.  It must keep applying (the
+    GPU suite also builds it and compares its last-arrival finish with the release watcher bit for bit)."""
+    import glob
+    for f in glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")):
+        n = open(f).read().count("ZS_EXPERIMENTS")
+        assert n == 0 or os.path.basename(f) == "zs_common.h", (f, n)
+    dst = tmp_path / "zhusuan-pytorch_amd" / "csrc"
+    dst.mkdir(parents=True)
+    for f in glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")):
+        shutil.copy(f, str(dst))
+    r = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(ROOT, "tools", "lab", "csrc_lab.patch")], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
