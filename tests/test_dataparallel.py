@@ -718,7 +718,7 @@ sys.path.insert(0, os.path.join(%r, "zhusuan-pytorch_amd"))
 import torch, torch.distributed as dist
 from zhusuan import dataparallel
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 d = dataparallel.DirectAllReduce.create(timeout_s=60)
 assert d is not None, dataparallel.DirectAllReduce.last_error
 assert d.world == 1
@@ -742,7 +742,7 @@ assert torch.equal(b.flat, before) and float(b.loss()) == 2.5 and b.grad_scale()
 d.close()
 dist.destroy_process_group()
 print("direct rccl ok")
-''' % ROOT
+''' % (ROOT, _free_port())
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and "direct rccl ok" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -108,7 +108,7 @@ tests)
   ;;
 final)
   python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/${TAG}_smoke.log
-  timeout 1700 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -16 | tee gpurun_out/${TAG}_gputests.log
+  timeout 1700 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -120 > gpurun_out/${TAG}_gputests.log; tail -16 gpurun_out/${TAG}_gputests.log
   timeout 600 python tools/soak.py 5000 > gpurun_out/soak_raw.txt 2>/dev/null; echo "soak rc=$?"; grep -v amdgpu.ids gpurun_out/soak_raw.txt > gpurun_out/${TAG}_soak.txt; tail -4 gpurun_out/${TAG}_soak.txt
   cd /tmp && export TMPDIR=/tmp
   for c in FETCH_SIZE WRITE_SIZE; do
