@@ -520,7 +520,7 @@ def run_single_gpu_config(name, dev, steps, warmup, tuned=True, torch_adam=False
             "optimizer": opt_label}
 
 
-def dp_step_on_one_rank(args, headline_value, timeout_s=420):
+def dp_step_on_one_rank(args, headline_value, timeout_s=240):
     """extra_configs.c3_dp_step_n1: the headline's settings through the DEFAULT MULTI-RANK FORM of the step (flat bucket filled
     by the backward pass, graph A -> all-reduce over RCCL on the compute stream -> graph B = the update) with ONE rank -- the
     fixed cost of the data-parallel path, which caps the 1 -> 8 curve before a byte crosses xGMI and is the only part of that
