@@ -152,7 +152,10 @@ def main():
               lambda: lib.call("zs_bernoulli_logprob_bwd_f32", P(p), P(x), B * X, P(glp), 1, K, P(gp), K, B, X, st), tag)
         timed("K3 bwd (logits)", "zs_bernoulli_logits_logprob_bwd_f32", 8 * N * X + 4 * B * X + 4 * N,
               lambda: lib.call("zs_bernoulli_logits_logprob_bwd_f32", P(p), P(x), B * X, P(glp), 1, K, P(gp), K, B, X, st), tag)
-        del p, gp, x
+        gx = torch.empty(B * X, device=dev)
+        timed("K3 bwd_x (observation gradient)", "zs_bernoulli_logprob_bwd_x_f32", 4 * N * X + 4 * N + 4 * B * X,
+              lambda: lib.call("zs_bernoulli_logprob_bwd_x_f32", P(p), 0, B * X, P(glp), 1, K, None, 0, P(gx), K, B, X, st), tag)
+        del p, gp, x, gx
         torch.cuda.empty_cache()
     if args.out:
         with open(args.out, "w") as f:

@@ -732,8 +732,9 @@ extern "C" int zs_bernoulli_logprob_bwd_f32(const float* p, const float* x, int6
 // [K, R, D] problem in ascending order -- consecutive threads read consecutive elements of p in every round (coalesced), the row
 // gradient is a broadcast load, the row index advances by Px / D per round without a division (rows_step; the general case, a
 // period that is not a whole number of rows, divides).  Four rounds in flight.  A rare path (an observed Bernoulli value that
-// comes out of a differentiable net): written for correctness and coalescing, not tuned.
-template <typename T, bool LOGITS>
+// comes out of a differentiable net); the form for rows of whole 16-byte pieces follows (k_bern_obs_grad_v4): this one serves the rest
+// and float64.
+template <typename T, bool LOGITS, int U>
 __global__ __launch_bounds__(256) void k_bern_obs_grad(const T* __restrict__ p, int64_t Px, const T* __restrict__ glp, int64_t sk,
                                                         int64_t sr, const T* __restrict__ gscale, int64_t gss, T* __restrict__ gx,
                                                         int64_t n, int64_t R, int64_t D, int64_t rows_step) {
@@ -741,10 +742,10 @@ __global__ __launch_bounds__(256) void k_bern_obs_grad(const T* __restrict__ p, 
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < Px; j += (int64_t)gridDim.x * 256) {
     T acc = (T)0;
     int64_t row = j / D, k = row / R, r = row - k * R;
-    for (int64_t m0 = 0; m0 < reps; m0 += 4) {
-      T pv[4], g[4];
+    for (int64_t m0 = 0; m0 < reps; m0 += U) {
+      T pv[U], g[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {             // U rounds of loads in flight before the first logarithm
         const int64_t m = m0 + u;
         const bool live = m < reps;
         const int64_t i = j + (live ? m : m0) * Px;
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(256) void k_bern_obs_grad(const T* __restrict__ p, 
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {             // (added in ascending element order: deterministic, and the oracle's order)
         T q = pv[u];
         if (LOGITS) q = sigmoid_any(q);
         acc += g[u] * log_ratio_any(q);
@@ -768,6 +769,94 @@ __global__ __launch_bounds__(256) void k_bern_obs_grad(const T* __restrict__ p, 
     gx[j] = acc;
   }
 }
+// The same for rows of whole 16-byte pieces (D % 4 == 0, Px % 4 == 0, aligned): a thread owns FOUR consecutive observations -- one
+// row, so one row gradient and one step of the row bookkeeping per 16-byte load instead of per element (the scalar form is bound
+// by exactly that bookkeeping: ~45 instructions per element, 21 % of the roofline at the config size).  Same order of additions
+// per element as the scalar form: the same bits.
+template <bool LOGITS, int U, int KS, bool SPLIT>
+__global__ __launch_bounds__(64 * KS) void k_bern_obs_grad_v4(const float4* __restrict__ p, int64_t Px4, const float* __restrict__ glp,
+                                                              int64_t sk, int64_t sr, const float* __restrict__ gscale, int64_t gss,
+                                                              float4* __restrict__ gx, int64_t n4, int64_t R, int64_t D4, int64_t rows_step) {
+  // SPLIT (few observations, many repetitions: the config sizes, where one thread walking all K repetitions of its piece is a
+  // chain of K / U dependent rounds): wave s of the workgroup takes the s-th share of the repetitions of ONE tile of 64 pieces, the
+  // partial sums meet in LDS and wave 0 adds them in slice order (deterministic).  Otherwise every wave owns a tile of its own.
+  __shared__ float4 part[SPLIT ? KS - 1 : 1][64];
+  const int64_t reps = n4 / Px4;
+  const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int64_t per = SPLIT ? (reps + KS - 1) / KS : reps, m_lo = SPLIT ? s * per : 0, m_hi = (m_lo + per < reps) ? m_lo + per : reps;
+  const int64_t tiles = SPLIT ? 1 : KS;
+  for (int64_t j0 = ((int64_t)blockIdx.x * tiles + (SPLIT ? 0 : s)) * 64; j0 < Px4; j0 += (int64_t)gridDim.x * tiles * 64) {   // (SPLIT: workgroup-uniform, barriers inside)
+    const int64_t j = j0 + lane;
+    const bool on = j < Px4;
+    const int64_t jc = on ? j : Px4 - 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t row = (jc + m_lo * Px4) / D4, k = row / R, r = row - k * R;
+    for (int64_t m0 = m_lo; m0 < m_hi; m0 += U) {
+      float4 pv[U];
+      float g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t m = m0 + u;
+        const bool live = m < m_hi;
+        const int64_t i = jc + (live ? m : m0) * Px4;
+        if (rows_step < 0 && live) {
+          row = i / D4; k = row / R; r = row - k * R;
+        }
+        pv[u] = live ? p[i] : make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+        g[u] = live ? glp[k * sk + r * sr] * (gscale ? gscale[r * gss] : 1.0f) : 0.f;
+        if (rows_step >= 0 && live) {
+          r += rows_step;
+          while (r >= R) { r -= R; ++k; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float4 q = pv[u];
+        if (LOGITS) { q.x = sigmoid_any(q.x); q.y = sigmoid_any(q.y); q.z = sigmoid_any(q.z); q.w = sigmoid_any(q.w); }
+        acc.x += g[u] * log_ratio_any(q.x);
+        acc.y += g[u] * log_ratio_any(q.y);
+        acc.z += g[u] * log_ratio_any(q.z);
+        acc.w += g[u] * log_ratio_any(q.w);
+      }
+    }
+    if (SPLIT) {
+      if (s > 0) part[s - 1][lane] = acc;
+      __syncthreads();
+      if (s == 0) {
+#pragma unroll
+        for (int t = 0; t < KS - 1; ++t) {
+          const float4 o = part[t][lane];
+          acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+      }
+      __syncthreads();
+    }
+    if ((!SPLIT || s == 0) && on) gx[j] = acc;
+  }
+}
+__host__ bool launch_bern_obs_grad_v4(const float* p, int from_logits, int64_t Px, const float* glp, int64_t sk, int64_t sr, const float* gscale,
+                                      int64_t gss, float* gx, int64_t n, int64_t R, int64_t D, hipStream_t st) {
+  if ((D % 4) || (Px % 4) || !aligned16(p) || !aligned16(gx)) return false;
+  const int64_t Px4 = Px / 4, D4 = D / 4;
+  const int64_t rows_step = (Px4 % D4 == 0) ? Px4 / D4 : -1;
+  const int64_t reps = n / Px;
+  // few observations, many repetitions (x [B, X] against p [K, B, X] at the config sizes): the repetitions are shared out over the
+  // four waves of a workgroup (11.0 against 24.2 us at B = 256, K = 50); otherwise a wave per 64 pieces walks them all, two waves
+  // per workgroup (70 - 72 % of 8 TB/s from 0.4 GB up)
+  const bool split = reps >= 8 && Px4 < (int64_t)64 * 4096;
+  const dim3 grid(grid_for(Px4, split ? 64 : 128));
+#define ZS_LAUNCH_OBS(L, KS, SP) ZS_LAUNCH(KID_BERN_LOGPROB_BWD_X, (k_bern_obs_grad_v4<L, 4, KS, SP>), grid, dim3(64 * KS), st, (const float4*)p, Px4, glp, \
+                                           sk, sr, gscale, gss, (float4*)gx, n / 4, R, D4, rows_step)
+  if (from_logits) { if (split) ZS_LAUNCH_OBS(true, 4, true); else ZS_LAUNCH_OBS(true, 2, false); }
+  else             { if (split) ZS_LAUNCH_OBS(false, 4, true); else ZS_LAUNCH_OBS(false, 2, false); }
+#undef ZS_LAUNCH_OBS
+  return true;
+}
+__host__ bool launch_bern_obs_grad_v4(const double*, int, int64_t, const double*, int64_t, int64_t, const double*, int64_t, double*, int64_t, int64_t, int64_t,
+                                      hipStream_t) {
+  return false;          // (float64: the scalar form)
+}
+
 template <typename T>
 int launch_bern_obs_grad(const T* p, int from_logits, int64_t Px, const T* glp, int64_t sk, int64_t sr, const T* gscale, int64_t gss,
                          T* gx, int64_t K, int64_t R, int64_t D, hipStream_t st) {
@@ -776,10 +865,14 @@ int launch_bern_obs_grad(const T* p, int from_logits, int64_t Px, const T* glp, 
   if (n == 0) return 0;
   if (!p || !glp || !gx) return ZS_EINVAL;
   if (n % Px) return ZS_EINVAL;
+  if (launch_bern_obs_grad_v4(p, from_logits, Px, glp, sk, sr, gscale, gss, gx, n, R, D, st)) {
+    ZS_CHECK_LAUNCH();
+    return 0;
+  }
   const int64_t rows_step = (Px % D == 0) ? Px / D : -1;
   const dim3 grid(grid_for(Px, 256));
-  if (from_logits) ZS_LAUNCH(KID_BERN_LOGPROB_BWD_X, (k_bern_obs_grad<T, true>), grid, dim3(256), st, p, Px, glp, sk, sr, gscale, gss, gx, n, R, D, rows_step);
-  else ZS_LAUNCH(KID_BERN_LOGPROB_BWD_X, (k_bern_obs_grad<T, false>), grid, dim3(256), st, p, Px, glp, sk, sr, gscale, gss, gx, n, R, D, rows_step);
+  if (from_logits) ZS_LAUNCH(KID_BERN_LOGPROB_BWD_X, (k_bern_obs_grad<T, true, 4>), grid, dim3(256), st, p, Px, glp, sk, sr, gscale, gss, gx, n, R, D, rows_step);
+  else ZS_LAUNCH(KID_BERN_LOGPROB_BWD_X, (k_bern_obs_grad<T, false, 4>), grid, dim3(256), st, p, Px, glp, sk, sr, gscale, gss, gx, n, R, D, rows_step);
   ZS_CHECK_LAUNCH();
   return 0;
 }
