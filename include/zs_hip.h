@@ -173,7 +173,8 @@ int zs_bernoulli_logprob_bwd_f32(const float* p, const float* x, int64_t Px,
  *   gx[j] = sum over i in [0, K*R*D), i % Px == j, of  glp[k, r] * s[r] * ( log(p_i + 1e-8) - log((1 - p_i) + 1e-8) ),
  * (k, r) = the row of element i, s[r] = gscale[r * gscale_stride] when gscale is given (the device-resident incoming
  * gradient of the objectives that keep their row gradients as coefficients), else 1; from_logits: p = sigmoid(streamed
- * operand).  gx has Px elements; added in ascending i (deterministic). */
+ * operand).  gx has Px elements; the additions are made in a fixed order (deterministic: ascending i, or -- few observations,
+ * many repetitions -- ascending within four equal shares of the repetitions that are then added in order). */
 int zs_bernoulli_logprob_bwd_x_f32(const float* p, int from_logits, int64_t Px,
                                    const float* glp, int64_t glp_stride_k, int64_t glp_stride_r,
                                    const float* gscale, int64_t gscale_stride,
