@@ -69,6 +69,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-direct-rccl", action="store_true",
                     help="all-reduce through torch.distributed (two HIP event records per call) instead of this job's own RCCL "
                          "communicator driven on the compute stream (zhusuan.dataparallel.DirectAllReduce)")
+    ap.add_argument("--gemm-picks", default="",
+                    help="(set by the parent of the c3_dp_step_n1 child) a TunableOp results file to start from: the same GEMM kernels "
+                         "as the process that wrote it")
     ap.add_argument("--timeline", default="",
                     help="write a chrome trace (torch.profiler: host runtime calls + device activity) of 5 steps in the timed "
                          "region's launch mode to this path (tools/timeline_gaps.py reads it)")
@@ -179,19 +182,35 @@ def baseline_metric():
         return "ELBO-evals/sec (batch\u00d7K particles) VAE-MNIST K=50 @1/2/4/8 GPU"
 
 
-def gemm_tuning(on, tune=True):
+GEMM_PICKS = {"loaded_from": None}
+
+
+def gemm_picks_file():
+    import tempfile                  # TunableOp writes its picks there: keep that file out of the repository
+    return os.path.join(tempfile.gettempdir(), "zs_bench_tunableop_%d.csv" % os.getpid())
+
+
+def gemm_tuning(on, tune=True, picks=None):
     """The callers' MLPs (outside the hot path, 72 % of the step) are fp32 GEMMs dispatched by PyTorch.  Its TunableOp
     times the available fp32 hipBLASLt / rocBLAS solutions for each GEMM shape once (during the eager warm-up steps,
     ~4 s in total for this workload) and uses the fastest from then on: same precision, same arithmetic, another tiling.
-    `--no-gemm-tuning` measures with PyTorch's default heuristic selection."""
+    `--no-gemm-tuning` measures with PyTorch's default heuristic selection.  `picks`: a results file of ANOTHER process to start
+    from (the one-rank child of c3_dp_step_n1 takes its parent's: the two processes then run the same GEMM kernels, and what is
+    left of `vs_headline` is the step's form, not two tuning runs' different winners); shapes it lacks are tuned as usual."""
     try:
         import torch.cuda.tunable as tunable
         tunable.enable(bool(on))
         tunable.tuning_enable(bool(on and tune))
         if on:
             tunable.set_max_tuning_duration(30)
-            import tempfile                  # TunableOp dumps its picks at exit: keep that file out of the repository
-            tunable.set_filename(os.path.join(tempfile.gettempdir(), "zs_bench_tunableop_%d.csv" % os.getpid()))
+            tunable.set_filename(gemm_picks_file())
+            if picks and os.path.exists(picks):
+                try:
+                    ok = tunable.read_file(picks)
+                    GEMM_PICKS["loaded_from"] = picks if ok else None
+                    sys.stderr.write("bench: GEMM picks of the parent process %s (%s)\n" % ("loaded" if ok else "NOT loaded", picks))
+                except Exception as e:                              # noqa: BLE001
+                    sys.stderr.write("bench: could not read the GEMM picks %s (%r); tuning afresh\n" % (picks, e))
         return bool(on)
     except Exception as e:                                          # noqa: BLE001
         sys.stderr.write("bench: TunableOp unavailable (%r); default GEMM selection\n" % (e,))
@@ -534,6 +553,8 @@ def dp_step_on_one_rank(args, headline_value, timeout_s=240):
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--force-collective-path", "--no-extras", "--no-cpu-baseline", "--full-record", os.devnull]
+    if not args.no_gemm_tuning and os.path.exists(gemm_picks_file()):
+        cmd += ["--gemm-picks", gemm_picks_file()]          # the child runs THIS process's GEMM kernels
     for flag, on in (("--fused-logits", args.fused_logits), ("--torch-adam", args.torch_adam), ("--torch-linear", args.torch_linear),
                      ("--no-gemm-tuning", args.no_gemm_tuning), ("--skip-discarded-draws", args.skip_discarded_draws),
                      ("--allow-experiments", args.allow_experiments), ("--unfused-activations", args.unfused_activations)):
@@ -549,6 +570,7 @@ def dp_step_on_one_rank(args, headline_value, timeout_s=240):
             "vs_headline": rec["value"] / headline_value, "launch_mode": rec["config"]["launch_mode"],
             "collective_library": rec.get("collective_library"), "collective_path": rec.get("collective_path"),
             "parallelism": rec["config"]["parallelism"], "final_loss": rec.get("final_loss"),
+            "mlp_gemm_selection": rec["config"].get("mlp_gemm_selection"),
             "same_process_single_graph_ms": sp.get("single_graph_ms_per_step"),
             "same_process_collective_path_ms": sp.get("collective_path_ms_per_step"),
             "same_process_ratio": sp.get("collective_path_vs_single_graph"), "extra_us_per_step": sp.get("extra_us_per_step")}
@@ -871,7 +893,7 @@ def main():
 
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library("cublaslt" if args.blas == "hipblaslt" else "cublas")
-    tuned = gemm_tuning(not args.no_gemm_tuning)
+    tuned = gemm_tuning(not args.no_gemm_tuning, picks=args.gemm_picks or None)
     import zhusuan  # noqa: F401
     from zhusuan import _hip, dataparallel
     if args.iw1_max_stream_bytes >= 0:
@@ -1281,7 +1303,8 @@ def main():
             "bernoulli_path": "logits (sigmoid inside the kernel)" if args.fused_logits else "probs (nn.Sigmoid pass, as the reference's example)",
             "dense_layers": DENSE_LABEL[dense],
             "mlp_gemm_library": args.blas,
-            "mlp_gemm_selection": "TunableOp (fastest fp32 solution per shape, callers' nn.Linear stack)" if tuned else "PyTorch default",
+            "mlp_gemm_selection": ("TunableOp (fastest fp32 solution per shape, callers' nn.Linear stack)" +
+                                   (": the picks of the parent process" if GEMM_PICKS["loaded_from"] else "")) if tuned else "PyTorch default",
             "optimizer": "torch.optim.Adam(lr=1e-3, fused=True, capturable=True)" if args.torch_adam else "zhusuan.optim.FlatAdam(lr=1e-3)",
             "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default, as the reference: both draws of the latent, in one launch)",
             "launch_mode": mode,

@@ -215,6 +215,7 @@ def test_bench_line_single_rank():
     dp = ex["c3_dp_step_n1"]
     assert rec["collective_library"] is None and dp["collective_library"].startswith("RCCL") and "hipgraph x2" in fx["c3_dp_step_n1"]["launch_mode"]
     assert fx["c3_dp_step_n1"]["collective_path"].startswith("RCCL called directly")
+    assert fx["c3_dp_step_n1"]["mlp_gemm_selection"].endswith("the picks of the parent process")      # the same GEMM kernels in both processes
     assert 0.8 < dp["vs_headline"] < 1.1 and 0.85 < dp["same_process_ratio"] < 1.05 and dp["extra_us_per_step"] < 60.0, dp
 
 
