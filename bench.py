@@ -143,7 +143,7 @@ def launch_ranks(n_ranks, argv):
 
 # ZS_* variables that are this script's own test hooks (reported, never refused); every other ZS_* variable is an experiment
 _BENCH_OWN_ENV = ("ZS_BENCH_SHARE_DEVICE", "ZS_BENCH_NO_TRACER", "ZS_BENCH_FAIL_CAPTURE_RANK", "ZS_BENCH_STALL_RANK",
-                  "ZS_BENCH_WATCHDOG_S")
+                  "ZS_BENCH_WATCHDOG_S", "ZS_BENCH_NO_SHARED_PICKS")
 
 
 def env_overrides():
@@ -208,7 +208,7 @@ def gemm_tuning(on, tune=True, picks=None):
                 try:
                     ok = tunable.read_file(picks)
                     GEMM_PICKS["loaded_from"] = picks if ok else None
-                    sys.stderr.write("bench: GEMM picks of the parent process %s (%s)\n" % ("loaded" if ok else "NOT loaded", picks))
+                    sys.stderr.write("bench: GEMM picks of another process %s (%s)\n" % ("loaded" if ok else "NOT loaded", picks))
                 except Exception as e:                              # noqa: BLE001
                     sys.stderr.write("bench: could not read the GEMM picks %s (%r); tuning afresh\n" % (picks, e))
         return bool(on)
@@ -941,6 +941,41 @@ def main():
 
     one = torch.ones((), device=dev)          # backward's seed, allocated once (loss.backward() fills a fresh one per step)
 
+    # Several ranks, tuned GEMMs: ONE tuning run for the job.  Left to themselves the ranks time the fp32 GEMM solutions independently
+    # and near-ties come out differently, so replicas run slightly different kernels and the step takes the time of the slowest
+    # rank's picks (the same effect put +- 1.5 % between the headline process and its one-rank child).  Rank 0 evaluates the
+    # objective's forward + backward three times -- every GEMM shape of the step, no collective involved --, writing its picks where
+    # the other ranks (one node: one /tmp) read them after a barrier; a rank that cannot read them tunes for itself as before.
+    gemm_picks_shared = None
+    if world > 1 and tuned and dist.is_initialized() and os.environ.get("ZS_BENCH_NO_SHARED_PICKS") != "1":
+        import tempfile
+        shared = os.path.join(tempfile.gettempdir(), "zs_bench_tunableop_job_%s.csv" % os.environ.get("MASTER_PORT", "0"))
+        kick("GEMM picks of rank 0")
+        try:
+            import torch.cuda.tunable as tunable
+            if rank == 0:
+                if os.path.exists(shared):
+                    os.remove(shared)
+                tunable.set_filename(shared)
+                # (torch.autograd.grad, not backward(): the parameters' AccumulateGrad nodes remember the stream they first ran on, and a
+                #  first use on the default stream breaks the capture that follows -- a segfault in capture_end, seen once here)
+                #  and on a side stream, like the warm-up of the capture itself: nothing of the step touches the default stream before it
+                params_ = [p_ for p_ in model.parameters() if p_.requires_grad]
+                pre = torch.cuda.Stream()
+                pre.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(pre), zhusuan.device_rng(rng):
+                    for _ in range(3):
+                        rng.begin_step()
+                        torch.autograd.grad(model(obs), params_, grad_outputs=one, allow_unused=True)
+                torch.cuda.current_stream().wait_stream(pre)
+                torch.cuda.synchronize()
+        except Exception as e:                                      # noqa: BLE001
+            sys.stderr.write("bench: rank %d: pre-tuning failed (%r); every rank tunes for itself\n" % (rank, e))
+        dist.barrier()
+        if rank != 0:
+            gemm_tuning(True, picks=shared)
+        gemm_picks_shared = dataparallel.all_ranks_agree(bool(rank == 0 or GEMM_PICKS["loaded_from"]), device=dev)
+
     def compute_part():
         """objective forward + backward (+ packing the flat [grads | loss] bucket when there is a collective)"""
         rng.begin_step()
@@ -1304,7 +1339,8 @@ def main():
             "dense_layers": DENSE_LABEL[dense],
             "mlp_gemm_library": args.blas,
             "mlp_gemm_selection": ("TunableOp (fastest fp32 solution per shape, callers' nn.Linear stack)" +
-                                   (": the picks of the parent process" if GEMM_PICKS["loaded_from"] else "")) if tuned else "PyTorch default",
+                                   (": the picks of the parent process" if (GEMM_PICKS["loaded_from"] and world == 1) else "") +
+                                   ("; one tuning run for the job (rank 0's picks on every rank)" if gemm_picks_shared else "")) if tuned else "PyTorch default",
             "optimizer": "torch.optim.Adam(lr=1e-3, fused=True, capturable=True)" if args.torch_adam else "zhusuan.optim.FlatAdam(lr=1e-3)",
             "discarded_draws": "skipped (zhusuan.skip_discarded_draws)" if skip_discarded else "executed (the package default, as the reference: both draws of the latent, in one launch)",
             "launch_mode": mode,

@@ -328,6 +328,23 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(extra):
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_share_one_gemm_tuning_run():
+    """Several ranks, tuned GEMMs (the driver's command line has no --no-gemm-tuning): rank 0 evaluates the objective three times on
+    a side stream before anything is captured, the other ranks read its picks after a barrier -- one tuning run for the job, the
+    same GEMM kernels on every rank.  (The first version ran that pass on the default stream: capture_end crashed on rank 0.)"""
+    env = dict(os.environ)
+    env["ZS_BENCH_SHARE_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_ranks_seen"] == 2 and rec["replicas_in_sync"] is True and np.isfinite(rec["final_loss"])
+    assert "one tuning run for the job" in rec["config"]["mlp_gemm_selection"] and "hipgraph x2" in rec["config"]["launch_mode"]
+    assert "GEMM picks of another process loaded" in r.stderr          # rank 1 read rank 0's file
+
+
+@pytest.mark.gpu
 def test_bench_eight_ranks_sharing_one_gpu_over_gloo():
     """The driver's N = 8 command line end to end on a one-GPU box: 8 ranks (torch.distributed.run) on GPU 0 over gloo --
     per-rank shards and Philox streams, the flat bucket (two hipGraphs per rank around one eagerly launched collective),

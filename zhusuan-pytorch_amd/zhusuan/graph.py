@@ -36,6 +36,9 @@ graphs), then graph B = the optimizer.
 Capture rules that this class takes care of (each one cost a crash while bench.py was written):
   * the eager warm-up runs on the capture side stream -- autograd's AccumulateGrad nodes remember the stream they were
     first used on, and a default-stream association breaks the capture;
+  * ... and so must anything else that runs the model before the capture (a pre-tuning pass, a sanity step): the step's GEMMs
+    launched once on the DEFAULT stream were enough for ``capture_end`` to crash (a segmentation fault, ROCm 7.2 / torch 2.10,
+    found in round 6 with bench.py's one-tuning-run-per-job pass): use a side stream there too;
   * ``capture_error_mode='thread_local'``, so that unrelated threads (e.g. a data loader) may keep calling HIP;
   * nothing inside the step may copy from the host (``torch.as_tensor(python_scalar, device=...)`` does);
   * the warm-up steps are real optimizer steps; with ``restore=True`` parameters, optimizer state and the RNG state are
