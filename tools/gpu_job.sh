@@ -4,6 +4,7 @@
 # Everything is written under gpurun_out/<tag>_* ; copy what should be judged into profiles/.
 #   dp_cost     the multi-rank step on one rank over RCCL against the single graph (same process), + timelines  -> profiles/r06_dp_step.txt
 #   links       what one link between two hipGraph replays costs (event record, fork / join, all_reduce forms) -> profiles/r06_stream_links.txt
+#   dp_soak     20 000 steps of each multi-rank form on one rank over RCCL; the final loss against the single graph's after as many steps -> profiles/r06_dp_soak.txt
 #   dp_tests    the GPU tests of the data-parallel path, the graphs, the fused objective and the bench's control flow
 #   iw1_ab      IW1 forward in the step and back to back: this tree against tools/_exp/libzs_hip_prev.so
 #   k2_ab       K2 / L2 / U2 at 1 M and 4.2 M rows: this tree against tools/_exp/libzs_hip_prev.so
@@ -24,7 +25,7 @@ mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 
 one_rank() {   # bench.py as ONE rank with a process group over RCCL (the driver's launcher form)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 1 \
+  timeout ${ONE_RANK_TIMEOUT:-900} python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 1 \
     --no-cpu-baseline --no-extras "$@" 2>> gpurun_out/${TAG}_${JOB}.err
 }
 
@@ -53,6 +54,29 @@ print('%-52s %.4f ms/step | same process: single graph %.4f, this form %.4f  (+%
   ;;
 links)
   timeout 600 python tools/stream_link_probe.py 2> gpurun_out/${TAG}_links.err | tee gpurun_out/${TAG}_stream_links.txt
+  ;;
+dp_soak)
+  # the eagerly launched RCCL calls between hipGraph replays, for N steps on end: no hang, no drift -- the objective after N updates
+  # is compared with the single graph's after N updates (same seed, same GEMM picks: world size 1 sums one rank's gradients)
+  N=${3:-20000}
+  OUT=gpurun_out/${TAG}_dp_soak.txt; : > $OUT
+  PICKS=gpurun_out/${TAG}_dp_soak_picks.csv; rm -f $PICKS
+  fl() { python -c "
+import sys, json
+r = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('%-46s %6d steps  %.4f ms/step  final loss %.6f  | %s' % (sys.argv[1], r['steps'], r['ms_per_step'], r['final_loss'], (r.get('collective_path') or r['config']['launch_mode'])[:70]))" "$1"; }
+  timeout 600 python bench.py --steps $N --warmup 10 --no-cpu-baseline --no-extras --gemm-picks $PICKS 2>> gpurun_out/${TAG}_${JOB}.err | fl "single graph (headline form)" >> $OUT
+  one_rank --steps $N --warmup 10 --force-collective-path --gemm-picks $PICKS | fl "one bucket, 2 graphs, RCCL direct (default)" >> $OUT
+  one_rank --steps $N --warmup 10 --force-collective-path --no-direct-rccl --gemm-picks $PICKS | fl "one bucket, 2 graphs, torch.distributed" >> $OUT
+  one_rank --steps $N --warmup 10 --force-collective-path --overlap --gemm-picks $PICKS | fl "staged, 3 graphs (--overlap)" >> $OUT
+  one_rank --steps $N --warmup 10 --force-collective-path --no-graph --gemm-picks $PICKS | fl "one bucket, eager launches" >> $OUT
+  python - $OUT <<'PY' | tee -a $OUT
+import sys
+v = [float(l.split("final loss")[1].split()[0]) for l in open(sys.argv[1]) if "final loss" in l]
+rel = max(abs(x - v[0]) / abs(v[0]) for x in v)
+print("forms: %d; largest relative difference of the final loss from the single graph's: %.2e  -> %s" % (len(v), rel, "ok" if len(v) == 5 and rel < 2e-3 else "DIFFERENT"))
+PY
+  cat $OUT
   ;;
 dp_tests)
   timeout 1700 python -m pytest -x -q -m gpu tests/test_dataparallel.py tests/test_graph.py tests/test_iw_fused.py tests/test_bench_contract.py \
