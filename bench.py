@@ -1139,6 +1139,8 @@ def main():
         if rank == stall_rank:              # test hook: this rank stops here; its peers wait in the first trial's barrier
             time.sleep(10 ** 6)
         trials, last = timed_trials(step, args.steps, world, dev, kick=kick)
+        # (read here: the same-process twin below trains the same model on -- tools/gpu_job.sh dp_soak compares the forms at equal step counts)
+        final_loss = float(last) * (grad_scale if slot_is_sum else 1.0)
         # one rank on the collective path: the SAME model, optimizer, GEMM picks and box as a single graph, alternating with
         # the multi-rank form -- what the path costs before a byte crosses xGMI, free of process-to-process differences
         same_process = None
@@ -1166,7 +1168,6 @@ def main():
             del twin
         kick("per-kernel timing passes")
         elapsed = float(np.median(trials))
-        final_loss = float(last) * (grad_scale if slot_is_sum else 1.0)
         # per-kernel durations: the same steps launched eagerly with start/stop HIP events bound to each
         # kernel dispatch on its stream (events cannot ride inside a graph replay)
         n_prof = min(args.steps, 50)

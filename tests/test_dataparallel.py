@@ -801,3 +801,63 @@ def test_direct_communicator_set_up_is_a_joint_decision(tmp_path, fail_rank):
     else:
         assert not any(r["created"] for r in res), res
         assert "injected" in res[1]["error"] and res[0]["error"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direct", [True, False])
+def test_the_two_graph_bucket_step_trains_bit_for_bit_like_the_single_graph(direct):
+    """The multi-rank form of the step as bench.py records it -- graph A = forward + backward INTO the flat bucket + the
+    objective's slot, (the collective's place), graph B = FlatAdam reading the bucket with grad_scale -- against the single
+    graph of the same model, seed and optimizer: the same objective on each of 40 replays and the same parameters at the end,
+    exactly (a one-rank sum changes nothing; the gradients' arithmetic does not depend on where they are written)."""
+    import zhusuan as zs
+    from examples import iwae
+    from zhusuan import dataparallel
+    dev = torch.device("cuda:0")
+
+    def make():
+        torch.manual_seed(11)
+        model = iwae.build(5, "vimco", hidden=64, device=dev, dense="fused")
+        return model, zs.optim.FlatAdam(model.parameters(), lr=1e-3), zs.DeviceRNG(dev, seed=7)
+    x = {"x": (torch.rand(16, 784, device=dev) < 0.5).float()}
+    one = torch.ones((), device=dev)
+    m1, o1, r1 = make()
+
+    def compute_single():
+        r1.begin_step()
+        for p in m1.parameters():
+            p.grad = None
+        loss = m1(x)
+        loss.backward(one)
+        return loss.detach()
+    single = zs.GraphedStep(compute_single, o1.step, rng=r1, warmup=3, restore=True)
+    m2, o2, r2 = make()
+    bucket = dataparallel.GradientBucket(m2, direct=direct)
+    seen = []
+
+    def compute_part():
+        r2.begin_step()
+        bucket.zero()
+        loss = m2(x)
+        loss.backward(one)
+        bucket.pack(loss)
+        return loss.detach()
+
+    def exchange_part(loss):
+        seen.append(1)
+        return bucket.flat[bucket.n_grad]
+    try:
+        two = zs.GraphedStep(compute_part, lambda: o2.step(grad_scale=1.0), exchange=exchange_part, rng=r2, warmup=3, restore=True,
+                             optimizer=o2)
+        assert len(two.graphs) == 2
+        if direct:       # the backward wrote every dense layer's gradients where the bucket keeps them
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+        seen.clear()
+        for i in range(40):
+            a, b = single(), two()
+            assert float(a) == float(b), (i, float(a), float(b))
+        assert len(seen) == 40
+        for p1, p2 in zip(m1.parameters(), m2.parameters()):
+            assert torch.equal(p1, p2)
+    finally:
+        bucket.release()

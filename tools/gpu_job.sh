@@ -4,7 +4,7 @@
 # Everything is written under gpurun_out/<tag>_* ; copy what should be judged into profiles/.
 #   dp_cost     the multi-rank step on one rank over RCCL against the single graph (same process), + timelines  -> profiles/r06_dp_step.txt
 #   links       what one link between two hipGraph replays costs (event record, fork / join, all_reduce forms) -> profiles/r06_stream_links.txt
-#   dp_soak     20 000 steps of each multi-rank form on one rank over RCCL; the final loss against the single graph's after as many steps -> profiles/r06_dp_soak.txt
+#   dp_soak     3 x 10 000 steps of each multi-rank form on one rank over RCCL; the final loss against the single graph's after as many steps -> profiles/r06_dp_soak.txt
 #   dp_tests    the GPU tests of the data-parallel path, the graphs, the fused objective and the bench's control flow
 #   iw1_ab      IW1 forward in the step and back to back: this tree against tools/_exp/libzs_hip_prev.so
 #   k2_ab       K2 / L2 / U2 at 1 M and 4.2 M rows: this tree against tools/_exp/libzs_hip_prev.so
@@ -58,7 +58,7 @@ links)
 dp_soak)
   # the eagerly launched RCCL calls between hipGraph replays, for N steps on end: no hang, no drift -- the objective after N updates
   # is compared with the single graph's after N updates (same seed, same GEMM picks: world size 1 sums one rank's gradients)
-  N=${3:-20000}
+  N=${3:-10000}
   OUT=gpurun_out/${TAG}_dp_soak.txt; : > $OUT
   PICKS=gpurun_out/${TAG}_dp_soak_picks.csv; rm -f $PICKS
   fl() { python -c "
@@ -76,6 +76,9 @@ v = [float(l.split("final loss")[1].split()[0]) for l in open(sys.argv[1]) if "f
 rel = max(abs(x - v[0]) / abs(v[0]) for x in v)
 print("forms: %d; largest relative difference of the final loss from the single graph's: %.2e  -> %s" % (len(v), rel, "ok" if len(v) == 5 and rel < 2e-3 else "DIFFERENT"))
 PY
+  # how the SAME single graph fares three times as long on its one resident minibatch (what the graphed forms above had behind them
+  # when bench.py still read the objective after its same-process twin runs: 9 N steps, not 3 N)
+  timeout 900 python bench.py --steps $((3 * N)) --warmup 10 --no-cpu-baseline --no-extras --gemm-picks $PICKS 2>> gpurun_out/${TAG}_${JOB}.err | fl "single graph, three times as long" | sed 's/final loss/objective at the end/' >> $OUT
   cat $OUT
   ;;
 dp_tests)
